@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the reference's own importable modules and (re)generate tests/golden/*.npz.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  Nothing here travels to the GPU box except the
+golden vectors it writes (inputs + outputs computed BY THE REFERENCE MODULES, weights regenerated from
+rangeldm_amd.synth on both sides).
+
+    python -m oracle.validate_against_reference            # check + write goldens
+    python -m oracle.validate_against_reference --check    # check only
+
+How each reference file is imported without its missing third-party dependencies:
+  * vae/sgm/modules/diffusionmodules/model.py : `import sgm` fails (pytorch_lightning); register empty namespace
+    packages sgm / sgm.modules / sgm.modules.diffusionmodules and import `modules/attention.py` + `model.py` by path.
+  * ldm/utils.py     : stub `diffusers` module object (only type lookups at call time).
+  * ldm/encoders.py  : pure torch.
+  * ldm/pipelines.py : stub diffusers.utils.randn_tensor / DiffusionPipeline / ImagePipelineOutput / DDIMScheduler
+    and drive the loops with the oracle's UNet / scheduler / VAE objects.
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from rangeldm_amd.config import UNetConfig, VAEConfig, SchedulerConfig  # noqa: E402
+from rangeldm_amd.params import unet_param_shapes, vae_param_shapes, sgm_to_diffusers_vae_key  # noqa: E402
+from rangeldm_amd.synth import synth_state_dict, normal  # noqa: E402
+from oracle import ops, unet as o_unet, vae as o_vae, schedulers as o_sched, pipelines as o_pipe  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_sgm_model():
+    base = os.path.join(REF, "vae", "sgm")
+    for pkg, sub in (("sgm", ""), ("sgm.modules", "modules"), ("sgm.modules.diffusionmodules", "modules/diffusionmodules")):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(base, sub)]
+            sys.modules[pkg] = m
+    _load("sgm.modules.attention", os.path.join(base, "modules", "attention.py"))
+    return _load("sgm.modules.diffusionmodules.model", os.path.join(base, "modules", "diffusionmodules", "model.py"))
+
+
+def import_ldm_utils():
+    if "diffusers" not in sys.modules:
+        sys.modules["diffusers"] = types.ModuleType("diffusers")
+    return _load("ref_ldm_utils", os.path.join(REF, "ldm", "utils.py"))
+
+
+def import_ldm_pipelines():
+    d = sys.modules.get("diffusers") or types.ModuleType("diffusers")
+    sys.modules["diffusers"] = d
+    du = types.ModuleType("diffusers.utils")
+
+    def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+        return torch.randn(tuple(shape), generator=generator, dtype=dtype or torch.float32)
+
+    du.randn_tensor = randn_tensor
+    dp = types.ModuleType("diffusers.pipelines")
+    dpu = types.ModuleType("diffusers.pipelines.pipeline_utils")
+
+    class DiffusionPipeline:
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        _execution_device = torch.device("cpu")
+
+        def progress_bar(self, it):
+            return it
+
+    class ImagePipelineOutput:
+        def __init__(self, images):
+            self.images = images
+
+    dpu.DiffusionPipeline, dpu.ImagePipelineOutput = DiffusionPipeline, ImagePipelineOutput
+    ds = types.ModuleType("diffusers.schedulers")
+
+    class DDIMScheduler(o_sched.OracleDDIMScheduler):
+        @classmethod
+        def from_config(cls, config):
+            return cls(config)
+
+    ds.DDIMScheduler = DDIMScheduler
+    for name, m in (("diffusers.utils", du), ("diffusers.pipelines", dp), ("diffusers.pipelines.pipeline_utils", dpu),
+                    ("diffusers.schedulers", ds)):
+        sys.modules[name] = m
+    return _load("ref_ldm_pipelines", os.path.join(REF, "ldm", "pipelines.py"))
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+CHECKS = []
+
+
+def check(name, a, b, tol):
+    d = maxdiff(a, b)
+    ok = d <= tol
+    CHECKS.append((name, d, tol, ok))
+    print(f"  [{'ok' if ok else 'FAIL'}] {name}: max|diff|={d:.3e} (tol {tol:.1e})")
+    return ok
+
+
+def diffusers_sd_to_sgm(sd_diff, sgm_module_sd, side, num_levels=3):
+    """Build the sgm module's state dict from a diffusers-keyed synthetic dict through the reference key map."""
+    out = {}
+    for k in sgm_module_sd:
+        dk = sgm_to_diffusers_vae_key(f"{side}.{k}", num_levels)
+        assert dk is not None and dk in sd_diff, (k, dk)
+        out[k] = torch.from_numpy(sd_diff[dk]).reshape(sgm_module_sd[k].shape)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gold = {}
+
+    print("== leaf ops vs ldm/utils.py and sgm model.py")
+    sgm = import_sgm_model()
+    lu = import_ldm_utils()
+    x = torch.from_numpy(normal(1, "leaf/x", (2, 8, 16, 6)))
+    for tag, mod in (("ldm.utils.Conv2d", lu.Conv2d), ("sgm.Conv2d", sgm.Conv2d)):
+        for (k, s, p) in ((3, 1, 1), (3, 2, 1), (1, 1, 0)):
+            c = mod(8, 12, k, stride=s, padding=p, circular=True)
+            ref = c(x)
+            mine = ops.circ_conv2d(x, c.weight, c.bias, s, p)
+            check(f"{tag} k{k}s{s}p{p}", mine, ref, 0.0)
+    d1 = lu.Downsample2D(8, use_conv=True, out_channels=8, padding=1, name="op")
+    check("ldm.utils.Downsample2D pad1", ops.downsample_unet(x, d1.conv.weight, d1.conv.bias), d1(x), 0.0)
+    assert sorted(d1.state_dict().keys()) == ["conv.bias", "conv.weight"]
+    d0 = lu.Downsample2D(8, use_conv=True, out_channels=8, padding=0, name="op")
+    check("ldm.utils.Downsample2D pad0", ops.downsample_vae(x, d0.conv.weight, d0.conv.bias), d0(x), 0.0)
+    sd_ = sgm.Downsample(8, True, False, circular=True)
+    check("sgm.Downsample circular", ops.downsample_vae(x, sd_.conv.weight, sd_.conv.bias), sd_(x), 0.0)
+    su = sgm.Upsample(8, True, False, circular=True)
+    check("sgm.Upsample circular", ops.upsample_conv(x, su.conv.weight, su.conv.bias), su(x), 0.0)
+    gold["leaf_x"] = x.numpy()
+    gold["leaf_down_unet_w"], gold["leaf_down_unet_b"] = d1.conv.weight.detach().numpy(), d1.conv.bias.detach().numpy()
+    gold["leaf_down_unet_y"] = d1(x).detach().numpy()
+    gold["leaf_down_vae_w"], gold["leaf_down_vae_b"] = sd_.conv.weight.detach().numpy(), sd_.conv.bias.detach().numpy()
+    gold["leaf_down_vae_y"] = sd_(x).detach().numpy()
+    gold["leaf_up_w"], gold["leaf_up_b"] = su.conv.weight.detach().numpy(), su.conv.bias.detach().numpy()
+    gold["leaf_up_y"] = su(x).detach().numpy()
+
+    print("== ResnetBlock (temb) and AttnBlock vs sgm")
+    rb = sgm.ResnetBlock(in_channels=64, out_channels=96, temb_channels=512, dropout=0.0, act="silu", circular=True)
+    rb.norm1.eps = rb.norm2.eps = 1e-5                     # diffusers UNet eps (model.py:59-62 hard-codes 1e-6)
+    with torch.no_grad():
+        for p_ in rb.parameters():
+            p_.copy_(torch.from_numpy(normal(2, f"rb/{tuple(p_.shape)}", p_.shape)) * (0.05 if p_.dim() > 1 else 0.5))
+    xr = torch.from_numpy(normal(3, "rb/x", (2, 64, 16, 8)))
+    temb = torch.from_numpy(normal(3, "rb/temb", (2, 512)))
+    sdr = {"r.norm1.weight": rb.norm1.weight, "r.norm1.bias": rb.norm1.bias, "r.conv1.weight": rb.conv1.weight,
+           "r.conv1.bias": rb.conv1.bias, "r.time_emb_proj.weight": rb.temb_proj.weight,
+           "r.time_emb_proj.bias": rb.temb_proj.bias, "r.norm2.weight": rb.norm2.weight, "r.norm2.bias": rb.norm2.bias,
+           "r.conv2.weight": rb.conv2.weight, "r.conv2.bias": rb.conv2.bias,
+           "r.conv_shortcut.weight": rb.nin_shortcut.weight, "r.conv_shortcut.bias": rb.nin_shortcut.bias}
+    sdr = {k: v.detach() for k, v in sdr.items()}
+    with torch.no_grad():
+        ref = rb(xr, temb)
+    check("sgm.ResnetBlock temb 64->96", o_unet.resnet_block(sdr, "r", xr, temb, 32, 1e-5), ref, 2e-6)
+    for k, v in sdr.items():
+        gold["resnet_" + k] = v.numpy()
+    gold["resnet_x"], gold["resnet_temb"], gold["resnet_y"] = xr.numpy(), temb.numpy(), ref.numpy()
+
+    ab = sgm.AttnBlock(64)
+    with torch.no_grad():
+        for p_ in ab.parameters():
+            p_.copy_(torch.from_numpy(normal(4, f"ab/{tuple(p_.shape)}", p_.shape)) * (0.1 if p_.dim() > 1 else 0.5))
+    xa = torch.from_numpy(normal(5, "ab/x", (2, 64, 16, 4)))
+    sda = {"a.group_norm.weight": ab.norm.weight, "a.group_norm.bias": ab.norm.bias}
+    for n_, m_ in (("to_q", ab.q), ("to_k", ab.k), ("to_v", ab.v), ("to_out.0", ab.proj_out)):
+        sda[f"a.{n_}.weight"] = m_.weight.reshape(64, 64)
+        sda[f"a.{n_}.bias"] = m_.bias
+    sda = {k: v.detach() for k, v in sda.items()}
+    with torch.no_grad():
+        ref = ab(xa)
+    check("sgm.AttnBlock == Attention(heads=1,d=C)", o_unet.attention_block(sda, "a", xa, 32, 1e-6, 64), ref, 5e-6)
+    for k, v in sda.items():
+        gold["attn_" + k] = v.numpy()
+    gold["attn_x"], gold["attn_y_single_head"] = xa.numpy(), ref.numpy()
+
+    print("== VAE Encoder / Decoder vs sgm (kitti360.yaml params, synthetic weights through the convert_vae key map)")
+    vcfg = VAEConfig()
+    kw = dict(attn_type="none", double_z=True, z_channels=4, resolution=256, in_channels=2, out_ch=2, ch=64,
+              ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0, act="silu", circular=True)
+    enc, dec = sgm.Encoder(**kw), sgm.Decoder(**kw)
+    assert sum(p.numel() for p in enc.parameters()) == 5341320 and sum(p.numel() for p in dec.parameters()) == 7989570
+    vsd = synth_state_dict(vae_param_shapes(vcfg), prefix="vae.")
+    enc.load_state_dict(diffusers_sd_to_sgm(vsd, enc.state_dict(), "encoder"))
+    dec.load_state_dict(diffusers_sd_to_sgm(vsd, dec.state_dict(), "decoder"))
+    xi = torch.from_numpy(normal(6, "vae/x", (1, 2, 256, 32)))
+    zi = torch.from_numpy(normal(6, "vae/z", (1, 4, 64, 8)))
+    with torch.no_grad():
+        ref_m, ref_img = enc(xi), dec(zi)
+    check("sgm.Encoder (1,2,256,32)", o_vae.vae_encode(vsd_t(vsd), vcfg, xi), ref_m, 2e-5)
+    check("sgm.Decoder (1,4,64,8)", o_vae.vae_decode(vsd_t(vsd), vcfg, zi), ref_img, 2e-5)
+    gold["vae_x"], gold["vae_moments_ref"] = xi.numpy(), ref_m.numpy()
+    gold["vae_z"], gold["vae_image_ref"] = zi.numpy(), ref_img.numpy()
+    # full-size decode golden (the BASELINE shape), stored as fp16 + checksum to stay small
+    zf = torch.from_numpy(normal(6, "vae/zfull", (1, 4, 256, 16)))
+    with torch.no_grad():
+        ref_full = dec(zf)
+    check("sgm.Decoder (1,4,256,16) full size", o_vae.vae_decode(vsd_t(vsd), vcfg, zf), ref_full, 5e-5)
+    gold["vae_zfull"] = zf.numpy()
+    gold["vae_image_full_ref_f16"] = ref_full.numpy().astype(np.float16)
+    gold["vae_image_full_ref_sum"] = np.array([ref_full.double().sum().item(), ref_full.double().abs().sum().item()])
+
+    print("== DiagonalGaussianDistribution vs sgm distributions.py")
+    dist = _load("ref_distributions", os.path.join(REF, "vae", "sgm", "modules", "distributions", "distributions.py"))
+    torch.manual_seed(123)
+    ref_s = dist.DiagonalGaussianDistribution(ref_m).sample()
+    torch.manual_seed(123)
+    noise = torch.randn(ref_s.shape)
+    check("DiagonalGaussian.sample", o_vae.DiagonalGaussian(ref_m).sample(noise=noise), ref_s, 0.0)
+    gold["dg_noise"], gold["dg_sample_ref"] = noise.numpy(), ref_s.numpy()
+
+    print("== SparseRangeImageEncoder2 vs ldm/encoders.py")
+    le = _load("ref_ldm_encoders", os.path.join(REF, "ldm", "encoders.py"))
+    xc = torch.from_numpy(normal(7, "cond/x", (2, 2, 64, 4)))
+    ref_c = le.SparseRangeImageEncoder2()(xc)
+    check("SparseRangeImageEncoder2", o_pipe.sparse_range_image_encoder2(xc), ref_c, 0.0)
+    gold["cond_x"], gold["cond_y_ref"] = xc.numpy(), ref_c.contiguous().numpy()
+
+    print("== pipeline loops vs ldm/pipelines.py (reference loop code driving oracle UNet/scheduler/VAE)")
+    lp = import_ldm_pipelines()
+    small = UNetConfig(sample_size=(32, 8), block_out_channels=(32, 32, 64, 64))
+    usd = synth_state_dict(unet_param_shapes(small), prefix="small.")
+    unet = o_unet.OracleUNet(small, usd)
+    vae = o_vae.OracleVAE(vcfg, vsd)
+    # LDMPipelineRange with the DDPM scheduler (reference-faithful latent sampler)
+    pipe = lp.LDMPipelineRange(vae=vae, unet=unet, scheduler=o_sched.OracleDDPMScheduler(), pos_encoding=True)
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(12)
+    ref_img = pipe(batch_size=2, generator=g, num_inference_steps=4, output_type="torch")
+    g = torch.Generator().manual_seed(11)
+    x_T = torch.randn((2, 4, 32, 8), generator=g)
+    torch.manual_seed(12)
+    zs = [torch.randn(2, 4, 32, 8) for _ in range(3)] + [None]      # last step t=0 draws nothing
+    mine = o_pipe.ldm_pipeline(vae, unet, o_sched.OracleDDPMScheduler(), x_T, 4, pos_encoding=True, step_noise=zs)
+    check("LDMPipelineRange (DDPM, 4 steps)", mine, ref_img, 0.0)
+    gold["ldm_x_T"], gold["ldm_step_noise"] = x_T.numpy(), torch.stack(zs[:3]).numpy()
+    gold["ldm_image_ref"] = ref_img.numpy()
+    # DDIMPipelineRange (pixel space, eta=0) on a 3-in/2-out UNet
+    small_dm = UNetConfig(sample_size=(32, 8), in_channels=3, out_channels=2, block_out_channels=(32, 32, 64, 64))
+    usd2 = synth_state_dict(unet_param_shapes(small_dm), prefix="smalldm.")
+    unet2 = o_unet.OracleUNet(small_dm, usd2)
+    pipe2 = lp.DDIMPipelineRange(unet=unet2, scheduler=o_sched.OracleDDPMScheduler(), pos_encoding=True)
+    g = torch.Generator().manual_seed(21)
+    ref2 = pipe2(batch_size=2, generator=g, num_inference_steps=5, output_type="torch")
+    g = torch.Generator().manual_seed(21)
+    x_T2 = torch.randn((2, 2, 32, 8), generator=g)
+    mine2 = o_pipe.ddim_pipeline(unet2, o_sched.OracleDDIMScheduler(), x_T2, 5, eta=0.0, pos_encoding=True)
+    check("DDIMPipelineRange (eta=0, 5 steps)", mine2, ref2, 0.0)
+    gold["ddim_x_T"], gold["ddim_image_ref"] = x_T2.numpy(), ref2.numpy()
+    # LDMUpscalePipelineRange with SparseRangeImageEncoder2 condition
+    small_up = UNetConfig(sample_size=(32, 8), in_channels=12, out_channels=4, block_out_channels=(32, 32, 64, 64))
+    usd3 = synth_state_dict(unet_param_shapes(small_up), prefix="smallup.")
+    unet3 = o_unet.OracleUNet(small_up, usd3)
+    pipe3 = lp.LDMUpscalePipelineRange(vae=vae, unet=unet3, scheduler=o_sched.OracleDDPMScheduler())
+    cond_img = torch.from_numpy(normal(8, "up/cond", (2, 2, 128, 8)))
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(32)
+    ref3 = pipe3(image=cond_img, condition_encoder=le.SparseRangeImageEncoder2(), batch_size=2, generator=g,
+                 num_inference_steps=3, output_type="torch")
+    g = torch.Generator().manual_seed(31)
+    x_T3 = torch.randn((2, 4, 32, 8), generator=g)
+    torch.manual_seed(32)
+    zs3 = [torch.randn(2, 4, 32, 8) for _ in range(2)] + [None]
+    mine3 = o_pipe.ldm_pipeline(vae, unet3, o_sched.OracleDDPMScheduler(), x_T3, 3, pos_encoding=False,
+                                step_noise=zs3, cond=o_pipe.sparse_range_image_encoder2(cond_img))
+    check("LDMUpscalePipelineRange (DDPM, 3 steps)", mine3, ref3, 0.0)
+    gold["up_cond"], gold["up_x_T"], gold["up_step_noise"] = cond_img.numpy(), x_T3.numpy(), torch.stack(zs3[:2]).numpy()
+    gold["up_image_ref"] = ref3.numpy()
+
+    print("== UNet2DModel (diffusers, absent): cross-checks only -- parity UNPINNED")
+    full = UNetConfig()
+    n = sum(int(np.prod(s)) for s in unet_param_shapes(full).values())
+    assert n == 30135684, n
+    print(f"  [ok] RangeLDM UNet parameter count {n} == 115.0 MiB fp32 (README.md:8)")
+    fsd = synth_state_dict(unet_param_shapes(full))
+    xu = torch.from_numpy(normal(9, "unet/x", (1, 5, 256, 16)))
+    eps = o_unet.unet_forward(vsd_t(fsd), full, xu, 480)
+    gold["unet_x"], gold["unet_t"], gold["unet_eps_oracle"] = xu.numpy(), np.array([480]), eps.numpy()
+
+    bad = [c for c in CHECKS if not c[3]]
+    print(f"\n{len(CHECKS) - len(bad)}/{len(CHECKS)} checks passed")
+    if bad:
+        sys.exit(1)
+    if not args.check:
+        os.makedirs(GOLD, exist_ok=True)
+        groups = {}
+        for k, v in gold.items():
+            groups.setdefault(k.split("_", 1)[0], {})[k] = np.ascontiguousarray(v)
+        for gname, d in groups.items():
+            path = os.path.join(GOLD, f"{gname}.npz")
+            np.savez_compressed(path, **d)
+            print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def vsd_t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+if __name__ == "__main__":
+    main()
