@@ -1,0 +1,171 @@
+/*
+ * rangeldm_hip.h -- C ABI of librangeldm_hip.so: the MI355X (gfx950) implementation of the RangeLDM denoising
+ * hot path (UNet2DModel forward, DDPM/DDIM scheduler step, AutoencoderKL encode/decode, whole sampling loop).
+ *
+ * The reference has no FFI: the path sits behind Python duck-typing.  Each entry point below names
+ * the reference call it replaces (file:line under the reference tree).  The python modules under rangeldm_amd/ are the thin ctypes shim
+ * that re-presents these as `unet(x, t).sample`, `scheduler.step(...).prev_sample`, `vae.decode(z).sample` and
+ * `pipe(batch_size=..., num_inference_steps=...)`; INTEGRATION.md shows the binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, non-zero on failure; the message is in rldm_last_error() (thread-local).
+ *     Nothing throws across the ABI.
+ *   - Tensors at the boundary are the reference's: fp32, NCHW with dim2 = W (azimuth), dim3 = H (beams)
+ *     (ldm/dataset.py:228-233), contiguous, resident in device (HBM) memory, owned by the caller.  Internally
+ *     activations are bf16 channels-last [B][W][H][C] with fp32 accumulation; weights are owned by the library.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is enqueued on it (the
+ *     sampler uses an internal stream fenced by events against `stream`).  Single caller thread per handle.
+ */
+#ifndef RANGELDM_HIP_H
+#define RANGELDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLDM_MAX_LEVELS 8
+
+typedef struct rldm_unet rldm_unet;       /* UNet2DModel replacement   */
+typedef struct rldm_vae rldm_vae;         /* AutoencoderKL replacement */
+typedef struct rldm_sampler rldm_sampler; /* Pipeline.__call__ loop    */
+
+/* UNet2DModel(**model_config): ldm/train_unconditional.py:237-242, ldm/configs/RangeLDM.yaml:17-24.
+ * Library defaults the reference relies on are explicit fields. */
+typedef struct rldm_unet_config {
+    int32_t sample_w, sample_h;                 /* sample_size = (W, H)                                  */
+    int32_t in_channels, out_channels;
+    int32_t layers_per_block;
+    int32_t num_levels;
+    int32_t block_out_channels[RLDM_MAX_LEVELS];
+    int32_t down_attn[RLDM_MAX_LEVELS];         /* 1: AttnDownBlock2D, 0: DownBlock2D                    */
+    int32_t up_attn[RLDM_MAX_LEVELS];           /* 1: AttnUpBlock2D,   0: UpBlock2D                      */
+    int32_t attention_head_dim;                 /* 8 (only value supported by the d=8 attention kernel)  */
+    int32_t norm_num_groups;                    /* 32                                                    */
+    float norm_eps;                             /* 1e-5                                                  */
+    int32_t mid_attention;                      /* add_attention                                         */
+} rldm_unet_config;
+
+/* sgm Encoder/Decoder kwargs: vae/configs/kitti360.yaml:30-62 (== AutoencoderKL after ldm/convert_vae.py:123-189). */
+typedef struct rldm_vae_config {
+    int32_t in_channels, out_channels;
+    int32_t ch;
+    int32_t num_levels;
+    int32_t ch_mult[RLDM_MAX_LEVELS];
+    int32_t num_res_blocks;
+    int32_t z_channels;
+    int32_t double_z;
+    int32_t norm_num_groups;
+    float norm_eps;                             /* 1e-6 */
+    float scaling_factor;                       /* 0.18215, ldm/convert_vae.py:159-168 */
+} rldm_vae_config;
+
+const char* rldm_last_error(void);
+/* 0 if a gfx950 device is usable; fills name (may be NULL). */
+int rldm_device_info(char* name, size_t name_len, int* compute_units);
+
+/* ---- UNet2DModel ------------------------------------------------------------------------------------------- */
+/* replaces UNet2DModel(**cfg) + replace_down/replace_conv surgery: ldm/inference.py:84-85,102-104 */
+int rldm_unet_create(const rldm_unet_config* cfg, rldm_unet** out);
+void rldm_unet_destroy(rldm_unet* m);
+/* replaces load_state_dict / safetensors.load_model (ldm/inference.py:120): one call per diffusers key,
+ * `data` = HOST fp32, `numel` elements in the reference's (C_out, C_in, kh, kw) / (out, in) order. */
+int rldm_unet_set_param(rldm_unet* m, const char* name, const float* data, int64_t numel);
+/* checks every key was supplied, packs bf16 MFMA-ordered weights to HBM */
+int rldm_unet_finalize(rldm_unet* m);
+/* replaces `unet(sample, timestep).sample` (ldm/pipelines.py:103,239,360,500; train: ldm/train_unconditional.py:512).
+ * sample: device fp32 [B, in_channels, W, H]; timesteps: HOST int64, nt == 1 (broadcast) or nt == B;
+ * out: device fp32 [B, out_channels, W, H]. */
+int rldm_unet_forward(rldm_unet* m, const float* sample, const int64_t* timesteps, int nt, int B, float* out,
+                      void* stream);
+
+/* ---- AutoencoderKL ------------------------------------------------------------------------------------------ */
+int rldm_vae_create(const rldm_vae_config* cfg, rldm_vae** out);     /* ldm/inference.py:86-96 */
+void rldm_vae_destroy(rldm_vae* m);
+int rldm_vae_set_param(rldm_vae* m, const char* name, const float* data, int64_t numel);  /* ldm/inference.py:97 */
+int rldm_vae_finalize(rldm_vae* m);
+/* replaces `vae.decode(z).sample` (ldm/pipelines.py:367,507).  z: device fp32 [B, z_channels, W/f, H/f] (already
+ * divided by scaling_factor by the caller, as the reference does at :365); image: device fp32 [B, out_ch, W, H]. */
+int rldm_vae_decode(rldm_vae* m, const float* z, int B, int latent_w, int latent_h, float* image, void* stream);
+/* replaces `vae.encode(x)` up to the moments (ldm/train_unconditional.py:480, ldm/pipelines.py:408).
+ * x: device fp32 [B, in_ch, W, H]; moments: device fp32 [B, 2*z, W/f, H/f] = [mean | logvar]. */
+int rldm_vae_encode(rldm_vae* m, const float* x, int B, int w, int h, float* moments, void* stream);
+/* replaces DiagonalGaussianDistribution.sample (vae/sgm/modules/distributions/distributions.py:24-41):
+ * out = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale.  All device fp32; n = B*z*w*h elements of `out`. */
+int rldm_diag_gaussian_sample(const float* moments, const float* noise, float scale, int B, int z, int spatial,
+                              float* out, void* stream);
+
+/* ---- scheduler steps (elementwise; coefficients computed by the host shim exactly as diffusers does) -------- */
+/* replaces DDIMScheduler.step (ldm/pipelines.py:244-246), SURVEY.md B.2:
+ *   x0 = (x - sqrt_beta_t*eps)/sqrt_alpha_t ; prev = sqrt_alpha_prev*x0 + dir_coef*eps + sigma*noise
+ * coef = {sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, dir_coef, sigma}; noise may be NULL when sigma == 0. */
+int rldm_sched_ddim_step(const float coef[5], const float* eps, const float* x, const float* noise, float* x_prev,
+                         int64_t n, void* stream);
+/* replaces DDPMScheduler.step (ldm/pipelines.py:106,362), SURVEY.md B.3:
+ *   x0 = (x - sqrt_beta_t*eps)/sqrt_alpha_t ; prev = c_x0*x0 + c_xt*x + sigma*noise
+ * coef = {sqrt_alpha_t, sqrt_beta_t, c_x0, c_xt, sigma}. */
+int rldm_sched_ddpm_step(const float coef[5], const float* eps, const float* x, const float* noise, float* x_prev,
+                         int64_t n, void* stream);
+/* replaces DDPMScheduler.add_noise (ldm/train_unconditional.py:498): out = sa[b]*x0 + sb[b]*noise (sa, sb HOST [B]). */
+int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_alpha, const float* sqrt_beta, int B,
+                         int64_t per_sample, float* out, void* stream);
+
+/* ---- whole sampling loop (HIP-graph captured) --------------------------------------------------------------- */
+#define RLDM_SAMPLER_DDIM 0   /* eta = 0 DDIM  (DDIMPipelineRange, ldm/pipelines.py:144-258; BASELINE metric) */
+#define RLDM_SAMPLER_DDPM 1   /* strided ancestral DDPM (LDMPipelineRange as shipped, ldm/pipelines.py:282-383) */
+
+typedef struct rldm_sampler_config {
+    int32_t batch;            /* per-GPU batch                                                                */
+    int32_t num_steps;        /* num_inference_steps                                                          */
+    int32_t mode;             /* RLDM_SAMPLER_*                                                               */
+    int32_t pos_encoding;     /* extra constant channel: 1 at azimuth 0 (ldm/pipelines.py:229-232,346-349)     */
+    int32_t cond_channels;    /* channels of the per-step concatenated condition (ldm/pipelines.py:498), or 0  */
+    /* per-step scheduler coefficients, HOST, [num_steps][5] in the layout of rldm_sched_{ddim,ddpm}_step      */
+    const float* coef;
+    /* timesteps, HOST int64 [num_steps] (scheduler.timesteps)                                                 */
+    const int64_t* timesteps;
+} rldm_sampler_config;
+
+/* replaces Pipeline.__init__ + the per-call setup of ldm/pipelines.py:329-349; vae may be NULL (pixel-space RangeDM) */
+int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_config* cfg, rldm_sampler** out);
+void rldm_sampler_destroy(rldm_sampler* s);
+/* replaces the loop + decode of ldm/pipelines.py:353-367 (:496-507 with cond, :234-246 without VAE).
+ * x_T: device fp32 [B, out_ch, W, H]; step_noise: device fp32 [num_steps, B, out_ch, W, H] or NULL (DDIM);
+ * cond: device fp32 [B, cond_channels, W, H] or NULL; images: device fp32 [B, 2, 4W, 4H] (or the final x_0 when
+ * the sampler has no VAE); latents_out: optional device fp32 [B, out_ch, W, H] receiving the final latent. */
+int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, const float* cond, float* images,
+                float* latents_out, void* stream);
+
+/* ---- introspection used by bench.py / tests ----------------------------------------------------------------- */
+/* algorithmic FLOPs (2*MACs of conv/linear/QK^T/PV) of one UNet forward / VAE decode / encode for batch B */
+double rldm_unet_flops(rldm_unet* m, int B);
+double rldm_vae_decode_flops(rldm_vae* m, int B, int latent_w, int latent_h);
+/* number of kernel launches in one UNet forward plan (for the launch-overhead budget in DESIGN.md) */
+int rldm_unet_num_launches(rldm_unet* m, int B);
+
+/* low-level op entry points (used by the parity tests to check each kernel in isolation) */
+typedef struct rldm_conv_desc {
+    int32_t B, Cin0, Cin1, Win, Hin;  /* inputs x0 [B][Win][Hin][Cin0] (+ x1 [..][Cin1] concatenated), bf16 NHWC */
+    int32_t Cout;
+    int32_t ksize;                    /* 1 or 3                                                                */
+    int32_t stride;                   /* 1 or 2                                                                */
+    int32_t pad_mode;                 /* 0: symmetric pad 1 (wrap W / zero H); 1: end-only pad (VAE downsample) */
+    int32_t upsample;                 /* 1: nearest x2 folded into the input indexing                          */
+    int32_t gn;                       /* 1: GroupNorm(32) prologue on the (concatenated) input                  */
+    int32_t silu;                     /* 1: SiLU after the norm                                                */
+    float eps;
+} rldm_conv_desc;
+/* One fused conv: y = conv(silu(GN(cat[x0,x1]))) + bias + temb[b] + res.  All device pointers; x0/x1/res/y are
+ * fp32 NCHW here (converted on device) so tests can feed reference tensors; weight (Cout, Cin, k, k), gamma/beta,
+ * bias, temb ([B][Cout] or NULL) are HOST fp32. */
+int rldm_test_conv(const rldm_conv_desc* d, const float* x0, const float* x1, const float* weight, const float* bias,
+                   const float* gamma, const float* beta, const float* temb, const float* res, float* y, void* stream);
+/* multi-head (d=8) self-attention core: qkv device fp32 [B][L][3C] -> out device fp32 [B][L][C] */
+int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANGELDM_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of librangeldm_hip.so (include/rangeldm_hip.h).  The product path has NO fallback: if the HIP
+library is missing or a call fails, a RuntimeError carrying rldm_last_error() is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librangeldm_hip.so")
+RLDM_MAX_LEVELS = 8
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [("sample_w", C.c_int32), ("sample_h", C.c_int32), ("in_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("layers_per_block", C.c_int32), ("num_levels", C.c_int32),
+                ("block_out_channels", C.c_int32 * RLDM_MAX_LEVELS), ("down_attn", C.c_int32 * RLDM_MAX_LEVELS),
+                ("up_attn", C.c_int32 * RLDM_MAX_LEVELS), ("attention_head_dim", C.c_int32),
+                ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float), ("mid_attention", C.c_int32)]
+
+
+class VAEConfigC(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("ch", C.c_int32), ("num_levels", C.c_int32),
+                ("ch_mult", C.c_int32 * RLDM_MAX_LEVELS), ("num_res_blocks", C.c_int32), ("z_channels", C.c_int32),
+                ("double_z", C.c_int32), ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float),
+                ("scaling_factor", C.c_float)]
+
+
+class SamplerConfigC(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("num_steps", C.c_int32), ("mode", C.c_int32), ("pos_encoding", C.c_int32),
+                ("cond_channels", C.c_int32), ("coef", C.POINTER(C.c_float)), ("timesteps", C.POINTER(C.c_int64))]
+
+
+class ConvDescC(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Cin0", C.c_int32), ("Cin1", C.c_int32), ("Win", C.c_int32), ("Hin", C.c_int32),
+                ("Cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32),
+                ("upsample", C.c_int32), ("gn", C.c_int32), ("silu", C.c_int32), ("eps", C.c_float)]
+
+
+_P = C.c_void_p
+# every symbol declared in include/rangeldm_hip.h: name -> (restype, argtypes)
+PROTOTYPES = {
+    "rldm_last_error": (C.c_char_p, []),
+    "rldm_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "rldm_unet_create": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(_P)]),
+    "rldm_unet_destroy": (None, [_P]),
+    "rldm_unet_set_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "rldm_unet_finalize": (C.c_int, [_P]),
+    "rldm_unet_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "rldm_vae_create": (C.c_int, [C.POINTER(VAEConfigC), C.POINTER(_P)]),
+    "rldm_vae_destroy": (None, [_P]),
+    "rldm_vae_set_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "rldm_vae_finalize": (C.c_int, [_P]),
+    "rldm_vae_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_vae_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_diag_gaussian_sample": (C.c_int, [_P, _P, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_sched_ddim_step": (C.c_int, [C.POINTER(C.c_float), _P, _P, _P, _P, C.c_int64, _P]),
+    "rldm_sched_ddpm_step": (C.c_int, [C.POINTER(C.c_float), _P, _P, _P, _P, C.c_int64, _P]),
+    "rldm_sched_add_noise": (C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int64, _P, _P]),
+    "rldm_sampler_create": (C.c_int, [_P, _P, C.POINTER(SamplerConfigC), C.POINTER(_P)]),
+    "rldm_sampler_destroy": (None, [_P]),
+    "rldm_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
+    "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
+    "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),
+    "rldm_test_conv": (C.c_int, [C.POINTER(ConvDescC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rldm_test_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built (`__graft_entry__.build()`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               f"(hipcc --offload-arch=gfx950).  rangeldm_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)           # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rldm_last_error()
+        raise RuntimeError(f"librangeldm_hip: {what} failed: {msg.decode() if msg else 'unknown error'}")
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("rangeldm_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU fallback")
+    name = C.create_string_buffer(64)
+    cus = C.c_int(0)
+    check(lib().rldm_device_info(name, 64, C.byref(cus)), "rldm_device_info")
+    return name.value.decode(), cus.value

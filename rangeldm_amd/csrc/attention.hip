@@ -1,0 +1,104 @@
+// Multi-head self-attention with head_dim = 8 for gfx950 (diffusers Attention/AttnProcessor2_0 as UNet2DModel uses it:
+// heads = C/8, softmax(q k^T / sqrt(8)) v; single-head analogue in the reference:
+// vae/sgm/modules/diffusionmodules/model.py:391-412).
+//
+// d = 8 is hostile to the K=16/32 MFMAs, so:
+//   S^T = K Q^T  uses v_mfma_f32_32x32x8_bf16 (K = 8 exactly, no padding): one MFMA per 32 keys x 32 queries.  In the
+//         result layout every lane owns ONE query (column) and 16 of the 32 keys (rows) -> the online softmax is
+//         lane-local except for one exchange with the partner half-wave.
+//   O^T += V^T P^T uses v_mfma_f32_32x32x16_bf16 with the contraction index permuted to exactly the key order the
+//         lane already holds after S^T (no cross-lane shuffles of P).  Only 8 of the 32 "M" rows carry V; row 8 is
+//         all-ones, so the MFMA also produces the softmax denominator for free.  The kernel is VALU(exp)-bound, not
+//         MFMA-bound, so the idle MFMA rows cost nothing.
+// Layouts: qk [B][L][2C] bf16 (q pre-multiplied by log2(e)/sqrt(8) through the packed Wq), vt [B][C/8][8][L] bf16
+// (written transposed by the QKV GEMM epilogue), out [B][L][C] bf16.  One wave = 32 queries of one (b, head).
+#include "kernels.h"
+
+namespace rldm {
+
+__global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, const int waves_per_block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int heads = p.C >> 3;
+    const int qtiles = p.L >> 5;
+    const int qblocks = qtiles / waves_per_block;
+    int bid = blockIdx.x;
+    const int qb = bid % qblocks;
+    bid /= qblocks;
+    const int h = bid % heads;
+    const int b = bid / heads;
+    const int q0 = (qb * waves_per_block + wave) * 32;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ld = 2 * p.C;
+
+    const bf16_t* qbase = p.qk + ((size_t)b * p.L) * ld + h * 8;
+    const bf16_t* kbase = qbase + p.C;
+    const bf16_t* vbase = p.vt + ((size_t)b * heads + h) * 8 * (size_t)p.L;
+
+    // B operand of S^T: Q^T, lane (query l31, half hh) holds q[query][4*hh .. 4*hh+3]
+    const s16x4 qf = *reinterpret_cast<const s16x4*>(qbase + (size_t)(q0 + l31) * ld + 4 * hh);
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -1e30f;
+
+    // A operand rows of the PV MFMA: row l31 < 8 -> V^T[d = l31], row 8 -> ones, rows 9..31 -> zero
+    const bool vrow = l31 < 8;
+    const bf16_t* vrow_ptr = vbase + (size_t)(vrow ? l31 : 0) * p.L + 4 * hh;
+    const uint32_t fill = (l31 == 8) ? 0x3f803f80u : 0u;   // bf16 1.0 pairs
+
+    for (int k0 = 0; k0 < p.L; k0 += 32) {
+        const s16x4 kf = *reinterpret_cast<const s16x4*>(kbase + (size_t)(k0 + l31) * ld + 4 * hh);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, s, 0, 0, 0);
+        // lane (query l31, half hh), register r <-> key k0 + (r&3) + 8*(r>>2) + 4*hh ; scores are in log2 units
+        float tmax = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(__builtin_amdgcn_exp2f(s[r] - mnew), __builtin_amdgcn_exp2f(s[r + 1] - mnew));
+#pragma unroll
+        for (int r = 0; r < 5; ++r) o[r] *= alpha;      // rows 0..8 only: V rows and the ones row (others stay 0)
+        // PV: MFMA t (t = 0, 1) contracts over the 16 keys {k0 + 16t + 4hh' + (e&3) + 8(e>>2)}, e = 0..7, hh' = 0, 1
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint4 vw = make_uint4(fill, fill, fill, fill);
+            if (vrow) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t + 8);
+                vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            const uint4 pw = make_uint4(pk[4 * t], pk[4 * t + 1], pk[4 * t + 2], pk[4 * t + 3]);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), __builtin_bit_cast(bf16x8, pw),
+                                                        o, 0, 0, 0);
+        }
+    }
+    // o rows: reg r of half hh <-> row (r&3) + 8*(r>>2) + 4*hh.  d = 4*hh + r for r < 4; denominator = row 8 = reg 4 of hh 0
+    float denom = __shfl(o[4], l31);
+    const float inv = 1.0f / denom;
+    uint2 ov;
+    ov.x = pack_bf16x2(o[0] * inv, o[1] * inv);
+    ov.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+    *reinterpret_cast<uint2*>(p.out + ((size_t)b * p.L + q0 + l31) * p.C + h * 8 + 4 * hh) = ov;
+}
+
+int launch_attention(const AttnParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(p.L % 32 == 0 && p.L >= 32, "attention: token count must be a multiple of 32");
+    RLDM_REQUIRE(p.C % 8 == 0, "attention: channels must be a multiple of head_dim 8");
+    const int qtiles = p.L / 32;
+    int wpb = 4;
+    while (qtiles % wpb) wpb >>= 1;
+    const int grid = p.B * (p.C / 8) * (qtiles / wpb);
+    hipLaunchKernelGGL(attention_d8_kernel, dim3(grid), dim3(64 * wpb), 0, stream, p, wpb);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rldm

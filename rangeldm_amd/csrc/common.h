@@ -1,0 +1,76 @@
+// Shared device helpers and host-side error plumbing for librangeldm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits in HBM / LDS
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RLDM_WAVE 64
+
+namespace rldm {
+
+void set_error(const std::string& msg);
+
+#define RLDM_HIP_CHECK(expr)                                                                        \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            rldm::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ +    \
+                            ":" + std::to_string(__LINE__) + ")");                                  \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)
+
+#define RLDM_REQUIRE(cond, msg)                                                                     \
+    do {                                                                                            \
+        if (!(cond)) {                                                                              \
+            rldm::set_error(std::string(msg) + " [" #cond "] (" + __FILE__ + ":" +                   \
+                            std::to_string(__LINE__) + ")");                                        \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------------------
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+    union { float f; uint32_t u; } v;
+    v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+// device: hardware v_cvt_pk_bf16_f32 (round-to-nearest-even) via the native __bf16 vector conversion
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ inline float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ inline float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware block remap (guide T1): blocks land on XCD (bid % 8); give each XCD a contiguous range of logical ids
+// so neighbouring tiles (which share input halos / weight panels) hit the same private L2.  Bijective for any n.
+__device__ inline int xcd_remap(int bid, int nblocks) {
+    const int nx = 8;
+    int q = nblocks / nx, r = nblocks % nx;
+    int xcd = bid % nx, k = bid / nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+}  // namespace rldm

@@ -1,0 +1,130 @@
+// Kernel parameter blocks and launchers of librangeldm_hip (gfx950).  Activations: bf16 channels-last [B][W][H][C].
+#pragma once
+#include "common.h"
+
+namespace rldm {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused circular implicit-GEMM convolution (conv_igemm.hip)
+//   y = conv_k( pad( silu?( GN?( cat[x0, x1] ) ) ) ) + bias (+ temb[row]) (+ res)
+// geometry: virtual input v(w', h') = x(w'/up, h'/up) of size (Win*up, Hin*up); output pixel (w, h) reads
+//   v(wrap(w*stride + i - pad_lo), h*stride + j - pad_lo) for taps i (azimuth), j (beams); h out of range -> 0.
+// Reference arithmetic: ldm/utils.py:40-55,107-116; vae/sgm/modules/diffusionmodules/model.py:93-125,164-172.
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvParams {
+    const bf16_t* x0;
+    const bf16_t* x1;       // second tensor of a channel concat (may be null)
+    int C0, C1;             // channels of x0 / x1; C0 + C1 is a multiple of the kernel's CK
+    int B, Win, Hin;
+    int up;                 // 1 | 2 (nearest upsample folded into indexing)
+    int stride;             // 1 | 2
+    int pad_lo;             // 1: symmetric pad 1, 0: end-only pad (or 1x1)
+    int Wout, Hout;
+    int TW, TH;             // output-pixel tile handled by one block (TW*TH <= BM)
+    // GroupNorm prologue (null gn_part -> none): partial (sum, sumsq) per [b][P][group] from gn_stats
+    const float2* gn_part;
+    int gn_P, gn_groups;
+    const float* gn_gamma;
+    const float* gn_beta;
+    float gn_eps;
+    int silu;
+    // weights: bf16, packed [ntile_n][Cin/CK][taps][BN][CK + 8 pad]
+    const bf16_t* wpk;
+    int N;                  // real output channels
+    int ntile_n;
+    const float* bias;      // padded to ntile_n * BN
+    // epilogue
+    const float* temb;      // null or [rows][temb_ld], row = step*rows_per_step + (per_sample ? b : 0)
+    int temb_ld;
+    const int* step_ptr;    // device int (null -> 0)
+    int temb_rows_per_step;
+    int temb_per_sample;
+    const bf16_t* res;      // null or [B][Wout][Hout][N]
+    bf16_t* y;              // bf16 output, row stride y_ld, channels [0, n_store)
+    int y_ld, n_store;
+    bf16_t* vt;             // channels >= n_store go transposed to vt[b][head][8][L] (attention V), or null
+    float* y_nchw;          // if set: fp32 NCHW output [B][N][Wout][Hout] instead of y
+};
+
+struct ConvTile {
+    int BM, BN, CK, taps;
+};
+// row stride (bytes) of one LDS / packed-weight row for a CK
+inline int conv_row_bytes(int CK) { return CK * 2 + 16; }
+size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p);
+bool conv_tile_supported(const ConvTile& t);
+int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics (norm.hip): deterministic partial (sum, sumsq) per (b, chunk p, group) over cat[x0, x1].
+// ---------------------------------------------------------------------------------------------------------------
+struct GnStatsParams {
+    const bf16_t* x0;
+    const bf16_t* x1;
+    int C0, C1;
+    int B, npix;            // pixels per image
+    int groups;
+    int P;                  // pixel chunks per image (grid.x)
+    float2* part;           // [B][P][groups]
+};
+int launch_gn_stats(const GnStatsParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-head self-attention with head_dim 8 (attention.hip).  qk: [B][L][2C] (q | k, q pre-scaled by
+// log2(e)/sqrt(8) through the packed weights), vt: [B][C/8][8][L], out: [B][L][C].
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnParams {
+    const bf16_t* qk;
+    const bf16_t* vt;
+    bf16_t* out;
+    int B, L, C;
+};
+int launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------------------------------------
+// conv_in input: [B][W][H][Cpad] bf16 from fp32 NCHW sources: x (cx ch, * scale), pos-encoding channel, cond (cc ch)
+struct PackInputParams {
+    const float* x; int cx; float scale;
+    int pos_encoding;
+    const float* cond; int cc;
+    int B, W, H, Cpad;
+    bf16_t* out;
+};
+int launch_pack_input(const PackInputParams& p, hipStream_t stream);
+int launch_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int W, int H, int Cpad, hipStream_t s);
+int launch_nhwc_bf16_to_nchw_f32(const bf16_t* src, float* dst, int B, int C, int W, int H, int ld, hipStream_t s);
+
+// time embedding + all per-resnet projections for `rows` timesteps:
+//   e=[cos(t f), sin(t f)] (dim0) -> Linear(dim0, D) -> SiLU -> Linear(D, D) -> SiLU -> Linear(D, total) (+bias)
+struct TembParams {
+    const float* t;          // [rows] timesteps as float (device)
+    int rows, dim0, D, total;
+    const float* w1; const float* b1;   // [D][dim0]
+    const float* w2; const float* b2;   // [D][D]
+    const float* wp; const float* bp;   // [total][D] concatenated time_emb_proj
+    float* out;              // [rows][total]
+};
+int launch_temb(const TembParams& p, hipStream_t stream);
+
+// scheduler steps; coef on host (baked) or read from device table row *step_ptr
+struct SchedParams {
+    int mode;                 // 0 ddim, 1 ddpm
+    float coef[5];
+    const float* coef_table;  // device [steps][5] or null
+    const int* step_ptr;
+    const float* eps; const float* x; const float* noise;   // noise may be null
+    long long noise_step_stride;                            // elements between steps in `noise` (table mode)
+    float* x_prev;
+    long long n;
+};
+int launch_sched_step(const SchedParams& p, hipStream_t stream);
+int launch_add_noise(const float* x0, const float* noise, const float* sa, const float* sb, int B, long long per,
+                     float* out, hipStream_t stream);
+int launch_diag_gaussian(const float* moments, const float* noise, float scale, int B, int z, int spatial, float* out,
+                         hipStream_t stream);
+int launch_step_counter(int* step_ptr, int set_to, int increment, hipStream_t stream);
+int launch_scale_f32(const float* src, float* dst, float scale, long long n, hipStream_t stream);
+
+}  // namespace rldm

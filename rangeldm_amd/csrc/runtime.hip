@@ -1,0 +1,1552 @@
+// librangeldm_hip runtime: model objects, weight packing, per-batch execution plans (one activation arena + an
+// ordered list of kernel launches), HIP-graph captured sampling loop, and the C ABI of include/rangeldm_hip.h.
+//
+// Network structure follows diffusers UNet2DModel.forward [3P; SURVEY.md A.2] as configured by
+// ldm/train_unconditional.py:237-242 and the sgm Encoder/Decoder forward
+// (vae/sgm/modules/diffusionmodules/model.py:852-896,1024-1057); the loop follows ldm/pipelines.py:353-367.
+#include "../../include/rangeldm_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+namespace rldm {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// device memory helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        reset();
+        if (n == 0) n = 16;
+        RLDM_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+static int upload(DevBuf& b, const void* host, size_t bytes) {
+    if (b.alloc(bytes)) return 1;
+    RLDM_HIP_CHECK(hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// first-fit offset allocator over one arena; plans are built twice (dry run for the peak, then for real)
+struct Arena {
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_list;
+    size_t top = 0, peak = 0;
+    size_t alloc(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        for (size_t i = 0; i < free_list.size(); ++i) {
+            if (free_list[i].size >= n) {
+                size_t off = free_list[i].off;
+                free_list[i].off += n;
+                free_list[i].size -= n;
+                if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+                return off;
+            }
+        }
+        size_t off = top;
+        top += n;
+        peak = std::max(peak, top);
+        return off;
+    }
+    void release(size_t off, size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        free_list.push_back({off, n});
+        std::sort(free_list.begin(), free_list.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < free_list.size();) {
+            if (free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+                free_list[i].size += free_list[i + 1].size;
+                free_list.erase(free_list.begin() + i + 1);
+            } else {
+                ++i;
+            }
+        }
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+            top = free_list.back().off;
+            free_list.pop_back();
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// layers: host fp32 parameters + lazily packed device images
+// ---------------------------------------------------------------------------------------------------------------
+struct NormParams {
+    DevBuf gamma, beta;
+    int C = 0;
+};
+
+struct ConvLayer {
+    std::string name;
+    int Cout = 0, Cin = 0, ksize = 3;          // real sizes
+    std::vector<float> w, b;                   // host fp32, (Cout, Cin, k, k) / (Cout)
+    struct Packed {
+        DevBuf w, bias;
+        int ntile_n = 0, Cin_pad = 0;
+    };
+    std::map<std::pair<int, int>, std::unique_ptr<Packed>> packed;   // (BN, CK) -> image
+
+    // [ntile_n][Cin_pad/CK][taps][BN][CK + 8] bf16; channel rows >= Cout and channels >= Cin are zero
+    int get_packed(int BN, int CK, int Cin_pad, Packed** out) {
+        auto key = std::make_pair(BN, CK);
+        auto it = packed.find(key);
+        if (it != packed.end()) {
+            RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
+            *out = it->second.get();
+            return 0;
+        }
+        const int taps = ksize * ksize;
+        const int ntile = (Cout + BN - 1) / BN;
+        const int ncc = Cin_pad / CK;
+        const int RSE = CK + 8;
+        std::vector<bf16_t> img((size_t)ntile * ncc * taps * BN * RSE, 0);
+        for (int n = 0; n < Cout; ++n) {
+            const int nt = n / BN, nr = n % BN;
+            for (int c = 0; c < Cin; ++c) {
+                const int cc = c / CK, ck = c % CK;
+                for (int tap = 0; tap < taps; ++tap) {
+                    const float v = w[((size_t)n * Cin + c) * taps + tap];
+                    img[((((size_t)nt * ncc + cc) * taps + tap) * BN + nr) * RSE + ck] = f32_to_bf16(v);
+                }
+            }
+        }
+        std::vector<float> bias((size_t)ntile * BN, 0.f);
+        for (int n = 0; n < Cout; ++n) bias[n] = b[n];
+        auto pk = std::make_unique<Packed>();
+        if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(pk->bias, bias.data(), bias.size() * sizeof(float))) return 1;
+        pk->ntile_n = ntile;
+        pk->Cin_pad = Cin_pad;
+        *out = pk.get();
+        packed[key] = std::move(pk);
+        return 0;
+    }
+};
+
+struct ParamStore {
+    std::map<std::string, std::vector<float>> host;
+    std::map<std::string, int64_t> expected;    // name -> numel
+    bool finalized = false;
+
+    int set(const char* name, const float* data, int64_t numel) {
+        auto it = expected.find(name);
+        RLDM_REQUIRE(it != expected.end(), std::string("unexpected parameter key: ") + name);
+        RLDM_REQUIRE(it->second == numel, std::string("size mismatch for ") + name + ": expected " +
+                                              std::to_string(it->second) + " got " + std::to_string(numel));
+        host[name].assign(data, data + numel);
+        finalized = false;
+        return 0;
+    }
+    int check_complete() const {
+        for (auto& kv : expected)
+            RLDM_REQUIRE(host.count(kv.first), std::string("missing parameter key: ") + kv.first);
+        return 0;
+    }
+    void expect_conv(const std::string& n, int co, int ci, int k) {
+        expected[n + ".weight"] = (int64_t)co * ci * k * k;
+        expected[n + ".bias"] = co;
+    }
+    void expect_lin(const std::string& n, int co, int ci) {
+        expected[n + ".weight"] = (int64_t)co * ci;
+        expected[n + ".bias"] = co;
+    }
+    void expect_norm(const std::string& n, int c) {
+        expected[n + ".weight"] = c;
+        expected[n + ".bias"] = c;
+    }
+    void expect_resnet(const std::string& p, int ci, int co, int temb) {
+        expect_norm(p + ".norm1", ci);
+        expect_conv(p + ".conv1", co, ci, 3);
+        if (temb) expect_lin(p + ".time_emb_proj", co, temb);
+        expect_norm(p + ".norm2", co);
+        expect_conv(p + ".conv2", co, co, 3);
+        if (ci != co) expect_conv(p + ".conv_shortcut", co, ci, 1);
+    }
+    void expect_attn(const std::string& p, int c) {
+        expect_norm(p + ".group_norm", c);
+        expect_lin(p + ".to_q", c, c);
+        expect_lin(p + ".to_k", c, c);
+        expect_lin(p + ".to_v", c, c);
+        expect_lin(p + ".to_out.0", c, c);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// execution plan
+// ---------------------------------------------------------------------------------------------------------------
+struct Tensor {
+    size_t off = 0;
+    int B = 0, W = 0, H = 0, C = 0;
+    int id = -1;
+    size_t bytes() const { return (size_t)B * W * H * C * sizeof(bf16_t); }
+    bool valid() const { return id >= 0; }
+};
+
+struct PlanIO {
+    // conv_in sources (fp32 NCHW, device)
+    const float* sample = nullptr;
+    int sample_channels = 0;
+    float sample_scale = 1.f;
+    int pos_encoding = 0;
+    const float* cond = nullptr;
+    int cond_channels = 0;
+    // output (fp32 NCHW, device)
+    float* out = nullptr;
+    // time-embedding table
+    const float* temb = nullptr;
+    const int* step_ptr = nullptr;
+    int temb_rows_per_step = 1;
+    int temb_per_sample = 0;
+};
+
+struct Plan {
+    int B = 0, W = 0, H = 0;
+    DevBuf arena;
+    PlanIO io;
+    std::vector<std::function<int(hipStream_t)>> ops;
+    double flops = 0;
+    int run(hipStream_t s) {
+        for (auto& f : ops)
+            if (f(s)) return 1;
+        return 0;
+    }
+};
+
+struct Layers {
+    std::map<std::string, std::unique_ptr<ConvLayer>> conv;
+    std::map<std::string, std::unique_ptr<NormParams>> norm;
+    ConvLayer* get_conv(const std::string& n) {
+        auto it = conv.find(n);
+        return it == conv.end() ? nullptr : it->second.get();
+    }
+    NormParams* get_norm(const std::string& n) {
+        auto it = norm.find(n);
+        return it == norm.end() ? nullptr : it->second.get();
+    }
+    int add_conv(ParamStore& ps, const std::string& n, int co, int ci, int k) {
+        auto L = std::make_unique<ConvLayer>();
+        L->name = n;
+        L->Cout = co;
+        L->Cin = ci;
+        L->ksize = k;
+        L->w = ps.host.at(n + ".weight");
+        L->b = ps.host.at(n + ".bias");
+        conv[n] = std::move(L);
+        return 0;
+    }
+    int add_norm(ParamStore& ps, const std::string& n, int c) {
+        auto N = std::make_unique<NormParams>();
+        N->C = c;
+        if (upload(N->gamma, ps.host.at(n + ".weight").data(), c * sizeof(float))) return 1;
+        if (upload(N->beta, ps.host.at(n + ".bias").data(), c * sizeof(float))) return 1;
+        norm[n] = std::move(N);
+        return 0;
+    }
+    // fused q|k|v projection; q rows pre-scaled by log2(e)/sqrt(head_dim) so attention works in exp2 units
+    int add_qkv(ParamStore& ps, const std::string& p, int c, int head_dim) {
+        auto L = std::make_unique<ConvLayer>();
+        L->name = p + ".qkv";
+        L->Cout = 3 * c;
+        L->Cin = c;
+        L->ksize = 1;
+        const float qs = 1.4426950408889634f / std::sqrt((float)head_dim);
+        const char* names[3] = {".to_q", ".to_k", ".to_v"};
+        for (int i = 0; i < 3; ++i) {
+            const auto& w = ps.host.at(p + names[i] + ".weight");
+            const auto& b = ps.host.at(p + names[i] + ".bias");
+            const float s = i == 0 ? qs : 1.f;
+            for (float v : w) L->w.push_back(v * s);
+            for (float v : b) L->b.push_back(v * s);
+        }
+        conv[L->name] = std::move(L);
+        return 0;
+    }
+};
+
+struct ConvArgs {
+    ConvLayer* layer = nullptr;
+    Tensor x0, x1;                 // x1 optional concat
+    int stride = 1, pad_mode = 0, up = 1;
+    NormParams* gn = nullptr;      // GroupNorm prologue over cat[x0, x1]
+    float eps = 1e-5f;
+    int groups = 32;
+    int silu = 0;
+    int temb_off = -1;             // channel offset into the temb table row
+    Tensor res;                    // optional residual
+    int n_store = -1;              // attention qkv: channels [0, n_store) -> y (ld n_store), rest -> vt
+    bool out_f32_nchw = false;     // conv_out: write plan->io.out
+};
+
+static ConvTile choose_tile(long long B, int Wout, int Hout, int N, int Cin_pad, int taps) {
+    ConvTile t;
+    t.taps = taps;
+    t.CK = (Cin_pad % 64 == 0) ? 64 : 16;
+    auto blocks = [&](int BM, int BN) {
+        const int TH = std::min(Hout, 16), TW = std::min(Wout, std::max(1, BM / TH));
+        return B * (Wout / TW) * (Hout / TH) * ((N + BN - 1) / BN);
+    };
+    const std::pair<int, int> pref[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+    if (N <= 32) {
+        t.BM = 128;
+        t.BN = 32;
+    } else if (N <= 64) {
+        t.BM = 128;
+        t.BN = 64;
+        if (blocks(128, 64) < 256) t.BM = 64;
+    } else {
+        t.BM = 128;
+        t.BN = 128;
+        if (blocks(128, 128) < 384) {
+            t.BM = 64;
+            t.BN = 64;
+        }
+    }
+    if (!conv_tile_supported(t)) {
+        for (auto& pr : pref) {
+            ConvTile u = t;
+            u.BM = pr.first;
+            u.BN = pr.second;
+            if (N <= 32 && u.BN != 32) continue;
+            if (conv_tile_supported(u)) return u;
+        }
+        ConvTile u = t;              // last resort: the generic small tile
+        u.BM = 64;
+        u.BN = 64;
+        return u;
+    }
+    return t;
+}
+
+struct Builder {
+    Plan* plan;
+    bool dry;
+    Arena arena;
+    int next_id = 0;
+    std::map<int, int> refs;
+    std::map<int, Tensor> live;
+    char* base = nullptr;
+    int launches = 0;
+    int temb_ld = 0;               // row stride of the time-embedding table (0: network has none)
+
+    Tensor make(int B, int W, int H, int C) {
+        Tensor t;
+        t.B = B; t.W = W; t.H = H; t.C = C;
+        t.id = next_id++;
+        t.off = arena.alloc(t.bytes());
+        refs[t.id] = 1;
+        live[t.id] = t;
+        return t;
+    }
+    void retain(const Tensor& t) { refs[t.id]++; }
+    void release(const Tensor& t) {
+        if (!t.valid()) return;
+        if (--refs[t.id] == 0) {
+            arena.release(t.off, t.bytes());
+            live.erase(t.id);
+        }
+    }
+    template <class T> T* ptr(size_t off) const { return reinterpret_cast<T*>(base + off); }
+    bf16_t* tptr(const Tensor& t) const { return t.valid() ? ptr<bf16_t>(t.off) : nullptr; }
+
+    // GroupNorm partial statistics over cat[x0, x1]; returns arena offset of the [B][P][groups] float2 buffer
+    int gn_stats(const Tensor& x0, const Tensor& x1, int groups, size_t* off_out, int* P_out) {
+        const int npix = x0.W * x0.H;
+        int P = std::max(1, std::min(16, npix / 64));
+        const size_t bytes = (size_t)x0.B * P * groups * sizeof(float2);
+        const size_t off = arena.alloc(bytes);
+        *off_out = off;
+        *P_out = P;
+        ++launches;
+        if (!dry) {
+            GnStatsParams g;
+            g.x0 = tptr(x0);
+            g.x1 = tptr(x1);
+            g.C0 = x0.C;
+            g.C1 = x1.valid() ? x1.C : 0;
+            g.B = x0.B;
+            g.npix = npix;
+            g.groups = groups;
+            g.P = P;
+            g.part = ptr<float2>(off);
+            plan->ops.push_back([g](hipStream_t s) { return launch_gn_stats(g, s); });
+        }
+        return 0;
+    }
+
+    // y = conv(...) ; consumes nothing (callers release inputs)
+    int conv(const ConvArgs& a, Tensor* out, Tensor* vt_out = nullptr) {
+        ConvLayer* L = a.layer;
+        RLDM_REQUIRE(L != nullptr, "internal: missing conv layer");
+        const Tensor& x0 = a.x0;
+        const int Cin_t = x0.C + (a.x1.valid() ? a.x1.C : 0);      // tensor (padded) channels
+        RLDM_REQUIRE(Cin_t >= L->Cin, "conv " + L->name + ": input tensor has fewer channels than the weights");
+        RLDM_REQUIRE(Cin_t % 16 == 0, "conv " + L->name + ": input channels must be a multiple of 16");
+        const int taps = L->ksize * L->ksize;
+        const int Wv = x0.W * a.up, Hv = x0.H * a.up;
+        const int Wout = Wv / a.stride, Hout = Hv / a.stride;
+        RLDM_REQUIRE(Wv % a.stride == 0 && Hv % a.stride == 0, "conv " + L->name + ": odd size under stride 2");
+        const int N = L->Cout;
+        ConvTile tile = choose_tile(x0.B, Wout, Hout, N, Cin_t, taps);
+        RLDM_REQUIRE(conv_tile_supported(tile), "conv " + L->name + ": no kernel instance");
+
+        ConvParams p;
+        memset(&p, 0, sizeof(p));
+        p.C0 = x0.C;
+        p.C1 = a.x1.valid() ? a.x1.C : 0;
+        p.B = x0.B; p.Win = x0.W; p.Hin = x0.H;
+        p.up = a.up; p.stride = a.stride;
+        p.pad_lo = (L->ksize == 1) ? 0 : (a.pad_mode == 0 ? 1 : 0);
+        p.Wout = Wout; p.Hout = Hout;
+        int TH = std::min(Hout, a.stride == 2 ? 8 : 16);
+        int TW = std::min(Wout, std::max(1, tile.BM / TH));
+        // keep the stride-2 halo inside the LDS budget
+        while (a.stride == 2 && TW > 1 && (size_t)((TW - 1) * 2 + 3) * ((TH - 1) * 2 + 3) * conv_row_bytes(tile.CK) > 60 * 1024)
+            TW >>= 1;
+        RLDM_REQUIRE(Wout % TW == 0 && Hout % TH == 0, "conv " + L->name + ": size not tileable (powers of two expected)");
+        p.TW = TW; p.TH = TH;
+        p.N = N;
+        p.silu = a.silu;
+        p.gn_eps = a.eps;
+        p.gn_groups = a.groups;
+
+        Tensor y, vt;
+        const bool qkv = a.n_store >= 0;
+        if (!a.out_f32_nchw) {
+            y = make(x0.B, Wout, Hout, qkv ? a.n_store : N);
+            if (qkv) vt = make(x0.B, Wout, Hout, N - a.n_store);
+        }
+        size_t gn_off = 0;
+        int gn_P = 0;
+        if (a.gn) {
+            RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
+            if (gn_stats(x0, a.x1, a.groups, &gn_off, &gn_P)) return 1;
+        }
+        plan->flops += 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * taps;
+        ++launches;
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_packed(tile.BN, tile.CK, Cin_t, &pk)) return 1;
+            p.x0 = tptr(x0);
+            p.x1 = tptr(a.x1);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            p.ntile_n = pk->ntile_n;
+            if (a.gn) {
+                p.gn_part = ptr<float2>(gn_off);
+                p.gn_P = gn_P;
+                p.gn_gamma = a.gn->gamma.as<float>();
+                p.gn_beta = a.gn->beta.as<float>();
+            }
+            p.res = tptr(a.res);
+            p.y = tptr(y);
+            p.y_ld = qkv ? a.n_store : N;
+            p.n_store = qkv ? a.n_store : N;
+            p.vt = qkv ? tptr(vt) : nullptr;
+            Plan* pl = plan;
+            p.temb_ld = temb_ld;
+            const int temb_off = a.temb_off;
+            const bool f32out = a.out_f32_nchw;
+            plan->ops.push_back([p, tile, pl, temb_off, f32out](hipStream_t s) mutable {
+                if (temb_off >= 0) {
+                    p.temb = pl->io.temb + temb_off;
+                    p.step_ptr = pl->io.step_ptr;
+                    p.temb_rows_per_step = pl->io.temb_rows_per_step;
+                    p.temb_per_sample = pl->io.temb_per_sample;
+                }
+                if (f32out) p.y_nchw = pl->io.out;
+                return launch_conv(tile, p, s);
+            });
+        }
+        if (a.gn) arena.release(gn_off, (size_t)x0.B * gn_P * a.groups * sizeof(float2));
+        *out = y;
+        if (vt_out) *vt_out = vt;
+        return 0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// shared network pieces
+// ---------------------------------------------------------------------------------------------------------------
+struct NetCommon {
+    Layers layers;
+    int groups = 32;
+    float eps = 1e-5f;
+    int temb_ld = 0;                                 // total projected channels (0: no time embedding)
+    std::map<std::string, int> temb_off;             // resnet prefix -> channel offset in the temb row
+
+    // ResnetBlock2D / sgm ResnetBlock (model.py:342-362).  Releases one reference of x and skip.
+    int resnet(Builder& b, const std::string& p, Tensor x, Tensor skip, Tensor* out) {
+        ConvArgs c1;
+        c1.layer = layers.get_conv(p + ".conv1");
+        c1.x0 = x; c1.x1 = skip;
+        c1.gn = layers.get_norm(p + ".norm1");
+        c1.eps = eps; c1.groups = groups; c1.silu = 1;
+        auto it = temb_off.find(p);
+        c1.temb_off = it == temb_off.end() ? -1 : it->second;
+        Tensor h1;
+        if (b.conv(c1, &h1)) return 1;
+        Tensor sc = x;
+        ConvLayer* scl = layers.get_conv(p + ".conv_shortcut");
+        if (scl) {
+            ConvArgs cs;
+            cs.layer = scl;
+            cs.x0 = x; cs.x1 = skip;
+            if (b.conv(cs, &sc)) return 1;
+        } else {
+            RLDM_REQUIRE(!skip.valid(), "resnet " + p + ": concat input without a shortcut conv");
+            b.retain(sc);
+        }
+        ConvArgs c2;
+        c2.layer = layers.get_conv(p + ".conv2");
+        c2.x0 = h1;
+        c2.gn = layers.get_norm(p + ".norm2");
+        c2.eps = eps; c2.groups = groups; c2.silu = 1;
+        c2.res = sc;
+        if (b.conv(c2, out)) return 1;
+        b.release(h1);
+        b.release(sc);
+        b.release(x);
+        b.release(skip);
+        return 0;
+    }
+
+    // diffusers Attention (+x residual).  Releases one reference of x.
+    int attention(Builder& b, const std::string& p, Tensor x, Tensor* out) {
+        ConvArgs cq;
+        cq.layer = layers.get_conv(p + ".qkv");
+        cq.x0 = x;
+        cq.gn = layers.get_norm(p + ".group_norm");
+        cq.eps = eps; cq.groups = groups; cq.silu = 0;
+        cq.n_store = 2 * x.C;
+        Tensor qk, vt;
+        if (b.conv(cq, &qk, &vt)) return 1;
+        Tensor o = b.make(x.B, x.W, x.H, x.C);
+        const int L = x.W * x.H;
+        b.plan->flops += 4.0 * (double)x.B * (x.C / 8) * (double)L * L * 8;
+        ++b.launches;
+        if (!b.dry) {
+            AttnParams ap;
+            ap.qk = b.tptr(qk); ap.vt = b.tptr(vt); ap.out = b.tptr(o);
+            ap.B = x.B; ap.L = L; ap.C = x.C;
+            b.plan->ops.push_back([ap](hipStream_t s) { return launch_attention(ap, s); });
+        }
+        b.release(qk);
+        b.release(vt);
+        ConvArgs co;
+        co.layer = layers.get_conv(p + ".to_out.0");
+        co.x0 = o;
+        co.res = x;
+        if (b.conv(co, out)) return 1;
+        b.release(o);
+        b.release(x);
+        return 0;
+    }
+
+    int add_resnet(ParamStore& ps, const std::string& p, int ci, int co, bool temb) {
+        if (layers.add_norm(ps, p + ".norm1", ci)) return 1;
+        if (layers.add_conv(ps, p + ".conv1", co, ci, 3)) return 1;
+        if (layers.add_norm(ps, p + ".norm2", co)) return 1;
+        if (layers.add_conv(ps, p + ".conv2", co, co, 3)) return 1;
+        if (ci != co && layers.add_conv(ps, p + ".conv_shortcut", co, ci, 1)) return 1;
+        if (temb) {
+            temb_off[p] = temb_ld;
+            temb_ld += co;
+        }
+        return 0;
+    }
+    int add_attn(ParamStore& ps, const std::string& p, int c, int head_dim) {
+        if (layers.add_norm(ps, p + ".group_norm", c)) return 1;
+        if (layers.add_qkv(ps, p, c, head_dim)) return 1;
+        if (layers.add_conv(ps, p + ".to_out.0", c, c, 1)) return 1;
+        return 0;
+    }
+};
+
+static int pad16(int c) { return (c + 15) / 16 * 16; }
+
+}  // namespace rldm
+
+using namespace rldm;
+
+// =================================================================================================================
+// UNet2DModel
+// =================================================================================================================
+struct rldm_unet {
+    rldm_unet_config cfg;
+    ParamStore params;
+    NetCommon net;
+    int temb_dim = 0;                               // time_embed_dim
+    DevBuf w1, b1, w2, b2, wp, bp;                  // fp32 time-embedding weights
+    std::map<int, std::unique_ptr<Plan>> plans;     // per batch size
+    DevBuf t_dev, temb_tab;                         // scratch for rldm_unet_forward
+    int temb_rows_cap = 0;
+    std::vector<std::string> resnet_order;
+
+    int levels() const { return cfg.num_levels; }
+};
+
+static void unet_expect(rldm_unet* m) {
+    const auto& c = m->cfg;
+    ParamStore& ps = m->params;
+    const int* boc = c.block_out_channels;
+    const int L = c.num_levels;
+    const int temb = boc[0] * 4;
+    ps.expect_conv("conv_in", boc[0], c.in_channels, 3);
+    ps.expect_lin("time_embedding.linear_1", temb, boc[0]);
+    ps.expect_lin("time_embedding.linear_2", temb, temb);
+    int out = boc[0];
+    for (int i = 0; i < L; ++i) {
+        int cin = out;
+        out = boc[i];
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            ps.expect_resnet("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? cin : out, out, temb);
+            if (c.down_attn[i]) ps.expect_attn("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), out);
+        }
+        if (i != L - 1) ps.expect_conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", out, out, 3);
+    }
+    const int cm = boc[L - 1];
+    ps.expect_resnet("mid_block.resnets.0", cm, cm, temb);
+    if (c.mid_attention) ps.expect_attn("mid_block.attentions.0", cm);
+    ps.expect_resnet("mid_block.resnets.1", cm, cm, temb);
+    out = boc[L - 1];
+    for (int i = 0; i < L; ++i) {
+        const int prev = out;
+        out = boc[L - 1 - i];
+        const int inp = boc[L - 1 - std::min(i + 1, L - 1)];
+        const int n = c.layers_per_block + 1;
+        for (int j = 0; j < n; ++j) {
+            const int skip = (j == n - 1) ? inp : out;
+            const int rin = (j == 0) ? prev : out;
+            ps.expect_resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), rin + skip, out, temb);
+            if (c.up_attn[i]) ps.expect_attn("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), out);
+        }
+        if (i != L - 1) ps.expect_conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out, out, 3);
+    }
+    ps.expect_norm("conv_norm_out", boc[0]);
+    ps.expect_conv("conv_out", c.out_channels, boc[0], 3);
+}
+
+static int unet_build_layers(rldm_unet* m) {
+    const auto& c = m->cfg;
+    ParamStore& ps = m->params;
+    NetCommon& net = m->net;
+    net = NetCommon();
+    net.groups = c.norm_num_groups;
+    net.eps = c.norm_eps;
+    const int* boc = c.block_out_channels;
+    const int L = c.num_levels;
+    const int hd = c.attention_head_dim;
+    m->temb_dim = boc[0] * 4;
+    if (net.layers.add_conv(ps, "conv_in", boc[0], c.in_channels, 3)) return 1;
+    int out = boc[0];
+    for (int i = 0; i < L; ++i) {
+        int cin = out;
+        out = boc[i];
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            const std::string r = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+            if (net.add_resnet(ps, r, j == 0 ? cin : out, out, true)) return 1;
+            m->resnet_order.push_back(r);
+            if (c.down_attn[i] && net.add_attn(ps, "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), out, hd)) return 1;
+        }
+        if (i != L - 1 && net.layers.add_conv(ps, "down_blocks." + std::to_string(i) + ".downsamplers.0.conv", out, out, 3)) return 1;
+    }
+    const int cm = boc[L - 1];
+    if (net.add_resnet(ps, "mid_block.resnets.0", cm, cm, true)) return 1;
+    m->resnet_order.push_back("mid_block.resnets.0");
+    if (c.mid_attention && net.add_attn(ps, "mid_block.attentions.0", cm, hd)) return 1;
+    if (net.add_resnet(ps, "mid_block.resnets.1", cm, cm, true)) return 1;
+    m->resnet_order.push_back("mid_block.resnets.1");
+    out = boc[L - 1];
+    for (int i = 0; i < L; ++i) {
+        const int prev = out;
+        out = boc[L - 1 - i];
+        const int inp = boc[L - 1 - std::min(i + 1, L - 1)];
+        const int n = c.layers_per_block + 1;
+        for (int j = 0; j < n; ++j) {
+            const int skip = (j == n - 1) ? inp : out;
+            const int rin = (j == 0) ? prev : out;
+            const std::string r = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+            if (net.add_resnet(ps, r, rin + skip, out, true)) return 1;
+            m->resnet_order.push_back(r);
+            if (c.up_attn[i] && net.add_attn(ps, "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), out, hd)) return 1;
+        }
+        if (i != L - 1 && net.layers.add_conv(ps, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out, out, 3)) return 1;
+    }
+    if (net.layers.add_norm(ps, "conv_norm_out", boc[0])) return 1;
+    if (net.layers.add_conv(ps, "conv_out", c.out_channels, boc[0], 3)) return 1;
+
+    // time-embedding weights (fp32): linear_1, linear_2, all time_emb_proj concatenated in resnet order
+    const int D = m->temb_dim;
+    if (upload(m->w1, ps.host.at("time_embedding.linear_1.weight").data(), (size_t)D * boc[0] * 4)) return 1;
+    if (upload(m->b1, ps.host.at("time_embedding.linear_1.bias").data(), (size_t)D * 4)) return 1;
+    if (upload(m->w2, ps.host.at("time_embedding.linear_2.weight").data(), (size_t)D * D * 4)) return 1;
+    if (upload(m->b2, ps.host.at("time_embedding.linear_2.bias").data(), (size_t)D * 4)) return 1;
+    std::vector<float> wp((size_t)net.temb_ld * D), bp(net.temb_ld);
+    for (auto& r : m->resnet_order) {
+        const int off = net.temb_off.at(r);
+        const auto& w = ps.host.at(r + ".time_emb_proj.weight");
+        const auto& b = ps.host.at(r + ".time_emb_proj.bias");
+        std::copy(w.begin(), w.end(), wp.begin() + (size_t)off * D);
+        std::copy(b.begin(), b.end(), bp.begin() + off);
+    }
+    if (upload(m->wp, wp.data(), wp.size() * 4)) return 1;
+    if (upload(m->bp, bp.data(), bp.size() * 4)) return 1;
+    return 0;
+}
+
+// one pass of the UNet walk (dry: sizes only)
+static int unet_walk(rldm_unet* m, Builder& b, int B) {
+    const auto& c = m->cfg;
+    NetCommon& net = m->net;
+    const int L = c.num_levels;
+    const int W = c.sample_w, H = c.sample_h;
+    const int Cpad = pad16(c.in_channels);
+    Plan* plan = b.plan;
+
+    Tensor xin = b.make(B, W, H, Cpad);
+    ++b.launches;
+    if (!b.dry) {
+        bf16_t* dst = b.tptr(xin);
+        plan->ops.push_back([plan, dst, B, W, H, Cpad](hipStream_t s) {
+            PackInputParams p;
+            p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
+            p.pos_encoding = plan->io.pos_encoding;
+            p.cond = plan->io.cond; p.cc = plan->io.cond_channels;
+            p.B = B; p.W = W; p.H = H; p.Cpad = Cpad;
+            p.out = dst;
+            return launch_pack_input(p, s);
+        });
+    }
+    Tensor h;
+    {
+        ConvArgs a;
+        a.layer = net.layers.get_conv("conv_in");
+        a.x0 = xin;
+        if (b.conv(a, &h)) return 1;
+        b.release(xin);
+    }
+    std::vector<Tensor> skips;
+    b.retain(h);
+    skips.push_back(h);
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            Tensor o;
+            if (net.resnet(b, "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h, Tensor(), &o)) return 1;
+            h = o;
+            if (c.down_attn[i]) {
+                if (net.attention(b, "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, &o)) return 1;
+                h = o;
+            }
+            b.retain(h);
+            skips.push_back(h);
+        }
+        if (i != L - 1) {
+            ConvArgs a;
+            a.layer = net.layers.get_conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv");
+            a.x0 = h;
+            a.stride = 2;
+            Tensor o;
+            if (b.conv(a, &o)) return 1;
+            b.release(h);
+            h = o;
+            b.retain(h);
+            skips.push_back(h);
+        }
+    }
+    {
+        Tensor o;
+        if (net.resnet(b, "mid_block.resnets.0", h, Tensor(), &o)) return 1;
+        h = o;
+        if (c.mid_attention) {
+            if (net.attention(b, "mid_block.attentions.0", h, &o)) return 1;
+            h = o;
+        }
+        if (net.resnet(b, "mid_block.resnets.1", h, Tensor(), &o)) return 1;
+        h = o;
+    }
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            RLDM_REQUIRE(!skips.empty(), "internal: skip stack underflow");
+            Tensor sk = skips.back();
+            skips.pop_back();
+            Tensor o;
+            if (net.resnet(b, "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h, sk, &o)) return 1;
+            h = o;
+            if (c.up_attn[i]) {
+                if (net.attention(b, "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, &o)) return 1;
+                h = o;
+            }
+        }
+        if (i != L - 1) {
+            ConvArgs a;
+            a.layer = net.layers.get_conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
+            a.x0 = h;
+            a.up = 2;
+            Tensor o;
+            if (b.conv(a, &o)) return 1;
+            b.release(h);
+            h = o;
+        }
+    }
+    RLDM_REQUIRE(skips.empty(), "internal: skip stack not drained");
+    {
+        ConvArgs a;
+        a.layer = net.layers.get_conv("conv_out");
+        a.x0 = h;
+        a.gn = net.layers.get_norm("conv_norm_out");
+        a.eps = net.eps; a.groups = net.groups; a.silu = 1;
+        a.out_f32_nchw = true;
+        Tensor none;
+        if (b.conv(a, &none)) return 1;
+        b.release(h);
+    }
+    return 0;
+}
+
+static int unet_make_plan(rldm_unet* m, int B, std::unique_ptr<Plan>* out, int* launches = nullptr) {
+    auto plan = std::make_unique<Plan>();
+    plan->B = B; plan->W = m->cfg.sample_w; plan->H = m->cfg.sample_h;
+    Builder dry;
+    dry.plan = plan.get();
+    dry.dry = true;
+    dry.temb_ld = m->net.temb_ld;
+    if (unet_walk(m, dry, B)) return 1;
+    if (launches) *launches = dry.launches;
+    if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
+    plan->flops = 0;
+    Builder real;
+    real.plan = plan.get();
+    real.dry = false;
+    real.base = plan->arena.as<char>();
+    real.temb_ld = m->net.temb_ld;
+    if (unet_walk(m, real, B)) return 1;
+    *out = std::move(plan);
+    return 0;
+}
+
+// time-embedding table for `rows` timesteps (host floats) into `tab`
+static int unet_temb(rldm_unet* m, const float* t_dev, int rows, float* tab, hipStream_t s) {
+    TembParams p;
+    p.t = t_dev; p.rows = rows;
+    p.dim0 = m->cfg.block_out_channels[0]; p.D = m->temb_dim; p.total = m->net.temb_ld;
+    p.w1 = m->w1.as<float>(); p.b1 = m->b1.as<float>();
+    p.w2 = m->w2.as<float>(); p.b2 = m->b2.as<float>();
+    p.wp = m->wp.as<float>(); p.bp = m->bp.as<float>();
+    p.out = tab;
+    return launch_temb(p, s);
+}
+
+// =================================================================================================================
+// VAE
+// =================================================================================================================
+struct rldm_vae {
+    rldm_vae_config cfg;
+    ParamStore params;
+    NetCommon net;
+    struct Key { int B, w, h, enc; bool operator<(const Key& o) const { return std::tie(B, w, h, enc) < std::tie(o.B, o.w, o.h, o.enc); } };
+    std::map<Key, std::unique_ptr<Plan>> plans;
+};
+
+static void vae_expect(rldm_vae* m) {
+    const auto& c = m->cfg;
+    ParamStore& ps = m->params;
+    const int L = c.num_levels;
+    std::vector<int> chs(L);
+    for (int i = 0; i < L; ++i) chs[i] = c.ch * c.ch_mult[i];
+    ps.expect_conv("encoder.conv_in", c.ch, c.in_channels, 3);
+    int cin = c.ch;
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.num_res_blocks; ++j) {
+            ps.expect_resnet("encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, chs[i], 0);
+            cin = chs[i];
+        }
+        if (i != L - 1) ps.expect_conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin, 3);
+    }
+    ps.expect_resnet("encoder.mid_block.resnets.0", cin, cin, 0);
+    ps.expect_resnet("encoder.mid_block.resnets.1", cin, cin, 0);
+    ps.expect_norm("encoder.conv_norm_out", cin);
+    ps.expect_conv("encoder.conv_out", c.double_z ? 2 * c.z_channels : c.z_channels, cin, 3);
+    cin = chs[L - 1];
+    ps.expect_conv("decoder.conv_in", cin, c.z_channels, 3);
+    ps.expect_resnet("decoder.mid_block.resnets.0", cin, cin, 0);
+    ps.expect_resnet("decoder.mid_block.resnets.1", cin, cin, 0);
+    for (int i = 0; i < L; ++i) {
+        const int cout = chs[L - 1 - i];
+        for (int j = 0; j < c.num_res_blocks + 1; ++j) {
+            ps.expect_resnet("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, cout, 0);
+            cin = cout;
+        }
+        if (i != L - 1) ps.expect_conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", cin, cin, 3);
+    }
+    ps.expect_norm("decoder.conv_norm_out", cin);
+    ps.expect_conv("decoder.conv_out", c.out_channels, cin, 3);
+}
+
+static int vae_build_layers(rldm_vae* m) {
+    const auto& c = m->cfg;
+    ParamStore& ps = m->params;
+    NetCommon& net = m->net;
+    net = NetCommon();
+    net.groups = c.norm_num_groups;
+    net.eps = c.norm_eps;
+    const int L = c.num_levels;
+    std::vector<int> chs(L);
+    for (int i = 0; i < L; ++i) chs[i] = c.ch * c.ch_mult[i];
+    if (net.layers.add_conv(ps, "encoder.conv_in", c.ch, c.in_channels, 3)) return 1;
+    int cin = c.ch;
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.num_res_blocks; ++j) {
+            if (net.add_resnet(ps, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, chs[i], false)) return 1;
+            cin = chs[i];
+        }
+        if (i != L - 1 && net.layers.add_conv(ps, "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin, 3)) return 1;
+    }
+    if (net.add_resnet(ps, "encoder.mid_block.resnets.0", cin, cin, false)) return 1;
+    if (net.add_resnet(ps, "encoder.mid_block.resnets.1", cin, cin, false)) return 1;
+    if (net.layers.add_norm(ps, "encoder.conv_norm_out", cin)) return 1;
+    if (net.layers.add_conv(ps, "encoder.conv_out", c.double_z ? 2 * c.z_channels : c.z_channels, cin, 3)) return 1;
+    cin = chs[L - 1];
+    if (net.layers.add_conv(ps, "decoder.conv_in", cin, c.z_channels, 3)) return 1;
+    if (net.add_resnet(ps, "decoder.mid_block.resnets.0", cin, cin, false)) return 1;
+    if (net.add_resnet(ps, "decoder.mid_block.resnets.1", cin, cin, false)) return 1;
+    for (int i = 0; i < L; ++i) {
+        const int cout = chs[L - 1 - i];
+        for (int j = 0; j < c.num_res_blocks + 1; ++j) {
+            if (net.add_resnet(ps, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, cout, false)) return 1;
+            cin = cout;
+        }
+        if (i != L - 1 && net.layers.add_conv(ps, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", cin, cin, 3)) return 1;
+    }
+    if (net.layers.add_norm(ps, "decoder.conv_norm_out", cin)) return 1;
+    if (net.layers.add_conv(ps, "decoder.conv_out", c.out_channels, cin, 3)) return 1;
+    return 0;
+}
+
+static void push_pack_input(Builder& b, Tensor xin) {
+    ++b.launches;
+    if (b.dry) return;
+    Plan* plan = b.plan;
+    bf16_t* dst = b.tptr(xin);
+    const int B = xin.B, W = xin.W, H = xin.H, Cpad = xin.C;
+    plan->ops.push_back([plan, dst, B, W, H, Cpad](hipStream_t s) {
+        PackInputParams p;
+        p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
+        p.pos_encoding = 0; p.cond = nullptr; p.cc = 0;
+        p.B = B; p.W = W; p.H = H; p.Cpad = Cpad;
+        p.out = dst;
+        return launch_pack_input(p, s);
+    });
+}
+
+static int vae_walk_decode(rldm_vae* m, Builder& b, int B, int w, int h) {
+    const auto& c = m->cfg;
+    NetCommon& net = m->net;
+    const int L = c.num_levels;
+    Tensor xin = b.make(B, w, h, pad16(c.z_channels));
+    push_pack_input(b, xin);
+    Tensor t;
+    ConvArgs a;
+    a.layer = net.layers.get_conv("decoder.conv_in");
+    a.x0 = xin;
+    if (b.conv(a, &t)) return 1;
+    b.release(xin);
+    Tensor o;
+    if (net.resnet(b, "decoder.mid_block.resnets.0", t, Tensor(), &o)) return 1;
+    t = o;
+    if (net.resnet(b, "decoder.mid_block.resnets.1", t, Tensor(), &o)) return 1;
+    t = o;
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.num_res_blocks + 1; ++j) {
+            if (net.resnet(b, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), t, Tensor(), &o)) return 1;
+            t = o;
+        }
+        if (i != L - 1) {
+            ConvArgs u;
+            u.layer = net.layers.get_conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
+            u.x0 = t;
+            u.up = 2;
+            if (b.conv(u, &o)) return 1;
+            b.release(t);
+            t = o;
+        }
+    }
+    ConvArgs co;
+    co.layer = net.layers.get_conv("decoder.conv_out");
+    co.x0 = t;
+    co.gn = net.layers.get_norm("decoder.conv_norm_out");
+    co.eps = net.eps; co.groups = net.groups; co.silu = 1;
+    co.out_f32_nchw = true;
+    Tensor none;
+    if (b.conv(co, &none)) return 1;
+    b.release(t);
+    return 0;
+}
+
+static int vae_walk_encode(rldm_vae* m, Builder& b, int B, int w, int h) {
+    const auto& c = m->cfg;
+    NetCommon& net = m->net;
+    const int L = c.num_levels;
+    Tensor xin = b.make(B, w, h, pad16(c.in_channels));
+    push_pack_input(b, xin);
+    Tensor t;
+    ConvArgs a;
+    a.layer = net.layers.get_conv("encoder.conv_in");
+    a.x0 = xin;
+    if (b.conv(a, &t)) return 1;
+    b.release(xin);
+    Tensor o;
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.num_res_blocks; ++j) {
+            if (net.resnet(b, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), t, Tensor(), &o)) return 1;
+            t = o;
+        }
+        if (i != L - 1) {
+            ConvArgs d;
+            d.layer = net.layers.get_conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv");
+            d.x0 = t;
+            d.stride = 2;
+            d.pad_mode = 1;                          // end-only pad: ldm/utils.py:109-111, model.py:164-172
+            if (b.conv(d, &o)) return 1;
+            b.release(t);
+            t = o;
+        }
+    }
+    if (net.resnet(b, "encoder.mid_block.resnets.0", t, Tensor(), &o)) return 1;
+    t = o;
+    if (net.resnet(b, "encoder.mid_block.resnets.1", t, Tensor(), &o)) return 1;
+    t = o;
+    ConvArgs co;
+    co.layer = net.layers.get_conv("encoder.conv_out");
+    co.x0 = t;
+    co.gn = net.layers.get_norm("encoder.conv_norm_out");
+    co.eps = net.eps; co.groups = net.groups; co.silu = 1;
+    co.out_f32_nchw = true;
+    Tensor none;
+    if (b.conv(co, &none)) return 1;
+    b.release(t);
+    return 0;
+}
+
+static int vae_make_plan(rldm_vae* m, int B, int w, int h, bool enc, std::unique_ptr<Plan>* out) {
+    auto plan = std::make_unique<Plan>();
+    plan->B = B; plan->W = w; plan->H = h;
+    Builder dry;
+    dry.plan = plan.get();
+    dry.dry = true;
+    if (enc ? vae_walk_encode(m, dry, B, w, h) : vae_walk_decode(m, dry, B, w, h)) return 1;
+    if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
+    plan->flops = 0;
+    Builder real;
+    real.plan = plan.get();
+    real.dry = false;
+    real.base = plan->arena.as<char>();
+    if (enc ? vae_walk_encode(m, real, B, w, h) : vae_walk_decode(m, real, B, w, h)) return 1;
+    *out = std::move(plan);
+    return 0;
+}
+
+static int vae_get_plan(rldm_vae* m, int B, int w, int h, bool enc, Plan** out) {
+    rldm_vae::Key k{B, w, h, enc ? 1 : 0};
+    auto it = m->plans.find(k);
+    if (it == m->plans.end()) {
+        std::unique_ptr<Plan> p;
+        if (vae_make_plan(m, B, w, h, enc, &p)) return 1;
+        it = m->plans.emplace(k, std::move(p)).first;
+    }
+    *out = it->second.get();
+    return 0;
+}
+
+// =================================================================================================================
+// sampler
+// =================================================================================================================
+struct rldm_sampler {
+    rldm_unet* unet = nullptr;
+    rldm_vae* vae = nullptr;
+    rldm_sampler_config cfg;
+    std::unique_ptr<Plan> uplan;                    // private UNet plan (graph-baked pointers)
+    std::unique_ptr<Plan> dplan;                    // private VAE decode plan
+    DevBuf x, eps, cond, coef, temb_tab, t_dev, step, image;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t step_graph = nullptr, decode_graph = nullptr;
+    const float* captured_noise = nullptr;
+    bool captured_has_cond = false;
+    long long n_latent = 0, n_image = 0;
+    ~rldm_sampler() {
+        if (step_graph) (void)hipGraphExecDestroy(step_graph);
+        if (decode_graph) (void)hipGraphExecDestroy(decode_graph);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_out) (void)hipEventDestroy(ev_out);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int sampler_enqueue_step(rldm_sampler* s, const float* noise, hipStream_t st) {
+    if (s->uplan->run(st)) return 1;
+    SchedParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
+    sp.coef_table = s->coef.as<float>();
+    sp.step_ptr = s->step.as<int>();
+    sp.eps = s->eps.as<float>();
+    sp.x = s->x.as<float>();
+    sp.noise = noise;
+    sp.noise_step_stride = s->n_latent;
+    sp.x_prev = s->x.as<float>();
+    sp.n = s->n_latent;
+    if (launch_sched_step(sp, st)) return 1;
+    return launch_step_counter(s->step.as<int>(), 0, 1, st);
+}
+
+static int capture(hipStream_t st, const std::function<int()>& body, hipGraphExec_t* exec) {
+    RLDM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return 1;
+    }
+    RLDM_HIP_CHECK(e);
+    if (*exec) {
+        (void)hipGraphExecDestroy(*exec);
+        *exec = nullptr;
+    }
+    RLDM_HIP_CHECK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
+    RLDM_HIP_CHECK(hipGraphDestroy(g));
+    return 0;
+}
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char* rldm_last_error(void) { return g_error.c_str(); }
+
+int rldm_device_info(char* name, size_t name_len, int* compute_units) {
+    int n = 0;
+    RLDM_HIP_CHECK(hipGetDeviceCount(&n));
+    RLDM_REQUIRE(n > 0, "no HIP device visible");
+    int dev = 0;
+    RLDM_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    RLDM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    RLDM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+                 std::string("librangeldm_hip is built for gfx950 only; device is ") + prop.gcnArchName);
+    return 0;
+}
+
+// ---- UNet -------------------------------------------------------------------------------------------------------
+int rldm_unet_create(const rldm_unet_config* cfg, rldm_unet** out) {
+    RLDM_REQUIRE(cfg && out, "null argument");
+    RLDM_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= RLDM_MAX_LEVELS, "num_levels out of range");
+    RLDM_REQUIRE(cfg->attention_head_dim == 8, "only attention_head_dim == 8 (the UNet2DModel default the reference uses) is supported");
+    RLDM_REQUIRE(cfg->in_channels <= 16, "in_channels > 16 not supported");
+    for (int i = 0; i < cfg->num_levels; ++i)
+        RLDM_REQUIRE(cfg->block_out_channels[i] % 32 == 0 && cfg->block_out_channels[i] <= 512,
+                     "block_out_channels must be multiples of 32, <= 512");
+    RLDM_REQUIRE((cfg->sample_w >> (cfg->num_levels - 1)) >= 2 && (cfg->sample_h >> (cfg->num_levels - 1)) >= 1 &&
+                     cfg->sample_w % (1 << (cfg->num_levels - 1)) == 0 && cfg->sample_h % (1 << (cfg->num_levels - 1)) == 0,
+                 "sample_size not divisible by 2^(levels-1)");
+    auto* m = new rldm_unet();
+    m->cfg = *cfg;
+    unet_expect(m);
+    *out = m;
+    return 0;
+}
+void rldm_unet_destroy(rldm_unet* m) { delete m; }
+
+int rldm_unet_set_param(rldm_unet* m, const char* name, const float* data, int64_t numel) {
+    RLDM_REQUIRE(m && name && data, "null argument");
+    m->plans.clear();
+    return m->params.set(name, data, numel);
+}
+
+int rldm_unet_finalize(rldm_unet* m) {
+    RLDM_REQUIRE(m, "null argument");
+    if (m->params.check_complete()) return 1;
+    m->resnet_order.clear();
+    m->plans.clear();
+    if (unet_build_layers(m)) return 1;
+    m->params.finalized = true;
+    return 0;
+}
+
+static int unet_get_plan(rldm_unet* m, int B, Plan** out) {
+    RLDM_REQUIRE(m->params.finalized, "rldm_unet_finalize has not been called");
+    auto it = m->plans.find(B);
+    if (it == m->plans.end()) {
+        std::unique_ptr<Plan> p;
+        if (unet_make_plan(m, B, &p)) return 1;
+        it = m->plans.emplace(B, std::move(p)).first;
+    }
+    *out = it->second.get();
+    return 0;
+}
+
+int rldm_unet_forward(rldm_unet* m, const float* sample, const int64_t* timesteps, int nt, int B, float* out, void* stream) {
+    RLDM_REQUIRE(m && sample && timesteps && out, "null argument");
+    RLDM_REQUIRE(B >= 1 && (nt == 1 || nt == B), "timesteps must have length 1 or B");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Plan* plan = nullptr;
+    if (unet_get_plan(m, B, &plan)) return 1;
+    if (m->temb_rows_cap < nt) {
+        if (m->t_dev.alloc((size_t)nt * 4)) return 1;
+        if (m->temb_tab.alloc((size_t)nt * m->net.temb_ld * 4)) return 1;
+        m->temb_rows_cap = nt;
+    }
+    std::vector<float> tf(nt);
+    for (int i = 0; i < nt; ++i) tf[i] = (float)timesteps[i];
+    RLDM_HIP_CHECK(hipMemcpyAsync(m->t_dev.p, tf.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));   // tf is a stack-lifetime staging buffer
+    if (unet_temb(m, m->t_dev.as<float>(), nt, m->temb_tab.as<float>(), st)) return 1;
+    plan->io = PlanIO();
+    plan->io.sample = sample;
+    plan->io.sample_channels = m->cfg.in_channels;
+    plan->io.out = out;
+    plan->io.temb = m->temb_tab.as<float>();
+    plan->io.step_ptr = nullptr;
+    plan->io.temb_rows_per_step = nt;
+    plan->io.temb_per_sample = (nt == B && B > 1) ? 1 : 0;
+    return plan->run(st);
+}
+
+double rldm_unet_flops(rldm_unet* m, int B) {
+    Plan* plan = nullptr;
+    if (!m || unet_get_plan(m, B, &plan)) return -1.0;
+    return plan->flops;
+}
+
+int rldm_unet_num_launches(rldm_unet* m, int B) {
+    if (!m || !m->params.finalized) return -1;
+    Plan tmp;
+    Builder dry;
+    dry.plan = &tmp;
+    dry.dry = true;
+    if (unet_walk(m, dry, B)) return -1;
+    return dry.launches + 1;   // + time-embedding kernel
+}
+
+// ---- VAE --------------------------------------------------------------------------------------------------------
+int rldm_vae_create(const rldm_vae_config* cfg, rldm_vae** out) {
+    RLDM_REQUIRE(cfg && out, "null argument");
+    RLDM_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= RLDM_MAX_LEVELS, "num_levels out of range");
+    RLDM_REQUIRE(cfg->in_channels <= 16 && cfg->z_channels <= 16, "in/z channels > 16 not supported");
+    for (int i = 0; i < cfg->num_levels; ++i)
+        RLDM_REQUIRE((cfg->ch * cfg->ch_mult[i]) % 32 == 0 && cfg->ch * cfg->ch_mult[i] <= 512, "ch*mult must be a multiple of 32, <= 512");
+    auto* m = new rldm_vae();
+    m->cfg = *cfg;
+    vae_expect(m);
+    *out = m;
+    return 0;
+}
+void rldm_vae_destroy(rldm_vae* m) { delete m; }
+int rldm_vae_set_param(rldm_vae* m, const char* name, const float* data, int64_t numel) {
+    RLDM_REQUIRE(m && name && data, "null argument");
+    m->plans.clear();
+    return m->params.set(name, data, numel);
+}
+int rldm_vae_finalize(rldm_vae* m) {
+    RLDM_REQUIRE(m, "null argument");
+    if (m->params.check_complete()) return 1;
+    m->plans.clear();
+    if (vae_build_layers(m)) return 1;
+    m->params.finalized = true;
+    return 0;
+}
+
+int rldm_vae_decode(rldm_vae* m, const float* z, int B, int latent_w, int latent_h, float* image, void* stream) {
+    RLDM_REQUIRE(m && z && image, "null argument");
+    RLDM_REQUIRE(m->params.finalized, "rldm_vae_finalize has not been called");
+    Plan* plan = nullptr;
+    if (vae_get_plan(m, B, latent_w, latent_h, false, &plan)) return 1;
+    plan->io = PlanIO();
+    plan->io.sample = z;
+    plan->io.sample_channels = m->cfg.z_channels;
+    plan->io.out = image;
+    return plan->run(reinterpret_cast<hipStream_t>(stream));
+}
+
+int rldm_vae_encode(rldm_vae* m, const float* x, int B, int w, int h, float* moments, void* stream) {
+    RLDM_REQUIRE(m && x && moments, "null argument");
+    RLDM_REQUIRE(m->params.finalized, "rldm_vae_finalize has not been called");
+    Plan* plan = nullptr;
+    if (vae_get_plan(m, B, w, h, true, &plan)) return 1;
+    plan->io = PlanIO();
+    plan->io.sample = x;
+    plan->io.sample_channels = m->cfg.in_channels;
+    plan->io.out = moments;
+    return plan->run(reinterpret_cast<hipStream_t>(stream));
+}
+
+double rldm_vae_decode_flops(rldm_vae* m, int B, int latent_w, int latent_h) {
+    Plan* plan = nullptr;
+    if (!m || !m->params.finalized || vae_get_plan(m, B, latent_w, latent_h, false, &plan)) return -1.0;
+    return plan->flops;
+}
+
+int rldm_diag_gaussian_sample(const float* moments, const float* noise, float scale, int B, int z, int spatial,
+                              float* out, void* stream) {
+    RLDM_REQUIRE(moments && noise && out, "null argument");
+    return launch_diag_gaussian(moments, noise, scale, B, z, spatial, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- scheduler steps ----------------------------------------------------------------------------------------------
+static int sched_step(int mode, const float coef[5], const float* eps, const float* x, const float* noise, float* x_prev,
+                      int64_t n, void* stream) {
+    RLDM_REQUIRE(coef && eps && x && x_prev, "null argument");
+    RLDM_REQUIRE(coef[4] == 0.f || noise != nullptr, "sigma != 0 requires a noise tensor");
+    SchedParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.mode = mode;
+    for (int i = 0; i < 5; ++i) sp.coef[i] = coef[i];
+    sp.eps = eps; sp.x = x; sp.noise = noise; sp.x_prev = x_prev; sp.n = n;
+    return launch_sched_step(sp, reinterpret_cast<hipStream_t>(stream));
+}
+int rldm_sched_ddim_step(const float coef[5], const float* eps, const float* x, const float* noise, float* x_prev,
+                         int64_t n, void* stream) {
+    return sched_step(0, coef, eps, x, noise, x_prev, n, stream);
+}
+int rldm_sched_ddpm_step(const float coef[5], const float* eps, const float* x, const float* noise, float* x_prev,
+                         int64_t n, void* stream) {
+    return sched_step(1, coef, eps, x, noise, x_prev, n, stream);
+}
+int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_alpha, const float* sqrt_beta, int B,
+                         int64_t per_sample, float* out, void* stream) {
+    RLDM_REQUIRE(x0 && noise && sqrt_alpha && sqrt_beta && out, "null argument");
+    return launch_add_noise(x0, noise, sqrt_alpha, sqrt_beta, B, per_sample, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- sampler ------------------------------------------------------------------------------------------------------
+int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_config* cfg, rldm_sampler** out) {
+    RLDM_REQUIRE(unet && cfg && out, "null argument");
+    RLDM_REQUIRE(unet->params.finalized, "unet not finalized");
+    RLDM_REQUIRE(!vae || vae->params.finalized, "vae not finalized");
+    RLDM_REQUIRE(cfg->batch >= 1 && cfg->num_steps >= 1 && cfg->coef && cfg->timesteps, "bad sampler config");
+    const auto& uc = unet->cfg;
+    RLDM_REQUIRE(uc.out_channels + (cfg->pos_encoding ? 1 : 0) + cfg->cond_channels == uc.in_channels,
+                 "unet.in_channels != out_channels + pos_encoding + cond_channels (ldm/pipelines.py:351,480)");
+    RLDM_REQUIRE(!vae || vae->cfg.z_channels == uc.out_channels, "vae latent channels != unet out_channels");
+    auto s = std::make_unique<rldm_sampler>();
+    s->unet = unet;
+    s->vae = vae;
+    s->cfg = *cfg;
+    s->cfg.coef = nullptr;
+    s->cfg.timesteps = nullptr;
+    const int B = cfg->batch, W = uc.sample_w, H = uc.sample_h;
+    s->n_latent = (long long)B * uc.out_channels * W * H;
+    RLDM_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    RLDM_HIP_CHECK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+    RLDM_HIP_CHECK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+    if (s->x.alloc(s->n_latent * 4) || s->eps.alloc(s->n_latent * 4) || s->step.alloc(64)) return 1;
+    if (cfg->cond_channels && s->cond.alloc((size_t)B * cfg->cond_channels * W * H * 4)) return 1;
+    if (upload(s->coef, cfg->coef, (size_t)cfg->num_steps * 5 * 4)) return 1;
+    std::vector<float> tf(cfg->num_steps);
+    for (int i = 0; i < cfg->num_steps; ++i) tf[i] = (float)cfg->timesteps[i];
+    if (upload(s->t_dev, tf.data(), tf.size() * 4)) return 1;
+    if (s->temb_tab.alloc((size_t)cfg->num_steps * unet->net.temb_ld * 4)) return 1;
+    if (unet_temb(unet, s->t_dev.as<float>(), cfg->num_steps, s->temb_tab.as<float>(), s->stream)) return 1;
+    if (unet_make_plan(unet, B, &s->uplan)) return 1;
+    PlanIO& io = s->uplan->io;
+    io.sample = s->x.as<float>();
+    io.sample_channels = uc.out_channels;
+    io.pos_encoding = cfg->pos_encoding;
+    io.cond = cfg->cond_channels ? s->cond.as<float>() : nullptr;
+    io.cond_channels = cfg->cond_channels;
+    io.out = s->eps.as<float>();
+    io.temb = s->temb_tab.as<float>();
+    io.step_ptr = s->step.as<int>();
+    io.temb_rows_per_step = 1;
+    io.temb_per_sample = 0;
+    if (vae) {
+        const int f = 1 << (vae->cfg.num_levels - 1);
+        s->n_image = (long long)B * vae->cfg.out_channels * (W * f) * (H * f);
+        if (s->image.alloc(s->n_image * 4)) return 1;
+        if (vae_make_plan(vae, B, W, H, false, &s->dplan)) return 1;
+        PlanIO& d = s->dplan->io;
+        d.sample = s->x.as<float>();
+        d.sample_channels = vae->cfg.z_channels;
+        d.sample_scale = 1.0f / vae->cfg.scaling_factor;      // latents / scaling_factor, ldm/pipelines.py:365
+        d.out = s->image.as<float>();
+    }
+    RLDM_HIP_CHECK(hipStreamSynchronize(s->stream));
+    *out = s.release();
+    return 0;
+}
+void rldm_sampler_destroy(rldm_sampler* s) { delete s; }
+
+int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, const float* cond, float* images,
+                float* latents_out, void* stream) {
+    RLDM_REQUIRE(s && x_T, "null argument");
+    RLDM_REQUIRE(images || latents_out, "no output requested");
+    RLDM_REQUIRE((s->cfg.cond_channels == 0) == (cond == nullptr), "cond tensor does not match sampler.cond_channels");
+    RLDM_REQUIRE(s->cfg.mode == RLDM_SAMPLER_DDIM || step_noise != nullptr, "DDPM sampling needs step_noise");
+    hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t st = s->stream;
+    RLDM_HIP_CHECK(hipEventRecord(s->ev_in, caller));
+    RLDM_HIP_CHECK(hipStreamWaitEvent(st, s->ev_in, 0));
+    RLDM_HIP_CHECK(hipMemcpyAsync(s->x.p, x_T, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
+    if (cond) RLDM_HIP_CHECK(hipMemcpyAsync(s->cond.p, cond, s->cond.bytes, hipMemcpyDeviceToDevice, st));
+    if (launch_step_counter(s->step.as<int>(), 0, 0, st)) return 1;
+    const float* noise = s->cfg.mode == RLDM_SAMPLER_DDPM ? step_noise : nullptr;
+    if (!s->step_graph || s->captured_noise != noise) {
+        // one eager step first (sets kernel attributes, packs weights), then rewind and capture
+        if (sampler_enqueue_step(s, noise, st)) return 1;
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        RLDM_HIP_CHECK(hipMemcpyAsync(s->x.p, x_T, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
+        if (launch_step_counter(s->step.as<int>(), 0, 0, st)) return 1;
+        if (capture(st, [&]() { return sampler_enqueue_step(s, noise, st); }, &s->step_graph)) return 1;
+        s->captured_noise = noise;
+    }
+    for (int i = 0; i < s->cfg.num_steps; ++i) RLDM_HIP_CHECK(hipGraphLaunch(s->step_graph, st));
+    if (latents_out) RLDM_HIP_CHECK(hipMemcpyAsync(latents_out, s->x.p, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
+    if (images) {
+        if (s->vae) {
+            if (!s->decode_graph) {
+                if (s->dplan->run(st)) return 1;
+                RLDM_HIP_CHECK(hipStreamSynchronize(st));
+                if (capture(st, [&]() { return s->dplan->run(st); }, &s->decode_graph)) return 1;
+            }
+            RLDM_HIP_CHECK(hipGraphLaunch(s->decode_graph, st));
+            RLDM_HIP_CHECK(hipMemcpyAsync(images, s->image.p, s->n_image * 4, hipMemcpyDeviceToDevice, st));
+        } else {
+            RLDM_HIP_CHECK(hipMemcpyAsync(images, s->x.p, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    RLDM_HIP_CHECK(hipEventRecord(s->ev_out, st));
+    RLDM_HIP_CHECK(hipStreamWaitEvent(caller, s->ev_out, 0));
+    return 0;
+}
+
+// ---- kernel-level test entry points ---------------------------------------------------------------------------------
+int rldm_test_conv(const rldm_conv_desc* d, const float* x0, const float* x1, const float* weight, const float* bias,
+                   const float* gamma, const float* beta, const float* temb, const float* res, float* y, void* stream) {
+    RLDM_REQUIRE(d && x0 && weight && bias && y, "null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Cin = d->Cin0 + d->Cin1;
+    const int C0p = d->Cin1 ? d->Cin0 : pad16(d->Cin0);
+    RLDM_REQUIRE(d->Cin1 == 0 || (d->Cin0 % 8 == 0 && Cin % 16 == 0), "concat test needs Cin0 % 8 == 0 and Cin % 16 == 0");
+    ParamStore ps;
+    ps.host["c.weight"].assign(weight, weight + (size_t)d->Cout * Cin * d->ksize * d->ksize);
+    ps.host["c.bias"].assign(bias, bias + d->Cout);
+    Layers layers;
+    if (layers.add_conv(ps, "c", d->Cout, Cin, d->ksize)) return 1;
+    if (d->gn) {
+        RLDM_REQUIRE(gamma && beta && C0p + d->Cin1 == Cin, "GroupNorm test needs unpadded channels");
+        ps.host["n.weight"].assign(gamma, gamma + Cin);
+        ps.host["n.bias"].assign(beta, beta + Cin);
+        if (layers.add_norm(ps, "n", Cin)) return 1;
+    }
+    Plan plan;
+    const int s = d->stride, up = d->upsample ? 2 : 1;
+    const int Wout = d->Win * up / s, Hout = d->Hin * up / s;
+    DevBuf tembd;
+    if (temb && upload(tembd, temb, (size_t)d->B * d->Cout * 4)) return 1;
+    Tensor t0, t1, tr, out;
+    auto walk = [&](Builder& bb) -> int {
+        t0 = bb.make(d->B, d->Win, d->Hin, C0p);
+        t1 = Tensor();
+        tr = Tensor();
+        if (d->Cin1) t1 = bb.make(d->B, d->Win, d->Hin, d->Cin1);
+        if (res) tr = bb.make(d->B, Wout, Hout, d->Cout);
+        ConvArgs a;
+        a.layer = layers.get_conv("c");
+        a.x0 = t0; a.x1 = t1;
+        a.stride = s; a.pad_mode = d->pad_mode; a.up = up;
+        a.gn = d->gn ? layers.get_norm("n") : nullptr;
+        a.eps = d->eps; a.silu = d->silu;
+        a.temb_off = temb ? 0 : -1;
+        a.res = tr;
+        return bb.conv(a, &out);
+    };
+    Builder dry;
+    dry.plan = &plan;
+    dry.dry = true;
+    dry.temb_ld = d->Cout;
+    if (walk(dry)) return 1;
+    if (plan.arena.alloc(dry.arena.peak + 256)) return 1;
+    Builder real;
+    real.plan = &plan;
+    real.dry = false;
+    real.temb_ld = d->Cout;
+    real.base = plan.arena.as<char>();
+    if (walk(real)) return 1;
+    if (launch_nchw_f32_to_nhwc_bf16(x0, real.tptr(t0), d->B, d->Cin0, d->Win, d->Hin, C0p, st)) return 1;
+    if (d->Cin1 && launch_nchw_f32_to_nhwc_bf16(x1, real.tptr(t1), d->B, d->Cin1, d->Win, d->Hin, d->Cin1, st)) return 1;
+    if (res && launch_nchw_f32_to_nhwc_bf16(res, real.tptr(tr), d->B, d->Cout, Wout, Hout, d->Cout, st)) return 1;
+    plan.io.temb = tembd.as<float>();
+    plan.io.temb_rows_per_step = d->B;
+    plan.io.temb_per_sample = 1;
+    if (plan.run(st)) return 1;
+    if (launch_nhwc_bf16_to_nchw_f32(real.tptr(out), y, d->B, d->Cout, Wout, Hout, d->Cout, st)) return 1;
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void* stream) {
+    RLDM_REQUIRE(qkv && out, "null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // host-side re-layout keeps this test path trivial: qk [B][L][2C] (q scaled), vt [B][C/8][8][L]
+    std::vector<float> h((size_t)B * L * 3 * C);
+    RLDM_HIP_CHECK(hipMemcpy(h.data(), qkv, h.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<bf16_t> qk((size_t)B * L * 2 * C), vt((size_t)B * C * L);
+    const float qs = 1.4426950408889634f / std::sqrt(8.0f);
+    const int heads = C / 8;
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < L; ++l) {
+            const float* row = &h[((size_t)b * L + l) * 3 * C];
+            for (int c = 0; c < C; ++c) {
+                qk[((size_t)b * L + l) * 2 * C + c] = f32_to_bf16(row[c] * qs);
+                qk[((size_t)b * L + l) * 2 * C + C + c] = f32_to_bf16(row[C + c]);
+                vt[(((size_t)b * heads + c / 8) * 8 + c % 8) * L + l] = f32_to_bf16(row[2 * C + c]);
+            }
+        }
+    DevBuf dqk, dvt, dout;
+    if (upload(dqk, qk.data(), qk.size() * 2) || upload(dvt, vt.data(), vt.size() * 2)) return 1;
+    if (dout.alloc((size_t)B * L * C * 2)) return 1;
+    AttnParams ap;
+    ap.qk = dqk.as<bf16_t>(); ap.vt = dvt.as<bf16_t>(); ap.out = dout.as<bf16_t>();
+    ap.B = B; ap.L = L; ap.C = C;
+    if (launch_attention(ap, st)) return 1;
+    // out is [B][L][C] channels-last == "NHWC" with W*H = L
+    std::vector<bf16_t> ho((size_t)B * L * C);
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    RLDM_HIP_CHECK(hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost));
+    std::vector<float> hf(ho.size());
+    for (size_t i = 0; i < ho.size(); ++i) hf[i] = bf16_to_f32(ho[i]);
+    RLDM_HIP_CHECK(hipMemcpy(out, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""GPU parity, kernel level: each HIP kernel against the CPU oracle's leaf ops on identical seeded inputs.
+
+Tolerances (stated per BASELINE.md section 4): the kernels read bf16 activations/weights and accumulate in fp32, so
+  * against the oracle evaluated on the SAME bf16-rounded operands  -> rel-L2 <= 4e-3 (one bf16 rounding of the output)
+  * against the pure fp32 oracle                                     -> rel-L2 <= 2e-2
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops
+from tests.hip_util import bf16r, rel_l2, hip_conv, hip_attention
+
+pytestmark = pytest.mark.gpu
+TOL_Q, TOL_F = 4e-3, 2e-2
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, W, H, k, stride, pad_mode, up)       -- shapes from SURVEY.md A.4 (reduced batch) + edge cases
+    (2, 128, 128, 32, 16, 3, 1, 0, False),     # L0-like, CK=64
+    (1, 128, 128, 256, 16, 3, 1, 0, False),    # full L0 width (wrap seam across many tiles)
+    (2, 256, 256, 32, 2, 3, 1, 0, False),      # L3: H=2, mostly zero padding
+    (2, 256, 256, 64, 4, 3, 1, 0, False),      # L2
+    (3, 128, 256, 16, 8, 3, 1, 0, False),      # odd batch
+    (2, 16, 128, 32, 16, 3, 1, 0, False),      # conv_in (padded 16-ch input), CK=16
+    (2, 5, 128, 32, 16, 3, 1, 0, False),       # conv_in with the real 5 channels
+    (2, 128, 4, 32, 16, 3, 1, 0, False),       # conv_out-like N=4 (BN=32, masked)
+    (2, 64, 2, 64, 32, 3, 1, 0, False),        # VAE conv_out N=2
+    (2, 128, 128, 32, 16, 3, 2, 0, False),     # UNet downsample s2 p1
+    (2, 64, 64, 64, 32, 3, 2, 1, False),       # VAE downsample s2 end-pad
+    (2, 128, 128, 16, 8, 3, 1, 0, True),       # nearest x2 folded
+    (1, 256, 256, 32, 16, 3, 1, 0, True),      # VAE decoder up conv
+    (2, 128, 256, 32, 8, 1, 1, 0, False),      # 1x1 shortcut
+    (2, 32, 32, 32, 8, 3, 1, 0, False),        # small-config channels (CK=16 path)
+    (2, 32, 64, 8, 1, 3, 1, 0, False),         # H=1 (nuScenes deepest level)
+    (1, 64, 64, 1024, 64, 3, 1, 0, False),     # VAE full resolution
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_geometry(case):
+    B, Cin, Cout, W, H, k, s, pm, up = case
+    x = _rand(B, Cin, W, H, seed=1)
+    w = _rand(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    y = hip_conv(x, w, b, stride=s, pad_mode=pm, upsample=up)
+    xq, wq = bf16r(x), bf16r(w)
+
+    def ref(xx, ww):
+        if up:
+            return ops.upsample_conv(xx, ww, b)
+        if s == 2 and pm == 1:
+            return ops.downsample_vae(xx, ww, b)
+        return ops.circ_conv2d(xx, ww, b, s, 1 if k == 3 else 0)
+
+    assert y.shape == ref(xq, wq).shape
+    assert rel_l2(y, ref(xq, wq)) < TOL_Q
+    assert rel_l2(y, ref(x, w)) < TOL_F
+
+
+def test_conv_wrap_seam_exact():
+    # an impulse at azimuth 0 must leak to azimuth W-1 (wrap) and an impulse at beam 0 must NOT leak to beam H-1 (zero pad)
+    W, H, C = 32, 16, 16
+    x = torch.zeros(1, C, W, H)
+    x[0, 0, 0, 0] = 1.0
+    w = torch.zeros(32, C, 3, 3)
+    w[0, 0, 0, 1] = 1.0     # tap (i=0: reads w-1, j=1: same beam)  -> out(w) = in(w-1)
+    w[1, 0, 2, 1] = 1.0     # reads w+1                               -> out(w) = in(w+1)
+    w[2, 0, 1, 2] = 1.0     # reads h+1                               -> out(h) = in(h+1)
+    y = hip_conv(x, w, torch.zeros(32))
+    ref = ops.circ_conv2d(x, w, torch.zeros(32))
+    assert torch.equal(y, ref)
+    assert y[0, 0, 1, 0] == 1 and y[0, 1, W - 1, 0] == 1        # wrap both ways
+    assert y[0, 2].abs().sum() == 0                             # beam -1 does not exist: zero padding
+
+
+@pytest.mark.parametrize("C0,C1,Cout,W,H", [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2),
+                                            (64, 32, 64, 16, 8)])
+def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H):
+    """The full ResnetBlock conv1 fusion: GN(32)+SiLU over cat[x0,x1] -> conv3x3 -> +bias +temb[b] (+res)."""
+    B = 2
+    x0, x1 = _rand(B, C0, W, H, seed=4) * 1.5 + 0.3, _rand(B, C1, W, H, seed=5) * 0.7 - 0.2
+    Cin = C0 + C1
+    w = _rand(Cout, Cin, 3, 3, seed=6, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, seed=7, scale=0.1)
+    gamma, beta = 1 + 0.2 * _rand(Cin, seed=8), 0.2 * _rand(Cin, seed=9)
+    temb = _rand(B, Cout, seed=10)
+    res = _rand(B, Cout, W, H, seed=11)
+    y = hip_conv(x0, w, b, x1=x1, gamma=gamma, beta=beta, silu=True, eps=1e-5, temb=temb, res=res)
+
+    def ref(q):
+        xc = torch.cat([q(x0), q(x1)], 1)
+        h = q(ops.group_norm_silu(xc, gamma, beta, 32, 1e-5))
+        return ops.circ_conv2d(h, q(w), b) + temb[:, :, None, None] + q(res)
+
+    assert rel_l2(y, ref(bf16r)) < TOL_Q
+    assert rel_l2(y, ref(lambda t: t)) < TOL_F
+
+
+def test_conv_gn_no_silu_1x1():
+    # attention's group_norm -> Linear path (no SiLU), eps 1e-6
+    B, C, W, H = 2, 128, 16, 8
+    x = _rand(B, C, W, H, seed=12) * 2 + 1
+    w = _rand(C, C, 1, 1, seed=13, scale=C ** -0.5)
+    b = _rand(C, seed=14, scale=0.1)
+    gamma, beta = 1 + 0.2 * _rand(C, seed=15), 0.2 * _rand(C, seed=16)
+    y = hip_conv(x, w, b, gamma=gamma, beta=beta, silu=False, eps=1e-6)
+    h = bf16r(F.group_norm(bf16r(x), 32, gamma, beta, 1e-6))
+    assert rel_l2(y, ops.circ_conv2d(h, bf16r(w), b, 1, 0)) < TOL_Q
+
+
+@pytest.mark.parametrize("B,L,C", [(2, 64, 64), (1, 1024, 128), (2, 256, 256), (1, 32, 32)])
+def test_attention_d8(B, L, C):
+    qkv = _rand(B, L, 3 * C, seed=20)
+    out = hip_attention(qkv, C)
+    q, k, v = bf16r(qkv[..., :C] * (1.4426950408889634 / 8 ** 0.5)) / 1.4426950408889634 * 8 ** 0.5, bf16r(qkv[..., C:2 * C]), bf16r(qkv[..., 2 * C:])
+    nh = C // 8
+    qh, kh, vh = (t.view(B, L, nh, 8).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
+    assert rel_l2(out, ref) < 1e-2
+
+
+def test_attention_large_logits():
+    # rows with one dominant key (forces the running-max rescale path) and large magnitudes
+    B, L, C = 1, 128, 16
+    qkv = _rand(B, L, 3 * C, seed=21)
+    qkv[:, :, :2 * C] *= 6.0
+    qkv[0, 77, C:2 * C] *= 4.0          # a key far outside the first tiles dominates
+    out = hip_attention(qkv, C)
+    q, k, v = bf16r(qkv[..., :C]), bf16r(qkv[..., C:2 * C]), bf16r(qkv[..., 2 * C:])
+    qh, kh, vh = (t.view(B, L, 2, 8).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-2
