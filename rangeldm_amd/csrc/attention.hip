@@ -19,7 +19,7 @@ namespace rldm {
 __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, const int waves_per_block) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int heads = p.C >> 3;
-    const int qtiles = p.L >> 5;
+    const int qtiles = (p.L + 31) >> 5;
     const int qblocks = qtiles / waves_per_block;
     int bid = blockIdx.x;
     const int qb = bid % qblocks;
@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
     const bf16_t* vbase = p.vt + ((size_t)b * heads + h) * 8 * (size_t)p.L;
 
     // B operand of S^T: Q^T, lane (query l31, half hh) holds q[query][4*hh .. 4*hh+3]
-    const s16x4 qf = *reinterpret_cast<const s16x4*>(qbase + (size_t)(q0 + l31) * ld + 4 * hh);
+    const int qrow = min(q0 + l31, p.L - 1);          // rows past L are computed on a clamped row, never stored
+    const s16x4 qf = *reinterpret_cast<const s16x4*>(qbase + (size_t)qrow * ld + 4 * hh);
 
     f32x16 o;
 #pragma unroll
@@ -48,12 +49,17 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
     const uint32_t fill = (l31 == 8) ? 0x3f803f80u : 0u;   // bf16 1.0 pairs
 
     for (int k0 = 0; k0 < p.L; k0 += 32) {
-        const s16x4 kf = *reinterpret_cast<const s16x4*>(kbase + (size_t)(k0 + l31) * ld + 4 * hh);
+        const s16x4 kf = *reinterpret_cast<const s16x4*>(kbase + (size_t)min(k0 + l31, p.L - 1) * ld + 4 * hh);
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, s, 0, 0, 0);
         // lane (query l31, half hh), register r <-> key k0 + (r&3) + 8*(r>>2) + 4*hh ; scores are in log2 units
+        if (k0 + 32 > p.L) {                                  // ragged last tile: keys >= L get -inf scores
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= p.L) s[r] = -1e30f;
+        }
         float tmax = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -71,8 +77,10 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
         for (int t = 0; t < 2; ++t) {
             uint4 vw = make_uint4(fill, fill, fill, fill);
             if (vrow) {
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t + 8);
+                const int ka = k0 + 16 * t + 4 * hh;              // L % 4 == 0: a 4-key group is all in or all out
+                uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+                if (ka < p.L) lo = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t);
+                if (ka + 8 < p.L) hi = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t + 8);
                 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             const uint4 pw = make_uint4(pk[4 * t], pk[4 * t + 1], pk[4 * t + 2], pk[4 * t + 3]);
@@ -86,13 +94,13 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
     uint2 ov;
     ov.x = pack_bf16x2(o[0] * inv, o[1] * inv);
     ov.y = pack_bf16x2(o[2] * inv, o[3] * inv);
-    *reinterpret_cast<uint2*>(p.out + ((size_t)b * p.L + q0 + l31) * p.C + h * 8 + 4 * hh) = ov;
+    if (q0 + l31 < p.L) *reinterpret_cast<uint2*>(p.out + ((size_t)b * p.L + q0 + l31) * p.C + h * 8 + 4 * hh) = ov;
 }
 
 int launch_attention(const AttnParams& p, hipStream_t stream) {
-    RLDM_REQUIRE(p.L % 32 == 0 && p.L >= 32, "attention: token count must be a multiple of 32");
+    RLDM_REQUIRE(p.L % 4 == 0 && p.L >= 4, "attention: token count must be a multiple of 4");
     RLDM_REQUIRE(p.C % 8 == 0, "attention: channels must be a multiple of head_dim 8");
-    const int qtiles = p.L / 32;
+    const int qtiles = (p.L + 31) / 32;
     int wpb = 4;
     while (qtiles % wpb) wpb >>= 1;
     const int grid = p.B * (p.C / 8) * (qtiles / wpb);

@@ -242,14 +242,25 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
                     v0 += tv.x; v1 += tv.y; v2 += tv.z; v3 += tv.w;
                 }
                 if (ch < p.n_store) {
-                    if (p.res) {
-                        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + pix * p.N + ch);
-                        v0 += bf16lo(rv.x); v1 += bf16hi(rv.x); v2 += bf16lo(rv.y); v3 += bf16hi(rv.y);
+                    if (ch + 3 < p.n_store) {
+                        if (p.res) {
+                            const uint2 rv = *reinterpret_cast<const uint2*>(p.res + pix * p.N + ch);
+                            v0 += bf16lo(rv.x); v1 += bf16hi(rv.x); v2 += bf16lo(rv.y); v3 += bf16hi(rv.y);
+                        }
+                        uint2 o;
+                        o.x = pack_bf16x2(v0, v1);
+                        o.y = pack_bf16x2(v2, v3);
+                        *reinterpret_cast<uint2*>(p.y + pix * p.y_ld + ch) = o;
+                    } else {                                   // channel count not a multiple of 4: scalar tail
+                        const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ch + e < p.n_store) {
+                                float t = vv[e];
+                                if (p.res) t += bf16_to_f32(p.res[pix * p.N + ch + e]);
+                                p.y[pix * p.y_ld + ch + e] = f32_to_bf16(t);
+                            }
                     }
-                    uint2 o;
-                    o.x = pack_bf16x2(v0, v1);
-                    o.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(p.y + pix * p.y_ld + ch) = o;
                 } else {
                     // attention V, stored transposed per head: vt[b][head][d][token]
                     const int cv = ch - p.n_store;

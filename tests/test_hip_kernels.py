@@ -114,7 +114,8 @@ def test_conv_gn_no_silu_1x1():
     assert rel_l2(y, ops.circ_conv2d(h, bf16r(w), b, 1, 0)) < TOL_Q
 
 
-@pytest.mark.parametrize("B,L,C", [(2, 64, 64), (1, 1024, 128), (2, 256, 256), (1, 32, 32)])
+@pytest.mark.parametrize("B,L,C", [(2, 64, 64), (1, 1024, 128), (2, 256, 256), (1, 32, 32), (1, 8, 32), (2, 48, 16),
+                                   (1, 4, 64), (1, 100, 8)])
 def test_attention_d8(B, L, C):
     qkv = _rand(B, L, 3 * C, seed=20)
     out = hip_attention(qkv, C)
