@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- range-images/sec for RangeLDM KITTI-360 64x1024, 50-step DDIM (eta=0) + VAE decode at batch 16 per GPU
+(BASELINE.json metric, configs[1]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: x_T (already resident in HBM) -> 50 x [UNet forward + DDIM step]
+-> VAE decode -> (N>1: RCCL all-gather of the finished range images).  Weak scaling: every GPU samples its own batch
+of 16 (whole samples are sharded; no collective on the data path except the final all-gather).  Weights are synthetic
+(rangeldm_amd.synth), the architecture and sizes are the reference's.
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline     -- dominant kernel: algorithmic FLOPs of its launches / HIP-event time of those launches, measured in this
+                  process right after the timed region by an instrumented eager pass on the sampler's stream
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference path; kind "port") timed on this host's
+                  cores on a bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X_MICROARCH.md (measured 2495)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_models(preset, seed):
+    from rangeldm_amd.config import PRESETS
+    from rangeldm_amd.params import unet_param_shapes, vae_param_shapes
+    from rangeldm_amd.synth import synth_state_dict
+    from rangeldm_amd.unet import UNet2DModelHIP
+    from rangeldm_amd.vae import AutoencoderKLHIP
+    p = PRESETS[preset]
+    usd = synth_state_dict(unet_param_shapes(p["unet"]), seed=seed)
+    unet = UNet2DModelHIP(p["unet"])
+    unet.load_state_dict(usd)
+    vae, vsd = None, None
+    if p["vae"] is not None:
+        vsd = synth_state_dict(vae_param_shapes(p["vae"]), seed=seed, prefix="vae.")
+        vae = AutoencoderKLHIP(p["vae"])
+        vae.load_state_dict(vsd)
+    return p, unet, vae, usd, vsd
+
+
+def cpu_baseline(p, usd, vsd, batch, steps):
+    """Oracle on the host cores: 1 UNet step at the full batch + VAE decode of 2 images, extrapolated to a batch."""
+    from oracle.unet import OracleUNet
+    from oracle.vae import OracleVAE
+    from rangeldm_amd.synth import normal
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    ucfg, vcfg = p["unet"], p["vae"]
+    ou = OracleUNet(ucfg, usd)
+    x = torch.from_numpy(normal(1, "cpu/x", (batch, ucfg.in_channels, *ucfg.sample_size)))
+    ou(x[:1], 480)                                   # warm the allocator / thread pool
+    t0 = time.perf_counter()
+    ou(x, 480)
+    t_unet = time.perf_counter() - t0
+    t_dec, ndec = 0.0, 2
+    if vcfg is not None:
+        ov = OracleVAE(vcfg, vsd)
+        z = torch.from_numpy(normal(1, "cpu/z", (ndec, vcfg.z_channels, *ucfg.sample_size)))
+        t0 = time.perf_counter()
+        ov.decode(z)
+        t_dec = time.perf_counter() - t0
+    per_batch = steps * t_unet + (batch / ndec) * t_dec
+    return {"value": batch / per_batch, "unit": "range-images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch {torch.__version__} fp32 CPU): 1 of {steps} UNet steps at batch {batch} "
+                      f"({t_unet:.2f} s) + VAE decode of {ndec} of {batch} images ({t_dec:.2f} s), extrapolated",
+            "seconds_per_batch_extrapolated": per_batch}
+
+
+def roofline(pipe, sampler_handle, x_T, steps):
+    from rangeldm_amd import _lib
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().rldm_sampler_profile(sampler_handle, C.c_void_p(x_T.data_ptr()), buf, len(buf)),
+               "rldm_sampler_profile")
+    prof = json.loads(buf.value.decode())
+    tot = {}
+    for part, mult in (("unet_step", steps), ("vae_decode", 1)):
+        for k, v in prof.get(part, {}).items():
+            t = tot.setdefault(k, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for f in t:
+                t[f] += v[f] * mult
+    all_ms = sum(v["ms"] for v in tot.values())
+    dom = max(tot, key=lambda k: tot[k]["ms"])
+    d = tot[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    kernels = {k: {"share": round(v["ms"] / all_ms, 4), "launches_per_batch": v["launches"],
+                   "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                   "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+               for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
+    rl = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+          "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+          "alg_flops_per_launch": d["flops"] / d["launches"], "alg_bytes_per_launch": d["bytes"] / d["launches"],
+          "launches_per_batch": d["launches"], "eager_kernel_ms_per_batch": round(all_ms, 3)}
+    return rl, kernels
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--sampler", choices=["ddim", "ddpm"], default="ddim")
+    ap.add_argument("--preset", default="RangeLDM")
+    ap.add_argument("--seed", type=int, default=20240310)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from rangeldm_amd import distributed as D
+    from rangeldm_amd.pipelines import LDMPipelineRange, DDIMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
+    from rangeldm_amd.synth import latent_noise, step_noise
+
+    rank, world, local = D.init_from_env("nccl")
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    p, unet, vae, usd, vsd = build_models(args.preset, args.seed)
+    sched = DDIMSchedulerHIP() if args.sampler == "ddim" else DDPMSchedulerHIP()
+    if vae is not None:
+        pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
+    else:
+        pipe = DDIMPipelineRange(unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
+    B, S = args.batch, args.inference_steps
+    lat_shape = (p["unet"].out_channels, *p["unet"].sample_size)
+    n_iter = args.warmup + args.steps
+
+    # inputs resident in HBM before the timed region; x_T is a function of the GLOBAL sample index
+    xs = []
+    for i in range(n_iter):
+        idx = D.global_sample_indices(i, B, rank, world)
+        xs.append(torch.from_numpy(np.stack([latent_noise(args.seed, j, lat_shape) for j in idx])).to(dev))
+    zs = None
+    if args.sampler == "ddpm":
+        zs = torch.from_numpy(np.stack([np.stack([step_noise(args.seed, j, s, lat_shape) for j in range(B)])
+                                        for s in range(S)])).to(dev)
+
+    def one_step(i):
+        kw = dict(batch_size=B, num_inference_steps=S, latents=xs[i], output_type="torch")
+        if zs is not None:
+            kw["step_noise"] = zs
+        img = pipe(**kw)
+        return D.all_gather_images(img)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_iter):
+        out = one_step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, dev)
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        res = {
+            "metric": "range-images/sec, KITTI-360 64x1024 50-step DDIM @ batch16, 1/2/4/8 GPU",
+            "value": total_images / dt, "unit": "range-images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.preset} KITTI-360 64x1024 (latent {lat_shape[0]}x{lat_shape[1]}x{lat_shape[2]}), "
+                                   f"{S}-step {args.sampler.upper()} + VAE decode (4x), batch {B} per GPU, "
+                                   f"synthetic weights, x_T resident in HBM",
+                       "global_batch": B * world, "batch_per_gpu": B, "inference_steps": S, "sampler": args.sampler,
+                       "parallelism": f"sample-sharded x{world}, RCCL all-gather of finished images"},
+        }
+        if world == 1:
+            h = pipe._fused.get(unet, vae, sched, B, S, 0 if args.sampler == "ddim" else 1, p["pos_encoding"], 0)
+            rl, kernels = roofline(pipe, h, xs[0], S)
+            gflop_per_image = (S * unet.flops(B) + (vae.decode_flops(B, *lat_shape[1:]) if vae else 0.0)) / B / 1e9
+            res["roofline"] = rl
+            res["kernels"] = kernels
+            res["gflop_per_image"] = round(gflop_per_image, 1)
+            res["end_to_end_tflops"] = round(res["value"] * gflop_per_image / 1e3, 1)
+            res["end_to_end_frac_of_mfma_peak"] = round(res["value"] * gflop_per_image / 1e3 / PEAK_BF16_TFLOPS, 4)
+            res["unet_launches_per_step"] = unet.num_launches(B)
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(p, usd, vsd, B, S)
+        print(json.dumps(res), flush=True)
+    D.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,12 @@ double rldm_vae_decode_flops(rldm_vae* m, int B, int latent_w, int latent_h);
 /* number of kernel launches in one UNet forward plan (for the launch-overhead budget in DESIGN.md) */
 int rldm_unet_num_launches(rldm_unet* m, int B);
 
+/* Instrumented pass used by bench.py for the roofline: runs ONE UNet step (+ one VAE decode) eagerly on the sampler's
+ * stream with a HIP event pair around every kernel launch and writes JSON
+ *   {"unet_step": {kernel: {launches, ms, flops, bytes}, ...}, "vae_decode": {...}}
+ * (flops/bytes = algorithmic work of those launches) into json_out. */
+int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size_t cap);
+
 /* low-level op entry points (used by the parity tests to check each kernel in isolation) */
 typedef struct rldm_conv_desc {
     int32_t B, Cin0, Cin1, Win, Hin;  /* inputs x0 [B][Win][Hin][Cin0] (+ x1 [..][Cin1] concatenated), bf16 NHWC */

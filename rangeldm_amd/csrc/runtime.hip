@@ -223,15 +223,49 @@ struct PlanIO {
     int temb_per_sample = 0;
 };
 
+struct Op {
+    std::function<int(hipStream_t)> fn;
+    std::string name;       // kernel (template instance) the op launches
+    double flops = 0;       // algorithmic FLOPs (2*MACs) of this launch
+    double bytes = 0;       // algorithmic HBM bytes: every input / weight / output touched once
+};
+
+struct KernelStat {
+    int launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
 struct Plan {
     int B = 0, W = 0, H = 0;
     DevBuf arena;
     PlanIO io;
-    std::vector<std::function<int(hipStream_t)>> ops;
+    std::vector<Op> ops;
     double flops = 0;
     int run(hipStream_t s) {
-        for (auto& f : ops)
-            if (f(s)) return 1;
+        for (auto& o : ops)
+            if (o.fn(s)) return 1;
+        return 0;
+    }
+    // eager pass with a HIP event pair around every launch on `s` (the stream the kernels run on)
+    int run_profiled(hipStream_t s, std::map<std::string, KernelStat>& stats) {
+        std::vector<hipEvent_t> ev(ops.size() + 1);
+        for (auto& e : ev) RLDM_HIP_CHECK(hipEventCreate(&e));
+        RLDM_HIP_CHECK(hipEventRecord(ev[0], s));
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (ops[i].fn(s)) return 1;
+            RLDM_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+        }
+        RLDM_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < ops.size(); ++i) {
+            float ms = 0.f;
+            RLDM_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            KernelStat& k = stats[ops[i].name];
+            k.launches += 1;
+            k.ms += ms;
+            k.flops += ops[i].flops;
+            k.bytes += ops[i].bytes;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
         return 0;
     }
 };
@@ -392,7 +426,8 @@ struct Builder {
             g.groups = groups;
             g.P = P;
             g.part = ptr<float2>(off);
-            plan->ops.push_back([g](hipStream_t s) { return launch_gn_stats(g, s); });
+            const double by = (double)x0.B * npix * (g.C0 + g.C1) * 2.0;
+            plan->ops.push_back({[g](hipStream_t s) { return launch_gn_stats(g, s); }, "gn_stats_kernel", 0.0, by});
         }
         return 0;
     }
@@ -470,7 +505,13 @@ struct Builder {
             p.temb_ld = temb_ld;
             const int temb_off = a.temb_off;
             const bool f32out = a.out_f32_nchw;
-            plan->ops.push_back([p, tile, pl, temb_off, f32out](hipStream_t s) mutable {
+            const double fl = 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * taps;
+            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * L->Cin * taps * 2.0 +
+                              (double)x0.B * Wout * Hout * N * (a.out_f32_nchw ? 4.0 : 2.0) +
+                              (a.res.valid() ? (double)x0.B * Wout * Hout * N * 2.0 : 0.0);
+            const std::string kname = "conv_igemm_kernel<" + std::to_string(tile.BM) + "," + std::to_string(tile.BN) +
+                                      ",CK" + std::to_string(tile.CK) + ",taps" + std::to_string(tile.taps) + ">";
+            plan->ops.push_back({[p, tile, pl, temb_off, f32out](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;
                     p.step_ptr = pl->io.step_ptr;
@@ -479,7 +520,7 @@ struct Builder {
                 }
                 if (f32out) p.y_nchw = pl->io.out;
                 return launch_conv(tile, p, s);
-            });
+            }, kname, fl, by});
         }
         if (a.gn) arena.release(gn_off, (size_t)x0.B * gn_P * a.groups * sizeof(float2));
         *out = y;
@@ -552,7 +593,8 @@ struct NetCommon {
             AttnParams ap;
             ap.qk = b.tptr(qk); ap.vt = b.tptr(vt); ap.out = b.tptr(o);
             ap.B = x.B; ap.L = L; ap.C = x.C;
-            b.plan->ops.push_back([ap](hipStream_t s) { return launch_attention(ap, s); });
+            b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention(ap, s); }, "attention_d8_kernel",
+                                   4.0 * (double)x.B * (x.C / 8) * (double)L * L * 8, (double)x.B * L * x.C * 2.0 * 4.0});
         }
         b.release(qk);
         b.release(vt);
@@ -731,7 +773,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
     ++b.launches;
     if (!b.dry) {
         bf16_t* dst = b.tptr(xin);
-        plan->ops.push_back([plan, dst, B, W, H, Cpad](hipStream_t s) {
+        plan->ops.push_back({[plan, dst, B, W, H, Cpad](hipStream_t s) {
             PackInputParams p;
             p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
             p.pos_encoding = plan->io.pos_encoding;
@@ -739,7 +781,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
             p.B = B; p.W = W; p.H = H; p.Cpad = Cpad;
             p.out = dst;
             return launch_pack_input(p, s);
-        });
+        }, "pack_input_kernel", 0.0, (double)B * W * H * (Cpad * 2.0 + 4.0 * 5)});
     }
     Tensor h;
     {
@@ -952,14 +994,14 @@ static void push_pack_input(Builder& b, Tensor xin) {
     Plan* plan = b.plan;
     bf16_t* dst = b.tptr(xin);
     const int B = xin.B, W = xin.W, H = xin.H, Cpad = xin.C;
-    plan->ops.push_back([plan, dst, B, W, H, Cpad](hipStream_t s) {
+    plan->ops.push_back({[plan, dst, B, W, H, Cpad](hipStream_t s) {
         PackInputParams p;
         p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
         p.pos_encoding = 0; p.cond = nullptr; p.cc = 0;
         p.B = B; p.W = W; p.H = H; p.Cpad = Cpad;
         p.out = dst;
         return launch_pack_input(p, s);
-    });
+    }, "pack_input_kernel", 0.0, (double)B * W * H * (Cpad * 2.0 + 4.0 * 4)});
 }
 
 static int vae_walk_decode(rldm_vae* m, Builder& b, int B, int w, int h) {
@@ -1446,6 +1488,44 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
     }
     RLDM_HIP_CHECK(hipEventRecord(s->ev_out, st));
     RLDM_HIP_CHECK(hipStreamWaitEvent(caller, s->ev_out, 0));
+    return 0;
+}
+
+// one instrumented UNet step + scheduler step (+ VAE decode): per-kernel launch counts, HIP-event time, algorithmic work
+int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size_t cap) {
+    RLDM_REQUIRE(s && x_T && json_out && cap > 2, "null argument");
+    hipStream_t st = s->stream;
+    RLDM_HIP_CHECK(hipMemcpyAsync(s->x.p, x_T, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
+    if (launch_step_counter(s->step.as<int>(), 0, 0, st)) return 1;
+    if (s->uplan->run(st)) return 1;                      // warm
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    std::map<std::string, KernelStat> unet_stats, vae_stats;
+    if (s->uplan->run_profiled(st, unet_stats)) return 1;
+    if (s->dplan) {
+        if (s->dplan->run(st)) return 1;
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (s->dplan->run_profiled(st, vae_stats)) return 1;
+    }
+    std::string js = "{";
+    auto dump = [&](const char* key, const std::map<std::string, KernelStat>& m) {
+        js += std::string("\"") + key + "\": {";
+        bool first = true;
+        for (auto& kv : m) {
+            if (!first) js += ", ";
+            first = false;
+            char buf[512];
+            snprintf(buf, sizeof(buf), "\"%s\": {\"launches\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                     kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+            js += buf;
+        }
+        js += "}";
+    };
+    dump("unet_step", unet_stats);
+    js += ", ";
+    dump("vae_decode", vae_stats);
+    js += "}";
+    RLDM_REQUIRE(js.size() + 1 <= cap, "profile buffer too small");
+    memcpy(json_out, js.c_str(), js.size() + 1);
     return 0;
 }
 

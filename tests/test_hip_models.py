@@ -51,7 +51,7 @@ SMALL = dict(sample_size=(64, 8), block_out_channels=(32, 32, 64, 64))
 @pytest.mark.parametrize("kw,B", [
     (dict(**SMALL), 2),
     (dict(**SMALL, in_channels=12), 1),                                   # upsample config channels
-    (dict(sample_size=(64, 4), block_out_channels=(32, 32, 64, 64)), 3),  # nuScenes-like aspect, odd batch
+    (dict(sample_size=(128, 8), block_out_channels=(32, 32, 64, 64)), 3),  # nuScenes-like aspect, odd batch
     (dict(sample_size=(128, 32), in_channels=3, out_channels=2, block_out_channels=(32, 32, 64, 64, 96, 96),
           down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
           up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4), 1),   # RangeDM topology
