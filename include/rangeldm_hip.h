@@ -168,6 +168,18 @@ typedef struct rldm_conv_desc {
  * bias, temb ([B][Cout] or NULL) are HOST fp32. */
 int rldm_test_conv(const rldm_conv_desc* d, const float* x0, const float* x1, const float* weight, const float* bias,
                    const float* gamma, const float* beta, const float* temb, const float* res, float* y, void* stream);
+/* kernel-tuning aids (tools/bench_conv.py): time the fused conv kernel alone on synthetic data with HIP events on
+ * `stream` (avg_us per launch over `iters` back-to-back launches; with_res = channels of the fused residual phase:
+ * 0 none, Cout identity, else a synthetic 1x1 shortcut); force the pixel/channel tile and split-K (0 = automatic). */
+int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int warmup, int iters, float* avg_us,
+                    char* kernel_name, size_t name_cap, void* stream);
+int rldm_debug_force_tile(int BM, int BN, int ksplit);
+int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
+int rldm_debug_set_flags(int flags);   /* kernel ablation switches, see ConvParams::dbg */
+/* statistics side-output of the conv epilogue (feeds the next GroupNorm): stats device fp32 [B][Cout][2] = per-image
+ * (sum, sum of squares) of the bf16 outputs of conv(x0); plain single-input conv only. */
+int rldm_test_conv_stats(const rldm_conv_desc* d, const float* x0, const float* weight, const float* bias, float* stats,
+                         void* stream);
 /* multi-head (d=8) self-attention core: qkv device fp32 [B][L][3C] -> out device fp32 [B][L][C] */
 int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void* stream);
 

@@ -10,32 +10,53 @@
 //         lane already holds after S^T (no cross-lane shuffles of P).  Only 8 of the 32 "M" rows carry V; row 8 is
 //         all-ones, so the MFMA also produces the softmax denominator for free.  The kernel is VALU(exp)-bound, not
 //         MFMA-bound, so the idle MFMA rows cost nothing.
-// Layouts: qk [B][L][2C] bf16 (q pre-multiplied by log2(e)/sqrt(8) through the packed Wq), vt [B][C/8][8][L] bf16
-// (written transposed by the QKV GEMM epilogue), out [B][L][C] bf16.  One wave = 32 queries of one (b, head).
+// Data: qkv [B][L][3C] bf16 straight out of the fused GroupNorm+QKV GEMM (q pre-multiplied by log2(e)/sqrt(8) through
+// the packed Wq).  A workgroup owns one (image, head): it stages that head's K rows (16 B each) and V TRANSPOSED
+// ([d][key], so the PV "A" fragments are 8-byte LDS reads) into LDS once -- 32 bytes per key -- and each of its waves
+// then runs 32 queries against all keys out of LDS.  out [B][L][C] bf16.
 #include "kernels.h"
 
 namespace rldm {
 
-__global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, const int waves_per_block) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ void __launch_bounds__(512) attention_d8_kernel(const AttnParams p, const int waves_per_block, const int Lp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = waves_per_block * 64;
     const int heads = p.C >> 3;
-    const int qtiles = (p.L + 31) >> 5;
-    const int qblocks = qtiles / waves_per_block;
+    const int qtiles = Lp >> 5;
+    const int qblocks = (qtiles + waves_per_block - 1) / waves_per_block;
     int bid = blockIdx.x;
     const int qb = bid % qblocks;
     bid /= qblocks;
     const int h = bid % heads;
     const int b = bid / heads;
-    const int q0 = (qb * waves_per_block + wave) * 32;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int ld = 2 * p.C;
+    const int ld = 3 * p.C;
+    const int vst = Lp + 4;                               // V^T row stride (elements): +8 B keeps the 8 d-rows on distinct banks
 
-    const bf16_t* qbase = p.qk + ((size_t)b * p.L) * ld + h * 8;
-    const bf16_t* kbase = qbase + p.C;
-    const bf16_t* vbase = p.vt + ((size_t)b * heads + h) * 8 * (size_t)p.L;
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);         // [Lp][8]
+    bf16_t* sVt = sK + (size_t)Lp * 8;                    // [8][Lp + 4]
+    const bf16_t* qbase = p.qkv + ((size_t)b * p.L) * ld + h * 8;
+
+    // ---- stage K rows and V^T of this head (keys >= L: zeros) ------------------------------------------------------
+    for (int key = tid; key < Lp; key += NT) {
+        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+        if (key < p.L) {
+            kv = *reinterpret_cast<const uint4*>(qbase + (size_t)key * ld + p.C);
+            vv = *reinterpret_cast<const uint4*>(qbase + (size_t)key * ld + 2 * p.C);
+        }
+        *reinterpret_cast<uint4*>(sK + (size_t)key * 8) = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) sVt[d * vst + key] = (bf16_t)((d & 1) ? (w[d >> 1] >> 16) : (w[d >> 1] & 0xffffu));
+    }
+    __syncthreads();
+
+    const int q0 = (qb * waves_per_block + wave) * 32;
+    if (q0 >= p.L) return;                                // no barriers below
 
     // B operand of S^T: Q^T, lane (query l31, half hh) holds q[query][4*hh .. 4*hh+3]
-    const int qrow = min(q0 + l31, p.L - 1);          // rows past L are computed on a clamped row, never stored
+    const int qrow = min(q0 + l31, p.L - 1);              // rows past L are computed on a clamped row, never stored
     const s16x4 qf = *reinterpret_cast<const s16x4*>(qbase + (size_t)qrow * ld + 4 * hh);
 
     f32x16 o;
@@ -45,11 +66,12 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
 
     // A operand rows of the PV MFMA: row l31 < 8 -> V^T[d = l31], row 8 -> ones, rows 9..31 -> zero
     const bool vrow = l31 < 8;
-    const bf16_t* vrow_ptr = vbase + (size_t)(vrow ? l31 : 0) * p.L + 4 * hh;
+    const bf16_t* vrow_ptr = sVt + (vrow ? l31 : 0) * vst + 4 * hh;
     const uint32_t fill = (l31 == 8) ? 0x3f803f80u : 0u;   // bf16 1.0 pairs
+    const bf16_t* krow_ptr = sK + l31 * 8 + 4 * hh;
 
-    for (int k0 = 0; k0 < p.L; k0 += 32) {
-        const s16x4 kf = *reinterpret_cast<const s16x4*>(kbase + (size_t)min(k0 + l31, p.L - 1) * ld + 4 * hh);
+    for (int k0 = 0; k0 < Lp; k0 += 32) {
+        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr + k0 * 8);
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -60,9 +82,10 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
             for (int r = 0; r < 16; ++r)
                 if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= p.L) s[r] = -1e30f;
         }
-        float tmax = s[0];
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
+        tmax = fmaxf(tmax, s[15]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mnew = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
@@ -77,10 +100,8 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
         for (int t = 0; t < 2; ++t) {
             uint4 vw = make_uint4(fill, fill, fill, fill);
             if (vrow) {
-                const int ka = k0 + 16 * t + 4 * hh;              // L % 4 == 0: a 4-key group is all in or all out
-                uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-                if (ka < p.L) lo = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t);
-                if (ka + 8 < p.L) hi = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t + 8);
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow_ptr + k0 + 16 * t + 8);
                 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             const uint4 pw = make_uint4(pk[4 * t], pk[4 * t + 1], pk[4 * t + 2], pk[4 * t + 3]);
@@ -98,13 +119,21 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AttnParams p, c
 }
 
 int launch_attention(const AttnParams& p, hipStream_t stream) {
-    RLDM_REQUIRE(p.L % 4 == 0 && p.L >= 4, "attention: token count must be a multiple of 4");
+    RLDM_REQUIRE(p.L >= 1 && p.L <= 4096, "attention: token count must be in [1, 4096] (K/V of one head are LDS-resident)");
     RLDM_REQUIRE(p.C % 8 == 0, "attention: channels must be a multiple of head_dim 8");
-    const int qtiles = (p.L + 31) / 32;
-    int wpb = 4;
-    while (qtiles % wpb) wpb >>= 1;
-    const int grid = p.B * (p.C / 8) * (qtiles / wpb);
-    hipLaunchKernelGGL(attention_d8_kernel, dim3(grid), dim3(64 * wpb), 0, stream, p, wpb);
+    const int Lp = (p.L + 31) / 32 * 32;
+    const int qtiles = Lp / 32;
+    const int wpb = qtiles < 8 ? qtiles : 8;
+    const int qblocks = (qtiles + wpb - 1) / wpb;
+    const int grid = p.B * (p.C / 8) * qblocks;
+    const size_t lds = (size_t)Lp * 16 + (size_t)8 * (Lp + 4) * 2;
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_d8_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(attention_d8_kernel, dim3(grid), dim3(64 * wpb), lds, stream, p, wpb, Lp);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

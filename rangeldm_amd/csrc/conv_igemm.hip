@@ -2,90 +2,284 @@
 //
 // Replaces the reference's `F.pad(circular W) + F.pad(zero H) + F.conv2d` (ldm/utils.py:46-49, dup
 // vae/sgm/modules/diffusionmodules/model.py:99-102), the stride-2 down-samplers (ldm/utils.py:107-116, model.py:164-172),
-// nearest-x2 + conv up-samplers (model.py:120-125), the 1x1 shortcuts and the attention Linear layers, with the
-// GroupNorm+SiLU that precedes every conv folded into the tile loader and bias / time-embedding / residual folded
-// into the epilogue.
+// nearest-x2 + conv up-samplers (model.py:120-125), the 1x1 shortcuts and the attention Linear layers.  One launch is a
+// whole "GroupNorm -> SiLU -> conv (+ time embedding) (+ shortcut / residual)" unit of ResnetBlock2D (model.py:342-362):
+//   * GroupNorm + SiLU of the INPUT are applied while the input tile is staged into LDS (the per-channel sums come from
+//     the producing launch, see "statistics" below) -- the normalised tensor never exists in HBM;
+//   * bias and the per-sample time-embedding projection are the initial value of the accumulators;
+//   * the residual branch is a second K-phase of the same GEMM: extra 1x1 "chunks" read the block input x (or the
+//     concatenation [h, skip]) and multiply it with the conv_shortcut weights -- or with an identity matrix when the
+//     block has no shortcut conv -- so `x + h` costs no epilogue traffic and is rounded to bf16 exactly once;
+//   * statistics: the epilogue emits per-(image, pixel-tile, channel) partial (sum, sum of squares) of the bf16 OUTPUT,
+//     which the next launch's prologue folds into its GroupNorm.  Fixed summation order everywhere: bit-reproducible.
 //
-// Mapping (one 256-thread workgroup = 4 waves):
+// Mapping (one workgroup = NW waves of 64):
 //   GEMM view  D[n][m] = sum_k W[n][k] * X[k][m],  n = output channel, m = output pixel, k = (tap, input channel).
 //   The MFMA "A" operand is the weight tile (32 channels x 16 k), the "B" operand the pixel tile (16 k x 32 pixels),
-//   so each lane ends up holding 4 consecutive output channels of ONE pixel per register quad -> 8-byte channels-last
-//   stores, per-pixel residual / per-channel bias adds without any cross-lane traffic.
+//   so each lane holds 4 consecutive output channels of ONE pixel per register quad.
 //   Input: for every CK-channel chunk the block stages the (TW*s+2) x (TH*s+2) input HALO of its TW x TH output tile
 //   in LDS once -- wrap-around along W (azimuth), zeros along H (beams), nearest-x2 and channel-concat resolved in the
-//   address computation, GroupNorm affine + SiLU applied on the way in -- and all 9 taps read it back with a
-//   per-tap constant offset: 9x fewer global/L2 reads and 9x fewer normalisation FLOPs than im2col-per-tap.
-//   Weights: packed on the host per (n-tile, chunk, tap) in exactly the padded LDS image (row = 2*CK + 16 bytes: the
-//   odd 16-byte-slot stride makes every ds_read_b128 lane group conflict-free), register-prefetched one tap ahead.
+//   address computation -- and all 9 taps read it back with a per-tap constant offset.  Chunk c+1 (and c+2) are
+//   prefetched into registers / the other half of a double buffer while chunk c computes.
+//   Weights: packed on the host per (n-tile, stage) in exactly the padded LDS image (row = 2*CK + 16 bytes: the odd
+//   16-byte-slot stride makes every ds_read_b128 lane group conflict-free) and streamed by LDS-DMA
+//   (global_load_lds_dwordx4, no VGPR round trip) into a 3-deep ring, two stages ahead of the MFMAs, with counted
+//   s_waitcnt vmcnt and ONE raw s_barrier per stage (a stage = one tap of one chunk).
+//   Output: accumulators -> bf16 -> LDS [pixel][channel] -> 16-byte fully coalesced channels-last stores.
+//   Split-K (small pixel counts): `ksplit` workgroups share an output tile, each sums a slice of the chunks, parks its
+//   fp32 accumulators in a slab, and the last one to arrive (agent-scope release/acquire around a ticket counter)
+//   adds the slabs in slice order and runs the epilogue.
 #include "kernels.h"
 
 namespace rldm {
 
-template <int BM, int BN, int WM, int WN, int CK, int TAPS>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) {
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr, lds_addr + 1024).  Inline asm so hipcc
+// neither counts it in its own vmcnt bookkeeping nor drains it before ds_reads (guide 5.7); m0 is saved/restored
+// inside the statement.  lds_addr must be wave-uniform.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// workgroup barrier that orders LDS traffic but leaves VMEM (DMA) operations in flight
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int ACH>
+__global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams p) {
+    constexpr int NT = 64 * NW;               // threads
     constexpr int MI = BM / (32 * WM);        // 32-pixel MFMA tiles per wave
     constexpr int NI = BN / (32 * WN);        // 32-channel MFMA tiles per wave
-    constexpr int RS = CK * 2 + 16;           // LDS row stride in bytes
-    constexpr int KS = CK / 16;               // MFMA k-steps per (tap, chunk)
+    constexpr int RS = CK * 2 + 16;           // LDS row stride in bytes (halo rows and weight rows)
+    constexpr int KS = CK / 16;               // MFMA k-steps per stage
     constexpr int KW = (TAPS == 9) ? 3 : 1;
     constexpr int C8 = CK / 8;                // 16-byte pieces per LDS row
-    constexpr int WCH = BN * RS / 16;         // 16-byte pieces per weight tile
-    constexpr int WFULL = WCH / 256;          // full 256-thread passes over a weight tile
-    constexpr int WTAIL = WCH % 256;          // pieces left for a partial pass
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
+    constexpr int WTILE = BN * RS;            // bytes of one weight stage
+    constexpr int WCH = WTILE / 16;           // 16-byte pieces per weight stage
+    constexpr int DPT = (WCH + NT - 1) / NT;  // DMA instructions per wave per stage
+    constexpr int NBUF = 3;                   // weight ring depth (prefetch distance 2)
+    constexpr int ERS = BN * 2 + 16;          // epilogue staging row stride (bytes)
+    constexpr int NC8 = BN / 8;               // 16-byte pieces per output pixel row
+    static_assert(WM * WN == NW, "wave grid");
+    static_assert(MI >= 1 && NI >= 1, "tile shape");
+    static_assert(WCH >= 64 && WTILE % 16 == 0, "weight stage too small for a full-wave DMA");
+    static_assert(NT % NC8 == 0 && NT % C8 == 0, "thread count must be a multiple of the pieces per row");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int kh = lane >> 5, l31 = lane & 31;
+    int ts_n = 0;
+    auto stamp = [&]() {
+        if (p.ts && blockIdx.x < 4 && tid == 0 && ts_n < 64) p.ts[blockIdx.x * 64 + ts_n++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();
 
-    // ---- which tile -----------------------------------------------------------------------------------------
+    // ---- which tile / K slice -----------------------------------------------------------------------------------
     const int tiles_h = p.Hout / p.TH;
     const int tiles_img = (p.Wout / p.TW) * tiles_h;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ksl = lid % p.ksplit;
+    lid /= p.ksplit;
     const int nt = lid % p.ntile_n;
     int mt = lid / p.ntile_n;
+    const int tile_id = lid;                  // (m-tile, n-tile) index: ticket / slab slot
     const int b = mt / tiles_img;
     mt -= b * tiles_img;
     const int tw = mt / tiles_h, th = mt - tw * tiles_h;
     const int w0 = tw * p.TW, h0 = th * p.TH;
     const int npx = p.TW * p.TH;
 
-    const int Cin = p.C0 + p.C1;
+    const int Cin = p.C0 + p.C1;              // main phase: TAPS taps per chunk, GroupNorm (+SiLU) prologue
     const int NCC = Cin / CK;
+    const int NCB = (p.R0 + p.R1) / CK;       // residual phase: 1 (centre) tap per chunk, raw input
+    const int NCT = NCC + NCB;
+    // this block's chunk range [cbeg, cend)
+    const int cper = (NCT + p.ksplit - 1) / p.ksplit;
+    const int cbeg = ksl * cper;
+    const int cend = (cbeg + cper < NCT) ? cbeg + cper : NCT;
+    auto stages_before = [&](int c) { return c <= NCC ? c * TAPS : NCC * TAPS + (c - NCC); };
+    const int sbeg = stages_before(cbeg);
+    const int NS = (p.dbg & 2) ? 0 : stages_before(cend) - sbeg;
+
     const int THv = (p.TH - 1) * p.stride + KW;
     const int TWv = (p.TW - 1) * p.stride + KW;
     const int nslots = TWv * THv;
+    const int abytes = (nslots * RS + 15) & ~15;
     const int Wv = p.Win * p.up, Hv = p.Hin * p.up;
     const int upshift = p.up - 1;             // up in {1,2}
 
-    unsigned char* sW = smem;
-    unsigned char* sA = smem + 2 * BN * RS;
-    float* sGa = reinterpret_cast<float*>(sA + ((nslots * RS + 15) & ~15));
-    float* sGs = sGa + Cin;
+    unsigned char* sW = smem;                                  // NBUF * WTILE
+    unsigned char* sA = smem + NBUF * WTILE;                   // 2 * abytes
+    float* sGa = reinterpret_cast<float*>(sA + 2 * abytes);    // Cin
+    float* sGs = sGa + Cin;                                    // Cin
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    // ---- GroupNorm finalize: (sum, sumsq) partials -> per-channel affine a*x + s ---------------------------------
-    const bool gn = p.gn_part != nullptr;
+    // ---- weight stream ----------------------------------------------------------------------------------------
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wpk) +
+                                ((size_t)nt * (NCC * TAPS + NCB) + sbeg) * WTILE;
+    auto issue_w = [&](int s) {   // stage s -> ring slot s % NBUF; every wave issues exactly DPT full-wave DMAs
+        const unsigned char* src = wsrc + (size_t)s * WTILE;
+        const unsigned dst = lds0 + (unsigned)((s % NBUF) * WTILE);
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) {
+            int piece = i * NT + wave * 64;
+            piece = piece > WCH - 64 ? WCH - 64 : piece;        // tail passes overlap instead of running short
+            lds_dma16(src + (size_t)(piece + lane) * 16, dst + (unsigned)piece * 16);
+        }
+    };
+    if (NS > 0) issue_w(0);
+    if (NS > 1) issue_w(1);
+
+    // ---- halo staging: thread-constant source pixel / LDS offset of each of its ACH 16-byte pieces ----------------
+    const int atotal = nslots * C8;
+    int apix[ACH];          // source pixel index ((b*Win + sw)*Hin + sh), or -1 for zero padding / out of range
+    int aoff[ACH];          // LDS byte offset inside a halo buffer, or -1 when this thread has no piece i
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int q = tid + i * NT;
+        const int slot = q / C8, c8 = q - slot * C8;
+        const int vwl = slot / THv, vhl = slot - vwl * THv;
+        const int vh = h0 * p.stride - p.pad_lo + vhl;
+        int vw = w0 * p.stride - p.pad_lo + vwl;
+        vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);          // azimuth: wrap-around
+        const bool ok = q < atotal && vh >= 0 && vh < Hv;            // beams: zero padding
+        apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
+        aoff[i] = q < atotal ? slot * RS + c8 * 16 : -1;
+    }
+    const int my_c8 = (tid % C8) * 8;          // NT % C8 == 0: a thread always handles the same 8-channel column
+
+    uint4 areg[ACH];
+    auto load_a = [&](int cc) {
+        const bf16_t* base;
+        int ld;
+        if (cc < NCC) {
+            const int c = cc * CK + my_c8;
+            const bool first = c < p.C0;
+            base = first ? p.x0 + c : p.x1 + (c - p.C0);
+            ld = first ? p.C0 : p.C1;
+        } else {
+            const int c = (cc - NCC) * CK + my_c8;
+            const bool first = c < p.R0;
+            base = first ? p.r0 + c : p.r1 + (c - p.R0);
+            ld = first ? p.R0 : p.R1;
+        }
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int pix = apix[i] < 0 ? 0 : apix[i];
+            areg[i] = *reinterpret_cast<const uint4*>(base + (size_t)pix * ld);
+        }
+    };
+    const bool gn = p.st0 != nullptr && !(p.dbg & 4);
+    auto store_a = [&](int cc) {
+        unsigned char* dstbuf = sA + (cc & 1) * abytes;
+        const bool norm = gn && cc < NCC;
+        float4 a0 = make_float4(1.f, 1.f, 1.f, 1.f), a1 = a0;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (norm) {
+            const int c = cc * CK + my_c8;
+            a0 = *reinterpret_cast<const float4*>(sGa + c);
+            a1 = *reinterpret_cast<const float4*>(sGa + c + 4);
+            s0 = *reinterpret_cast<const float4*>(sGs + c);
+            s1 = *reinterpret_cast<const float4*>(sGs + c + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            uint4 v = areg[i];
+            if (apix[i] < 0) {
+                v = make_uint4(0u, 0u, 0u, 0u);
+            } else if (norm) {
+                float f0 = bf16lo(v.x) * a0.x + s0.x, f1 = bf16hi(v.x) * a0.y + s0.y;
+                float f2 = bf16lo(v.y) * a0.z + s0.z, f3 = bf16hi(v.y) * a0.w + s0.w;
+                float f4 = bf16lo(v.z) * a1.x + s1.x, f5 = bf16hi(v.z) * a1.y + s1.y;
+                float f6 = bf16lo(v.w) * a1.z + s1.z, f7 = bf16hi(v.w) * a1.w + s1.w;
+                if (p.silu) {
+                    f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
+                    f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+                }
+                v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
+                v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);
+            }
+            if (aoff[i] >= 0) *reinterpret_cast<uint4*>(dstbuf + aoff[i]) = v;
+        }
+    };
+    stamp();
+    if (NS > 0) load_a(cbeg);                 // in flight while the GroupNorm statistics are folded
+
+    // ---- GroupNorm finalize: per-channel partial (sum, sumsq) of the producers -> per-channel affine a*x + s --------
     if (gn) {
+        double* sD = reinterpret_cast<double*>(sA);           // scratch: [2][Cin] doubles + [2][groups] (halo not yet written)
         const int cpg = Cin / p.gn_groups;
-        const double inv_n = 1.0 / ((double)p.Win * (double)p.Hin * (double)cpg);
-        for (int c = tid; c < Cin; c += 256) {
-            const int g = c / cpg;
+        for (int t = tid; t < Cin; t += NT) {
+            const bool first = t < p.C0;
+            const int c = first ? t : t - p.C0;
+            const int C = first ? p.C0 : p.C1;
+            const int P = first ? p.P0 : p.P1;
+            const float2* src = (first ? p.st0 : p.st1) + (size_t)b * P * C + c;
             double S = 0.0, SS = 0.0;
-            for (int q = 0; q < p.gn_P; ++q) {
-                const float2 v = p.gn_part[((size_t)b * p.gn_P + q) * p.gn_groups + g];
+            int q = 0;
+            for (; q + 8 <= P; q += 8) {
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(q + j) * C];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
+            }
+            for (; q < P; ++q) {
+                const float2 v = src[(size_t)q * C];
                 S += (double)v.x;
                 SS += (double)v.y;
             }
+            sD[t] = S;
+            sD[Cin + t] = SS;
+        }
+        __syncthreads();
+        if (tid < p.gn_groups) {
+            double S = 0.0, SS = 0.0;
+            for (int i = 0; i < cpg; ++i) {
+                S += sD[tid * cpg + i];
+                SS += sD[Cin + tid * cpg + i];
+            }
+            const double inv_n = 1.0 / ((double)p.Win * (double)p.Hin * (double)cpg);
             const double mean = S * inv_n;
             double var = SS * inv_n - mean * mean;
             var = var < 0.0 ? 0.0 : var;
-            const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-            const float a = p.gn_gamma[c] * rstd;
-            sGa[c] = a;
-            sGs[c] = p.gn_beta[c] - (float)mean * a;
+            sD[2 * Cin + tid] = mean;
+            sD[2 * Cin + p.gn_groups + tid] = 1.0 / sqrt(var + (double)p.gn_eps);
         }
+        __syncthreads();
+        float ga[2], gs[2];                     // Cin <= 2 * NT
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = tid + j * NT;
+            if (t < Cin) {
+                const int g = t / cpg;
+                ga[j] = p.gn_gamma[t] * (float)sD[2 * Cin + p.gn_groups + g];
+                gs[j] = p.gn_beta[t] - (float)sD[2 * Cin + g] * ga[j];
+            }
+        }
+        __syncthreads();                       // sD (aliasing nothing live yet) fully consumed before sGa/sGs, halo writes
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = tid + j * NT;
+            if (t < Cin) { sGa[t] = ga[j]; sGs[t] = gs[j]; }
+        }
+        __syncthreads();
+    }
+    stamp();
+    int loaded = cbeg, stored = cbeg;          // halo chunks whose loads were issued / whose LDS image is written
+    if (NS > 0) {
+        store_a(cbeg);
+        if (cbeg + 1 < cend) { load_a(cbeg + 1); loaded = cbeg + 1; }
     }
 
     // ---- per-lane LDS byte offsets of the MFMA operands ----------------------------------------------------------
@@ -100,239 +294,334 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) woff[ni] = (wn * (NI * 32) + ni * 32 + l31) * RS + kh * 16;
 
+    // ---- accumulators start at bias (+ time-embedding projection of this sample); K-slices > 0 start at zero -------
     f32x16 acc[NI][MI];
+    {
+        const float* temb_row = nullptr;
+        if (p.temb) {
+            const int step = p.step_ptr ? *p.step_ptr : 0;
+            temb_row = p.temb + (size_t)(step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld;
+        }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-
-    const uint4* wsrc_base = reinterpret_cast<const uint4*>(p.wpk) + (size_t)nt * NCC * TAPS * WCH;
-
-    for (int cc = 0; cc < NCC; ++cc) {
-        __syncthreads();   // previous chunk's MFMAs are done with sA / sW (also orders sGa writes on cc == 0)
-        // ---- stage the input halo for channels [cc*CK, cc*CK + CK) ------------------------------------------------
-        {
-            const int total = nslots * C8;
-            for (int q = tid; q < total; q += 256) {
-                const int slot = q / C8, c8 = q - slot * C8;
-                const int vwl = slot / THv, vhl = slot - vwl * THv;
-                const int vh = h0 * p.stride - p.pad_lo + vhl;
-                int vw = w0 * p.stride - p.pad_lo + vwl;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (vh >= 0 && vh < Hv) {                       // beams: zero padding
-                    vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);   // azimuth: wrap-around
-                    const int sw = vw >> upshift, sh = vh >> upshift;
-                    const int c = cc * CK + c8 * 8;
-                    const size_t pix = ((size_t)b * p.Win + sw) * p.Hin + sh;
-                    const bf16_t* src = (c < p.C0) ? p.x0 + pix * p.C0 + c : p.x1 + pix * p.C1 + (c - p.C0);
-                    v = *reinterpret_cast<const uint4*>(src);
-                    if (gn) {
-                        const float4 a0 = *reinterpret_cast<const float4*>(sGa + c);
-                        const float4 a1 = *reinterpret_cast<const float4*>(sGa + c + 4);
-                        const float4 s0 = *reinterpret_cast<const float4*>(sGs + c);
-                        const float4 s1 = *reinterpret_cast<const float4*>(sGs + c + 4);
-                        float f0 = bf16lo(v.x) * a0.x + s0.x, f1 = bf16hi(v.x) * a0.y + s0.y;
-                        float f2 = bf16lo(v.y) * a0.z + s0.z, f3 = bf16hi(v.y) * a0.w + s0.w;
-                        float f4 = bf16lo(v.z) * a1.x + s1.x, f5 = bf16hi(v.z) * a1.y + s1.y;
-                        float f6 = bf16lo(v.w) * a1.z + s1.z, f7 = bf16hi(v.w) * a1.w + s1.w;
-                        if (p.silu) {
-                            f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
-                            f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
-                        }
-                        v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
-                        v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ch = nt * BN + wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ksl == 0) {
+                    bv = *reinterpret_cast<const float4*>(p.bias + ch);
+                    if (temb_row && ch < p.N) {      // N % 4 == 0 whenever a time embedding is present
+                        const float4 tv = *reinterpret_cast<const float4*>(temb_row + ch);
+                        bv.x += tv.x; bv.y += tv.y; bv.z += tv.z; bv.w += tv.w;
                     }
                 }
-                *reinterpret_cast<uint4*>(sA + slot * RS + c8 * 16) = v;
-            }
-        }
-        // ---- first weight tile of the chunk ----------------------------------------------------------------------
-        {
-            const uint4* src = wsrc_base + (size_t)cc * TAPS * WCH;
-            uint4* dst = reinterpret_cast<uint4*>(sW);
 #pragma unroll
-            for (int i = 0; i < WFULL; ++i) dst[tid + i * 256] = src[tid + i * 256];
-            if constexpr (WTAIL > 0) {
-                if (tid < WTAIL) dst[WFULL * 256 + tid] = src[WFULL * 256 + tid];
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc[ni][mi][r4 * 4 + 0] = bv.x; acc[ni][mi][r4 * 4 + 1] = bv.y;
+                    acc[ni][mi][r4 * 4 + 2] = bv.z; acc[ni][mi][r4 * 4 + 3] = bv.w;
+                }
             }
-        }
-        __syncthreads();
+    }
 
-        auto compute = [&](int tap) {
-            const int ti = tap / 3, tj = tap - ti * 3;
-            const int tapoff = (ti * THv + tj) * RS;
-            const unsigned char* wb = sW + (tap & 1) * (BN * RS);
+    stamp();
+    // ---- main loop: one raw barrier per stage; weights two stages ahead; halo chunks up to two chunks ahead ---------
+    int cc = cbeg, st = 0;
+    const int ctap = (TAPS == 9) ? 4 : 0;      // centre tap for the residual-phase chunks
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+        // W(s) has landed once at most the DMAs of W(s+1) are outstanding (VMEM retires in order; the compiler's own
+        // waits on the halo loads only ever wait for MORE, never less)
+        if (s + 1 < NS) wait_vmcnt<DPT>(); else wait_vmcnt<0>();
+        lds_barrier();     // everyone's share of W(s) + halo(cc) visible; everyone finished reading ring slot (s+2)%3
+        // halo pipeline: (a) write a chunk whose loads were issued in an earlier stage, as soon as its buffer is free
+        //                (b) then issue the next chunk's loads (one register set: only after the previous write)
+        if (!(p.dbg & 32)) {
+            if (loaded > stored && stored + 1 <= cc + 1) { store_a(stored + 1); ++stored; }
+            if (loaded == stored && loaded + 1 < cend && loaded <= cc + 1) { load_a(loaded + 1); ++loaded; }
+        }
+        if (s + 2 < NS && !(p.dbg & 16)) issue_w(s + 2);
+
+        const unsigned char* wb = sW + (s % NBUF) * WTILE;
+        const unsigned char* ab = sA + (cc & 1) * abytes;
+        const int tap = (cc < NCC) ? st : ctap;
+        const int ti = tap / 3, tj = tap - ti * 3;
+        const int tapoff = (TAPS == 9) ? (ti * THv + tj) * RS : 0;
+        bf16x8 wf[KS][NI], xf[KS][MI];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                wf[ks][ni] = *reinterpret_cast<const bf16x8*>(wb + woff[ni] + ks * 32);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                xf[ks][mi] = *reinterpret_cast<const bf16x8*>(ab + xoff[mi] + tapoff + ks * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the whole stage's ds_reads ahead of its MFMAs (latency hiding)
+        if (p.dbg & 8) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 wf[NI], xf[MI];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(wb + woff[ni] + ks * 32);
+                for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[ks][ni]));
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    xf[mi] = *reinterpret_cast<const bf16x8*>(sA + xoff[mi] + tapoff + ks * 32);
+                for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xf[ks][mi]));
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-            }
-        };
-#pragma unroll 1
-        for (int tap = 0; tap < TAPS - 1; ++tap) {
-            // register-prefetch the next tap's weights (unconditional clamped loads keep wreg in VGPRs)
-            // (named scalars, not an array: hipcc leaves dead scratch stores behind for a uint4[] here)
-            static_assert(WFULL <= 5, "weight tile too large for the register prefetch");
-            uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0, w2 = w0, w3 = w0, w4 = w0, wtail = w0;
-            const uint4* src = wsrc_base + ((size_t)cc * TAPS + tap + 1) * WCH + tid;
-            if constexpr (WFULL > 0) w0 = src[0];
-            if constexpr (WFULL > 1) w1 = src[256];
-            if constexpr (WFULL > 2) w2 = src[512];
-            if constexpr (WFULL > 3) w3 = src[768];
-            if constexpr (WFULL > 4) w4 = src[1024];
-            if constexpr (WTAIL > 0) wtail = src[tid < WTAIL ? WFULL * 256 : 0];
-            compute(tap);
-            uint4* dst = reinterpret_cast<uint4*>(sW + ((tap + 1) & 1) * (BN * RS)) + tid;
-            if constexpr (WFULL > 0) dst[0] = w0;
-            if constexpr (WFULL > 1) dst[256] = w1;
-            if constexpr (WFULL > 2) dst[512] = w2;
-            if constexpr (WFULL > 3) dst[768] = w3;
-            if constexpr (WFULL > 4) dst[1024] = w4;
-            if constexpr (WTAIL > 0) {
-                if (tid < WTAIL) dst[WFULL * 256] = wtail;
-            }
-            __syncthreads();
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
         }
-        compute(TAPS - 1);
+        if (++st == ((cc < NCC) ? TAPS : 1)) { st = 0; ++cc; }
+        stamp();
+    }
+    lds_barrier();                             // all waves are done with the ring / halo: LDS is reused below
+    stamp();
+
+    // ---- split-K: park the slice, last arriver combines (guide 6 G16 recipe: release -> ticket -> acquire) ----------
+    if (p.ksplit > 1) {
+        int* flag = reinterpret_cast<int*>(smem);
+        float* slab = p.slab + ((size_t)tile_id * p.ksplit) * (size_t)(BM * BN);
+        float* mine = slab + (size_t)ksl * (BM * BN);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 v = make_float4(acc[ni][mi][r4 * 4], acc[ni][mi][r4 * 4 + 1], acc[ni][mi][r4 * 4 + 2],
+                                                 acc[ni][mi][r4 * 4 + 3]);
+                    *reinterpret_cast<float4*>(mine + ((((ni * MI + mi) * 4 + r4) * NT) + tid) * 4) = v;
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = __hip_atomic_fetch_add(p.ticket + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == p.ksplit - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(p.ticket + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __syncthreads();                       // flag is read by everyone before the staging below overwrites it
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < p.ksplit; ++k) {      // slice order: deterministic
+                        const float4 v = *reinterpret_cast<const float4*>(
+                            slab + (size_t)k * (BM * BN) + ((((ni * MI + mi) * 4 + r4) * NT) + tid) * 4);
+                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    }
+                    acc[ni][mi][r4 * 4] = sum.x; acc[ni][mi][r4 * 4 + 1] = sum.y;
+                    acc[ni][mi][r4 * 4 + 2] = sum.z; acc[ni][mi][r4 * 4 + 3] = sum.w;
+                }
     }
 
-    // ---- epilogue: bias (+ time embedding) (+ residual) -> bf16 channels-last (or fp32 NCHW / transposed V) ----------
-    const float* temb_row = nullptr;
-    if (p.temb) {
-        const int step = p.step_ptr ? *p.step_ptr : 0;
-        temb_row = p.temb + (size_t)(step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld;
+    // ---- epilogue ----------------------------------------------------------------------------------------------------
+    if (p.y_nchw) {                            // fp32 NCHW (network outputs: few channels), straight from the registers
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int pidx = wm * (MI * 32) + mi * 32 + l31;
+            if (pidx >= npx) continue;
+            const int pw = pidx / p.TH, ph = pidx - pw * p.TH;
+            const int ow = w0 + pw, oh = h0 + ph;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = nt * BN + wn * (NI * 32) + ni * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    if (ch < p.N && !(p.dbg & 1))
+                        p.y_nchw[(((size_t)b * p.N + ch) * p.Wout + ow) * p.Hout + oh] = acc[ni][mi][r];
+                }
+        }
+        return;
     }
-    const int L = p.Wout * p.Hout;
+    // (1) accumulators -> bf16 -> LDS [pixel][channel]
+    unsigned char* sE = smem;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int pidx = wm * (MI * 32) + mi * 32 + l31;
-        const bool pvalid = pidx < npx;
-        const int pw = pidx / p.TH, ph = pidx - pw * p.TH;
-        const int ow = w0 + pw, oh = h0 + ph;
-        const size_t pix = ((size_t)b * p.Wout + ow) * p.Hout + oh;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int ch = nt * BN + wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh;
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + ch);
-                float v0 = acc[ni][mi][r4 * 4 + 0] + bv.x, v1 = acc[ni][mi][r4 * 4 + 1] + bv.y;
-                float v2 = acc[ni][mi][r4 * 4 + 2] + bv.z, v3 = acc[ni][mi][r4 * 4 + 3] + bv.w;
-                if (!pvalid || ch >= p.N) continue;
-                if (p.y_nchw) {
-                    const float vv[4] = {v0, v1, v2, v3};
+                const int chl = wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh;
+                uint2 o;
+                o.x = pack_bf16x2(acc[ni][mi][r4 * 4 + 0], acc[ni][mi][r4 * 4 + 1]);
+                o.y = pack_bf16x2(acc[ni][mi][r4 * 4 + 2], acc[ni][mi][r4 * 4 + 3]);
+                *reinterpret_cast<uint2*>(sE + pidx * ERS + chl * 2) = o;
+            }
+    }
+    __syncthreads();
+    stamp();
+    // (2) 16-byte pieces, channel-fastest: fully coalesced stores; per-channel statistics of exactly the stored values
+    const int c8 = tid % NC8;
+    const int chg = nt * BN + c8 * 8;
+    const bool cvalid = chg < p.N;
+    const bool vec_ok = (p.N & 7) == 0;        // rows 16-byte aligned and whole pieces only
+    float s8[8], q8[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (ch + e < p.N) p.y_nchw[(((size_t)b * p.N + ch + e) * p.Wout + ow) * p.Hout + oh] = vv[e];
-                    continue;
-                }
-                if (temb_row) {
-                    const float4 tv = *reinterpret_cast<const float4*>(temb_row + ch);
-                    v0 += tv.x; v1 += tv.y; v2 += tv.z; v3 += tv.w;
-                }
-                if (ch < p.n_store) {
-                    if (ch + 3 < p.n_store) {
-                        if (p.res) {
-                            const uint2 rv = *reinterpret_cast<const uint2*>(p.res + pix * p.N + ch);
-                            v0 += bf16lo(rv.x); v1 += bf16hi(rv.x); v2 += bf16lo(rv.y); v3 += bf16hi(rv.y);
-                        }
-                        uint2 o;
-                        o.x = pack_bf16x2(v0, v1);
-                        o.y = pack_bf16x2(v2, v3);
-                        *reinterpret_cast<uint2*>(p.y + pix * p.y_ld + ch) = o;
-                    } else {                                   // channel count not a multiple of 4: scalar tail
-                        const float vv[4] = {v0, v1, v2, v3};
+    for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+    for (int pidx = tid / NC8; pidx < npx; pidx += NT / NC8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sE + pidx * ERS + c8 * 16);
+        const int pw = pidx / p.TH, ph = pidx - pw * p.TH;
+        const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
+        if (cvalid && !(p.dbg & 1)) {
+            if (vec_ok) {
+                *reinterpret_cast<uint4*>(p.y + pix * p.y_ld + chg) = v;
+            } else {                           // odd channel counts (test shapes): element stores
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (ch + e < p.n_store) {
-                                float t = vv[e];
-                                if (p.res) t += bf16_to_f32(p.res[pix * p.N + ch + e]);
-                                p.y[pix * p.y_ld + ch + e] = f32_to_bf16(t);
-                            }
-                    }
-                } else {
-                    // attention V, stored transposed per head: vt[b][head][d][token]
-                    const int cv = ch - p.n_store;
-                    const int heads = (p.N - p.n_store) >> 3;
-                    bf16_t* dst = p.vt + (((size_t)b * heads + (cv >> 3)) * 8 + (cv & 7)) * L + (ow * p.Hout + oh);
-                    dst[0] = f32_to_bf16(v0);
-                    dst[(size_t)L] = f32_to_bf16(v1);
-                    dst[(size_t)2 * L] = f32_to_bf16(v2);
-                    dst[(size_t)3 * L] = f32_to_bf16(v3);
-                }
+                for (int e = 0; e < 8; ++e)
+                    if (chg + e < p.N) p.y[pix * p.y_ld + chg + e] = (bf16_t)((e & 1) ? (wv[e >> 1] >> 16) : (wv[e >> 1] & 0xffffu));
             }
         }
+        const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y),
+                            bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s8[e] += f[e];
+            q8[e] += f[e] * f[e];
+        }
     }
+    stamp();
+    if (p.y_stats) {
+        // lanes with equal (lane % NC8) hold the same channels: butterfly over the lane bits above NC8
+#pragma unroll
+        for (int off = NC8; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s8[e] += __shfl_xor(s8[e], off);
+                q8[e] += __shfl_xor(q8[e], off);
+            }
+        float* sS = reinterpret_cast<float*>(sE + BM * ERS);   // [NW][BN] sums, [NW][BN] squares
+        if (lane < NC8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sS[wave * BN + lane * 8 + e] = s8[e];
+                sS[(NW + wave) * BN + lane * 8 + e] = q8[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && nt * BN + tid < p.N) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                S += sS[w * BN + tid];
+                Q += sS[(NW + w) * BN + tid];
+            }
+            p.y_stats[((size_t)b * tiles_img + mt) * p.N + nt * BN + tid] = make_float2(S, Q);
+        }
+    }
+    stamp();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
+//          NW   BM   BN  WM WN  CK TAPS ACH
+#define RLDM_CONV_INSTANCES(X)                                                                                  \
+    X(8, 256, 128, 4, 2, 64, 9, 6) X(8, 256, 64, 4, 2, 64, 9, 6) X(8, 256, 32, 8, 1, 64, 9, 6)                   \
+    X(4, 128, 128, 2, 2, 64, 9, 7) X(4, 128, 64, 2, 2, 64, 9, 7) X(4, 64, 64, 2, 2, 64, 9, 7)                    \
+    X(4, 128, 32, 4, 1, 64, 9, 7)                                                                               \
+    X(8, 256, 128, 4, 2, 64, 1, 4) X(8, 256, 64, 4, 2, 64, 1, 4)                                                 \
+    X(4, 128, 128, 2, 2, 64, 1, 4) X(4, 128, 64, 2, 2, 64, 1, 4) X(4, 64, 64, 2, 2, 64, 1, 2)                    \
+    X(8, 256, 128, 4, 2, 16, 9, 2) X(8, 256, 64, 4, 2, 16, 9, 2)                                                 \
+    X(4, 128, 128, 2, 2, 16, 9, 2) X(4, 128, 64, 2, 2, 16, 9, 2) X(4, 64, 64, 2, 2, 16, 9, 2)                    \
+    X(4, 128, 32, 4, 1, 16, 9, 2) X(4, 64, 64, 2, 2, 16, 1, 1)
+
+struct ConvInst {
+    int NW, BM, BN, CK, taps, ACH;
+};
+static const ConvInst* find_inst(const ConvTile& t) {
+    static const ConvInst table[] = {
+#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, ach_) {nw_, bm_, bn_, ck_, taps_, ach_},
+        RLDM_CONV_INSTANCES(X)
+#undef X
+    };
+    for (const auto& i : table)
+        if (i.BM == t.BM && i.BN == t.BN && i.CK == t.CK && i.taps == t.taps) return &i;
+    return nullptr;
+}
+
+bool conv_tile_supported(const ConvTile& t) { return find_inst(t) != nullptr; }
+
+int conv_max_halo_slots(const ConvTile& t) {
+    const ConvInst* i = find_inst(t);
+    return i ? i->ACH * 64 * i->NW / (t.CK / 8) : 0;
+}
+int conv_tile_threads(const ConvTile& t) {
+    const ConvInst* i = find_inst(t);
+    return i ? 64 * i->NW : 0;
+}
+
 size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
+    const ConvInst* inst = find_inst(t);
+    const int NW = inst ? inst->NW : 4;
     const int RS = conv_row_bytes(t.CK);
     const int KW = t.taps == 9 ? 3 : 1;
     const int THv = (p.TH - 1) * p.stride + KW, TWv = (p.TW - 1) * p.stride + KW;
-    size_t a = ((size_t)TWv * THv * RS + 15) & ~(size_t)15;
-    size_t g = p.gn_part ? (size_t)(p.C0 + p.C1) * 8 : 0;
-    return (size_t)2 * t.BN * RS + a + g;
+    const size_t a = ((size_t)TWv * THv * RS + 15) & ~(size_t)15;
+    const size_t g = p.st0 ? (size_t)(p.C0 + p.C1) * 8 : 0;
+    const size_t w = (size_t)3 * t.BN * RS;
+    size_t main_bytes = w + 2 * a + g;
+    // GroupNorm finalize scratch lives in the (not yet written) halo buffers: 2*Cin + 2*groups doubles
+    const size_t gscratch = p.st0 ? w + ((size_t)2 * (p.C0 + p.C1) + 2 * p.gn_groups) * 8 : 0;
+    const size_t epi = (size_t)t.BM * (t.BN * 2 + 16) + (size_t)2 * NW * t.BN * 4;
+    return std::max(std::max(main_bytes, gscratch), epi);
 }
 
-template <int BM, int BN, int WM, int WN, int CK, int TAPS>
+template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int ACH>
 static int launch_inst(const ConvParams& p, int grid, size_t lds, hipStream_t stream) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, CK, TAPS>;
+    auto kern = conv_igemm_kernel<NW, BM, BN, WM, WN, CK, TAPS, ACH>;
     static size_t max_set = 0;
     if (lds > max_set) {
         RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         max_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, p);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
-}
-
-#define RLDM_CONV_INSTANCES(X)                                                                                  \
-    X(128, 128, 2, 2, 64, 9) X(128, 128, 2, 2, 64, 1) X(64, 64, 2, 2, 64, 9) X(64, 64, 2, 2, 64, 1)             \
-    X(128, 64, 2, 2, 64, 9) X(128, 64, 2, 2, 64, 1) X(128, 32, 4, 1, 64, 9)                                     \
-    X(128, 128, 2, 2, 16, 9) X(128, 64, 2, 2, 16, 9) X(64, 64, 2, 2, 16, 9) X(64, 64, 2, 2, 16, 1)              \
-    X(128, 32, 4, 1, 16, 9)
-
-bool conv_tile_supported(const ConvTile& t) {
-#define X(bm_, bn_, wm_, wn_, ck_, taps_) \
-    if (t.BM == bm_ && t.BN == bn_ && t.CK == ck_ && t.taps == taps_) return true;
-    RLDM_CONV_INSTANCES(X)
-#undef X
-    return false;
 }
 
 int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(p.Wout % p.TW == 0 && p.Hout % p.TH == 0, "conv: output size is not a multiple of the pixel tile");
     RLDM_REQUIRE(p.TW * p.TH <= t.BM, "conv: pixel tile larger than BM");
     RLDM_REQUIRE((p.C0 + p.C1) % t.CK == 0, "conv: input channels not a multiple of CK");
-    RLDM_REQUIRE(p.C1 == 0 || p.C0 % 8 == 0, "conv: concat boundary must be a multiple of 8 channels");
+    RLDM_REQUIRE(p.C1 == 0 || p.C0 % t.CK == 0, "conv: concat boundary must be a multiple of the channel chunk");
+    RLDM_REQUIRE((p.R0 + p.R1) % t.CK == 0 && (p.R1 == 0 || p.R0 % t.CK == 0), "conv: residual channels vs chunk size");
+    RLDM_REQUIRE((p.R0 + p.R1) == 0 || (p.stride == 1 && p.up == 1), "conv: residual phase needs stride 1, no upsample");
     RLDM_REQUIRE(p.up == 1 || p.up == 2, "conv: upsample factor must be 1 or 2");
     RLDM_REQUIRE(p.Win * p.up >= 2 || t.taps == 1, "conv: azimuth extent too small for wrap-around");
-    const int grid = p.B * (p.Wout / p.TW) * (p.Hout / p.TH) * p.ntile_n;
+    RLDM_REQUIRE(p.ksplit >= 1 && (p.ksplit == 1 || (p.slab && p.ticket)), "conv: split-K needs slab and ticket buffers");
+    const ConvInst* inst = find_inst(t);
+    RLDM_REQUIRE(inst != nullptr, "conv: no kernel instance for tile BM=" + std::to_string(t.BM) + " BN=" +
+                                      std::to_string(t.BN) + " CK=" + std::to_string(t.CK) + " taps=" + std::to_string(t.taps));
+    RLDM_REQUIRE(!p.st0 || (p.C0 + p.C1) <= 128 * inst->NW, "conv: GroupNorm prologue needs Cin <= 2 * threads");
+    RLDM_REQUIRE(!p.st0 || p.gn_groups <= 64, "conv: GroupNorm prologue supports at most 64 groups");
+    const int KW = t.taps == 9 ? 3 : 1;
+    const int nslots = ((p.TW - 1) * p.stride + KW) * ((p.TH - 1) * p.stride + KW);
+    RLDM_REQUIRE(nslots <= conv_max_halo_slots(t), "conv: halo larger than the instance's register staging capacity");
+    const int grid = p.B * (p.Wout / p.TW) * (p.Hout / p.TH) * p.ntile_n * p.ksplit;
     const size_t lds = conv_lds_bytes(t, p);
     RLDM_REQUIRE(lds <= 160 * 1024, "conv: LDS footprint exceeds 160 KiB");
-#define X(bm_, bn_, wm_, wn_, ck_, taps_) \
-    if (t.BM == bm_ && t.BN == bn_ && t.CK == ck_ && t.taps == taps_) \
-        return launch_inst<bm_, bn_, wm_, wn_, ck_, taps_>(p, grid, lds, stream);
+#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, ach_)                                      \
+    if (t.BM == bm_ && t.BN == bn_ && t.CK == ck_ && t.taps == taps_)                     \
+        return launch_inst<nw_, bm_, bn_, wm_, wn_, ck_, taps_, ach_>(p, grid, lds, stream);
     RLDM_CONV_INSTANCES(X)
 #undef X
-    set_error("conv: no kernel instance for tile BM=" + std::to_string(t.BM) + " BN=" + std::to_string(t.BN) +
-              " CK=" + std::to_string(t.CK) + " taps=" + std::to_string(t.taps));
     return 1;
 }
 

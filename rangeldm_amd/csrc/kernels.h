@@ -12,38 +12,52 @@ namespace rldm {
 // Reference arithmetic: ldm/utils.py:40-55,107-116; vae/sgm/modules/diffusionmodules/model.py:93-125,164-172.
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvParams {
+    // main phase: TAPS taps per CK-channel chunk over cat[x0, x1], GroupNorm (+SiLU) applied on the way into LDS
     const bf16_t* x0;
     const bf16_t* x1;       // second tensor of a channel concat (may be null)
-    int C0, C1;             // channels of x0 / x1; C0 + C1 is a multiple of the kernel's CK
+    int C0, C1;             // channels of x0 / x1; C0 and C0 + C1 are multiples of the kernel's CK
+    // residual phase: one centre tap per chunk over cat[r0, r1] (raw, at OUTPUT resolution) with the 1x1 shortcut
+    // weights (or an identity) appended to the weight stream; R0 + R1 == 0: none
+    const bf16_t* r0;
+    const bf16_t* r1;
+    int R0, R1;
     int B, Win, Hin;
     int up;                 // 1 | 2 (nearest upsample folded into indexing)
     int stride;             // 1 | 2
     int pad_lo;             // 1: symmetric pad 1, 0: end-only pad (or 1x1)
     int Wout, Hout;
     int TW, TH;             // output-pixel tile handled by one block (TW*TH <= BM)
-    // GroupNorm prologue (null gn_part -> none): partial (sum, sumsq) per [b][P][group] from gn_stats
-    const float2* gn_part;
-    int gn_P, gn_groups;
+    // GroupNorm prologue (null st0 -> none): per-channel partial (sum, sumsq) [B][P][C] written by the producers of x0/x1
+    const float2* st0;
+    const float2* st1;
+    int P0, P1;
+    int gn_groups;
     const float* gn_gamma;
     const float* gn_beta;
     float gn_eps;
     int silu;
-    // weights: bf16, packed [ntile_n][Cin/CK][taps][BN][CK + 8 pad]
+    // weights: bf16, packed [ntile_n][Cin/CK * taps + (R0+R1)/CK][BN][CK + 8 pad]
     const bf16_t* wpk;
     int N;                  // real output channels
     int ntile_n;
     const float* bias;      // padded to ntile_n * BN
-    // epilogue
+    // accumulator init: bias + temb row
     const float* temb;      // null or [rows][temb_ld], row = step*rows_per_step + (per_sample ? b : 0)
     int temb_ld;
     const int* step_ptr;    // device int (null -> 0)
     int temb_rows_per_step;
     int temb_per_sample;
-    const bf16_t* res;      // null or [B][Wout][Hout][N]
-    bf16_t* y;              // bf16 output, row stride y_ld, channels [0, n_store)
-    int y_ld, n_store;
-    bf16_t* vt;             // channels >= n_store go transposed to vt[b][head][8][L] (attention V), or null
+    // outputs
+    bf16_t* y;              // bf16 channels-last [B][Wout][Hout][y_ld]
+    int y_ld;
+    float2* y_stats;        // null or [B][tiles per image][N] partial (sum, sumsq) of the stored bf16 values
     float* y_nchw;          // if set: fp32 NCHW output [B][N][Wout][Hout] instead of y
+    // split-K over channel chunks
+    int ksplit;             // >= 1
+    float* slab;            // [tiles][ksplit][BM*BN] fp32 (ksplit > 1)
+    int* ticket;            // [tiles] zero-initialised arrival counters (re-armed by the last arriver)
+    unsigned long long* ts;  // tuning: s_memtime stamps of blocks 0..3, wave 0 ([4][64]) or null
+    int dbg;                // tuning ablations (rldm_debug_set_flags): 1 skip stores, 2 skip main loop, 4 skip GN finalize
 };
 
 struct ConvTile {
@@ -53,29 +67,29 @@ struct ConvTile {
 inline int conv_row_bytes(int CK) { return CK * 2 + 16; }
 size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p);
 bool conv_tile_supported(const ConvTile& t);
+int conv_max_halo_slots(const ConvTile& t);
+int conv_tile_threads(const ConvTile& t);
 int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
-// GroupNorm statistics (norm.hip): deterministic partial (sum, sumsq) per (b, chunk p, group) over cat[x0, x1].
+// Per-channel statistics (norm.hip) for tensors that did not come out of a conv epilogue (tests, external inputs):
+// deterministic partial (sum, sumsq) per (b, pixel chunk p, channel).
 // ---------------------------------------------------------------------------------------------------------------
 struct GnStatsParams {
-    const bf16_t* x0;
-    const bf16_t* x1;
-    int C0, C1;
+    const bf16_t* x;        // [B][npix][C]
+    int C;
     int B, npix;            // pixels per image
-    int groups;
     int P;                  // pixel chunks per image (grid.x)
-    float2* part;           // [B][P][groups]
+    float2* part;           // [B][P][C] per-channel (sum, sumsq)
 };
 int launch_gn_stats(const GnStatsParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
-// Multi-head self-attention with head_dim 8 (attention.hip).  qk: [B][L][2C] (q | k, q pre-scaled by
-// log2(e)/sqrt(8) through the packed weights), vt: [B][C/8][8][L], out: [B][L][C].
+// Multi-head self-attention with head_dim 8 (attention.hip).  qkv: [B][L][3C] (q | k | v, q pre-scaled by
+// log2(e)/sqrt(8) through the packed weights), out: [B][L][C].
 // ---------------------------------------------------------------------------------------------------------------
 struct AttnParams {
-    const bf16_t* qk;
-    const bf16_t* vt;
+    const bf16_t* qkv;
     bf16_t* out;
     int B, L, C;
 };

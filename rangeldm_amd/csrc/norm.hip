@@ -1,6 +1,7 @@
-// GroupNorm statistics for gfx950: deterministic partial (sum, sum of squares) per (image, pixel-chunk, group) over a
-// channels-last bf16 tensor or the channel-concatenation of two (the up-block `torch.cat([h, skip], 1)` is never
-// materialised).  The per-channel affine is finalised inside the consuming conv's prologue (conv_igemm.hip).
+// Per-channel statistics for gfx950: deterministic partial (sum, sum of squares) per (image, pixel-chunk, channel) of a
+// channels-last bf16 tensor, in the exact [B][P][C] float2 layout the conv epilogue emits (conv_igemm.hip), for
+// tensors that did not come out of a conv launch (external inputs of the kernel-level entry points).  The consuming
+// conv's prologue folds them into the GroupNorm affine.
 // Reference op: torch.nn.GroupNorm(32, C, eps) in ResnetBlock2D / Attention [3P diffusers] and
 // `Normalize` (vae/sgm/modules/diffusionmodules/model.py:59-62).
 //
@@ -13,10 +14,8 @@ namespace rldm {
 __global__ void __launch_bounds__(256) gn_stats_kernel(const GnStatsParams p) {
     __shared__ float sSum[256 * 8];
     __shared__ float sSq[256 * 8];
-    __shared__ float cSum[512];
-    __shared__ float cSq[512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = p.C0 + p.C1;
+    const int C = p.C;
     const int nch8 = C >> 3;                 // 16-byte pieces per pixel (<= 64)
     const int ppw = 64 / nch8;               // pixels per wave pass
     const int c8 = lane % nch8, sub = lane / nch8;
@@ -30,12 +29,9 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const GnStatsParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (active) {
-        const int c = c8 * 8;
-        const bool first = c < p.C0;
-        const bf16_t* base = first ? p.x0 + c : p.x1 + (c - p.C0);
-        const int ld = first ? p.C0 : p.C1;
+        const bf16_t* base = p.x + c8 * 8;
         for (int px = px0 + wave * ppw + sub; px < px1; px += 4 * ppw) {
-            const uint4 v = *reinterpret_cast<const uint4*>(base + ((size_t)b * p.npix + px) * ld);
+            const uint4 v = *reinterpret_cast<const uint4*>(base + ((size_t)b * p.npix + px) * C);
             const float f[8] = {bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y),
                                 bf16lo(v.z), bf16hi(v.z), bf16lo(v.w), bf16hi(v.w)};
 #pragma unroll
@@ -61,26 +57,12 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const GnStatsParams p) {
                 a += sSum[t * 8 + e];
                 d += sSq[t * 8 + e];
             }
-        cSum[c] = a;
-        cSq[c] = d;
-    }
-    __syncthreads();
-    if (tid < p.groups) {
-        const int cpg = C / p.groups;
-        float a = 0.f, d = 0.f;
-        for (int i = 0; i < cpg; ++i) {
-            a += cSum[tid * cpg + i];
-            d += cSq[tid * cpg + i];
-        }
-        p.part[((size_t)b * p.P + chunk) * p.groups + tid] = make_float2(a, d);
+        p.part[((size_t)b * p.P + chunk) * C + c] = make_float2(a, d);
     }
 }
 
 int launch_gn_stats(const GnStatsParams& p, hipStream_t stream) {
-    const int C = p.C0 + p.C1;
-    RLDM_REQUIRE(C % 8 == 0 && C <= 512 && C % p.groups == 0, "gn_stats: channels must be a multiple of 8, <= 512");
-    RLDM_REQUIRE(p.C1 == 0 || p.C0 % 8 == 0, "gn_stats: concat boundary must be a multiple of 8 channels");
-    RLDM_REQUIRE(p.groups <= 256, "gn_stats: too many groups");
+    RLDM_REQUIRE(p.C % 8 == 0 && p.C <= 512, "gn_stats: channels must be a multiple of 8, <= 512");
     hipLaunchKernelGGL(gn_stats_kernel, dim3(p.P, p.B), dim3(256), 0, stream, p);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -104,13 +104,18 @@ struct ConvLayer {
     std::string name;
     int Cout = 0, Cin = 0, ksize = 3;          // real sizes
     std::vector<float> w, b;                   // host fp32, (Cout, Cin, k, k) / (Cout)
+    // residual phase fused into this conv's K loop (conv_igemm.hip): a 1x1 map over R channels of the block input.
+    // sc_w = conv_shortcut weights (Cout, R) [its bias is folded into b], or empty + sc_identity for a plain `x + h`.
+    int R = 0;
+    bool sc_identity = false;
+    std::vector<float> sc_w;
     struct Packed {
         DevBuf w, bias;
         int ntile_n = 0, Cin_pad = 0;
     };
     std::map<std::pair<int, int>, std::unique_ptr<Packed>> packed;   // (BN, CK) -> image
 
-    // [ntile_n][Cin_pad/CK][taps][BN][CK + 8] bf16; channel rows >= Cout and channels >= Cin are zero
+    // [ntile_n][Cin_pad/CK * taps + R/CK][BN][CK + 8] bf16; channel rows >= Cout and channels >= Cin are zero
     int get_packed(int BN, int CK, int Cin_pad, Packed** out) {
         auto key = std::make_pair(BN, CK);
         auto it = packed.find(key);
@@ -119,19 +124,25 @@ struct ConvLayer {
             *out = it->second.get();
             return 0;
         }
+        RLDM_REQUIRE(R % CK == 0, "conv " + name + ": residual channels not a multiple of the channel chunk");
         const int taps = ksize * ksize;
         const int ntile = (Cout + BN - 1) / BN;
-        const int ncc = Cin_pad / CK;
+        const int ncc = Cin_pad / CK, ncb = R / CK;
         const int RSE = CK + 8;
-        std::vector<bf16_t> img((size_t)ntile * ncc * taps * BN * RSE, 0);
+        const size_t stages = (size_t)ncc * taps + ncb;
+        std::vector<bf16_t> img((size_t)ntile * stages * BN * RSE, 0);
         for (int n = 0; n < Cout; ++n) {
             const int nt = n / BN, nr = n % BN;
             for (int c = 0; c < Cin; ++c) {
                 const int cc = c / CK, ck = c % CK;
                 for (int tap = 0; tap < taps; ++tap) {
                     const float v = w[((size_t)n * Cin + c) * taps + tap];
-                    img[((((size_t)nt * ncc + cc) * taps + tap) * BN + nr) * RSE + ck] = f32_to_bf16(v);
+                    img[(((size_t)nt * stages + (size_t)cc * taps + tap) * BN + nr) * RSE + ck] = f32_to_bf16(v);
                 }
+            }
+            for (int c = 0; c < R; ++c) {
+                const float v = sc_identity ? (c == n ? 1.f : 0.f) : sc_w[(size_t)n * R + c];
+                img[(((size_t)nt * stages + (size_t)ncc * taps + c / CK) * BN + nr) * RSE + c % CK] = f32_to_bf16(v);
             }
         }
         std::vector<float> bias((size_t)ntile * BN, 0.f);
@@ -202,6 +213,9 @@ struct Tensor {
     size_t off = 0;
     int B = 0, W = 0, H = 0, C = 0;
     int id = -1;
+    size_t st_off = 0;     // per-channel partial statistics [B][P][C] float2 (P == 0: none)
+    int P = 0;
+    size_t st_bytes() const { return (size_t)B * P * C * sizeof(float2); }
     size_t bytes() const { return (size_t)B * W * H * C * sizeof(bf16_t); }
     bool valid() const { return id >= 0; }
 };
@@ -238,6 +252,7 @@ struct KernelStat {
 struct Plan {
     int B = 0, W = 0, H = 0;
     DevBuf arena;
+    DevBuf tickets;                // split-K arrival counters of every conv in the plan
     PlanIO io;
     std::vector<Op> ops;
     double flops = 0;
@@ -325,54 +340,110 @@ struct ConvArgs {
     ConvLayer* layer = nullptr;
     Tensor x0, x1;                 // x1 optional concat
     int stride = 1, pad_mode = 0, up = 1;
-    NormParams* gn = nullptr;      // GroupNorm prologue over cat[x0, x1]
+    NormParams* gn = nullptr;      // GroupNorm prologue over cat[x0, x1] (needs their statistics)
     float eps = 1e-5f;
     int groups = 32;
     int silu = 0;
     int temb_off = -1;             // channel offset into the temb table row
-    Tensor res;                    // optional residual
-    int n_store = -1;              // attention qkv: channels [0, n_store) -> y (ld n_store), rest -> vt
+    Tensor r0, r1;                 // residual-phase sources (layer->R channels in total), at output resolution
+    bool want_stats = false;       // emit per-channel statistics of the output (a GroupNorm will read it)
     bool out_f32_nchw = false;     // conv_out: write plan->io.out
 };
 
-static ConvTile choose_tile(long long B, int Wout, int Hout, int N, int Cin_pad, int taps) {
-    ConvTile t;
+static int g_dbg_flags = 0;
+static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;     // rldm_debug_force_tile: tuning override (0: automatic)
+
+struct TileChoice {
+    ConvTile tile;
+    int TW = 1, TH = 1, ksplit = 1;
+};
+
+// output-pixel tile of a block: as tall as the image allows (<= 16 beams), then as wide as BM allows
+static void pixel_tile(int BM, int Wout, int Hout, int stride, int* TW, int* TH) {
+    int th = 1;
+    while (th * 2 <= Hout && th * 2 <= 16 && Hout % (th * 2) == 0) th *= 2;
+    int tw = 1;
+    while (tw * 2 * th <= BM && Wout % (tw * 2) == 0) tw *= 2;
+    (void)stride;
+    *TW = tw;
+    *TH = th;
+}
+
+static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N, int Cin_pad, int R, int taps, bool nchw) {
+    TileChoice c;
+    ConvTile& t = c.tile;
     t.taps = taps;
-    t.CK = (Cin_pad % 64 == 0) ? 64 : 16;
-    auto blocks = [&](int BM, int BN) {
-        const int TH = std::min(Hout, 16), TW = std::min(Wout, std::max(1, BM / TH));
-        return B * (Wout / TW) * (Hout / TH) * ((N + BN - 1) / BN);
+    t.CK = (Cin_pad % 64 == 0 && R % 64 == 0) ? 64 : 16;
+    const int KW = taps == 9 ? 3 : 1;
+    const int ncc = Cin_pad / t.CK, ncb = R / t.CK;
+    auto fits = [&](const ConvTile& u, int* tw, int* th) {
+        if (!conv_tile_supported(u)) return false;
+        pixel_tile(u.BM, Wout, Hout, stride, tw, th);
+        // shrink the tile until the halo fits the instance's register staging capacity
+        while (((*tw - 1) * stride + KW) * ((*th - 1) * stride + KW) > conv_max_halo_slots(u)) {
+            if (*tw > 1) *tw >>= 1; else if (*th > 1) *th >>= 1; else return false;
+        }
+        return true;
     };
-    const std::pair<int, int> pref[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-    if (N <= 32) {
-        t.BM = 128;
-        t.BN = 32;
-    } else if (N <= 64) {
-        t.BM = 128;
-        t.BN = 64;
-        if (blocks(128, 64) < 256) t.BM = 64;
-    } else {
-        t.BM = 128;
-        t.BN = 128;
-        if (blocks(128, 128) < 384) {
-            t.BM = 64;
-            t.BN = 64;
+    auto blocks = [&](const ConvTile& u, int tw, int th) {
+        return B * (Wout / tw) * (Hout / th) * ((N + u.BN - 1) / u.BN);
+    };
+    const int bn_pref = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+    // candidates in order of preference (largest first); take the first that fills the chip, else the one with most blocks
+    const int bms[3] = {256, 128, 64};
+    const int bns[3] = {bn_pref, bn_pref > 64 ? 64 : bn_pref, bn_pref > 32 && N <= 32 ? 32 : bn_pref};
+    long long best_blocks = -1;
+    TileChoice best;
+    bool found = false;
+    for (int pass = 0; pass < 2 && best_blocks < 0; ++pass)      // pass 1 also accepts tiles that are mostly padding
+        for (int bi = 0; bi < 3 && !found; ++bi)
+            for (int ni = 0; ni < 2 && !found; ++ni) {
+                ConvTile u = t;
+                u.BM = bms[bi];
+                u.BN = bns[ni];
+                if (ni == 1 && bns[1] == bns[0]) continue;
+                int tw, th;
+                if (!fits(u, &tw, &th)) continue;
+                if (pass == 0 && tw * th * 2 <= u.BM && bi < 2) continue;   // more than half empty: try a smaller BM first
+                const long long nb = blocks(u, tw, th);
+                if (nb > best_blocks) {
+                    best_blocks = nb;
+                    best.tile = u;
+                    best.TW = tw;
+                    best.TH = th;
+                }
+                if (nb >= 200) found = true;
+            }
+    if (g_force_bm && g_force_bn) {
+        ConvTile u = t;
+        u.BM = g_force_bm;
+        u.BN = g_force_bn;
+        int tw, th;
+        if (fits(u, &tw, &th)) {
+            best.tile = u;
+            best.TW = tw;
+            best.TH = th;
+            best_blocks = blocks(u, tw, th);
         }
     }
-    if (!conv_tile_supported(t)) {
-        for (auto& pr : pref) {
-            ConvTile u = t;
-            u.BM = pr.first;
-            u.BN = pr.second;
-            if (N <= 32 && u.BN != 32) continue;
-            if (conv_tile_supported(u)) return u;
-        }
-        ConvTile u = t;              // last resort: the generic small tile
-        u.BM = 64;
-        u.BN = 64;
-        return u;
+    c = best;
+    if (best_blocks < 0) {
+        c.tile = t;
+        c.tile.BM = 64;
+        c.tile.BN = 64;
+        return c;                    // caller reports "no kernel instance"
     }
-    return t;
+    // split-K over channel chunks when the tile grid leaves most CUs idle (fp32 NCHW outputs skip it: tiny N anyway)
+    c.ksplit = 1;
+    if (!nchw) {
+        int ks = 1;
+        while (best_blocks * ks * 2 <= 320 && ks * 2 <= ncc && ncc % (ks * 2) == 0) ks *= 2;
+        c.ksplit = ks;
+        if (g_force_ks > 0 && g_force_ks <= std::max(1, ncc)) c.ksplit = g_force_ks;
+    }
+    (void)ncb;
+    return c;
 }
 
 struct Builder {
@@ -385,6 +456,8 @@ struct Builder {
     char* base = nullptr;
     int launches = 0;
     int temb_ld = 0;               // row stride of the time-embedding table (0: network has none)
+    int* ticket_ptr = nullptr;     // split-K arrival counters (plan->tickets, zeroed at allocation; null in the dry pass)
+    int tickets = 0;
 
     Tensor make(int B, int W, int H, int C) {
         Tensor t;
@@ -395,120 +468,139 @@ struct Builder {
         live[t.id] = t;
         return t;
     }
+    void add_stats(Tensor& t, int P) {
+        t.P = P;
+        t.st_off = arena.alloc(t.st_bytes());
+        live[t.id] = t;
+    }
     void retain(const Tensor& t) { refs[t.id]++; }
     void release(const Tensor& t) {
         if (!t.valid()) return;
         if (--refs[t.id] == 0) {
             arena.release(t.off, t.bytes());
+            if (t.P) arena.release(t.st_off, t.st_bytes());
             live.erase(t.id);
         }
     }
     template <class T> T* ptr(size_t off) const { return reinterpret_cast<T*>(base + off); }
     bf16_t* tptr(const Tensor& t) const { return t.valid() ? ptr<bf16_t>(t.off) : nullptr; }
+    const float2* sptr(const Tensor& t) const { return (t.valid() && t.P) ? ptr<float2>(t.st_off) : nullptr; }
 
-    // GroupNorm partial statistics over cat[x0, x1]; returns arena offset of the [B][P][groups] float2 buffer
-    int gn_stats(const Tensor& x0, const Tensor& x1, int groups, size_t* off_out, int* P_out) {
-        const int npix = x0.W * x0.H;
-        int P = std::max(1, std::min(16, npix / 64));
-        const size_t bytes = (size_t)x0.B * P * groups * sizeof(float2);
-        const size_t off = arena.alloc(bytes);
-        *off_out = off;
-        *P_out = P;
+    // per-channel statistics of a tensor that did not come out of a conv epilogue (external inputs in the test entry points)
+    int gn_stats(Tensor& x) {
+        const int npix = x.W * x.H;
+        const int P = std::max(1, std::min(16, npix / 64));
+        add_stats(x, P);
         ++launches;
         if (!dry) {
             GnStatsParams g;
-            g.x0 = tptr(x0);
-            g.x1 = tptr(x1);
-            g.C0 = x0.C;
-            g.C1 = x1.valid() ? x1.C : 0;
-            g.B = x0.B;
+            g.x = tptr(x);
+            g.C = x.C;
+            g.B = x.B;
             g.npix = npix;
-            g.groups = groups;
             g.P = P;
-            g.part = ptr<float2>(off);
-            const double by = (double)x0.B * npix * (g.C0 + g.C1) * 2.0;
+            g.part = ptr<float2>(x.st_off);
+            const double by = (double)x.B * npix * x.C * 2.0;
             plan->ops.push_back({[g](hipStream_t s) { return launch_gn_stats(g, s); }, "gn_stats_kernel", 0.0, by});
         }
         return 0;
     }
 
     // y = conv(...) ; consumes nothing (callers release inputs)
-    int conv(const ConvArgs& a, Tensor* out, Tensor* vt_out = nullptr) {
+    int conv(const ConvArgs& a, Tensor* out) {
         ConvLayer* L = a.layer;
         RLDM_REQUIRE(L != nullptr, "internal: missing conv layer");
         const Tensor& x0 = a.x0;
         const int Cin_t = x0.C + (a.x1.valid() ? a.x1.C : 0);      // tensor (padded) channels
         RLDM_REQUIRE(Cin_t >= L->Cin, "conv " + L->name + ": input tensor has fewer channels than the weights");
         RLDM_REQUIRE(Cin_t % 16 == 0, "conv " + L->name + ": input channels must be a multiple of 16");
+        const int R_t = (a.r0.valid() ? a.r0.C : 0) + (a.r1.valid() ? a.r1.C : 0);
+        RLDM_REQUIRE(R_t == L->R, "conv " + L->name + ": residual sources do not match the layer's residual phase");
         const int taps = L->ksize * L->ksize;
         const int Wv = x0.W * a.up, Hv = x0.H * a.up;
         const int Wout = Wv / a.stride, Hout = Hv / a.stride;
         RLDM_REQUIRE(Wv % a.stride == 0 && Hv % a.stride == 0, "conv " + L->name + ": odd size under stride 2");
+        RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
-        ConvTile tile = choose_tile(x0.B, Wout, Hout, N, Cin_t, taps);
+        const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, R_t, taps, a.out_f32_nchw);
+        const ConvTile tile = tc.tile;
         RLDM_REQUIRE(conv_tile_supported(tile), "conv " + L->name + ": no kernel instance");
 
         ConvParams p;
         memset(&p, 0, sizeof(p));
         p.C0 = x0.C;
         p.C1 = a.x1.valid() ? a.x1.C : 0;
+        p.R0 = a.r0.valid() ? a.r0.C : 0;
+        p.R1 = a.r1.valid() ? a.r1.C : 0;
         p.B = x0.B; p.Win = x0.W; p.Hin = x0.H;
         p.up = a.up; p.stride = a.stride;
         p.pad_lo = (L->ksize == 1) ? 0 : (a.pad_mode == 0 ? 1 : 0);
         p.Wout = Wout; p.Hout = Hout;
-        int TH = std::min(Hout, a.stride == 2 ? 8 : 16);
-        int TW = std::min(Wout, std::max(1, tile.BM / TH));
-        // keep the stride-2 halo inside the LDS budget
-        while (a.stride == 2 && TW > 1 && (size_t)((TW - 1) * 2 + 3) * ((TH - 1) * 2 + 3) * conv_row_bytes(tile.CK) > 60 * 1024)
-            TW >>= 1;
-        RLDM_REQUIRE(Wout % TW == 0 && Hout % TH == 0, "conv " + L->name + ": size not tileable (powers of two expected)");
-        p.TW = TW; p.TH = TH;
+        p.TW = tc.TW; p.TH = tc.TH;
+        RLDM_REQUIRE(Wout % p.TW == 0 && Hout % p.TH == 0, "conv " + L->name + ": size not tileable (powers of two expected)");
         p.N = N;
         p.silu = a.silu;
         p.gn_eps = a.eps;
+        p.dbg = g_dbg_flags;
+        p.ts = g_ts_buf;
         p.gn_groups = a.groups;
+        p.ksplit = tc.ksplit;
+        const int tiles_img = (Wout / p.TW) * (Hout / p.TH);
+        const int ntile_n = (N + tile.BN - 1) / tile.BN;
+        const long long tiles = (long long)x0.B * tiles_img * ntile_n;
 
-        Tensor y, vt;
-        const bool qkv = a.n_store >= 0;
+        Tensor y;
         if (!a.out_f32_nchw) {
-            y = make(x0.B, Wout, Hout, qkv ? a.n_store : N);
-            if (qkv) vt = make(x0.B, Wout, Hout, N - a.n_store);
+            y = make(x0.B, Wout, Hout, N);
+            if (a.want_stats) add_stats(y, tiles_img);
         }
-        size_t gn_off = 0;
-        int gn_P = 0;
         if (a.gn) {
             RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
-            if (gn_stats(x0, a.x1, a.groups, &gn_off, &gn_P)) return 1;
+            RLDM_REQUIRE(x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
         }
-        plan->flops += 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * taps;
+        size_t slab_off = 0, slab_bytes = 0;
+        int ticket_base = 0;
+        if (tc.ksplit > 1) {
+            slab_bytes = (size_t)tiles * tc.ksplit * tile.BM * tile.BN * sizeof(float);
+            slab_off = arena.alloc(slab_bytes);
+            ticket_base = tickets;
+            tickets += (int)tiles;
+        }
+        plan->flops += 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
         ++launches;
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
             if (L->get_packed(tile.BN, tile.CK, Cin_t, &pk)) return 1;
             p.x0 = tptr(x0);
             p.x1 = tptr(a.x1);
+            p.r0 = tptr(a.r0);
+            p.r1 = tptr(a.r1);
             p.wpk = pk->w.as<bf16_t>();
             p.bias = pk->bias.as<float>();
             p.ntile_n = pk->ntile_n;
             if (a.gn) {
-                p.gn_part = ptr<float2>(gn_off);
-                p.gn_P = gn_P;
+                p.st0 = sptr(x0);
+                p.st1 = sptr(a.x1);
+                p.P0 = x0.P;
+                p.P1 = a.x1.valid() ? a.x1.P : 0;
                 p.gn_gamma = a.gn->gamma.as<float>();
                 p.gn_beta = a.gn->beta.as<float>();
             }
-            p.res = tptr(a.res);
             p.y = tptr(y);
-            p.y_ld = qkv ? a.n_store : N;
-            p.n_store = qkv ? a.n_store : N;
-            p.vt = qkv ? tptr(vt) : nullptr;
+            p.y_ld = N;
+            p.y_stats = (y.valid() && y.P) ? ptr<float2>(y.st_off) : nullptr;
+            if (tc.ksplit > 1) {
+                p.slab = ptr<float>(slab_off);
+                p.ticket = ticket_ptr + ticket_base;
+            }
             Plan* pl = plan;
             p.temb_ld = temb_ld;
             const int temb_off = a.temb_off;
             const bool f32out = a.out_f32_nchw;
-            const double fl = 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * taps;
-            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * L->Cin * taps * 2.0 +
+            const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
+            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * taps + L->R) * 2.0 +
                               (double)x0.B * Wout * Hout * N * (a.out_f32_nchw ? 4.0 : 2.0) +
-                              (a.res.valid() ? (double)x0.B * Wout * Hout * N * 2.0 : 0.0);
+                              (double)x0.B * Wout * Hout * R_t * 2.0;
             const std::string kname = "conv_igemm_kernel<" + std::to_string(tile.BM) + "," + std::to_string(tile.BN) +
                                       ",CK" + std::to_string(tile.CK) + ",taps" + std::to_string(tile.taps) + ">";
             plan->ops.push_back({[p, tile, pl, temb_off, f32out](hipStream_t s) mutable {
@@ -522,12 +614,35 @@ struct Builder {
                 return launch_conv(tile, p, s);
             }, kname, fl, by});
         }
-        if (a.gn) arena.release(gn_off, (size_t)x0.B * gn_P * a.groups * sizeof(float2));
+        if (tc.ksplit > 1) arena.release(slab_off, slab_bytes);
         *out = y;
-        if (vt_out) *vt_out = vt;
         return 0;
     }
 };
+
+// Two passes over the same walk: a dry one sizes the activation arena (and the split-K counters), the real one bakes
+// device pointers into the launch list.
+static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)>& walk, int* launches = nullptr) {
+    Builder dry;
+    dry.plan = plan;
+    dry.dry = true;
+    dry.temb_ld = temb_ld;
+    if (walk(dry)) return 1;
+    if (launches) *launches = dry.launches;
+    if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
+    if (plan->tickets.alloc((size_t)std::max(1, dry.tickets) * sizeof(int))) return 1;
+    RLDM_HIP_CHECK(hipMemset(plan->tickets.p, 0, plan->tickets.bytes));
+    plan->flops = 0;
+    plan->ops.clear();
+    Builder real;
+    real.plan = plan;
+    real.dry = false;
+    real.base = plan->arena.as<char>();
+    real.ticket_ptr = plan->tickets.as<int>();
+    real.temb_ld = temb_ld;
+    if (walk(real)) return 1;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // shared network pieces
@@ -539,7 +654,8 @@ struct NetCommon {
     int temb_ld = 0;                                 // total projected channels (0: no time embedding)
     std::map<std::string, int> temb_off;             // resnet prefix -> channel offset in the temb row
 
-    // ResnetBlock2D / sgm ResnetBlock (model.py:342-362).  Releases one reference of x and skip.
+    // ResnetBlock2D / sgm ResnetBlock (model.py:342-362) in two launches: conv1 = GN1+SiLU+conv+temb, conv2 =
+    // GN2+SiLU+conv with the shortcut (1x1 conv or identity) as the residual K-phase.  Releases one reference of x and skip.
     int resnet(Builder& b, const std::string& p, Tensor x, Tensor skip, Tensor* out) {
         ConvArgs c1;
         c1.layer = layers.get_conv(p + ".conv1");
@@ -548,60 +664,50 @@ struct NetCommon {
         c1.eps = eps; c1.groups = groups; c1.silu = 1;
         auto it = temb_off.find(p);
         c1.temb_off = it == temb_off.end() ? -1 : it->second;
+        c1.want_stats = true;
         Tensor h1;
         if (b.conv(c1, &h1)) return 1;
-        Tensor sc = x;
-        ConvLayer* scl = layers.get_conv(p + ".conv_shortcut");
-        if (scl) {
-            ConvArgs cs;
-            cs.layer = scl;
-            cs.x0 = x; cs.x1 = skip;
-            if (b.conv(cs, &sc)) return 1;
-        } else {
-            RLDM_REQUIRE(!skip.valid(), "resnet " + p + ": concat input without a shortcut conv");
-            b.retain(sc);
-        }
         ConvArgs c2;
         c2.layer = layers.get_conv(p + ".conv2");
         c2.x0 = h1;
         c2.gn = layers.get_norm(p + ".norm2");
         c2.eps = eps; c2.groups = groups; c2.silu = 1;
-        c2.res = sc;
+        c2.r0 = x; c2.r1 = skip;
+        c2.want_stats = true;
         if (b.conv(c2, out)) return 1;
         b.release(h1);
-        b.release(sc);
         b.release(x);
         b.release(skip);
         return 0;
     }
 
-    // diffusers Attention (+x residual).  Releases one reference of x.
+    // diffusers Attention (+x residual): qkv = GN + Linear(C, 3C); softmax(q k^T / sqrt(8)) v per head; to_out + x.
+    // Releases one reference of x.
     int attention(Builder& b, const std::string& p, Tensor x, Tensor* out) {
         ConvArgs cq;
         cq.layer = layers.get_conv(p + ".qkv");
         cq.x0 = x;
         cq.gn = layers.get_norm(p + ".group_norm");
         cq.eps = eps; cq.groups = groups; cq.silu = 0;
-        cq.n_store = 2 * x.C;
-        Tensor qk, vt;
-        if (b.conv(cq, &qk, &vt)) return 1;
+        Tensor qkv;
+        if (b.conv(cq, &qkv)) return 1;
         Tensor o = b.make(x.B, x.W, x.H, x.C);
         const int L = x.W * x.H;
         b.plan->flops += 4.0 * (double)x.B * (x.C / 8) * (double)L * L * 8;
         ++b.launches;
         if (!b.dry) {
             AttnParams ap;
-            ap.qk = b.tptr(qk); ap.vt = b.tptr(vt); ap.out = b.tptr(o);
+            ap.qkv = b.tptr(qkv); ap.out = b.tptr(o);
             ap.B = x.B; ap.L = L; ap.C = x.C;
             b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention(ap, s); }, "attention_d8_kernel",
                                    4.0 * (double)x.B * (x.C / 8) * (double)L * L * 8, (double)x.B * L * x.C * 2.0 * 4.0});
         }
-        b.release(qk);
-        b.release(vt);
+        b.release(qkv);
         ConvArgs co;
         co.layer = layers.get_conv(p + ".to_out.0");
         co.x0 = o;
-        co.res = x;
+        co.r0 = x;
+        co.want_stats = true;
         if (b.conv(co, out)) return 1;
         b.release(o);
         b.release(x);
@@ -613,7 +719,16 @@ struct NetCommon {
         if (layers.add_conv(ps, p + ".conv1", co, ci, 3)) return 1;
         if (layers.add_norm(ps, p + ".norm2", co)) return 1;
         if (layers.add_conv(ps, p + ".conv2", co, co, 3)) return 1;
-        if (ci != co && layers.add_conv(ps, p + ".conv_shortcut", co, ci, 1)) return 1;
+        ConvLayer* c2 = layers.get_conv(p + ".conv2");
+        if (ci != co) {                              // conv_shortcut(x) folded into conv2: weights appended, biases summed
+            c2->R = ci;
+            c2->sc_w = ps.host.at(p + ".conv_shortcut.weight");
+            const auto& sb = ps.host.at(p + ".conv_shortcut.bias");
+            for (int i = 0; i < co; ++i) c2->b[i] += sb[i];
+        } else {
+            c2->R = co;
+            c2->sc_identity = true;
+        }
         if (temb) {
             temb_off[p] = temb_ld;
             temb_ld += co;
@@ -624,6 +739,9 @@ struct NetCommon {
         if (layers.add_norm(ps, p + ".group_norm", c)) return 1;
         if (layers.add_qkv(ps, p, c, head_dim)) return 1;
         if (layers.add_conv(ps, p + ".to_out.0", c, c, 1)) return 1;
+        ConvLayer* o = layers.get_conv(p + ".to_out.0");
+        o->R = c;
+        o->sc_identity = true;
         return 0;
     }
 };
@@ -788,6 +906,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
         ConvArgs a;
         a.layer = net.layers.get_conv("conv_in");
         a.x0 = xin;
+        a.want_stats = true;
         if (b.conv(a, &h)) return 1;
         b.release(xin);
     }
@@ -811,6 +930,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
             a.layer = net.layers.get_conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv");
             a.x0 = h;
             a.stride = 2;
+            a.want_stats = true;
             Tensor o;
             if (b.conv(a, &o)) return 1;
             b.release(h);
@@ -848,6 +968,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
             a.layer = net.layers.get_conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
             a.x0 = h;
             a.up = 2;
+            a.want_stats = true;
             Tensor o;
             if (b.conv(a, &o)) return 1;
             b.release(h);
@@ -872,20 +993,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
 static int unet_make_plan(rldm_unet* m, int B, std::unique_ptr<Plan>* out, int* launches = nullptr) {
     auto plan = std::make_unique<Plan>();
     plan->B = B; plan->W = m->cfg.sample_w; plan->H = m->cfg.sample_h;
-    Builder dry;
-    dry.plan = plan.get();
-    dry.dry = true;
-    dry.temb_ld = m->net.temb_ld;
-    if (unet_walk(m, dry, B)) return 1;
-    if (launches) *launches = dry.launches;
-    if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
-    plan->flops = 0;
-    Builder real;
-    real.plan = plan.get();
-    real.dry = false;
-    real.base = plan->arena.as<char>();
-    real.temb_ld = m->net.temb_ld;
-    if (unet_walk(m, real, B)) return 1;
+    if (build_plan(plan.get(), m->net.temb_ld, [&](Builder& b) { return unet_walk(m, b, B); }, launches)) return 1;
     *out = std::move(plan);
     return 0;
 }
@@ -1014,6 +1122,7 @@ static int vae_walk_decode(rldm_vae* m, Builder& b, int B, int w, int h) {
     ConvArgs a;
     a.layer = net.layers.get_conv("decoder.conv_in");
     a.x0 = xin;
+    a.want_stats = true;
     if (b.conv(a, &t)) return 1;
     b.release(xin);
     Tensor o;
@@ -1031,6 +1140,7 @@ static int vae_walk_decode(rldm_vae* m, Builder& b, int B, int w, int h) {
             u.layer = net.layers.get_conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
             u.x0 = t;
             u.up = 2;
+            u.want_stats = true;
             if (b.conv(u, &o)) return 1;
             b.release(t);
             t = o;
@@ -1058,6 +1168,7 @@ static int vae_walk_encode(rldm_vae* m, Builder& b, int B, int w, int h) {
     ConvArgs a;
     a.layer = net.layers.get_conv("encoder.conv_in");
     a.x0 = xin;
+    a.want_stats = true;
     if (b.conv(a, &t)) return 1;
     b.release(xin);
     Tensor o;
@@ -1071,6 +1182,7 @@ static int vae_walk_encode(rldm_vae* m, Builder& b, int B, int w, int h) {
             d.layer = net.layers.get_conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv");
             d.x0 = t;
             d.stride = 2;
+            d.want_stats = true;
             d.pad_mode = 1;                          // end-only pad: ldm/utils.py:109-111, model.py:164-172
             if (b.conv(d, &o)) return 1;
             b.release(t);
@@ -1096,17 +1208,8 @@ static int vae_walk_encode(rldm_vae* m, Builder& b, int B, int w, int h) {
 static int vae_make_plan(rldm_vae* m, int B, int w, int h, bool enc, std::unique_ptr<Plan>* out) {
     auto plan = std::make_unique<Plan>();
     plan->B = B; plan->W = w; plan->H = h;
-    Builder dry;
-    dry.plan = plan.get();
-    dry.dry = true;
-    if (enc ? vae_walk_encode(m, dry, B, w, h) : vae_walk_decode(m, dry, B, w, h)) return 1;
-    if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
-    plan->flops = 0;
-    Builder real;
-    real.plan = plan.get();
-    real.dry = false;
-    real.base = plan->arena.as<char>();
-    if (enc ? vae_walk_encode(m, real, B, w, h) : vae_walk_decode(m, real, B, w, h)) return 1;
+    if (build_plan(plan.get(), 0, [&](Builder& b) { return enc ? vae_walk_encode(m, b, B, w, h) : vae_walk_decode(m, b, B, w, h); }))
+        return 1;
     *out = std::move(plan);
     return 0;
 }
@@ -1296,6 +1399,7 @@ int rldm_unet_num_launches(rldm_unet* m, int B) {
     Builder dry;
     dry.plan = &tmp;
     dry.dry = true;
+    dry.temb_ld = m->net.temb_ld;
     if (unet_walk(m, dry, B)) return -1;
     return dry.launches + 1;   // + time-embedding kernel
 }
@@ -1530,96 +1634,217 @@ int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size
 }
 
 // ---- kernel-level test entry points ---------------------------------------------------------------------------------
+namespace {
+struct ConvCase {
+    Layers layers;
+    Plan plan;
+    Tensor t0, t1, tr, out;
+    int Wout = 0, Hout = 0, C0p = 0;
+};
+// one fused conv as a plan: [statistics of x0/x1 when gn] + conv
+int make_conv_case(ConvCase& cc, const rldm_conv_desc* d, const float* weight, const float* bias, const float* gamma,
+                   const float* beta, int res_channels, bool with_temb) {
+    const bool with_res = res_channels > 0;
+    const int Cin = d->Cin0 + d->Cin1;
+    cc.C0p = d->Cin1 ? d->Cin0 : pad16(d->Cin0);
+    RLDM_REQUIRE(d->Cin1 == 0 || (d->Cin0 % 16 == 0 && Cin % 16 == 0), "concat test needs Cin0 % 16 == 0 and Cin % 16 == 0");
+    ParamStore ps;
+    ps.host["c.weight"].assign(weight, weight + (size_t)d->Cout * Cin * d->ksize * d->ksize);
+    ps.host["c.bias"].assign(bias, bias + d->Cout);
+    if (cc.layers.add_conv(ps, "c", d->Cout, Cin, d->ksize)) return 1;
+    if (with_res) {                                   // `+ res`: identity residual phase over Cout channels, or (bench
+        ConvLayer* L = cc.layers.get_conv("c");       // only) a synthetic 1x1 shortcut over res_channels
+        L->R = res_channels;
+        L->sc_identity = res_channels == d->Cout;
+        if (!L->sc_identity) {
+            L->sc_w.resize((size_t)d->Cout * res_channels);
+            uint32_t rng = 777u;
+            for (auto& v : L->sc_w) {
+                rng = rng * 1664525u + 1013904223u;
+                v = (((rng >> 8) & 0xffff) / 32768.0f - 1.0f) / std::sqrt((float)res_channels);
+            }
+        }
+    }
+    if (d->gn) {
+        RLDM_REQUIRE(gamma && beta && cc.C0p + d->Cin1 == Cin, "GroupNorm test needs unpadded channels");
+        ps.host["n.weight"].assign(gamma, gamma + Cin);
+        ps.host["n.bias"].assign(beta, beta + Cin);
+        if (cc.layers.add_norm(ps, "n", Cin)) return 1;
+    }
+    const int s = d->stride, up = d->upsample ? 2 : 1;
+    cc.Wout = d->Win * up / s;
+    cc.Hout = d->Hin * up / s;
+    auto walk = [&cc, d, with_res, res_channels, with_temb, s, up](Builder& bb) -> int {
+        cc.t0 = bb.make(d->B, d->Win, d->Hin, cc.C0p);
+        cc.t1 = Tensor();
+        cc.tr = Tensor();
+        if (d->Cin1) cc.t1 = bb.make(d->B, d->Win, d->Hin, d->Cin1);
+        if (with_res) cc.tr = bb.make(d->B, cc.Wout, cc.Hout, res_channels);
+        if (d->gn) {
+            if (bb.gn_stats(cc.t0)) return 1;
+            if (d->Cin1 && bb.gn_stats(cc.t1)) return 1;
+        }
+        ConvArgs a;
+        a.layer = cc.layers.get_conv("c");
+        a.x0 = cc.t0; a.x1 = cc.t1;
+        a.stride = s; a.pad_mode = d->pad_mode; a.up = up;
+        a.gn = d->gn ? cc.layers.get_norm("n") : nullptr;
+        a.eps = d->eps; a.silu = d->silu;
+        a.temb_off = with_temb ? 0 : -1;
+        a.r0 = cc.tr;
+        a.want_stats = true;
+        return bb.conv(a, &cc.out);
+    };
+    return build_plan(&cc.plan, d->Cout, walk);
+}
+}  // namespace
+
 int rldm_test_conv(const rldm_conv_desc* d, const float* x0, const float* x1, const float* weight, const float* bias,
                    const float* gamma, const float* beta, const float* temb, const float* res, float* y, void* stream) {
     RLDM_REQUIRE(d && x0 && weight && bias && y, "null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int Cin = d->Cin0 + d->Cin1;
-    const int C0p = d->Cin1 ? d->Cin0 : pad16(d->Cin0);
-    RLDM_REQUIRE(d->Cin1 == 0 || (d->Cin0 % 8 == 0 && Cin % 16 == 0), "concat test needs Cin0 % 8 == 0 and Cin % 16 == 0");
-    ParamStore ps;
-    ps.host["c.weight"].assign(weight, weight + (size_t)d->Cout * Cin * d->ksize * d->ksize);
-    ps.host["c.bias"].assign(bias, bias + d->Cout);
-    Layers layers;
-    if (layers.add_conv(ps, "c", d->Cout, Cin, d->ksize)) return 1;
-    if (d->gn) {
-        RLDM_REQUIRE(gamma && beta && C0p + d->Cin1 == Cin, "GroupNorm test needs unpadded channels");
-        ps.host["n.weight"].assign(gamma, gamma + Cin);
-        ps.host["n.bias"].assign(beta, beta + Cin);
-        if (layers.add_norm(ps, "n", Cin)) return 1;
-    }
-    Plan plan;
-    const int s = d->stride, up = d->upsample ? 2 : 1;
-    const int Wout = d->Win * up / s, Hout = d->Hin * up / s;
+    ConvCase cc;
+    if (make_conv_case(cc, d, weight, bias, gamma, beta, res ? d->Cout : 0, temb != nullptr)) return 1;
     DevBuf tembd;
     if (temb && upload(tembd, temb, (size_t)d->B * d->Cout * 4)) return 1;
-    Tensor t0, t1, tr, out;
-    auto walk = [&](Builder& bb) -> int {
-        t0 = bb.make(d->B, d->Win, d->Hin, C0p);
-        t1 = Tensor();
-        tr = Tensor();
-        if (d->Cin1) t1 = bb.make(d->B, d->Win, d->Hin, d->Cin1);
-        if (res) tr = bb.make(d->B, Wout, Hout, d->Cout);
-        ConvArgs a;
-        a.layer = layers.get_conv("c");
-        a.x0 = t0; a.x1 = t1;
-        a.stride = s; a.pad_mode = d->pad_mode; a.up = up;
-        a.gn = d->gn ? layers.get_norm("n") : nullptr;
-        a.eps = d->eps; a.silu = d->silu;
-        a.temb_off = temb ? 0 : -1;
-        a.res = tr;
-        return bb.conv(a, &out);
-    };
-    Builder dry;
-    dry.plan = &plan;
-    dry.dry = true;
-    dry.temb_ld = d->Cout;
-    if (walk(dry)) return 1;
-    if (plan.arena.alloc(dry.arena.peak + 256)) return 1;
-    Builder real;
-    real.plan = &plan;
-    real.dry = false;
-    real.temb_ld = d->Cout;
-    real.base = plan.arena.as<char>();
-    if (walk(real)) return 1;
-    if (launch_nchw_f32_to_nhwc_bf16(x0, real.tptr(t0), d->B, d->Cin0, d->Win, d->Hin, C0p, st)) return 1;
-    if (d->Cin1 && launch_nchw_f32_to_nhwc_bf16(x1, real.tptr(t1), d->B, d->Cin1, d->Win, d->Hin, d->Cin1, st)) return 1;
-    if (res && launch_nchw_f32_to_nhwc_bf16(res, real.tptr(tr), d->B, d->Cout, Wout, Hout, d->Cout, st)) return 1;
-    plan.io.temb = tembd.as<float>();
-    plan.io.temb_rows_per_step = d->B;
-    plan.io.temb_per_sample = 1;
-    if (plan.run(st)) return 1;
-    if (launch_nhwc_bf16_to_nchw_f32(real.tptr(out), y, d->B, d->Cout, Wout, Hout, d->Cout, st)) return 1;
+    char* base = cc.plan.arena.as<char>();
+    auto tp = [&](const Tensor& t) { return reinterpret_cast<bf16_t*>(base + t.off); };
+    if (launch_nchw_f32_to_nhwc_bf16(x0, tp(cc.t0), d->B, d->Cin0, d->Win, d->Hin, cc.C0p, st)) return 1;
+    if (d->Cin1 && launch_nchw_f32_to_nhwc_bf16(x1, tp(cc.t1), d->B, d->Cin1, d->Win, d->Hin, d->Cin1, st)) return 1;
+    if (res && launch_nchw_f32_to_nhwc_bf16(res, tp(cc.tr), d->B, d->Cout, cc.Wout, cc.Hout, d->Cout, st)) return 1;
+    cc.plan.io.temb = tembd.as<float>();
+    cc.plan.io.temb_rows_per_step = d->B;
+    cc.plan.io.temb_per_sample = 1;
+    if (cc.plan.run(st)) return 1;
+    if (launch_nhwc_bf16_to_nchw_f32(tp(cc.out), y, d->B, d->Cout, cc.Wout, cc.Hout, d->Cout, st)) return 1;
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// per-channel statistics the conv epilogue emitted for its output: (sum, sumsq) over each image -> stats [B][Cout][2]
+int rldm_test_conv_stats(const rldm_conv_desc* d, const float* x0, const float* weight, const float* bias, float* stats,
+                         void* stream) {
+    RLDM_REQUIRE(d && x0 && weight && bias && stats, "null argument");
+    RLDM_REQUIRE(d->Cin1 == 0 && !d->gn, "stats test: plain single-input conv only");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ConvCase cc;
+    if (make_conv_case(cc, d, weight, bias, nullptr, nullptr, 0, false)) return 1;
+    char* base = cc.plan.arena.as<char>();
+    if (launch_nchw_f32_to_nhwc_bf16(x0, reinterpret_cast<bf16_t*>(base + cc.t0.off), d->B, d->Cin0, d->Win, d->Hin, cc.C0p, st)) return 1;
+    if (cc.plan.run(st)) return 1;
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    RLDM_REQUIRE(cc.out.P > 0, "internal: conv output carries no statistics");
+    std::vector<float2> part((size_t)d->B * cc.out.P * d->Cout);
+    RLDM_HIP_CHECK(hipMemcpy(part.data(), base + cc.out.st_off, part.size() * sizeof(float2), hipMemcpyDeviceToHost));
+    std::vector<float> hs((size_t)d->B * d->Cout * 2, 0.f);
+    for (int b = 0; b < d->B; ++b)
+        for (int q = 0; q < cc.out.P; ++q)
+            for (int c = 0; c < d->Cout; ++c) {
+                const float2 v = part[((size_t)b * cc.out.P + q) * d->Cout + c];
+                hs[((size_t)b * d->Cout + c) * 2] += v.x;
+                hs[((size_t)b * d->Cout + c) * 2 + 1] += v.y;
+            }
+    RLDM_HIP_CHECK(hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int rldm_debug_set_flags(int flags) {
+    g_dbg_flags = flags;
+    return 0;
+}
+
+// enable (host_out == NULL: allocate + zero) or read back (host_out = 256 x u64) the in-kernel timestamps of the conv kernel
+int rldm_debug_timestamps(unsigned long long* host_out) {
+    if (!g_ts_buf) {
+        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_ts_buf), 256 * 8));
+        RLDM_HIP_CHECK(hipMemset(g_ts_buf, 0, 256 * 8));
+    }
+    if (host_out) {
+        RLDM_HIP_CHECK(hipDeviceSynchronize());
+        RLDM_HIP_CHECK(hipMemcpy(host_out, g_ts_buf, 256 * 8, hipMemcpyDeviceToHost));
+        RLDM_HIP_CHECK(hipMemset(g_ts_buf, 0, 256 * 8));
+    }
+    return 0;
+}
+
+int rldm_debug_force_tile(int BM, int BN, int ksplit) {
+    g_force_bm = BM;
+    g_force_bn = BN;
+    g_force_ks = ksplit;
+    return 0;
+}
+
+// times the fused conv kernel alone (HIP events on `stream`) on synthetic device data; the statistics launches of a
+// GroupNorm case run once before the timed region
+int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int warmup, int iters, float* avg_us,
+                    char* kernel_name, size_t name_cap, void* stream) {
+    RLDM_REQUIRE(d && avg_us && iters >= 1, "bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Cin = d->Cin0 + d->Cin1;
+    const int taps = d->ksize * d->ksize;
+    std::vector<float> w((size_t)d->Cout * Cin * taps), bias(d->Cout), gamma(Cin, 1.f), beta(Cin, 0.f);
+    uint32_t rng = 12345u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    const float ws = 1.0f / std::sqrt((float)Cin * taps);
+    for (auto& v : w) v = rnd() * ws;
+    for (auto& v : bias) v = rnd() * 0.1f;
+    ConvCase cc;
+    if (make_conv_case(cc, d, w.data(), bias.data(), gamma.data(), beta.data(), with_res, with_temb != 0)) return 1;
+    DevBuf tembd;
+    if (with_temb) {
+        std::vector<float> t((size_t)d->B * d->Cout);
+        for (auto& v : t) v = rnd();
+        if (upload(tembd, t.data(), t.size() * 4)) return 1;
+    }
+    {   // synthetic activations: bf16 uniform(-1, 1)
+        std::vector<bf16_t> h(cc.plan.arena.bytes / 2);
+        for (auto& v : h) v = f32_to_bf16(rnd());
+        RLDM_HIP_CHECK(hipMemcpy(cc.plan.arena.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
+    cc.plan.io.temb = tembd.as<float>();
+    cc.plan.io.temb_rows_per_step = d->B;
+    cc.plan.io.temb_per_sample = 1;
+    RLDM_REQUIRE(!cc.plan.ops.empty(), "internal: empty plan");
+    Op& conv_op = cc.plan.ops.back();
+    if (kernel_name && name_cap) {
+        strncpy(kernel_name, conv_op.name.c_str(), name_cap - 1);
+        kernel_name[name_cap - 1] = 0;
+    }
+    if (cc.plan.run(st)) return 1;
+    for (int i = 0; i < warmup; ++i)
+        if (conv_op.fn(st)) return 1;
+    hipEvent_t e0, e1;
+    RLDM_HIP_CHECK(hipEventCreate(&e0));
+    RLDM_HIP_CHECK(hipEventCreate(&e1));
+    RLDM_HIP_CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i)
+        if (conv_op.fn(st)) return 1;
+    RLDM_HIP_CHECK(hipEventRecord(e1, st));
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    RLDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = ms * 1000.0f / iters;
     return 0;
 }
 
 int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void* stream) {
     RLDM_REQUIRE(qkv && out, "null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // host-side re-layout keeps this test path trivial: qk [B][L][2C] (q scaled), vt [B][C/8][8][L]
+    // host-side conversion keeps this test path trivial: qkv [B][L][3C] bf16 with q pre-scaled by log2(e)/sqrt(8)
     std::vector<float> h((size_t)B * L * 3 * C);
     RLDM_HIP_CHECK(hipMemcpy(h.data(), qkv, h.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<bf16_t> qk((size_t)B * L * 2 * C), vt((size_t)B * C * L);
+    std::vector<bf16_t> hq(h.size());
     const float qs = 1.4426950408889634f / std::sqrt(8.0f);
-    const int heads = C / 8;
-    for (int b = 0; b < B; ++b)
-        for (int l = 0; l < L; ++l) {
-            const float* row = &h[((size_t)b * L + l) * 3 * C];
-            for (int c = 0; c < C; ++c) {
-                qk[((size_t)b * L + l) * 2 * C + c] = f32_to_bf16(row[c] * qs);
-                qk[((size_t)b * L + l) * 2 * C + C + c] = f32_to_bf16(row[C + c]);
-                vt[(((size_t)b * heads + c / 8) * 8 + c % 8) * L + l] = f32_to_bf16(row[2 * C + c]);
-            }
-        }
-    DevBuf dqk, dvt, dout;
-    if (upload(dqk, qk.data(), qk.size() * 2) || upload(dvt, vt.data(), vt.size() * 2)) return 1;
+    for (size_t i = 0; i < h.size(); ++i) hq[i] = f32_to_bf16((int)(i % (3 * (size_t)C)) < C ? h[i] * qs : h[i]);
+    DevBuf dq, dout;
+    if (upload(dq, hq.data(), hq.size() * 2)) return 1;
     if (dout.alloc((size_t)B * L * C * 2)) return 1;
     AttnParams ap;
-    ap.qk = dqk.as<bf16_t>(); ap.vt = dvt.as<bf16_t>(); ap.out = dout.as<bf16_t>();
+    ap.qkv = dq.as<bf16_t>(); ap.out = dout.as<bf16_t>();
     ap.B = B; ap.L = L; ap.C = C;
     if (launch_attention(ap, st)) return 1;
-    // out is [B][L][C] channels-last == "NHWC" with W*H = L
     std::vector<bf16_t> ho((size_t)B * L * C);
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
     RLDM_HIP_CHECK(hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost));

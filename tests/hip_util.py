@@ -66,3 +66,22 @@ def hip_attention(qkv, C_):
                                               _lib.stream_ptr(dev)), "rldm_test_attention")
     torch.cuda.synchronize()
     return out.cpu()
+
+
+def hip_conv_stats(x0, weight, bias, stride=1):
+    """rldm_test_conv_stats: per-image per-channel (sum, sumsq) the conv epilogue emitted for its bf16 output."""
+    dev = torch.device("cuda")
+    d = _lib.ConvDescC()
+    B, C0, W, H = x0.shape
+    d.B, d.Cin0, d.Win, d.Hin, d.Cin1 = B, C0, W, H, 0
+    d.Cout, d.ksize = weight.shape[0], weight.shape[2]
+    d.stride, d.pad_mode, d.upsample, d.gn, d.silu, d.eps = stride, 0, 0, 0, 0, 1e-5
+    xs = x0.to(dev, torch.float32).contiguous()
+    hw = np.ascontiguousarray(weight.numpy(), dtype=np.float32)
+    hb = np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+    st = torch.empty((B, d.Cout, 2), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().rldm_test_conv_stats(C.byref(d), C.c_void_p(xs.data_ptr()), hw.ctypes.data_as(C.c_void_p),
+                                               hb.ctypes.data_as(C.c_void_p), C.c_void_p(st.data_ptr()),
+                                               _lib.stream_ptr(dev)), "rldm_test_conv_stats")
+    torch.cuda.synchronize()
+    return st.cpu()

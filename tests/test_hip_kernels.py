@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ops
-from tests.hip_util import bf16r, rel_l2, hip_conv, hip_attention
+from tests.hip_util import bf16r, rel_l2, hip_conv, hip_attention, hip_conv_stats
 
 pytestmark = pytest.mark.gpu
 TOL_Q, TOL_F = 4e-3, 2e-2
@@ -100,6 +100,23 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H):
 
     assert rel_l2(y, ref(bf16r)) < TOL_Q
     assert rel_l2(y, ref(lambda t: t)) < TOL_F
+
+
+@pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
+                                                (1, 128, 128, 256, 16, 3)])
+def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
+    """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
+    the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
+    x = _rand(B, Cin, W, H, seed=30)
+    w = _rand(Cout, Cin, k, k, seed=31, scale=(Cin * k * k) ** -0.5)
+    b = _rand(Cout, seed=32, scale=0.5)
+    y = hip_conv(x, w, b)                       # bf16 outputs, widened to fp32
+    st = hip_conv_stats(x, w, b)
+    ref_s = y.double().sum(dim=(2, 3))
+    ref_q = (y.double() ** 2).sum(dim=(2, 3))
+    n = W * H
+    assert float((st[..., 0].double() - ref_s).abs().max()) < 1e-4 * n
+    assert float(((st[..., 1].double() - ref_q).abs() / (ref_q + 1e-6)).max()) < 1e-4
 
 
 def test_conv_gn_no_silu_1x1():
