@@ -370,11 +370,12 @@ static void pixel_tile(int BM, int Wout, int Hout, int stride, int* TW, int* TH)
     *TH = th;
 }
 
-static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N, int Cin_pad, int R, int taps, bool nchw) {
+static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N, int Cin_pad, int C0, int R, int R0,
+                              int taps, bool nchw) {
     TileChoice c;
     ConvTile& t = c.tile;
     t.taps = taps;
-    t.CK = (Cin_pad % 64 == 0 && R % 64 == 0) ? 64 : 16;
+    t.CK = (Cin_pad % 64 == 0 && C0 % 64 == 0 && R % 64 == 0 && R0 % 64 == 0) ? 64 : 16;   // chunks never straddle a concat
     const int KW = taps == 9 ? 3 : 1;
     const int ncc = Cin_pad / t.CK, ncb = R / t.CK;
     auto fits = [&](const ConvTile& u, int* tw, int* th) {
@@ -390,19 +391,22 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
         return B * (Wout / tw) * (Hout / th) * ((N + u.BN - 1) / u.BN);
     };
     const int bn_pref = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
-    // candidates in order of preference (largest first); take the first that fills the chip, else the one with most blocks
+    // candidates in order of preference (preferred channel tile first, largest pixel tile first); take the first that
+    // fills the chip, else the one with the most blocks.  Pass 1 also accepts tiles that are mostly padding; pass 2 any
+    // channel tile (small test configurations have few instances).
     const int bms[3] = {256, 128, 64};
-    const int bns[3] = {bn_pref, bn_pref > 64 ? 64 : bn_pref, bn_pref > 32 && N <= 32 ? 32 : bn_pref};
+    std::vector<int> bns = {bn_pref};
+    if (bn_pref > 64) bns.push_back(64);
     long long best_blocks = -1;
     TileChoice best;
     bool found = false;
-    for (int pass = 0; pass < 2 && best_blocks < 0; ++pass)      // pass 1 also accepts tiles that are mostly padding
+    for (int pass = 0; pass < 3 && best_blocks < 0; ++pass) {
+        if (pass == 2) bns = {32, 64, 128};
         for (int bi = 0; bi < 3 && !found; ++bi)
-            for (int ni = 0; ni < 2 && !found; ++ni) {
+            for (size_t ni = 0; ni < bns.size() && !found; ++ni) {
                 ConvTile u = t;
                 u.BM = bms[bi];
                 u.BN = bns[ni];
-                if (ni == 1 && bns[1] == bns[0]) continue;
                 int tw, th;
                 if (!fits(u, &tw, &th)) continue;
                 if (pass == 0 && tw * th * 2 <= u.BM && bi < 2) continue;   // more than half empty: try a smaller BM first
@@ -415,6 +419,7 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
                 }
                 if (nb >= 200) found = true;
             }
+    }
     if (g_force_bm && g_force_bn) {
         ConvTile u = t;
         u.BM = g_force_bm;
@@ -522,7 +527,8 @@ struct Builder {
         RLDM_REQUIRE(Wv % a.stride == 0 && Hv % a.stride == 0, "conv " + L->name + ": odd size under stride 2");
         RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
-        const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, R_t, taps, a.out_f32_nchw);
+        const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, x0.C, R_t, a.r0.valid() ? a.r0.C : 0, taps,
+                                          a.out_f32_nchw);
         const ConvTile tile = tc.tile;
         RLDM_REQUIRE(conv_tile_supported(tile), "conv " + L->name + ": no kernel instance");
 
