@@ -61,7 +61,10 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
 __device__ inline float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) on the hardware exp2 / rcp units (1 ulp class; the result is rounded to bf16 right after)
+__device__ inline float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // XCD-aware block remap (guide T1): blocks land on XCD (bid % 8); give each XCD a contiguous range of logical ids
 // so neighbouring tiles (which share input halos / weight panels) hit the same private L2.  Bijective for any n.

@@ -27,6 +27,7 @@ struct ConvParams {
     int pad_lo;             // 1: symmetric pad 1, 0: end-only pad (or 1x1)
     int Wout, Hout;
     int TW, TH;             // output-pixel tile handled by one block (TW*TH <= BM)
+    int colb;               // halo column pitch in bytes (conv_halo_col_bytes)
     // GroupNorm prologue (null st0 -> none): per-channel partial (sum, sumsq) [B][P][C] written by the producers of x0/x1
     const float2* st0;
     const float2* st1;
@@ -68,6 +69,7 @@ inline int conv_row_bytes(int CK) { return CK * 2 + 16; }
 size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p);
 bool conv_tile_supported(const ConvTile& t);
 int conv_max_halo_slots(const ConvTile& t);
+int conv_halo_col_bytes(const ConvTile& t, int TH, int stride);
 int conv_tile_threads(const ConvTile& t);
 int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream);
 

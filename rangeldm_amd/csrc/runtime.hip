@@ -543,6 +543,7 @@ struct Builder {
         p.pad_lo = (L->ksize == 1) ? 0 : (a.pad_mode == 0 ? 1 : 0);
         p.Wout = Wout; p.Hout = Hout;
         p.TW = tc.TW; p.TH = tc.TH;
+        p.colb = conv_halo_col_bytes(tile, tc.TH, a.stride);
         RLDM_REQUIRE(Wout % p.TW == 0 && Hout % p.TH == 0, "conv " + L->name + ": size not tileable (powers of two expected)");
         p.N = N;
         p.silu = a.silu;
