@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     stamp();
 
     // ---- which tile / K slice -----------------------------------------------------------------------------------
-    const int tiles_h = p.Hout / p.TH;
-    const int tiles_img = (p.Wout / p.TW) * tiles_h;
+    const int tiles_h = p.tiles_h;
+    const int tiles_img = p.tiles_img;
     int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int ksl = lid % p.ksplit;
     lid /= p.ksplit;
@@ -137,7 +137,6 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     float* sGa = reinterpret_cast<float*>(sA + 2 * abytes);    // Cin
     float* sGs = sGa + Cin;                                    // Cin
     float* sBias = sGs + Cin;                                  // BN
-    if (tid < BN) sBias[tid] = bias_v;         // visible after the barriers below
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     // ---- weight stream ----------------------------------------------------------------------------------------
@@ -164,7 +163,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     for (int i = 0; i < ACH; ++i) {
         const int q = tid + i * NT;
         const int slot = q / C8, c8 = q - slot * C8;
-        const int vwl = slot / THv, vhl = slot - vwl * THv;
+        const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;    // exact for slot * THv < 2^20
         const int vh = h0 * p.stride - p.pad_lo + vhl;
         int vw = w0 * p.stride - p.pad_lo + vwl;
         vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);          // azimuth: wrap-around
@@ -234,6 +233,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     };
     stamp();
     if (NS > 0) load_a(cbeg);                 // in flight while the GroupNorm statistics are folded
+    if (tid < BN) sBias[tid] = bias_v;         // visible after the barriers below
 
     // ---- GroupNorm finalize: per-channel partial (sum, sumsq) of the producers -> per-channel affine a*x + s --------
     if (gn) {
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         for (int j = 0; j < 2; ++j) {
             const int t = tid + j * NT;
             if (t < Cin) {
-                const int g = t / cpg;
+                const int g = (t * p.magic_cpg) >> 20;
                 ga[j] = p.gn_gamma[t] * (float)sD[2 * Cin + p.gn_groups + g];
                 gs[j] = p.gn_beta[t] - (float)sD[2 * Cin + g] * ga[j];
             }
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     if (NS > 0) {
         load_affine(cbeg);
         store_a(cbeg);
-        if (cbeg + 1 < cend) { load_a(cbeg + 1); loaded = cbeg + 1; }
+        if ((TAPS == 1 || cbeg >= NCC) && cbeg + 1 < cend) { load_a(cbeg + 1); loaded = cbeg + 1; }   // 1-stage chunks: two ahead
     }
 
     // ---- per-lane LDS byte offsets of the MFMA operands ----------------------------------------------------------
@@ -316,14 +316,14 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     for (int mi = 0; mi < MI; ++mi) {
         int pidx = wm * (MI * 32) + mi * 32 + l31;
         if (pidx >= npx) pidx = 0;            // masked at the store
-        const int pw = pidx / p.TH, ph = pidx - pw * p.TH;
+        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
         xoff[mi] = (pw * p.stride) * colb + (ph * p.stride) * RS + kh * 16;
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) woff[ni] = (wn * (NI * 32) + ni * 32 + l31) * RS + kh * 16;
 
     f32x16 acc[NI][MI];
-    __syncthreads();                           // sBias (and, without GroupNorm, the first halo chunk) written
+    lds_barrier();                             // sBias (and, without GroupNorm, the first halo chunk) written
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         for (int mi = 0; mi < MI; ++mi) {
             const int pidx = wm * (MI * 32) + mi * 32 + l31;
             if (pidx >= npx) continue;
-            const int pw = pidx / p.TH, ph = pidx - pw * p.TH;
+            const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
             const int ow = w0 + pw, oh = h0 + ph;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                 *reinterpret_cast<uint2*>(sE + pidx * ERS + chl * 2) = o;
             }
     }
-    __syncthreads();
+    lds_barrier();
     stamp();
     // (2) 16-byte pieces, channel-fastest: fully coalesced stores; per-channel statistics of exactly the stored values
     const int c8 = tid % NC8;
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
     for (int pidx = tid / NC8; pidx < npx; pidx += NT / NC8) {
         const uint4 v = *reinterpret_cast<const uint4*>(sE + pidx * ERS + c8 * 16);
-        const int pw = pidx / p.TH, ph = pidx - pw * p.TH;
+        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
         const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
         if (cvalid && !(p.dbg & 1)) {
             if (vec_ok) {
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         *reinterpret_cast<float4*>(sS + g * BN + c8 * 8 + 4) = make_float4(s8[4], s8[5], s8[6], s8[7]);
         *reinterpret_cast<float4*>(sS + (G + g) * BN + c8 * 8) = make_float4(q8[0], q8[1], q8[2], q8[3]);
         *reinterpret_cast<float4*>(sS + (G + g) * BN + c8 * 8 + 4) = make_float4(q8[4], q8[5], q8[6], q8[7]);
-        __syncthreads();
+        lds_barrier();                         // (not __syncthreads: that would also drain the output stores)
         for (int t = tid; t < 2 * BN; t += NT) {
             const int kind = t / BN, c = t - kind * BN;
             float S = 0.f;

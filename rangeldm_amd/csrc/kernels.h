@@ -28,6 +28,10 @@ struct ConvParams {
     int Wout, Hout;
     int TW, TH;             // output-pixel tile handled by one block (TW*TH <= BM)
     int colb;               // halo column pitch in bytes (conv_halo_col_bytes)
+    int tiles_h, tiles_img; // Hout / TH, (Wout / TW) * tiles_h
+    int th_shift;           // log2(TH) (TH is a power of two)
+    int magic_thv;          // ceil(2^20 / halo rows): slot / THv == (slot * magic) >> 20
+    int magic_cpg;          // ceil(2^20 / channels per group)
     // GroupNorm prologue (null st0 -> none): per-channel partial (sum, sumsq) [B][P][C] written by the producers of x0/x1
     const float2* st0;
     const float2* st1;

@@ -544,6 +544,17 @@ struct Builder {
         p.Wout = Wout; p.Hout = Hout;
         p.TW = tc.TW; p.TH = tc.TH;
         p.colb = conv_halo_col_bytes(tile, tc.TH, a.stride);
+        p.tiles_h = Hout / p.TH;
+        p.tiles_img = (Wout / p.TW) * p.tiles_h;
+        RLDM_REQUIRE((p.TH & (p.TH - 1)) == 0, "conv " + L->name + ": pixel tile height must be a power of two");
+        p.th_shift = 0;
+        while ((1 << p.th_shift) < p.TH) ++p.th_shift;
+        {
+            const int thv = (p.TH - 1) * a.stride + (L->ksize == 3 ? 3 : 1);
+            p.magic_thv = ((1 << 20) + thv - 1) / thv;
+            const int cpg = std::max(1, Cin_t / a.groups);
+            p.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+        }
         RLDM_REQUIRE(Wout % p.TW == 0 && Hout % p.TH == 0, "conv " + L->name + ": size not tileable (powers of two expected)");
         p.N = N;
         p.silu = a.silu;
