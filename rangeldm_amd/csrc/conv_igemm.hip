@@ -53,7 +53,7 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int ACH>
+template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int TG, int ACH>
 __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = 64 * NW;               // threads
     constexpr int MI = BM / (32 * WM);        // 32-pixel MFMA tiles per wave
@@ -62,10 +62,18 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     constexpr int KS = CK / 16;               // MFMA k-steps per stage
     constexpr int KW = (TAPS == 9) ? 3 : 1;
     constexpr int C8 = CK / 8;                // 16-byte pieces per LDS row
-    constexpr int WTILE = BN * RS;            // bytes of one weight stage
-    constexpr int WCH = WTILE / 16;           // 16-byte pieces per weight stage
-    constexpr int DPT = (WCH + NT - 1) / NT;  // DMA instructions per wave per stage
-    constexpr int NBUF = 3;                   // weight ring depth
+    constexpr int WTILE = BN * RS;            // bytes of one tap of weights (one residual-phase stage)
+    constexpr int WCH = WTILE / 16;           // ... in 16-byte pieces
+    constexpr int STILE = TG * WTILE;         // bytes of one main-phase stage (TG taps) = one ring slot
+    constexpr int SCH = STILE / 16;
+    constexpr int SPC = TAPS / TG;            // stages per main-phase chunk
+    constexpr int DPT = (SCH + NT - 1) / NT;  // DMA instructions per wave per main-phase stage
+    constexpr int DPTR = (WCH + NT - 1) / NT; // ... per residual-phase stage
+    constexpr int PPT = (DPT + TG - 1) / TG;  // DMA instructions issued in the shadow of one tap
+    constexpr int NBUF = (TG == 9) ? 2 : 3;   // weight ring depth
+    constexpr int DD = NBUF - 1;              // the DMA of stage s + DD is issued during stage s
+    static_assert(TAPS % TG == 0 && (TG == 1 || TG == 3 || TG == 9), "taps per stage");
+    static_assert(PPT >= DPTR, "residual-stage DMA must fit the first tap's shadow");
     constexpr int ERS = BN * 2 + 16;          // epilogue staging row stride (bytes)
     constexpr int NC8 = BN / 8;               // 16-byte pieces per output pixel row
     static_assert(WM * WN == NW, "wave grid");
@@ -121,7 +129,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     const int cper = (NCT + p.ksplit - 1) / p.ksplit;
     const int cbeg = ksl * cper;
     const int cend = (cbeg + cper < NCT) ? cbeg + cper : NCT;
-    auto stages_before = [&](int c) { return c <= NCC ? c * TAPS : NCC * TAPS + (c - NCC); };
+    auto stages_before = [&](int c) { return c <= NCC ? c * SPC : NCC * SPC + (c - NCC); };
+    const int NMS = NCC * SPC;                // main-phase stages of the whole conv (absolute stage index < NMS: TG taps)
     const int sbeg = stages_before(cbeg);
     const int NS = (p.dbg & 2) ? 0 : stages_before(cend) - sbeg;
 
@@ -132,28 +141,35 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     const int Wv = p.Win * p.up, Hv = p.Hin * p.up;
     const int upshift = p.up - 1;             // up in {1,2}
 
-    unsigned char* sW = smem;                                  // NBUF * WTILE
-    unsigned char* sA = smem + NBUF * WTILE;                   // 2 * abytes
+    unsigned char* sW = smem;                                  // NBUF * STILE
+    unsigned char* sA = smem + NBUF * STILE;                   // 2 * abytes
     float* sGa = reinterpret_cast<float*>(sA + 2 * abytes);    // Cin
     float* sGs = sGa + Cin;                                    // Cin
     float* sBias = sGs + Cin;                                  // BN
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    // ---- weight stream ----------------------------------------------------------------------------------------
-    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wpk) +
-                                ((size_t)nt * (NCC * TAPS + NCB) + sbeg) * WTILE;
-    auto issue_w = [&](int s) __attribute__((always_inline)) {   // stage s -> ring slot s % NBUF; every wave issues exactly DPT full-wave DMAs
-        const unsigned char* src = wsrc + (size_t)s * WTILE;
-        const unsigned dst = lds0 + (unsigned)((s % NBUF) * WTILE);
+    // ---- weight stream: per n-tile [NMS main stages of STILE bytes][NCB residual stages of WTILE bytes] ---------------
+    const unsigned char* wtile0 = reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)nt * (NCC * TAPS + NCB) * WTILE;
+    auto wbyte = [&](int sa) __attribute__((always_inline)) {     // byte offset of absolute stage sa
+        return sa < NMS ? (size_t)sa * STILE : (size_t)NMS * STILE + (size_t)(sa - NMS) * WTILE;
+    };
+    auto issue_pieces = [&](const unsigned char* src, unsigned dst, int lo, int hi, bool is_main) __attribute__((always_inline)) {
+        // pieces [lo, hi) of a stage; every wave issues full-wave DMAs, tail passes overlap instead of running short
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
+            if (i < lo || i >= hi) continue;
+            const int last = (is_main ? SCH : WCH) - 64;
             int piece = i * NT + wave * 64;
-            piece = piece > WCH - 64 ? WCH - 64 : piece;        // tail passes overlap instead of running short
-            lds_dma16(src + (size_t)(piece + lane) * 16, dst + (unsigned)piece * 16);
+            piece = piece > last ? last : piece;
+            lds_dma16(src + (size_t)(piece + lane) * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)piece * 16)));
         }
     };
-    if (NS > 0) issue_w(0);
-    if (NS > 1) issue_w(1);
+#pragma unroll
+    for (int j = 0; j < DD; ++j)
+        if (j < NS) {
+            const bool m = (sbeg + j) < NMS;
+            issue_pieces(wtile0 + wbyte(sbeg + j), lds0 + (unsigned)(j * STILE), 0, m ? DPT : DPTR, m);
+        }
 
     // ---- halo staging: thread-constant source pixel / LDS offset of each of its ACH 16-byte pieces ----------------
     const int atotal = TWv * THv * C8;
@@ -307,7 +323,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     if (NS > 0) {
         load_affine(cbeg);
         store_a(cbeg);
-        if ((TAPS == 1 || cbeg >= NCC) && cbeg + 1 < cend) { load_a(cbeg + 1); loaded = cbeg + 1; }   // 1-stage chunks: two ahead
+        if ((SPC == 1 || cbeg >= NCC) && cbeg + 1 < cend) { load_a(cbeg + 1); loaded = cbeg + 1; }   // 1-stage chunks: two ahead
     }
 
     // ---- per-lane LDS byte offsets of the MFMA operands ----------------------------------------------------------
@@ -335,93 +351,112 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                 acc[ni][mi][r4 * 4 + 2] = bv.z; acc[ni][mi][r4 * 4 + 3] = bv.w;
             }
         }
-    const int ctap = (TAPS == 9) ? 4 : 0;      // centre tap for the residual-phase chunks
-    auto tap_offset = [&](int cc, int st) __attribute__((always_inline)) {
-        const int tap = (cc < NCC) ? st : ctap;
-        const int ti = tap / 3, tj = tap - ti * 3;
-        return (TAPS == 9) ? ti * colb + tj * RS : 0;
-    };
     stamp();
 
     // ---- main loop ---------------------------------------------------------------------------------------------------
-    // One stage = one tap of one chunk, one raw barrier per stage.  A wave can start an MFMA only every 32 cycles while
-    // the pipe needs 16, so everything else a stage has to do is placed in the shadows between the wave's own MFMAs
-    // (tools/ubench/stage_model.hip: 842 -> 667 ns per stage): after each k-step's MFMAs the wave issues one LDS-DMA
-    // piece of W(s+2) and the ds_reads of the NEXT stage's pixel fragments for that k-step (second register set; the
-    // halo is stable across a chunk's taps, and the next chunk's image is complete one stage after its tap 0).  Only the
-    // weight fragments of the current stage are read right after the barrier.  Ping-pong of the two pixel-fragment
-    // sets = loop unrolled by two.
+    // A stage = TG taps of one CK-channel chunk (main phase) or the centre tap of one residual chunk, one raw barrier per
+    // stage.  A wave can start an MFMA only every 32 cycles while the pipe needs 16, so everything else is placed in the
+    // shadows between the wave's own MFMAs (tools/ubench/stage_model.hip: 842 -> 667 ns per stage): while the MFMAs of
+    // one tap run, the wave reads the NEXT tap's fragments into the other register set -- weights and pixels when that
+    // tap belongs to the same stage, pixels only across a stage boundary (the halo is stable across a chunk's stages;
+    // the weights of the next stage become visible at its barrier) -- and issues its share of the LDS-DMA of the stage
+    // DD stages ahead.  TG = 9 (small pixel tiles: the whole 3x3 of a chunk is resident) leaves one barrier per chunk.
+    // All taps-per-stage are odd, so the register-set parity alternates from stage to stage: loop unrolled by two.
     {
-        int cc = cbeg, st = 0;
-        bool x_ready = false;                  // the current stage's pixel fragments were prefetched
+        int cc = cbeg, sg = 0;                 // chunk, stage within the chunk
+        int toff = (cbeg < NCC || TAPS == 1) ? 0 : colb + RS;     // tap offset of the stage's first tap (residual: centre)
+        int tj = 0;                            // TG == 1: column of the 3x3 the stage is in
+        int wslot = 0, dslot = DD % NBUF;      // ring slot of stage s / of the stage whose DMA stage s issues
+        size_t doff = wbyte(sbeg + DD);        // ... and its byte offset in the stream
+        bool x_ready = false;                  // the stage's first pixel fragments were prefetched
         bool hl_prev = loaded > stored;        // halo loads were issued after the last weight DMA
-        bf16x8 wf[KS][NI], xa[KS][MI], xb[KS][MI];
+        bf16x8 wf[2][KS][NI], xf[2][KS][MI];
         int s = 0;
-#define RLDM_STAGE(XC, XN)                                                                                           \
+#define RLDM_STAGE(P)                                                                                                \
         {                                                                                                            \
             /* W(s) has landed once only the operations issued after its DMAs are outstanding (VMEM retires in order) */ \
-            if (s + 1 >= NS) wait_vmcnt<0>();                                                                        \
-            else if (hl_prev) wait_vmcnt<DPT + ACH>();                                                               \
-            else wait_vmcnt<DPT>();                                                                                  \
+            if (NBUF == 2 || s + 1 >= NS) {                                                                          \
+                wait_vmcnt<0>();                                                                                     \
+            } else if ((sbeg + s + 1) < NMS) {                                                                       \
+                if (hl_prev) wait_vmcnt<DPT + ACH>(); else wait_vmcnt<DPT>();                                        \
+            } else {                                                                                                 \
+                if (hl_prev) wait_vmcnt<DPTR + ACH>(); else wait_vmcnt<DPTR>();                                      \
+            }                                                                                                        \
             lds_barrier();                                                                                           \
             const int vis = stored;            /* halo images complete and visible to every wave */                 \
-            const unsigned char* wbuf = sW + (s % NBUF) * WTILE;                                                     \
+            const bool cmain = cc < NCC;                                                                             \
+            const unsigned char* wbase = sW + wslot * STILE;                                                         \
+            const unsigned char* abase = sA + (cc & 1) * abytes + toff;                                              \
             _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                        \
                 _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                    \
-                    wf[ks][ni] = *reinterpret_cast<const bf16x8*>(wbuf + woff[ni] + ks * 32);                        \
+                    wf[P][ks][ni] = *reinterpret_cast<const bf16x8*>(wbase + woff[ni] + ks * 32);                    \
             if (!x_ready) {                                                                                          \
-                const unsigned char* abuf = sA + (cc & 1) * abytes + tap_offset(cc, st);                             \
                 _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                    \
                     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
-                        XC[ks][mi] = *reinterpret_cast<const bf16x8*>(abuf + xoff[mi] + ks * 32);                    \
+                        xf[P][ks][mi] = *reinterpret_cast<const bf16x8*>(abase + xoff[mi] + ks * 32);                \
             }                                                                                                        \
             hl_prev = false;                                                                                         \
             if (!(p.dbg & 32)) {                                                                                     \
                 if (loaded > stored && stored + 1 <= cc + 1) { load_affine(stored + 1); store_a(stored + 1); ++stored; } \
                 if (loaded == stored && loaded + 1 < cend && loaded <= cc + 1) { load_a(loaded + 1); ++loaded; hl_prev = true; } \
             }                                                                                                        \
-            int ncc = cc, nst = st + 1;                                                                              \
-            if (nst == ((cc < NCC) ? TAPS : 1)) { nst = 0; ++ncc; }                                                  \
+            /* coordinates of the next stage */                                                                     \
+            int ncc = cc, nsg = sg + 1, ntoff = toff, ntj = tj;                                                      \
+            if (nsg == (cmain ? SPC : 1)) {                                                                          \
+                nsg = 0; ++ncc; ntj = 0;                                                                             \
+                ntoff = (ncc < NCC || TAPS == 1) ? 0 : colb + RS;                                                    \
+            } else if (TG == 1) {                                                                                    \
+                ntoff += RS;                                                                                         \
+                if (++ntj == 3) { ntj = 0; ntoff += colb - 3 * RS; }                                                 \
+            } else {                                                                                                 \
+                ntoff += colb;                 /* TG == 3: one row of the 3x3 per stage */                          \
+            }                                                                                                        \
             const bool nx = (s + 1 < NS) && (ncc <= vis);                                                            \
-            const unsigned char* nbuf = sA + (ncc & 1) * abytes + tap_offset(ncc, nst);                              \
-            const bool dma = (s + 2 < NS) && !(p.dbg & 16);                                                          \
-            const unsigned char* dsrc = wsrc + (size_t)(s + 2) * WTILE;                                              \
-            const unsigned ddst = lds0 + (unsigned)(((s + 2) % NBUF) * WTILE);                                       \
+            const unsigned char* nbase = sA + (ncc & 1) * abytes + ntoff;                                            \
+            const bool dma = (s + DD < NS) && !(p.dbg & 16);                                                         \
+            const bool dmain = (sbeg + s + DD) < NMS;                                                                \
+            const unsigned char* dsrc = wtile0 + doff;                                                               \
+            const unsigned ddst = lds0 + (unsigned)(dslot * STILE);                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                      \
-                if (!(p.dbg & 8)) {                                                                                  \
-                    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                \
-                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], XC[ks][mi], acc[ni][mi], 0, 0, 0); \
-                } else {                                                                                             \
-                    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[ks][ni]));            \
-                    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(XC[ks][mi]));            \
-                }                                                                                                    \
-                __builtin_amdgcn_sched_barrier(0);                                                                   \
-                if (dma) {                                                                                           \
-                    _Pragma("unroll") for (int i = ks; i < DPT; i += KS) {                                           \
-                        int piece = i * NT + wave * 64;                                                              \
-                        piece = piece > WCH - 64 ? WCH - 64 : piece;                                                 \
-                        lds_dma16(dsrc + (size_t)(piece + lane) * 16,                                                \
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(ddst + (unsigned)piece * 16)));      \
+            _Pragma("unroll") for (int tt = 0; tt < TG; ++tt) {                                                      \
+                if (tt > 0 && !cmain) break;   /* residual stage: one tap */                                        \
+                const int CUR = (P + tt) & 1, NXT = CUR ^ 1;                                                         \
+                const int td1 = (TG == 9) ? ((tt + 1) / 3) * colb + ((tt + 1) % 3) * RS : (TG == 3 ? (tt + 1) * RS : 0); \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
+                    if (!(p.dbg & 8)) {                                                                              \
+                        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                            \
+                            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                        \
+                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[CUR][ks][ni], xf[CUR][ks][mi], acc[ni][mi], 0, 0, 0); \
+                    } else {                                                                                         \
+                        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[CUR][ks][ni]));   \
+                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xf[CUR][ks][mi]));   \
                     }                                                                                                \
+                    __builtin_amdgcn_sched_barrier(0);                                                               \
+                    if (ks == 0 && dma) issue_pieces(dsrc, ddst, tt * PPT, dmain ? ((tt + 1) * PPT < DPT ? (tt + 1) * PPT : DPT) : (tt == 0 ? DPTR : 0), dmain); \
+                    if (tt + 1 < TG && cmain) {                                                                      \
+                        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                            \
+                            wf[NXT][ks][ni] = *reinterpret_cast<const bf16x8*>(wbase + (tt + 1) * WTILE + woff[ni] + ks * 32); \
+                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
+                            xf[NXT][ks][mi] = *reinterpret_cast<const bf16x8*>(abase + td1 + xoff[mi] + ks * 32);    \
+                    } else if (nx) {                                                                                 \
+                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
+                            xf[NXT][ks][mi] = *reinterpret_cast<const bf16x8*>(nbase + xoff[mi] + ks * 32);          \
+                    }                                                                                                \
+                    __builtin_amdgcn_sched_barrier(0);                                                               \
                 }                                                                                                    \
-                if (nx) {                                                                                            \
-                    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
-                        XN[ks][mi] = *reinterpret_cast<const bf16x8*>(nbuf + xoff[mi] + ks * 32);                    \
-                }                                                                                                    \
-                __builtin_amdgcn_sched_barrier(0);                                                                   \
             }                                                                                                        \
             x_ready = nx;                                                                                            \
-            cc = ncc;                                                                                                \
-            st = nst;                                                                                                \
+            cc = ncc; sg = nsg; toff = ntoff; tj = ntj;                                                              \
+            wslot = (wslot + 1 == NBUF) ? 0 : wslot + 1;                                                             \
+            dslot = (dslot + 1 == NBUF) ? 0 : dslot + 1;                                                             \
+            doff += dmain ? (size_t)STILE : (size_t)WTILE;                                                           \
             ++s;                                                                                                     \
             stamp();                                                                                                 \
         }
 #pragma unroll 1
         while (s < NS) {
-            RLDM_STAGE(xa, xb)
-            if (s < NS) RLDM_STAGE(xb, xa)
+            RLDM_STAGE(0)
+            if (s < NS) RLDM_STAGE(1)
         }
 #undef RLDM_STAGE
     }
@@ -570,23 +605,25 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-//          NW   BM   BN  WM WN  CK TAPS ACH
+//          NW   BM   BN  WM WN  CK TAPS TG ACH
+// Large pixel tiles (256 px: L0, VAE) are LDS-limited to one tap per stage; the small ones keep the whole 3x3 of a
+// 32-channel chunk resident (TG = 9: one barrier per chunk).  ACH = halo 16-byte pieces a thread stages per chunk.
 #define RLDM_CONV_INSTANCES(X)                                                                                  \
-    X(8, 256, 128, 4, 2, 64, 9, 6) X(8, 256, 64, 4, 2, 64, 9, 6) X(8, 256, 32, 8, 1, 64, 9, 6)                   \
-    X(4, 128, 128, 2, 2, 64, 9, 7) X(4, 128, 64, 2, 2, 64, 9, 7) X(4, 64, 64, 2, 2, 64, 9, 7)                    \
-    X(4, 128, 32, 4, 1, 64, 9, 7)                                                                               \
-    X(8, 256, 128, 4, 2, 64, 1, 4) X(8, 256, 64, 4, 2, 64, 1, 4)                                                 \
-    X(4, 128, 128, 2, 2, 64, 1, 4) X(4, 128, 64, 2, 2, 64, 1, 4) X(4, 64, 64, 2, 2, 64, 1, 2)                    \
-    X(8, 256, 128, 4, 2, 16, 9, 2) X(8, 256, 64, 4, 2, 16, 9, 2)                                                 \
-    X(4, 128, 128, 2, 2, 16, 9, 2) X(4, 128, 64, 2, 2, 16, 9, 2) X(4, 64, 64, 2, 2, 16, 9, 2)                    \
-    X(4, 128, 32, 4, 1, 16, 9, 2) X(4, 64, 64, 2, 2, 16, 1, 1)
+    X(8, 256, 128, 4, 2, 64, 9, 1, 6) X(8, 256, 64, 4, 2, 64, 9, 1, 6) X(8, 256, 32, 8, 1, 64, 9, 1, 6)          \
+    X(4, 128, 128, 2, 2, 64, 9, 1, 7) X(4, 128, 64, 2, 2, 32, 9, 9, 4) X(4, 64, 64, 2, 2, 32, 9, 9, 4)           \
+    X(4, 128, 32, 4, 1, 64, 9, 1, 7)                                                                            \
+    X(8, 256, 128, 4, 2, 64, 1, 1, 4) X(8, 256, 64, 4, 2, 64, 1, 1, 4)                                           \
+    X(4, 128, 128, 2, 2, 64, 1, 1, 4) X(4, 128, 64, 2, 2, 64, 1, 1, 4) X(4, 64, 64, 2, 2, 64, 1, 1, 2)           \
+    X(8, 256, 128, 4, 2, 16, 9, 1, 2) X(8, 256, 64, 4, 2, 16, 9, 1, 2)                                           \
+    X(4, 128, 128, 2, 2, 16, 9, 1, 2) X(4, 128, 64, 2, 2, 16, 9, 1, 2) X(4, 64, 64, 2, 2, 16, 9, 1, 2)           \
+    X(4, 128, 32, 4, 1, 16, 9, 1, 2) X(4, 64, 64, 2, 2, 16, 1, 1, 1)
 
 struct ConvInst {
-    int NW, BM, BN, CK, taps, ACH;
+    int NW, BM, BN, CK, taps, TG, ACH;
 };
 static const ConvInst* find_inst(const ConvTile& t) {
     static const ConvInst table[] = {
-#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, ach_) {nw_, bm_, bn_, ck_, taps_, ach_},
+#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, tg_, ach_) {nw_, bm_, bn_, ck_, taps_, tg_, ach_},
         RLDM_CONV_INSTANCES(X)
 #undef X
     };
@@ -627,7 +664,8 @@ size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
     const int TWv = (p.TW - 1) * p.stride + KW;
     const size_t a = (size_t)TWv * p.colb;
     const size_t g = (size_t)(p.C0 + p.C1) * 8 + (size_t)t.BN * 4;       // sGa, sGs, sBias
-    const size_t w = (size_t)3 * t.BN * RS;
+    const int TG = inst ? inst->TG : 1;
+    const size_t w = (size_t)(TG == 9 ? 2 : 3) * TG * t.BN * RS;
     size_t main_bytes = w + 2 * a + g;
     // GroupNorm finalize scratch lives in the (not yet written) halo buffers: 2*Cin + 2*groups doubles
     const size_t gscratch = p.st0 ? w + ((size_t)2 * (p.C0 + p.C1) + 2 * p.gn_groups) * 8 : 0;
@@ -635,9 +673,9 @@ size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
     return std::max(std::max(main_bytes, gscratch), epi);
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int ACH>
+template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int TG, int ACH>
 static int launch_inst(const ConvParams& p, int grid, size_t lds, hipStream_t stream) {
-    auto kern = conv_igemm_kernel<NW, BM, BN, WM, WN, CK, TAPS, ACH>;
+    auto kern = conv_igemm_kernel<NW, BM, BN, WM, WN, CK, TAPS, TG, ACH>;
     static size_t max_set = 0;
     if (lds > max_set) {
         RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -671,9 +709,9 @@ int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream) {
     const int grid = p.B * (p.Wout / p.TW) * (p.Hout / p.TH) * p.ntile_n * p.ksplit;
     const size_t lds = conv_lds_bytes(t, p);
     RLDM_REQUIRE(lds <= 160 * 1024, "conv: LDS footprint exceeds 160 KiB");
-#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, ach_)                                      \
+#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, tg_, ach_)                                 \
     if (t.BM == bm_ && t.BN == bn_ && t.CK == ck_ && t.taps == taps_)                     \
-        return launch_inst<nw_, bm_, bn_, wm_, wn_, ck_, taps_, ach_>(p, grid, lds, stream);
+        return launch_inst<nw_, bm_, bn_, wm_, wn_, ck_, taps_, tg_, ach_>(p, grid, lds, stream);
     RLDM_CONV_INSTANCES(X)
 #undef X
     return 1;

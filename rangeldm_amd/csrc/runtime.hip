@@ -352,7 +352,8 @@ struct ConvArgs {
 
 static int g_dbg_flags = 0;
 static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
-static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;     // rldm_debug_force_tile: tuning override (0: automatic)
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
+static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
 
 struct TileChoice {
     ConvTile tile;
@@ -373,19 +374,28 @@ static void pixel_tile(int BM, int Wout, int Hout, int stride, int* TW, int* TH)
 static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N, int Cin_pad, int C0, int R, int R0,
                               int taps, bool nchw) {
     TileChoice c;
-    ConvTile& t = c.tile;
-    t.taps = taps;
-    t.CK = (Cin_pad % 64 == 0 && C0 % 64 == 0 && R % 64 == 0 && R0 % 64 == 0) ? 64 : 16;   // chunks never straddle a concat
     const int KW = taps == 9 ? 3 : 1;
-    const int ncc = Cin_pad / t.CK, ncb = R / t.CK;
-    auto fits = [&](const ConvTile& u, int* tw, int* th) {
-        if (!conv_tile_supported(u)) return false;
-        pixel_tile(u.BM, Wout, Hout, stride, tw, th);
-        // shrink the tile until the halo fits the instance's register staging capacity
-        while (((*tw - 1) * stride + KW) * ((*th - 1) * stride + KW) > conv_max_halo_slots(u)) {
-            if (*tw > 1) *tw >>= 1; else if (*th > 1) *th >>= 1; else return false;
+    // a channel chunk never straddles a concat boundary
+    auto ck_ok = [&](int ck) { return Cin_pad % ck == 0 && C0 % ck == 0 && R % ck == 0 && R0 % ck == 0; };
+    // instance for a (BM, BN): the widest channel chunk it exists with
+    auto pick = [&](int BM, int BN, ConvTile* u, int* tw, int* th) {
+        const int cks[3] = {64, 32, 16};
+        for (int ck : cks) {
+            if (!ck_ok(ck)) continue;
+            ConvTile v;
+            v.BM = BM; v.BN = BN; v.CK = ck; v.taps = taps;
+            if (!conv_tile_supported(v)) continue;
+            pixel_tile(BM, Wout, Hout, stride, tw, th);
+            // shrink the tile until the halo fits the instance's register staging capacity
+            bool ok = true;
+            while (((*tw - 1) * stride + KW) * ((*th - 1) * stride + KW) > conv_max_halo_slots(v)) {
+                if (*tw > 1) *tw >>= 1; else if (*th > 1) *th >>= 1; else { ok = false; break; }
+            }
+            if (!ok) continue;
+            *u = v;
+            return true;
         }
-        return true;
+        return false;
     };
     auto blocks = [&](const ConvTile& u, int tw, int th) {
         return B * (Wout / tw) * (Hout / th) * ((N + u.BN - 1) / u.BN);
@@ -404,11 +414,9 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
         if (pass == 2) bns = {32, 64, 128};
         for (int bi = 0; bi < 3 && !found; ++bi)
             for (size_t ni = 0; ni < bns.size() && !found; ++ni) {
-                ConvTile u = t;
-                u.BM = bms[bi];
-                u.BN = bns[ni];
+                ConvTile u;
                 int tw, th;
-                if (!fits(u, &tw, &th)) continue;
+                if (!pick(bms[bi], bns[ni], &u, &tw, &th)) continue;
                 if (pass == 0 && tw * th * 2 <= u.BM && bi < 2) continue;   // more than half empty: try a smaller BM first
                 const long long nb = blocks(u, tw, th);
                 if (nb > best_blocks) {
@@ -421,11 +429,9 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
             }
     }
     if (g_force_bm && g_force_bn) {
-        ConvTile u = t;
-        u.BM = g_force_bm;
-        u.BN = g_force_bn;
+        ConvTile u;
         int tw, th;
-        if (fits(u, &tw, &th)) {
+        if (pick(g_force_bm, g_force_bn, &u, &tw, &th)) {
             best.tile = u;
             best.TW = tw;
             best.TH = th;
@@ -434,20 +440,19 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
     }
     c = best;
     if (best_blocks < 0) {
-        c.tile = t;
-        c.tile.BM = 64;
-        c.tile.BN = 64;
-        return c;                    // caller reports "no kernel instance"
+        c.tile.BM = 64; c.tile.BN = 64; c.tile.CK = 16; c.tile.taps = taps;
+        return c;                    // caller reports "no kernel instance" if this one does not exist either
     }
     // split-K over channel chunks when the tile grid leaves most CUs idle (fp32 NCHW outputs skip it: tiny N anyway)
     c.ksplit = 1;
+    const int ncc = Cin_pad / c.tile.CK;
     if (!nchw) {
         int ks = 1;
-        while (best_blocks * ks * 2 <= 320 && ks * 2 <= ncc && ncc % (ks * 2) == 0) ks *= 2;
+        if (g_split_auto)
+            while (best_blocks * ks * 2 <= 320 && ks * 2 <= ncc && ncc % (ks * 2) == 0) ks *= 2;
         c.ksplit = ks;
         if (g_force_ks > 0 && g_force_ks <= std::max(1, ncc)) c.ksplit = g_force_ks;
     }
-    (void)ncb;
     return c;
 }
 

@@ -158,7 +158,7 @@ def main():
     tiles = [t if len(t) == 3 else (t[0], t[1], 0) for t in tiles]
     tot = collections.defaultdict(float)
     print(f"{'case':18s} {'n':>3s} {'C0+C1':>9s} {'WxH':>8s} {'N':>4s} k s u g   r | " +
-          " | ".join(f"{('auto' if t == (0, 0, 0) else f'{t[0]}x{t[1]}k{t[2]}'):>22s}" for t in tiles))
+          " | ".join(f"{('auto' if t == (0, 0, 0) else f'{t[0]}x{t[1]}k{t[2]}'):>29s}" for t in tiles))
     for c, n in cases:
         if a.only and a.only not in c.name:
             continue
@@ -168,7 +168,7 @@ def main():
             try:
                 us, kn = bench_case(c, iters=a.iters)
                 tf = flops(c) / us / 1e6
-                cols.append(f"{us:8.1f}us {tf:6.0f}TF {kn.split('<')[1].split(',CK')[0]:>7s}")
+                cols.append(f"{us:8.1f}us {tf:6.0f}TF {kn.split('<')[1].rstrip('>').replace(',taps', 't').replace('CK', 'c'):>14s}")
                 tot[t] += us * n
                 if a.ts:
                     buf = (C.c_ulonglong * 256)()
@@ -178,7 +178,7 @@ def main():
                         v = [x for x in v if x]
                         print(f"    block {blk} stamps (cycles since start):", [int(x - v[0]) for x in v], file=sys.stderr)
             except RuntimeError as e:
-                cols.append(f"{'fail':>22s}")
+                cols.append(f"{'fail':>29s}")
                 print("   ", str(e)[:150], file=sys.stderr)
         print(f"{c.name:18s} {n:3d} {c.C0:4d}+{c.C1:<4d} {c.W:4d}x{c.H:<3d} {c.Cout:4d} {c.k} {c.stride} {c.up} {c.gn} {c.res:3d} | " +
               " | ".join(cols))
