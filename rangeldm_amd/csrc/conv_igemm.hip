@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     constexpr int PPT = (DPT + TG - 1) / TG;  // DMA instructions issued in the shadow of one tap
     constexpr int NBUF = (TG == 9) ? 2 : 3;   // weight ring depth
     constexpr int DD = NBUF - 1;              // the DMA of stage s + DD is issued during stage s
-    static_assert(TAPS % TG == 0 && (TG == 1 || TG == 3 || TG == 9), "taps per stage");
+    static_assert(TAPS % TG == 0 && (TG == 1 || TG == 9), "taps per stage");
     static_assert(PPT >= DPTR, "residual-stage DMA must fit the first tap's shadow");
     constexpr int ERS = BN * 2 + 16;          // epilogue staging row stride (bytes)
     constexpr int NC8 = BN / 8;               // 16-byte pieces per output pixel row
@@ -153,12 +153,12 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     auto wbyte = [&](int sa) __attribute__((always_inline)) {     // byte offset of absolute stage sa
         return sa < NMS ? (size_t)sa * STILE : (size_t)NMS * STILE + (size_t)(sa - NMS) * WTILE;
     };
-    auto issue_pieces = [&](const unsigned char* src, unsigned dst, int lo, int hi, bool is_main) __attribute__((always_inline)) {
-        // pieces [lo, hi) of a stage; every wave issues full-wave DMAs, tail passes overlap instead of running short
+    auto issue_pieces = [&](const unsigned char* src, unsigned dst, int lo, int hi, int last) __attribute__((always_inline)) {
+        // pieces [lo, hi) of a stage (compile-time bounds); every wave issues full-wave DMAs, passes beyond the stage's
+        // last 64-piece block (`last`) overlap it instead of running short
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
             if (i < lo || i >= hi) continue;
-            const int last = (is_main ? SCH : WCH) - 64;
             int piece = i * NT + wave * 64;
             piece = piece > last ? last : piece;
             lds_dma16(src + (size_t)(piece + lane) * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)piece * 16)));
@@ -168,13 +168,12 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     for (int j = 0; j < DD; ++j)
         if (j < NS) {
             const bool m = (sbeg + j) < NMS;
-            issue_pieces(wtile0 + wbyte(sbeg + j), lds0 + (unsigned)(j * STILE), 0, m ? DPT : DPTR, m);
+            issue_pieces(wtile0 + wbyte(sbeg + j), lds0 + (unsigned)(j * STILE), 0, DPT, (m ? SCH : WCH) - 64);
         }
 
     // ---- halo staging: thread-constant source pixel / LDS offset of each of its ACH 16-byte pieces ----------------
     const int atotal = TWv * THv * C8;
     int apix[ACH];          // source pixel index ((b*Win + sw)*Hin + sh), or -1 for zero padding / out of range
-    int aoff[ACH];          // LDS byte offset inside a halo buffer, or -1 when this thread has no piece i
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
         const int q = tid + i * NT;
@@ -185,7 +184,6 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);          // azimuth: wrap-around
         const bool ok = q < atotal && vh >= 0 && vh < Hv;            // beams: zero padding
         apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
-        aoff[i] = q < atotal ? vwl * colb + vhl * RS + c8 * 16 : -1;
     }
     const int my_c8 = (tid % C8) * 8;          // NT % C8 == 0: a thread always handles the same 8-channel column
 
@@ -241,7 +239,11 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
             v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);
         }
-        if (aoff[i] >= 0) *reinterpret_cast<uint4*>(dstbuf + aoff[i]) = v;
+        // LDS offset recomputed (a handful of VALU ops per chunk) instead of held in registers across the main loop
+        const int q = tid + i * NT;
+        const int slot = q / C8, c8 = q - slot * C8;
+        const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
+        if (q < atotal) *reinterpret_cast<uint4*>(dstbuf + vwl * colb + vhl * RS + c8 * 16) = v;
     };
     auto store_a = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
@@ -338,7 +340,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) woff[ni] = (wn * (NI * 32) + ni * 32 + l31) * RS + kh * 16;
 
-    f32x16 acc[NI][MI];
+    constexpr int AS = (NI * MI >= 4) ? 1 : 4 / (NI * MI);     // accumulator sets
+    f32x16 acc[AS][NI][MI];
     lds_barrier();                             // sBias (and, without GroupNorm, the first halo chunk) written
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -347,8 +350,13 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             const float4 bv = *reinterpret_cast<const float4*>(sBias + wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                acc[ni][mi][r4 * 4 + 0] = bv.x; acc[ni][mi][r4 * 4 + 1] = bv.y;
-                acc[ni][mi][r4 * 4 + 2] = bv.z; acc[ni][mi][r4 * 4 + 3] = bv.w;
+                acc[0][ni][mi][r4 * 4 + 0] = bv.x; acc[0][ni][mi][r4 * 4 + 1] = bv.y;
+                acc[0][ni][mi][r4 * 4 + 2] = bv.z; acc[0][ni][mi][r4 * 4 + 3] = bv.w;
+#pragma unroll
+                for (int a = 1; a < AS; ++a) {
+                    acc[a][ni][mi][r4 * 4 + 0] = 0.f; acc[a][ni][mi][r4 * 4 + 1] = 0.f;
+                    acc[a][ni][mi][r4 * 4 + 2] = 0.f; acc[a][ni][mi][r4 * 4 + 3] = 0.f;
+                }
             }
         }
     stamp();
@@ -356,109 +364,147 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     // ---- main loop ---------------------------------------------------------------------------------------------------
     // A stage = TG taps of one CK-channel chunk (main phase) or the centre tap of one residual chunk, one raw barrier per
     // stage.  A wave can start an MFMA only every 32 cycles while the pipe needs 16, so everything else is placed in the
-    // shadows between the wave's own MFMAs (tools/ubench/stage_model.hip: 842 -> 667 ns per stage): while the MFMAs of
-    // one tap run, the wave reads the NEXT tap's fragments into the other register set -- weights and pixels when that
-    // tap belongs to the same stage, pixels only across a stage boundary (the halo is stable across a chunk's stages;
-    // the weights of the next stage become visible at its barrier) -- and issues its share of the LDS-DMA of the stage
-    // DD stages ahead.  TG = 9 (small pixel tiles: the whole 3x3 of a chunk is resident) leaves one barrier per chunk.
-    // All taps-per-stage are odd, so the register-set parity alternates from stage to stage: loop unrolled by two.
+    // shadows between the wave's own MFMAs (tools/ubench/stage_model.hip: 842 -> 667 ns per stage); the tap loops are
+    // branch-free (a weight DMA past the last stage re-copies a valid stage into a free slot).
+    //   TG == 1 (256-pixel tiles, LDS-limited to one tap of weights per stage): right after the MFMAs of k-step ks the
+    //     wave re-loads the SAME pixel-fragment registers with the next stage's k-step ks (the halo is stable across a
+    //     chunk's taps; a prefetch from a halo image that is not complete yet is repeated after the barrier) and issues
+    //     its share of the LDS-DMA of the stage DD ahead; only the weight fragments are read after the barrier.
+    //   TG == 9 (small pixel tiles: the whole 3x3 of a 32-channel chunk is resident, one barrier per chunk): a ring of
+    //     NSET fragment register sets, tap tt + NSET - 1 is read while tap tt computes.  Small wave tiles rotate over AS
+    //     accumulator sets so that consecutive MFMAs never depend on each other (summed before the epilogue).
     {
+        constexpr int NSET = (TG == 1) ? 1 : 4;
         int cc = cbeg, sg = 0;                 // chunk, stage within the chunk
         int toff = (cbeg < NCC || TAPS == 1) ? 0 : colb + RS;     // tap offset of the stage's first tap (residual: centre)
         int tj = 0;                            // TG == 1: column of the 3x3 the stage is in
         int wslot = 0, dslot = DD % NBUF;      // ring slot of stage s / of the stage whose DMA stage s issues
-        size_t doff = wbyte(sbeg + DD);        // ... and its byte offset in the stream
-        bool x_ready = false;                  // the stage's first pixel fragments were prefetched
+        int dsa = sbeg + DD;                   // absolute index of the stage whose DMA stage s issues
+        bool x_ready = false;                  // TG == 1: the stage's pixel fragments were prefetched (and valid)
         bool hl_prev = loaded > stored;        // halo loads were issued after the last weight DMA
-        bf16x8 wf[2][KS][NI], xf[2][KS][MI];
+        bool pm_prev = true;                   // the previous stage was a main-phase stage (it issued DPT DMAs, else PPT)
+        bf16x8 wf[NSET][KS][NI], xf[NSET][KS][MI];
         int s = 0;
-#define RLDM_STAGE(P)                                                                                                \
-        {                                                                                                            \
-            /* W(s) has landed once only the operations issued after its DMAs are outstanding (VMEM retires in order) */ \
-            if (NBUF == 2 || s + 1 >= NS) {                                                                          \
-                wait_vmcnt<0>();                                                                                     \
-            } else if ((sbeg + s + 1) < NMS) {                                                                       \
-                if (hl_prev) wait_vmcnt<DPT + ACH>(); else wait_vmcnt<DPT>();                                        \
-            } else {                                                                                                 \
-                if (hl_prev) wait_vmcnt<DPTR + ACH>(); else wait_vmcnt<DPTR>();                                      \
-            }                                                                                                        \
-            lds_barrier();                                                                                           \
-            const int vis = stored;            /* halo images complete and visible to every wave */                 \
-            const bool cmain = cc < NCC;                                                                             \
-            const unsigned char* wbase = sW + wslot * STILE;                                                         \
-            const unsigned char* abase = sA + (cc & 1) * abytes + toff;                                              \
-            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                        \
-                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                    \
-                    wf[P][ks][ni] = *reinterpret_cast<const bf16x8*>(wbase + woff[ni] + ks * 32);                    \
-            if (!x_ready) {                                                                                          \
-                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                    \
-                    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
-                        xf[P][ks][mi] = *reinterpret_cast<const bf16x8*>(abase + xoff[mi] + ks * 32);                \
-            }                                                                                                        \
-            hl_prev = false;                                                                                         \
-            if (!(p.dbg & 32)) {                                                                                     \
-                if (loaded > stored && stored + 1 <= cc + 1) { load_affine(stored + 1); store_a(stored + 1); ++stored; } \
-                if (loaded == stored && loaded + 1 < cend && loaded <= cc + 1) { load_a(loaded + 1); ++loaded; hl_prev = true; } \
-            }                                                                                                        \
-            /* coordinates of the next stage */                                                                     \
-            int ncc = cc, nsg = sg + 1, ntoff = toff, ntj = tj;                                                      \
-            if (nsg == (cmain ? SPC : 1)) {                                                                          \
-                nsg = 0; ++ncc; ntj = 0;                                                                             \
-                ntoff = (ncc < NCC || TAPS == 1) ? 0 : colb + RS;                                                    \
-            } else if (TG == 1) {                                                                                    \
-                ntoff += RS;                                                                                         \
-                if (++ntj == 3) { ntj = 0; ntoff += colb - 3 * RS; }                                                 \
-            } else {                                                                                                 \
-                ntoff += colb;                 /* TG == 3: one row of the 3x3 per stage */                          \
-            }                                                                                                        \
-            const bool nx = (s + 1 < NS) && (ncc <= vis);                                                            \
-            const unsigned char* nbase = sA + (ncc & 1) * abytes + ntoff;                                            \
-            const bool dma = (s + DD < NS) && !(p.dbg & 16);                                                         \
-            const bool dmain = (sbeg + s + DD) < NMS;                                                                \
-            const unsigned char* dsrc = wtile0 + doff;                                                               \
-            const unsigned ddst = lds0 + (unsigned)(dslot * STILE);                                                  \
+#define RLDM_READ_TAP(SET, WPTR, XPTR)                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                        \
+                wf[SET][ks][ni] = *reinterpret_cast<const bf16x8*>((WPTR) + woff[ni] + ks * 32);                     \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                        \
+                xf[SET][ks][mi] = *reinterpret_cast<const bf16x8*>((XPTR) + xoff[mi] + ks * 32);                     \
+        }
+#define RLDM_MMA(SET, KSTEP, AIDX)                                                                                   \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                        \
+                acc[(AIDX) % AS][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
+                    wf[SET][KSTEP][ni], xf[SET][KSTEP][mi], acc[(AIDX) % AS][ni][mi], 0, 0, 0);
+        // tap TT of a TG == 9 stage: MFMAs of set TT % NSET; in their shadow the DMA share of the tap and the reads of tap
+        // TT + NSET - 1 (into the set the previous tap just released)
+#define RLDM_TAP9(TT)                                                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+            RLDM_MMA((TT) % NSET, ks, (TT) * KS + ks)                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            _Pragma("unroll") for (int tt = 0; tt < TG; ++tt) {                                                      \
-                if (tt > 0 && !cmain) break;   /* residual stage: one tap */                                        \
-                const int CUR = (P + tt) & 1, NXT = CUR ^ 1;                                                         \
-                const int td1 = (TG == 9) ? ((tt + 1) / 3) * colb + ((tt + 1) % 3) * RS : (TG == 3 ? (tt + 1) * RS : 0); \
-                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
-                    if (!(p.dbg & 8)) {                                                                              \
-                        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                            \
-                            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                        \
-                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[CUR][ks][ni], xf[CUR][ks][mi], acc[ni][mi], 0, 0, 0); \
-                    } else {                                                                                         \
-                        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[CUR][ks][ni]));   \
-                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xf[CUR][ks][mi]));   \
-                    }                                                                                                \
-                    __builtin_amdgcn_sched_barrier(0);                                                               \
-                    if (ks == 0 && dma) issue_pieces(dsrc, ddst, tt * PPT, dmain ? ((tt + 1) * PPT < DPT ? (tt + 1) * PPT : DPT) : (tt == 0 ? DPTR : 0), dmain); \
-                    if (tt + 1 < TG && cmain) {                                                                      \
-                        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                            \
-                            wf[NXT][ks][ni] = *reinterpret_cast<const bf16x8*>(wbase + (tt + 1) * WTILE + woff[ni] + ks * 32); \
-                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
-                            xf[NXT][ks][mi] = *reinterpret_cast<const bf16x8*>(abase + td1 + xoff[mi] + ks * 32);    \
-                    } else if (nx) {                                                                                 \
-                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
-                            xf[NXT][ks][mi] = *reinterpret_cast<const bf16x8*>(nbase + xoff[mi] + ks * 32);          \
-                    }                                                                                                \
-                    __builtin_amdgcn_sched_barrier(0);                                                               \
-                }                                                                                                    \
+            if (ks == 0) issue_pieces(dsrc, ddst, (TT) * PPT, ((TT) + 1) * PPT < DPT ? ((TT) + 1) * PPT : DPT, dlast); \
+            if ((TT) + NSET - 1 < TG) {                                                                              \
+                const int t2 = (TT) + NSET - 1;                                                                      \
+                const unsigned char* w2 = wbase + t2 * WTILE;                                                        \
+                const unsigned char* x2 = abase + (t2 / 3) * colb + (t2 % 3) * RS;                                   \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                    \
+                    wf[t2 % NSET][ks][ni] = *reinterpret_cast<const bf16x8*>(w2 + woff[ni] + ks * 32);               \
+                _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                    \
+                    xf[t2 % NSET][ks][mi] = *reinterpret_cast<const bf16x8*>(x2 + xoff[mi] + ks * 32);               \
             }                                                                                                        \
-            x_ready = nx;                                                                                            \
-            cc = ncc; sg = nsg; toff = ntoff; tj = ntj;                                                              \
-            wslot = (wslot + 1 == NBUF) ? 0 : wslot + 1;                                                             \
-            dslot = (dslot + 1 == NBUF) ? 0 : dslot + 1;                                                             \
-            doff += dmain ? (size_t)STILE : (size_t)WTILE;                                                           \
-            ++s;                                                                                                     \
-            stamp();                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
         }
 #pragma unroll 1
         while (s < NS) {
-            RLDM_STAGE(0)
-            if (s < NS) RLDM_STAGE(1)
+            // W(s) has landed once only the operations issued after its DMAs are outstanding (VMEM retires in order)
+            if (NBUF == 2 || s + 1 >= NS) {
+                wait_vmcnt<0>();
+            } else if (pm_prev) {
+                if (hl_prev) wait_vmcnt<DPT + ACH>(); else wait_vmcnt<DPT>();
+            } else {
+                if (hl_prev) wait_vmcnt<PPT + ACH>(); else wait_vmcnt<PPT>();
+            }
+            lds_barrier();
+            const int vis = stored;            // halo images complete and visible to every wave
+            const bool cmain = cc < NCC;
+            const unsigned char* wbase = sW + wslot * STILE;
+            const unsigned char* abase = sA + (cc & 1) * abytes + toff;
+            if (TG == 1 || !cmain) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) wf[0][ks][ni] = *reinterpret_cast<const bf16x8*>(wbase + woff[ni] + ks * 32);
+                if (TG != 1 || !x_ready) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) xf[0][ks][mi] = *reinterpret_cast<const bf16x8*>(abase + xoff[mi] + ks * 32);
+                }
+            } else {
+                RLDM_READ_TAP(0, wbase, abase)
+                RLDM_READ_TAP(1, wbase + WTILE, abase + RS)
+                RLDM_READ_TAP(2, wbase + 2 * WTILE, abase + 2 * RS)
+            }
+            hl_prev = false;
+            if (loaded > stored && stored + 1 <= cc + 1) { load_affine(stored + 1); store_a(stored + 1); ++stored; }
+            if (loaded == stored && loaded + 1 < cend && loaded <= cc + 1) { load_a(loaded + 1); ++loaded; hl_prev = true; }
+            // coordinates of the next stage
+            int ncc = cc, nsg = sg + 1, ntoff = toff, ntj = tj;
+            if (nsg == (cmain ? SPC : 1)) {
+                nsg = 0; ++ncc; ntj = 0;
+                ntoff = (ncc < NCC || TAPS == 1) ? 0 : colb + RS;
+            } else {                           // TG == 1: next tap of the 3x3
+                ntoff += RS;
+                if (++ntj == 3) { ntj = 0; ntoff += colb - 3 * RS; }
+            }
+            const unsigned char* nbase = sA + (ncc & 1) * abytes + ntoff;
+            // DMA target: stage s + DD, or (past the end) this stage again: a valid source into a free slot
+            const int dst_sa = (s + DD < NS) ? dsa : sbeg + s;
+            const bool dmain = dst_sa < NMS;
+            const int dlast = (dmain ? SCH : WCH) - 64;
+            const unsigned char* dsrc = wtile0 + wbyte(dst_sa);
+            const unsigned ddst = lds0 + (unsigned)(dslot * STILE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (TG == 1 || !cmain) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    RLDM_MMA(0, ks, ks)
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the stage's DMA share, spread over its k-steps
+#pragma unroll
+                    for (int i = ks; i < PPT; i += KS) issue_pieces(dsrc, ddst, i, i + 1, dlast);
+                    if (TG == 1) {             // in-place prefetch of the next stage's pixel fragments
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) xf[0][ks][mi] = *reinterpret_cast<const bf16x8*>(nbase + xoff[mi] + ks * 32);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                RLDM_TAP9(0) RLDM_TAP9(1) RLDM_TAP9(2) RLDM_TAP9(3) RLDM_TAP9(4) RLDM_TAP9(5) RLDM_TAP9(6) RLDM_TAP9(7) RLDM_TAP9(8)
+            }
+            pm_prev = cmain;
+            x_ready = (s + 1 < NS) && (ncc <= vis);
+            cc = ncc; sg = nsg; toff = ntoff; tj = ntj;
+            wslot = (wslot + 1 == NBUF) ? 0 : wslot + 1;
+            dslot = (dslot + 1 == NBUF) ? 0 : dslot + 1;
+            ++dsa;
+            ++s;
+            stamp();
         }
-#undef RLDM_STAGE
+#undef RLDM_TAP9
+#undef RLDM_MMA
+#undef RLDM_READ_TAP
+        wait_vmcnt<0>();                       // the unconditional tail DMAs
+        // fold the accumulator sets
+#pragma unroll
+        for (int a = 1; a < AS; ++a)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][ni][mi][r] += acc[a][ni][mi][r];
     }
     lds_barrier();                             // all waves are done with the ring / halo: LDS is reused below
     stamp();
@@ -474,8 +520,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 v = make_float4(acc[ni][mi][r4 * 4], acc[ni][mi][r4 * 4 + 1], acc[ni][mi][r4 * 4 + 2],
-                                                 acc[ni][mi][r4 * 4 + 3]);
+                    const float4 v = make_float4(acc[0][ni][mi][r4 * 4], acc[0][ni][mi][r4 * 4 + 1], acc[0][ni][mi][r4 * 4 + 2],
+                                                 acc[0][ni][mi][r4 * 4 + 3]);
                     *reinterpret_cast<float4*>(mine + ((((ni * MI + mi) * 4 + r4) * NT) + tid) * 4) = v;
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,8 +552,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                             slab + (size_t)k * (BM * BN) + ((((ni * MI + mi) * 4 + r4) * NT) + tid) * 4);
                         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                     }
-                    acc[ni][mi][r4 * 4] = sum.x; acc[ni][mi][r4 * 4 + 1] = sum.y;
-                    acc[ni][mi][r4 * 4 + 2] = sum.z; acc[ni][mi][r4 * 4 + 3] = sum.w;
+                    acc[0][ni][mi][r4 * 4] = sum.x; acc[0][ni][mi][r4 * 4 + 1] = sum.y;
+                    acc[0][ni][mi][r4 * 4 + 2] = sum.z; acc[0][ni][mi][r4 * 4 + 3] = sum.w;
                 }
     }
 
@@ -525,7 +571,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                 for (int r = 0; r < 16; ++r) {
                     const int ch = nt * BN + wn * (NI * 32) + ni * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
                     if (ch < p.N && !(p.dbg & 1))
-                        p.y_nchw[(((size_t)b * p.N + ch) * p.Wout + ow) * p.Hout + oh] = acc[ni][mi][r];
+                        p.y_nchw[(((size_t)b * p.N + ch) * p.Wout + ow) * p.Hout + oh] = acc[0][ni][mi][r];
                 }
         }
         return;
@@ -541,8 +587,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int chl = wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh;
                 uint2 o;
-                o.x = pack_bf16x2(acc[ni][mi][r4 * 4 + 0], acc[ni][mi][r4 * 4 + 1]);
-                o.y = pack_bf16x2(acc[ni][mi][r4 * 4 + 2], acc[ni][mi][r4 * 4 + 3]);
+                o.x = pack_bf16x2(acc[0][ni][mi][r4 * 4 + 0], acc[0][ni][mi][r4 * 4 + 1]);
+                o.y = pack_bf16x2(acc[0][ni][mi][r4 * 4 + 2], acc[0][ni][mi][r4 * 4 + 3]);
                 *reinterpret_cast<uint2*>(sE + pidx * ERS + chl * 2) = o;
             }
     }
