@@ -53,13 +53,14 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int TG, int ACH>
+template <int NW, int BM, int BN, int WM, int WN, int KG, int CK, int TAPS, int TG, int ACH>
 __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = 64 * NW;               // threads
     constexpr int MI = BM / (32 * WM);        // 32-pixel MFMA tiles per wave
     constexpr int NI = BN / (32 * WN);        // 32-channel MFMA tiles per wave
     constexpr int RS = CK * 2 + 16;           // LDS row stride in bytes (halo rows and weight rows)
-    constexpr int KS = CK / 16;               // MFMA k-steps per stage
+    constexpr int KSF = CK / 16;              // MFMA k-steps per tap of a chunk ...
+    constexpr int KS = KSF / KG;              // ... and the share of one wave (KG wave groups split the k-steps)
     constexpr int KW = (TAPS == 9) ? 3 : 1;
     constexpr int C8 = CK / 8;                // 16-byte pieces per LDS row
     constexpr int WTILE = BN * RS;            // bytes of one tap of weights (one residual-phase stage)
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     static_assert(PPT >= DPTR, "residual-stage DMA must fit the first tap's shadow");
     constexpr int ERS = BN * 2 + 16;          // epilogue staging row stride (bytes)
     constexpr int NC8 = BN / 8;               // 16-byte pieces per output pixel row
-    static_assert(WM * WN == NW, "wave grid");
+    static_assert(WM * WN * KG == NW && KSF % KG == 0 && KS >= 1, "wave grid: WM x WN spatial, KG k-groups");
     static_assert(MI >= 1 && NI >= 1, "tile shape");
     static_assert(WCH >= 64 && WTILE % 16 == 0, "weight stage too small for a full-wave DMA");
     static_assert(NT % NC8 == 0 && NT % C8 == 0, "thread count must be a multiple of the pieces per row");
@@ -84,7 +85,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
+    const int kg = wave / (WM * WN);           // k-group: this wave's k-steps are [kg*KS, (kg+1)*KS) of every tap
+    const int wmn = wave - kg * (WM * WN);
+    const int wm = wmn % WM, wn = wmn / WM;
     const int kh = lane >> 5, l31 = lane & 31;
     int ts_n = 0;
     auto stamp = [&]() {
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             double var = SS * inv_n - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             sD[2 * Cin + tid] = mean;
-            sD[2 * Cin + p.gn_groups + tid] = 1.0 / sqrt(var + (double)p.gn_eps);
+            sD[2 * Cin + p.gn_groups + tid] = (double)__builtin_amdgcn_rsqf((float)var + p.gn_eps);   // hardware rsqrt, 1 ulp
         }
         __syncthreads();
         float ga[2], gs[2];                     // Cin <= 2 * NT
@@ -335,10 +338,10 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         int pidx = wm * (MI * 32) + mi * 32 + l31;
         if (pidx >= npx) pidx = 0;            // masked at the store
         const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        xoff[mi] = (pw * p.stride) * colb + (ph * p.stride) * RS + kh * 16;
+        xoff[mi] = (pw * p.stride) * colb + (ph * p.stride) * RS + kh * 16 + kg * (KS * 32);
     }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) woff[ni] = (wn * (NI * 32) + ni * 32 + l31) * RS + kh * 16;
+    for (int ni = 0; ni < NI; ++ni) woff[ni] = (wn * (NI * 32) + ni * 32 + l31) * RS + kh * 16 + kg * (KS * 32);
 
     constexpr int AS = (NI * MI >= 4) ? 1 : 4 / (NI * MI);     // accumulator sets
     f32x16 acc[AS][NI][MI];
@@ -347,7 +350,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 bv = *reinterpret_cast<const float4*>(sBias + wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh);
+            float4 bv = *reinterpret_cast<const float4*>(sBias + wn * (NI * 32) + ni * 32 + 8 * r4 + 4 * kh);
+            if (kg != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 acc[0][ni][mi][r4 * 4 + 0] = bv.x; acc[0][ni][mi][r4 * 4 + 1] = bv.y;
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     //     NSET fragment register sets, tap tt + NSET - 1 is read while tap tt computes.  Small wave tiles rotate over AS
     //     accumulator sets so that consecutive MFMAs never depend on each other (summed before the epilogue).
     {
-        constexpr int NSET = (TG == 1) ? 1 : 4;
+        constexpr int NSET = (TG == 1) ? 1 : 9;     // TG == 9: the fragments of all nine taps are read right after the barrier
         int cc = cbeg, sg = 0;                 // chunk, stage within the chunk
         int toff = (cbeg < NCC || TAPS == 1) ? 0 : colb + RS;     // tap offset of the stage's first tap (residual: centre)
         int tj = 0;                            // TG == 1: column of the 3x3 the stage is in
@@ -393,26 +397,21 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                 xf[SET][ks][mi] = *reinterpret_cast<const bf16x8*>((XPTR) + xoff[mi] + ks * 32);                     \
         }
 #define RLDM_MMA(SET, KSTEP, AIDX)                                                                                   \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                        \
-                acc[(AIDX) % AS][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
-                    wf[SET][KSTEP][ni], xf[SET][KSTEP][mi], acc[(AIDX) % AS][ni][mi], 0, 0, 0);
-        // tap TT of a TG == 9 stage: MFMAs of set TT % NSET; in their shadow the DMA share of the tap and the reads of tap
-        // TT + NSET - 1 (into the set the previous tap just released)
+        if (!nomma) {                                                                                                \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                        \
+                _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                    \
+                    acc[(AIDX) % AS][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                              \
+                        wf[SET][KSTEP][ni], xf[SET][KSTEP][mi], acc[(AIDX) % AS][ni][mi], 0, 0, 0);                  \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[SET][KSTEP][ni]));            \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xf[SET][KSTEP][mi]));            \
+        }
+        // tap TT of a TG == 9 stage: the MFMAs of fragment set TT and, in their shadow, the DMA share of the tap
 #define RLDM_TAP9(TT)                                                                                                \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
-            RLDM_MMA((TT) % NSET, ks, (TT) * KS + ks)                                                                \
+            RLDM_MMA(TT, ks, (TT) * KS + ks)                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            if (ks == 0) issue_pieces(dsrc, ddst, (TT) * PPT, ((TT) + 1) * PPT < DPT ? ((TT) + 1) * PPT : DPT, dlast); \
-            if ((TT) + NSET - 1 < TG) {                                                                              \
-                const int t2 = (TT) + NSET - 1;                                                                      \
-                const unsigned char* w2 = wbase + t2 * WTILE;                                                        \
-                const unsigned char* x2 = abase + (t2 / 3) * colb + (t2 % 3) * RS;                                   \
-                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                    \
-                    wf[t2 % NSET][ks][ni] = *reinterpret_cast<const bf16x8*>(w2 + woff[ni] + ks * 32);               \
-                _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                    \
-                    xf[t2 % NSET][ks][mi] = *reinterpret_cast<const bf16x8*>(x2 + xoff[mi] + ks * 32);               \
-            }                                                                                                        \
+            if (ks == 0 && !nodma) issue_pieces(dsrc, ddst, (TT) * PPT, ((TT) + 1) * PPT < DPT ? ((TT) + 1) * PPT : DPT, dlast); \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }
 #pragma unroll 1
@@ -425,7 +424,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             } else {
                 if (hl_prev) wait_vmcnt<PPT + ACH>(); else wait_vmcnt<PPT>();
             }
+            if (p.dbg & 64) stamp();
             lds_barrier();
+            if (p.dbg & 64) stamp();
             const int vis = stored;            // halo images complete and visible to every wave
             const bool cmain = cc < NCC;
             const unsigned char* wbase = sW + wslot * STILE;
@@ -442,13 +443,33 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                         for (int mi = 0; mi < MI; ++mi) xf[0][ks][mi] = *reinterpret_cast<const bf16x8*>(abase + xoff[mi] + ks * 32);
                 }
             } else {
+                // the small wave tiles do 1-2 MFMAs per tap -- far less than an LDS round trip -- so all nine taps'
+                // fragments are requested at once and the MFMAs consume them as they return
                 RLDM_READ_TAP(0, wbase, abase)
                 RLDM_READ_TAP(1, wbase + WTILE, abase + RS)
                 RLDM_READ_TAP(2, wbase + 2 * WTILE, abase + 2 * RS)
+                RLDM_READ_TAP(3, wbase + 3 * WTILE, abase + colb)
+                RLDM_READ_TAP(4, wbase + 4 * WTILE, abase + colb + RS)
+                RLDM_READ_TAP(5, wbase + 5 * WTILE, abase + colb + 2 * RS)
+                RLDM_READ_TAP(6, wbase + 6 * WTILE, abase + 2 * colb)
+                RLDM_READ_TAP(7, wbase + 7 * WTILE, abase + 2 * colb + RS)
+                RLDM_READ_TAP(8, wbase + 8 * WTILE, abase + 2 * colb + 2 * RS)
             }
             hl_prev = false;
-            if (loaded > stored && stored + 1 <= cc + 1) { load_affine(stored + 1); store_a(stored + 1); ++stored; }
-            if (loaded == stored && loaded + 1 < cend && loaded <= cc + 1) { load_a(loaded + 1); ++loaded; hl_prev = true; }
+            // halo pipeline: write the chunk whose loads are in flight (GroupNorm + SiLU: VALU work), load the one after.
+            // With two k-groups on a TG == 9 stage, group 1 does it before its taps and group 0 after, so that one
+            // group's VALU work runs under the other group's MFMAs.
+            const bool halo_first = !(KG == 2 && TG == 9 && kg == 0);
+#define RLDM_HALO_STEP                                                                                               \
+            {                                                                                                        \
+                if (loaded > stored && stored + 1 <= cc + 1) { load_affine(stored + 1); store_a(stored + 1); ++stored; } \
+                if (loaded == stored && loaded + 1 < cend && loaded <= cc + 1) { load_a(loaded + 1); ++loaded; hl_prev = true; } \
+            }
+            const int cc_now = cc;
+            (void)cc_now;
+            if (p.dbg & 64) stamp();
+            if (halo_first && !(p.dbg & 32)) RLDM_HALO_STEP
+            if (p.dbg & 64) stamp();
             // coordinates of the next stage
             int ncc = cc, nsg = sg + 1, ntoff = toff, ntj = tj;
             if (nsg == (cmain ? SPC : 1)) {
@@ -465,6 +486,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             const int dlast = (dmain ? SCH : WCH) - 64;
             const unsigned char* dsrc = wtile0 + wbyte(dst_sa);
             const unsigned ddst = lds0 + (unsigned)(dslot * STILE);
+            const bool nodma = (p.dbg & 16) != 0;      // tuning ablations: no weight streaming after the prologue,
+            const bool nomma = (p.dbg & 8) != 0;       // no MFMAs
             __builtin_amdgcn_sched_barrier(0);
             if (TG == 1 || !cmain) {
 #pragma unroll
@@ -473,7 +496,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                     __builtin_amdgcn_sched_barrier(0);
                     // the stage's DMA share, spread over its k-steps
 #pragma unroll
-                    for (int i = ks; i < PPT; i += KS) issue_pieces(dsrc, ddst, i, i + 1, dlast);
+                    for (int i = ks; i < PPT; i += KS) if (!nodma) issue_pieces(dsrc, ddst, i, i + 1, dlast);
                     if (TG == 1) {             // in-place prefetch of the next stage's pixel fragments
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) xf[0][ks][mi] = *reinterpret_cast<const bf16x8*>(nbase + xoff[mi] + ks * 32);
@@ -483,6 +506,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             } else {
                 RLDM_TAP9(0) RLDM_TAP9(1) RLDM_TAP9(2) RLDM_TAP9(3) RLDM_TAP9(4) RLDM_TAP9(5) RLDM_TAP9(6) RLDM_TAP9(7) RLDM_TAP9(8)
             }
+            if (!halo_first && !(p.dbg & 32)) RLDM_HALO_STEP
+#undef RLDM_HALO_STEP
             pm_prev = cmain;
             x_ready = (s + 1 < NS) && (ncc <= vis);
             cc = ncc; sg = nsg; toff = ntoff; tj = ntj;
@@ -508,6 +533,37 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     }
     lds_barrier();                             // all waves are done with the ring / halo: LDS is reused below
     stamp();
+    if constexpr (KG == 2) {
+        // k-group 1 hands its partial accumulators to group 0 through LDS (fragment order: conflict-free float4s)
+        constexpr int NTG = 64 * WM * WN;
+        float* sX = reinterpret_cast<float*>(smem);
+        const int tg = tid - kg * NTG;
+        if (kg == 1) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        *reinterpret_cast<float4*>(sX + ((((ni * MI + mi) * 4 + r4) * NTG) + tg) * 4) =
+                            make_float4(acc[0][ni][mi][r4 * 4], acc[0][ni][mi][r4 * 4 + 1], acc[0][ni][mi][r4 * 4 + 2],
+                                        acc[0][ni][mi][r4 * 4 + 3]);
+        }
+        lds_barrier();
+        if (kg == 0) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 v = *reinterpret_cast<const float4*>(sX + ((((ni * MI + mi) * 4 + r4) * NTG) + tg) * 4);
+                        acc[0][ni][mi][r4 * 4] += v.x; acc[0][ni][mi][r4 * 4 + 1] += v.y;
+                        acc[0][ni][mi][r4 * 4 + 2] += v.z; acc[0][ni][mi][r4 * 4 + 3] += v.w;
+                    }
+        }
+        lds_barrier();                         // sX is dead before the staging below reuses the same bytes
+    }
 
     // ---- split-K: park the slice, last arriver combines (guide 6 G16 recipe: release -> ticket -> acquire) ----------
     if (p.ksplit > 1) {
@@ -559,6 +615,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------
     if (p.y_nchw) {                            // fp32 NCHW (network outputs: few channels), straight from the registers
+        if (kg != 0) return;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int pidx = wm * (MI * 32) + mi * 32 + l31;
@@ -578,6 +635,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     }
     // (1) accumulators -> bf16 -> LDS [pixel][channel]
     unsigned char* sE = smem;
+    if (kg == 0) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int pidx = wm * (MI * 32) + mi * 32 + l31;
@@ -591,6 +649,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                 o.y = pack_bf16x2(acc[0][ni][mi][r4 * 4 + 2], acc[0][ni][mi][r4 * 4 + 3]);
                 *reinterpret_cast<uint2*>(sE + pidx * ERS + chl * 2) = o;
             }
+    }
     }
     lds_barrier();
     stamp();
@@ -651,25 +710,27 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-//          NW   BM   BN  WM WN  CK TAPS TG ACH
+//          NW   BM   BN  WM WN KG  CK TAPS TG ACH
 // Large pixel tiles (256 px: L0, VAE) are LDS-limited to one tap per stage; the small ones keep the whole 3x3 of a
-// 32-channel chunk resident (TG = 9: one barrier per chunk).  ACH = halo 16-byte pieces a thread stages per chunk.
+// 32-channel chunk resident (TG = 9: one barrier per chunk) and run two k-groups of waves on the same tile (KG = 2):
+// two waves per SIMD, the GroupNorm+SiLU staging work split over twice the threads and overlapped with the other
+// group's MFMAs.  ACH = halo 16-byte pieces a thread stages per chunk.
 #define RLDM_CONV_INSTANCES(X)                                                                                  \
-    X(8, 256, 128, 4, 2, 64, 9, 1, 6) X(8, 256, 64, 4, 2, 64, 9, 1, 6) X(8, 256, 32, 8, 1, 64, 9, 1, 6)          \
-    X(4, 128, 128, 2, 2, 64, 9, 1, 7) X(4, 128, 64, 2, 2, 32, 9, 9, 4) X(4, 64, 64, 2, 2, 32, 9, 9, 4)           \
-    X(4, 128, 32, 4, 1, 64, 9, 1, 7)                                                                            \
-    X(8, 256, 128, 4, 2, 64, 1, 1, 4) X(8, 256, 64, 4, 2, 64, 1, 1, 4)                                           \
-    X(4, 128, 128, 2, 2, 64, 1, 1, 4) X(4, 128, 64, 2, 2, 64, 1, 1, 4) X(4, 64, 64, 2, 2, 64, 1, 1, 2)           \
-    X(8, 256, 128, 4, 2, 16, 9, 1, 2) X(8, 256, 64, 4, 2, 16, 9, 1, 2)                                           \
-    X(4, 128, 128, 2, 2, 16, 9, 1, 2) X(4, 128, 64, 2, 2, 16, 9, 1, 2) X(4, 64, 64, 2, 2, 16, 9, 1, 2)           \
-    X(4, 128, 32, 4, 1, 16, 9, 1, 2) X(4, 64, 64, 2, 2, 16, 1, 1, 1)
+    X(8, 256, 128, 4, 2, 1, 64, 9, 1, 6) X(8, 256, 64, 4, 2, 1, 64, 9, 1, 6) X(8, 256, 32, 8, 1, 1, 64, 9, 1, 6) \
+    X(4, 128, 128, 2, 2, 1, 64, 9, 1, 7) X(8, 128, 64, 2, 2, 2, 32, 9, 9, 2) X(8, 64, 64, 2, 2, 2, 32, 9, 9, 2)  \
+    X(4, 128, 32, 4, 1, 1, 64, 9, 1, 7)                                                                         \
+    X(8, 256, 128, 4, 2, 1, 64, 1, 1, 4) X(8, 256, 64, 4, 2, 1, 64, 1, 1, 4)                                     \
+    X(4, 128, 128, 2, 2, 1, 64, 1, 1, 4) X(4, 128, 64, 2, 2, 1, 64, 1, 1, 4) X(4, 64, 64, 2, 2, 1, 64, 1, 1, 2)  \
+    X(8, 256, 128, 4, 2, 1, 16, 9, 1, 2) X(8, 256, 64, 4, 2, 1, 16, 9, 1, 2)                                     \
+    X(4, 128, 128, 2, 2, 1, 16, 9, 1, 2) X(4, 128, 64, 2, 2, 1, 16, 9, 1, 2) X(4, 64, 64, 2, 2, 1, 16, 9, 1, 2)  \
+    X(4, 128, 32, 4, 1, 1, 16, 9, 1, 2) X(4, 64, 64, 2, 2, 1, 16, 1, 1, 1)
 
 struct ConvInst {
-    int NW, BM, BN, CK, taps, TG, ACH;
+    int NW, BM, BN, KG, CK, taps, TG, ACH;
 };
 static const ConvInst* find_inst(const ConvTile& t) {
     static const ConvInst table[] = {
-#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, tg_, ach_) {nw_, bm_, bn_, ck_, taps_, tg_, ach_},
+#define X(nw_, bm_, bn_, wm_, wn_, kg_, ck_, taps_, tg_, ach_) {nw_, bm_, bn_, kg_, ck_, taps_, tg_, ach_},
         RLDM_CONV_INSTANCES(X)
 #undef X
     };
@@ -715,13 +776,14 @@ size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
     size_t main_bytes = w + 2 * a + g;
     // GroupNorm finalize scratch lives in the (not yet written) halo buffers: 2*Cin + 2*groups doubles
     const size_t gscratch = p.st0 ? w + ((size_t)2 * (p.C0 + p.C1) + 2 * p.gn_groups) * 8 : 0;
-    const size_t epi = (size_t)t.BM * (t.BN * 2 + 16) + (size_t)2 * (64 * NW / (t.BN / 8)) * t.BN * 4;
+    size_t epi = (size_t)t.BM * (t.BN * 2 + 16) + (size_t)2 * (64 * NW / (t.BN / 8)) * t.BN * 4;
+    if (inst && inst->KG == 2) epi = std::max(epi, (size_t)t.BM * t.BN * 4);      // k-group accumulator hand-over
     return std::max(std::max(main_bytes, gscratch), epi);
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int CK, int TAPS, int TG, int ACH>
+template <int NW, int BM, int BN, int WM, int WN, int KG, int CK, int TAPS, int TG, int ACH>
 static int launch_inst(const ConvParams& p, int grid, size_t lds, hipStream_t stream) {
-    auto kern = conv_igemm_kernel<NW, BM, BN, WM, WN, CK, TAPS, TG, ACH>;
+    auto kern = conv_igemm_kernel<NW, BM, BN, WM, WN, KG, CK, TAPS, TG, ACH>;
     static size_t max_set = 0;
     if (lds > max_set) {
         RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -743,6 +805,7 @@ int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(p.up == 1 || p.up == 2, "conv: upsample factor must be 1 or 2");
     RLDM_REQUIRE(p.Win * p.up >= 2 || t.taps == 1, "conv: azimuth extent too small for wrap-around");
     RLDM_REQUIRE(p.ksplit >= 1 && (p.ksplit == 1 || (p.slab && p.ticket)), "conv: split-K needs slab and ticket buffers");
+    RLDM_REQUIRE(p.ksplit == 1 || (find_inst(t) && find_inst(t)->KG == 1), "conv: split-K is not combined with k-group instances");
     const ConvInst* inst = find_inst(t);
     RLDM_REQUIRE(inst != nullptr, "conv: no kernel instance for tile BM=" + std::to_string(t.BM) + " BN=" +
                                       std::to_string(t.BN) + " CK=" + std::to_string(t.CK) + " taps=" + std::to_string(t.taps));
@@ -755,9 +818,9 @@ int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream) {
     const int grid = p.B * (p.Wout / p.TW) * (p.Hout / p.TH) * p.ntile_n * p.ksplit;
     const size_t lds = conv_lds_bytes(t, p);
     RLDM_REQUIRE(lds <= 160 * 1024, "conv: LDS footprint exceeds 160 KiB");
-#define X(nw_, bm_, bn_, wm_, wn_, ck_, taps_, tg_, ach_)                                 \
+#define X(nw_, bm_, bn_, wm_, wn_, kg_, ck_, taps_, tg_, ach_)                            \
     if (t.BM == bm_ && t.BN == bn_ && t.CK == ck_ && t.taps == taps_)                     \
-        return launch_inst<nw_, bm_, bn_, wm_, wn_, ck_, taps_, tg_, ach_>(p, grid, lds, stream);
+        return launch_inst<nw_, bm_, bn_, wm_, wn_, kg_, ck_, taps_, tg_, ach_>(p, grid, lds, stream);
     RLDM_CONV_INSTANCES(X)
 #undef X
     return 1;
