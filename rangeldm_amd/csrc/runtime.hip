@@ -372,7 +372,7 @@ static void pixel_tile(int BM, int Wout, int Hout, int stride, int* TW, int* TH)
 }
 
 static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N, int Cin_pad, int C0, int R, int R0,
-                              int taps, bool nchw) {
+                              int taps, bool nchw, bool gn) {
     TileChoice c;
     const int KW = taps == 9 ? 3 : 1;
     // a channel chunk never straddles a concat boundary
@@ -425,7 +425,9 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
                     best.TW = tw;
                     best.TH = th;
                 }
-                if (nb >= 200) found = true;
+                // enough blocks?  A 1x1 conv with a GroupNorm prologue (attention q/k/v) re-normalises its input once per
+                // channel tile, so a wide tile on half the CUs beats two rounds of narrow ones (measured, tools/bench_conv.py)
+                if (nb >= ((taps == 1 && gn) ? 128 : 200)) found = true;
             }
     }
     if (g_force_bm && g_force_bn) {
@@ -533,7 +535,7 @@ struct Builder {
         RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
         const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, x0.C, R_t, a.r0.valid() ? a.r0.C : 0, taps,
-                                          a.out_f32_nchw);
+                                          a.out_f32_nchw, a.gn != nullptr);
         const ConvTile tile = tc.tile;
         RLDM_REQUIRE(conv_tile_supported(tile), "conv " + L->name + ": no kernel instance");
 
