@@ -93,8 +93,9 @@ def roofline(pipe, sampler_handle, x_T, steps):
     _lib.check(_lib.lib().rldm_sampler_profile(sampler_handle, C.c_void_p(x_T.data_ptr()), buf, len(buf)),
                "rldm_sampler_profile")
     prof = json.loads(buf.value.decode())
+    lanes = prof.get("lanes", 1)       # the sampler runs `lanes` concurrent chains of batch/lanes samples; lane 0 is profiled
     tot = {}
-    for part, mult in (("unet_step", steps), ("vae_decode", 1)):
+    for part, mult in (("unet_step", steps * lanes), ("vae_decode", lanes)):
         for k, v in prof.get(part, {}).items():
             t = tot.setdefault(k, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             for f in t:
@@ -119,7 +120,8 @@ def roofline(pipe, sampler_handle, x_T, steps):
           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
           "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
           "alg_flops_per_launch": d["flops"] / d["launches"], "alg_bytes_per_launch": d["bytes"] / d["launches"],
-          "launches_per_batch": d["launches"], "eager_kernel_ms_per_batch": round(all_ms, 3)}
+          "launches_per_batch": d["launches"], "eager_kernel_ms_per_batch": round(all_ms, 3),
+          "concurrent_chains": lanes, "chain_batch": prof.get("lane_batch")}
     return rl, kernels
 
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -1254,43 +1255,56 @@ static int vae_get_plan(rldm_vae* m, int B, int w, int h, bool enc, Plan** out) 
 // =================================================================================================================
 // sampler
 // =================================================================================================================
-struct rldm_sampler {
-    rldm_unet* unet = nullptr;
-    rldm_vae* vae = nullptr;
-    rldm_sampler_config cfg;
+// One lane = an independent slice of the batch with its own plans, buffers, stream and captured graphs.  Whole samples
+// never interact, so the lanes' 50-step chains run concurrently on separate streams: the low-resolution UNet levels
+// launch far fewer workgroups than the chip has CUs, and a second (third, fourth) chain fills the idle ones.
+struct SamplerLane {
+    int b0 = 0, nb = 0;                             // samples [b0, b0 + nb) of the batch
     std::unique_ptr<Plan> uplan;                    // private UNet plan (graph-baked pointers)
     std::unique_ptr<Plan> dplan;                    // private VAE decode plan
-    DevBuf x, eps, cond, coef, temb_tab, t_dev, step, image;
+    DevBuf x, eps, cond, step, image;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t ev_out = nullptr;
     hipGraphExec_t step_graph = nullptr, decode_graph = nullptr;
     const float* captured_noise = nullptr;
-    bool captured_has_cond = false;
-    long long n_latent = 0, n_image = 0;
-    ~rldm_sampler() {
+    long long n_latent = 0, n_image = 0, n_cond = 0;
+    ~SamplerLane() {
         if (step_graph) (void)hipGraphExecDestroy(step_graph);
         if (decode_graph) (void)hipGraphExecDestroy(decode_graph);
-        if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_out) (void)hipEventDestroy(ev_out);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
-static int sampler_enqueue_step(rldm_sampler* s, const float* noise, hipStream_t st) {
-    if (s->uplan->run(st)) return 1;
+struct rldm_sampler {
+    rldm_unet* unet = nullptr;
+    rldm_vae* vae = nullptr;
+    rldm_sampler_config cfg;
+    DevBuf coef, temb_tab, t_dev;                   // shared, read-only after creation
+    std::vector<std::unique_ptr<SamplerLane>> lanes;
+    hipEvent_t ev_in = nullptr;
+    long long n_latent = 0, n_image = 0;            // whole batch
+    ~rldm_sampler() {
+        lanes.clear();
+        if (ev_in) (void)hipEventDestroy(ev_in);
+    }
+};
+
+static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* noise, hipStream_t st) {
+    if (ln->uplan->run(st)) return 1;
     SchedParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
     sp.coef_table = s->coef.as<float>();
-    sp.step_ptr = s->step.as<int>();
-    sp.eps = s->eps.as<float>();
-    sp.x = s->x.as<float>();
-    sp.noise = noise;
-    sp.noise_step_stride = s->n_latent;
-    sp.x_prev = s->x.as<float>();
-    sp.n = s->n_latent;
+    sp.step_ptr = ln->step.as<int>();
+    sp.eps = ln->eps.as<float>();
+    sp.x = ln->x.as<float>();
+    sp.noise = noise;                               // already offset to this lane's first sample
+    sp.noise_step_stride = s->n_latent;             // the caller's tensor is [steps][whole batch][...]
+    sp.x_prev = ln->x.as<float>();
+    sp.n = ln->n_latent;
     if (launch_sched_step(sp, st)) return 1;
-    return launch_step_counter(s->step.as<int>(), 0, 1, st);
+    return launch_step_counter(ln->step.as<int>(), 0, 1, st);
 }
 
 static int capture(hipStream_t st, const std::function<int()>& body, hipGraphExec_t* exec) {
@@ -1520,6 +1534,18 @@ int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_
 }
 
 // ---- sampler ------------------------------------------------------------------------------------------------------
+static int sampler_num_lanes(int batch) {
+    // Default ONE chain: on MI355X / ROCm 7.2 graph launches on separate streams did not overlap usefully -- at batch 16
+    // two chains of 8 measured 105 img/s and four chains of 4 measured 67 img/s against 122 img/s for a single chain
+    // (every launch pays its fixed cost again and the workgroups use most of a CU's LDS).  RLDM_LANES=n overrides.
+    int want = 1;
+    if (const char* e = getenv("RLDM_LANES")) want = atoi(e);
+    if (want <= 0) want = 1;
+    want = std::max(1, std::min(want, batch));
+    while (batch % want) --want;
+    return want;
+}
+
 int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_config* cfg, rldm_sampler** out) {
     RLDM_REQUIRE(unet && cfg && out, "null argument");
     RLDM_REQUIRE(unet->params.finalized, "unet not finalized");
@@ -1536,42 +1562,58 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
     s->cfg.coef = nullptr;
     s->cfg.timesteps = nullptr;
     const int B = cfg->batch, W = uc.sample_w, H = uc.sample_h;
-    s->n_latent = (long long)B * uc.out_channels * W * H;
-    RLDM_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const long long per_latent = (long long)uc.out_channels * W * H;
+    const long long per_cond = (long long)cfg->cond_channels * W * H;
+    long long per_image = 0;
+    if (vae) {
+        const int f = 1 << (vae->cfg.num_levels - 1);
+        per_image = (long long)vae->cfg.out_channels * (W * f) * (H * f);
+    }
+    s->n_latent = B * per_latent;
+    s->n_image = B * per_image;
     RLDM_HIP_CHECK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
-    RLDM_HIP_CHECK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
-    if (s->x.alloc(s->n_latent * 4) || s->eps.alloc(s->n_latent * 4) || s->step.alloc(64)) return 1;
-    if (cfg->cond_channels && s->cond.alloc((size_t)B * cfg->cond_channels * W * H * 4)) return 1;
     if (upload(s->coef, cfg->coef, (size_t)cfg->num_steps * 5 * 4)) return 1;
     std::vector<float> tf(cfg->num_steps);
     for (int i = 0; i < cfg->num_steps; ++i) tf[i] = (float)cfg->timesteps[i];
     if (upload(s->t_dev, tf.data(), tf.size() * 4)) return 1;
     if (s->temb_tab.alloc((size_t)cfg->num_steps * unet->net.temb_ld * 4)) return 1;
-    if (unet_temb(unet, s->t_dev.as<float>(), cfg->num_steps, s->temb_tab.as<float>(), s->stream)) return 1;
-    if (unet_make_plan(unet, B, &s->uplan)) return 1;
-    PlanIO& io = s->uplan->io;
-    io.sample = s->x.as<float>();
-    io.sample_channels = uc.out_channels;
-    io.pos_encoding = cfg->pos_encoding;
-    io.cond = cfg->cond_channels ? s->cond.as<float>() : nullptr;
-    io.cond_channels = cfg->cond_channels;
-    io.out = s->eps.as<float>();
-    io.temb = s->temb_tab.as<float>();
-    io.step_ptr = s->step.as<int>();
-    io.temb_rows_per_step = 1;
-    io.temb_per_sample = 0;
-    if (vae) {
-        const int f = 1 << (vae->cfg.num_levels - 1);
-        s->n_image = (long long)B * vae->cfg.out_channels * (W * f) * (H * f);
-        if (s->image.alloc(s->n_image * 4)) return 1;
-        if (vae_make_plan(vae, B, W, H, false, &s->dplan)) return 1;
-        PlanIO& d = s->dplan->io;
-        d.sample = s->x.as<float>();
-        d.sample_channels = vae->cfg.z_channels;
-        d.sample_scale = 1.0f / vae->cfg.scaling_factor;      // latents / scaling_factor, ldm/pipelines.py:365
-        d.out = s->image.as<float>();
+    if (unet_temb(unet, s->t_dev.as<float>(), cfg->num_steps, s->temb_tab.as<float>(), nullptr)) return 1;
+    RLDM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    const int nl = sampler_num_lanes(B);
+    for (int l = 0; l < nl; ++l) {
+        auto ln = std::make_unique<SamplerLane>();
+        ln->nb = B / nl;
+        ln->b0 = l * ln->nb;
+        ln->n_latent = ln->nb * per_latent;
+        ln->n_image = ln->nb * per_image;
+        ln->n_cond = ln->nb * per_cond;
+        RLDM_HIP_CHECK(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
+        RLDM_HIP_CHECK(hipEventCreateWithFlags(&ln->ev_out, hipEventDisableTiming));
+        if (ln->x.alloc(ln->n_latent * 4) || ln->eps.alloc(ln->n_latent * 4) || ln->step.alloc(64)) return 1;
+        if (cfg->cond_channels && ln->cond.alloc((size_t)ln->n_cond * 4)) return 1;
+        if (unet_make_plan(unet, ln->nb, &ln->uplan)) return 1;
+        PlanIO& io = ln->uplan->io;
+        io.sample = ln->x.as<float>();
+        io.sample_channels = uc.out_channels;
+        io.pos_encoding = cfg->pos_encoding;
+        io.cond = cfg->cond_channels ? ln->cond.as<float>() : nullptr;
+        io.cond_channels = cfg->cond_channels;
+        io.out = ln->eps.as<float>();
+        io.temb = s->temb_tab.as<float>();
+        io.step_ptr = ln->step.as<int>();
+        io.temb_rows_per_step = 1;
+        io.temb_per_sample = 0;
+        if (vae) {
+            if (ln->image.alloc(ln->n_image * 4)) return 1;
+            if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan)) return 1;
+            PlanIO& d = ln->dplan->io;
+            d.sample = ln->x.as<float>();
+            d.sample_channels = vae->cfg.z_channels;
+            d.sample_scale = 1.0f / vae->cfg.scaling_factor;      // latents / scaling_factor, ldm/pipelines.py:365
+            d.out = ln->image.as<float>();
+        }
+        s->lanes.push_back(std::move(ln));
     }
-    RLDM_HIP_CHECK(hipStreamSynchronize(s->stream));
     *out = s.release();
     return 0;
 }
@@ -1584,56 +1626,76 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
     RLDM_REQUIRE((s->cfg.cond_channels == 0) == (cond == nullptr), "cond tensor does not match sampler.cond_channels");
     RLDM_REQUIRE(s->cfg.mode == RLDM_SAMPLER_DDIM || step_noise != nullptr, "DDPM sampling needs step_noise");
     hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
-    hipStream_t st = s->stream;
     RLDM_HIP_CHECK(hipEventRecord(s->ev_in, caller));
-    RLDM_HIP_CHECK(hipStreamWaitEvent(st, s->ev_in, 0));
-    RLDM_HIP_CHECK(hipMemcpyAsync(s->x.p, x_T, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
-    if (cond) RLDM_HIP_CHECK(hipMemcpyAsync(s->cond.p, cond, s->cond.bytes, hipMemcpyDeviceToDevice, st));
-    if (launch_step_counter(s->step.as<int>(), 0, 0, st)) return 1;
-    const float* noise = s->cfg.mode == RLDM_SAMPLER_DDPM ? step_noise : nullptr;
-    if (!s->step_graph || s->captured_noise != noise) {
-        // one eager step first (sets kernel attributes, packs weights), then rewind and capture
-        if (sampler_enqueue_step(s, noise, st)) return 1;
-        RLDM_HIP_CHECK(hipStreamSynchronize(st));
-        RLDM_HIP_CHECK(hipMemcpyAsync(s->x.p, x_T, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
-        if (launch_step_counter(s->step.as<int>(), 0, 0, st)) return 1;
-        if (capture(st, [&]() { return sampler_enqueue_step(s, noise, st); }, &s->step_graph)) return 1;
-        s->captured_noise = noise;
-    }
-    for (int i = 0; i < s->cfg.num_steps; ++i) RLDM_HIP_CHECK(hipGraphLaunch(s->step_graph, st));
-    if (latents_out) RLDM_HIP_CHECK(hipMemcpyAsync(latents_out, s->x.p, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
-    if (images) {
-        if (s->vae) {
-            if (!s->decode_graph) {
-                if (s->dplan->run(st)) return 1;
-                RLDM_HIP_CHECK(hipStreamSynchronize(st));
-                if (capture(st, [&]() { return s->dplan->run(st); }, &s->decode_graph)) return 1;
-            }
-            RLDM_HIP_CHECK(hipGraphLaunch(s->decode_graph, st));
-            RLDM_HIP_CHECK(hipMemcpyAsync(images, s->image.p, s->n_image * 4, hipMemcpyDeviceToDevice, st));
-        } else {
-            RLDM_HIP_CHECK(hipMemcpyAsync(images, s->x.p, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
+    // per lane: inputs, (first call) eager warm step + graph capture
+    for (auto& lnp : s->lanes) {
+        SamplerLane* ln = lnp.get();
+        hipStream_t st = ln->stream;
+        const size_t lat_off = (size_t)ln->b0 * (ln->n_latent / ln->nb);
+        RLDM_HIP_CHECK(hipStreamWaitEvent(st, s->ev_in, 0));
+        RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+        if (cond)
+            RLDM_HIP_CHECK(hipMemcpyAsync(ln->cond.p, cond + (size_t)ln->b0 * (ln->n_cond / ln->nb), ln->n_cond * 4,
+                                          hipMemcpyDeviceToDevice, st));
+        if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
+        const float* noise = s->cfg.mode == RLDM_SAMPLER_DDPM ? step_noise + lat_off : nullptr;
+        if (!ln->step_graph || ln->captured_noise != noise) {
+            // one eager step first (sets kernel attributes, packs weights), then rewind and capture
+            if (sampler_enqueue_step(s, ln, noise, st)) return 1;
+            RLDM_HIP_CHECK(hipStreamSynchronize(st));
+            RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+            if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
+            if (capture(st, [&]() { return sampler_enqueue_step(s, ln, noise, st); }, &ln->step_graph)) return 1;
+            ln->captured_noise = noise;
+        }
+        if (images && s->vae && !ln->decode_graph) {
+            // (the decode runs on whatever x holds now: only its launch list is recorded)
+            if (ln->dplan->run(st)) return 1;
+            RLDM_HIP_CHECK(hipStreamSynchronize(st));
+            if (capture(st, [&]() { return ln->dplan->run(st); }, &ln->decode_graph)) return 1;
+            RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
         }
     }
-    RLDM_HIP_CHECK(hipEventRecord(s->ev_out, st));
-    RLDM_HIP_CHECK(hipStreamWaitEvent(caller, s->ev_out, 0));
+    // the chains: step-major so every stream always has work queued
+    for (int i = 0; i < s->cfg.num_steps; ++i)
+        for (auto& lnp : s->lanes) RLDM_HIP_CHECK(hipGraphLaunch(lnp->step_graph, lnp->stream));
+    for (auto& lnp : s->lanes) {
+        SamplerLane* ln = lnp.get();
+        hipStream_t st = ln->stream;
+        const size_t lat_off = (size_t)ln->b0 * (ln->n_latent / ln->nb);
+        if (latents_out)
+            RLDM_HIP_CHECK(hipMemcpyAsync(latents_out + lat_off, ln->x.p, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+        if (images) {
+            if (s->vae) {
+                RLDM_HIP_CHECK(hipGraphLaunch(ln->decode_graph, st));
+                RLDM_HIP_CHECK(hipMemcpyAsync(images + (size_t)ln->b0 * (ln->n_image / ln->nb), ln->image.p, ln->n_image * 4,
+                                              hipMemcpyDeviceToDevice, st));
+            } else {
+                RLDM_HIP_CHECK(hipMemcpyAsync(images + lat_off, ln->x.p, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        RLDM_HIP_CHECK(hipEventRecord(ln->ev_out, st));
+        RLDM_HIP_CHECK(hipStreamWaitEvent(caller, ln->ev_out, 0));
+    }
     return 0;
 }
 
-// one instrumented UNet step + scheduler step (+ VAE decode): per-kernel launch counts, HIP-event time, algorithmic work
+// one instrumented UNet step + scheduler step (+ VAE decode) of lane 0: per-kernel launch counts, HIP-event time,
+// algorithmic work.  JSON also carries "lanes" and "lane_batch" so the caller can scale to the whole batch.
 int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size_t cap) {
     RLDM_REQUIRE(s && x_T && json_out && cap > 2, "null argument");
-    hipStream_t st = s->stream;
-    RLDM_HIP_CHECK(hipMemcpyAsync(s->x.p, x_T, s->n_latent * 4, hipMemcpyDeviceToDevice, st));
-    if (launch_step_counter(s->step.as<int>(), 0, 0, st)) return 1;
-    if (s->uplan->run(st)) return 1;                      // warm
+    SamplerLane* ln = s->lanes[0].get();
+    hipStream_t st = ln->stream;
+    RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+    if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
+    if (ln->uplan->run(st)) return 1;                      // warm
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
     std::map<std::string, KernelStat> unet_stats, vae_stats;
-    if (s->uplan->run_profiled(st, unet_stats)) return 1;
-    if (s->dplan) {
-        if (s->dplan->run(st)) return 1;
+    if (ln->uplan->run_profiled(st, unet_stats)) return 1;
+    if (ln->dplan) {
+        if (ln->dplan->run(st)) return 1;
         RLDM_HIP_CHECK(hipStreamSynchronize(st));
-        if (s->dplan->run_profiled(st, vae_stats)) return 1;
+        if (ln->dplan->run_profiled(st, vae_stats)) return 1;
     }
     std::string js = "{";
     auto dump = [&](const char* key, const std::map<std::string, KernelStat>& m) {
@@ -1652,7 +1714,7 @@ int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size
     dump("unet_step", unet_stats);
     js += ", ";
     dump("vae_decode", vae_stats);
-    js += "}";
+    js += ", \"lanes\": " + std::to_string(s->lanes.size()) + ", \"lane_batch\": " + std::to_string(ln->nb) + "}";
     RLDM_REQUIRE(js.size() + 1 <= cap, "profile buffer too small");
     memcpy(json_out, js.c_str(), js.size() + 1);
     return 0;
