@@ -44,6 +44,14 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
         : "v"(gsrc), "s"(lds_addr)
         : "memory");
 }
+// Hot-loop ablation switches (ConvParams::dbg bits 8/16/32/64) and in-kernel timestamps cost scalar branches in every
+// stage: compiled in only with -DRLDM_ABLATE (make ABLATE=1); bits 1/2/4 (outside the loop) are always available.
+#ifdef RLDM_ABLATE
+#define RLDM_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define RLDM_DBG(p, bit) false
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -91,7 +99,11 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     const int kh = lane >> 5, l31 = lane & 31;
     int ts_n = 0;
     auto stamp = [&]() {
+#ifdef RLDM_ABLATE
         if (p.ts && blockIdx.x < 4 && tid == 0 && ts_n < 64) p.ts[blockIdx.x * 64 + ts_n++] = __builtin_amdgcn_s_memtime();
+#else
+        (void)ts_n;
+#endif
     };
     stamp();
 
@@ -424,9 +436,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             } else {
                 if (hl_prev) wait_vmcnt<PPT + ACH>(); else wait_vmcnt<PPT>();
             }
-            if (p.dbg & 64) stamp();
+            if (RLDM_DBG(p, 64)) stamp();
             lds_barrier();
-            if (p.dbg & 64) stamp();
+            if (RLDM_DBG(p, 64)) stamp();
             const int vis = stored;            // halo images complete and visible to every wave
             const bool cmain = cc < NCC;
             const unsigned char* wbase = sW + wslot * STILE;
@@ -467,9 +479,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             }
             const int cc_now = cc;
             (void)cc_now;
-            if (p.dbg & 64) stamp();
-            if (halo_first && !(p.dbg & 32)) RLDM_HALO_STEP
-            if (p.dbg & 64) stamp();
+            if (RLDM_DBG(p, 64)) stamp();
+            if (halo_first && !RLDM_DBG(p, 32)) RLDM_HALO_STEP
+            if (RLDM_DBG(p, 64)) stamp();
             // coordinates of the next stage
             int ncc = cc, nsg = sg + 1, ntoff = toff, ntj = tj;
             if (nsg == (cmain ? SPC : 1)) {
@@ -486,8 +498,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             const int dlast = (dmain ? SCH : WCH) - 64;
             const unsigned char* dsrc = wtile0 + wbyte(dst_sa);
             const unsigned ddst = lds0 + (unsigned)(dslot * STILE);
-            const bool nodma = (p.dbg & 16) != 0;      // tuning ablations: no weight streaming after the prologue,
-            const bool nomma = (p.dbg & 8) != 0;       // no MFMAs
+            const bool nodma = RLDM_DBG(p, 16);        // tuning ablations: no weight streaming after the prologue,
+            const bool nomma = RLDM_DBG(p, 8);         // no MFMAs
             __builtin_amdgcn_sched_barrier(0);
             if (TG == 1 || !cmain) {
 #pragma unroll
@@ -506,7 +518,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             } else {
                 RLDM_TAP9(0) RLDM_TAP9(1) RLDM_TAP9(2) RLDM_TAP9(3) RLDM_TAP9(4) RLDM_TAP9(5) RLDM_TAP9(6) RLDM_TAP9(7) RLDM_TAP9(8)
             }
-            if (!halo_first && !(p.dbg & 32)) RLDM_HALO_STEP
+            if (!halo_first && !RLDM_DBG(p, 32)) RLDM_HALO_STEP
 #undef RLDM_HALO_STEP
             pm_prev = cmain;
             x_ready = (s + 1 < NS) && (ncc <= vis);
