@@ -52,6 +52,12 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
 #define RLDM_DBG(p, bit) false
 #endif
 
+// Same with a wave-uniform (SGPR) base and a per-lane byte offset: no 64-bit VALU address per piece.  m0 is not saved:
+// nothing hipcc emits for these kernels on gfx950 reads it (DS instructions have not needed M0 since gfx9).
+__device__ __forceinline__ void lds_dma16s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr)
+                 : "memory", "m0");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -168,15 +174,16 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     auto wbyte = [&](int sa) __attribute__((always_inline)) {     // byte offset of absolute stage sa
         return sa < NMS ? (size_t)sa * STILE : (size_t)NMS * STILE + (size_t)(sa - NMS) * WTILE;
     };
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_pieces = [&](const unsigned char* src, unsigned dst, int lo, int hi, int last) __attribute__((always_inline)) {
         // pieces [lo, hi) of a stage (compile-time bounds); every wave issues full-wave DMAs, passes beyond the stage's
-        // last 64-piece block (`last`) overlap it instead of running short
+        // last 64-piece block (`last`) overlap it instead of running short.  All address math is scalar.
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
             if (i < lo || i >= hi) continue;
             int piece = i * NT + wave * 64;
             piece = piece > last ? last : piece;
-            lds_dma16(src + (size_t)(piece + lane) * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)piece * 16)));
+            lds_dma16s(src + (size_t)piece * 16, lane16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)piece * 16)));
         }
     };
 #pragma unroll
