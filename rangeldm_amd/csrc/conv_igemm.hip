@@ -30,6 +30,7 @@
 //   fp32 accumulators in a slab, and the last one to arrive (agent-scope release/acquire around a ticket counter)
 //   adds the slabs in slice order and runs the epilogue.
 #include "kernels.h"
+#include <type_traits>
 
 namespace rldm {
 
@@ -433,8 +434,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             if (ks == 0 && !nodma) issue_pieces(dsrc, ddst, (TT) * PPT, ((TT) + 1) * PPT < DPT ? ((TT) + 1) * PPT : DPT, dlast); \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }
-#pragma unroll 1
-        while (s < NS) {
+        // One stage; `cmain_c` selects the main-phase / residual-phase code at compile time: two loops, no join of the two
+        // accumulator-register layouts inside one loop body.
+        auto stage = [&](auto cmain_c) __attribute__((always_inline)) {
             // W(s) has landed once only the operations issued after its DMAs are outstanding (VMEM retires in order)
             if (NBUF == 2 || s + 1 >= NS) {
                 wait_vmcnt<0>();
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             lds_barrier();
             if (RLDM_DBG(p, 64)) stamp();
             const int vis = stored;            // halo images complete and visible to every wave
-            const bool cmain = cc < NCC;
+            constexpr bool cmain = decltype(cmain_c)::value;     // main-phase stage (TG taps) or residual-phase stage (1 tap)
             const unsigned char* wbase = sW + wslot * STILE;
             const unsigned char* abase = sA + (cc & 1) * abytes + toff;
             if (TG == 1 || !cmain) {
@@ -535,7 +537,12 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             ++dsa;
             ++s;
             stamp();
-        }
+        };
+        const int nsm = (NMS - sbeg) < 0 ? 0 : ((NMS - sbeg) < NS ? (NMS - sbeg) : NS);    // main-phase stages of this slice
+#pragma unroll 1
+        while (s < nsm) stage(std::true_type{});
+#pragma unroll 1
+        while (s < NS) stage(std::false_type{});
 #undef RLDM_TAP9
 #undef RLDM_MMA
 #undef RLDM_READ_TAP
