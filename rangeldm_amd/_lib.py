@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librangeldm_hip.so")
+# RLDM_LIB selects another build of the same library (tools/: the -DRLDM_ABLATE timeline build); never a fallback
+LIB_PATH = os.environ.get("RLDM_LIB") or os.path.join(_HERE, "librangeldm_hip.so")
 RLDM_MAX_LEVELS = 8
 
 

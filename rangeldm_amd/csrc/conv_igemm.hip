@@ -105,11 +105,20 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     const int wm = wmn % WM, wn = wmn / WM;
     const int kh = lane >> 5, l31 = lane & 31;
     int ts_n = 0;
+    // in-kernel timeline (ABLATE builds): s_memtime stamps go to the last 512 bytes of the LDS allocation (no VMEM
+    // traffic that would perturb the counted waits) and are copied out at the very end by `flush_stamps`
     auto stamp = [&]() {
 #ifdef RLDM_ABLATE
-        if (p.ts && blockIdx.x < 4 && tid == 0 && ts_n < 64) p.ts[blockIdx.x * 64 + ts_n++] = __builtin_amdgcn_s_memtime();
+        if (p.ts && blockIdx.x < 4 && tid == 0 && ts_n < 64)
+            reinterpret_cast<unsigned long long*>(smem + p.lds_total - 512)[ts_n++] = __builtin_amdgcn_s_memtime();
 #else
         (void)ts_n;
+#endif
+    };
+    auto flush_stamps = [&]() {
+#ifdef RLDM_ABLATE
+        if (p.ts && blockIdx.x < 4 && tid == 0)
+            for (int i = 0; i < ts_n; ++i) p.ts[blockIdx.x * 64 + i] = reinterpret_cast<unsigned long long*>(smem + p.lds_total - 512)[i];
 #endif
     };
     stamp();
@@ -431,14 +440,16 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
             RLDM_MMA(TT, ks, (TT) * KS + ks)                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            if (ks == 0 && !nodma) issue_pieces(dsrc, ddst, (TT) * PPT, ((TT) + 1) * PPT < DPT ? ((TT) + 1) * PPT : DPT, dlast); \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }
         // One stage; `cmain_c` selects the main-phase / residual-phase code at compile time: two loops, no join of the two
         // accumulator-register layouts inside one loop body.
         auto stage = [&](auto cmain_c) __attribute__((always_inline)) {
             // W(s) has landed once only the operations issued after its DMAs are outstanding (VMEM retires in order)
-            if (NBUF == 2 || s + 1 >= NS) {
+            if (NBUF == 2) {
+                // the previous stage requested W(s) first thing after its barrier; only its halo loads are younger
+                if (hl_prev) wait_vmcnt<ACH>(); else wait_vmcnt<0>();
+            } else if (s + 1 >= NS) {
                 wait_vmcnt<0>();
             } else if (pm_prev) {
                 if (hl_prev) wait_vmcnt<DPT + ACH>(); else wait_vmcnt<DPT>();
@@ -452,6 +463,18 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             constexpr bool cmain = decltype(cmain_c)::value;     // main-phase stage (TG taps) or residual-phase stage (1 tap)
             const unsigned char* wbase = sW + wslot * STILE;
             const unsigned char* abase = sA + (cc & 1) * abytes + toff;
+            // DMA target: stage s + DD, or (past the end) this stage again: a valid source into a free slot
+            const int dst_sa = (s + DD < NS) ? dsa : sbeg + s;
+            const bool dmain = dst_sa < NMS;
+            const int dlast = (dmain ? SCH : WCH) - 64;
+            const unsigned char* dsrc = wtile0 + wbyte(dst_sa);
+            const unsigned ddst = lds0 + (unsigned)(dslot * STILE);
+            const bool nodma = RLDM_DBG(p, 16);        // tuning ablations: no weight streaming after the prologue,
+            const bool nomma = RLDM_DBG(p, 8);         // no MFMAs
+            // TG == 9: the whole next stage is requested right at the barrier (its slot was vacated by the stage before
+            // this one), so the DMA has the entire stage to land -- and every later VMEM operation of the stage (the halo
+            // loads) is younger, which is what the counted wait at the top of the next stage relies on
+            if (TG == 9 && !nodma) issue_pieces(dsrc, ddst, 0, cmain ? DPT : PPT, dlast);
             if (TG == 1 || !cmain) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
@@ -480,7 +503,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             // halo pipeline: write the chunk whose loads are in flight (GroupNorm + SiLU: VALU work), load the one after.
             // With two k-groups on a TG == 9 stage, group 1 does it before its taps and group 0 after, so that one
             // group's VALU work runs under the other group's MFMAs.
-            const bool halo_first = !(KG == 2 && TG == 9 && kg == 0);
+            const bool halo_first = !(KG == 2 && TG == 9 && kg == 0) || RLDM_DBG(p, 128);
 #define RLDM_HALO_STEP                                                                                               \
             {                                                                                                        \
                 if (loaded > stored && stored + 1 <= cc + 1) { load_affine(stored + 1); store_a(stored + 1); ++stored; } \
@@ -501,14 +524,6 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                 if (++ntj == 3) { ntj = 0; ntoff += colb - 3 * RS; }
             }
             const unsigned char* nbase = sA + (ncc & 1) * abytes + ntoff;
-            // DMA target: stage s + DD, or (past the end) this stage again: a valid source into a free slot
-            const int dst_sa = (s + DD < NS) ? dsa : sbeg + s;
-            const bool dmain = dst_sa < NMS;
-            const int dlast = (dmain ? SCH : WCH) - 64;
-            const unsigned char* dsrc = wtile0 + wbyte(dst_sa);
-            const unsigned ddst = lds0 + (unsigned)(dslot * STILE);
-            const bool nodma = RLDM_DBG(p, 16);        // tuning ablations: no weight streaming after the prologue,
-            const bool nomma = RLDM_DBG(p, 8);         // no MFMAs
             __builtin_amdgcn_sched_barrier(0);
             if (TG == 1 || !cmain) {
 #pragma unroll
@@ -517,7 +532,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                     __builtin_amdgcn_sched_barrier(0);
                     // the stage's DMA share, spread over its k-steps
 #pragma unroll
-                    for (int i = ks; i < PPT; i += KS) if (!nodma) issue_pieces(dsrc, ddst, i, i + 1, dlast);
+                    for (int i = ks; i < PPT; i += KS) if (TG == 1 && !nodma) issue_pieces(dsrc, ddst, i, i + 1, dlast);
                     if (TG == 1) {             // in-place prefetch of the next stage's pixel fragments
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) xf[0][ks][mi] = *reinterpret_cast<const bf16x8*>(nbase + xoff[mi] + ks * 32);
@@ -527,7 +542,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             } else {
                 RLDM_TAP9(0) RLDM_TAP9(1) RLDM_TAP9(2) RLDM_TAP9(3) RLDM_TAP9(4) RLDM_TAP9(5) RLDM_TAP9(6) RLDM_TAP9(7) RLDM_TAP9(8)
             }
+            if (RLDM_DBG(p, 64)) stamp();
             if (!halo_first && !RLDM_DBG(p, 32)) RLDM_HALO_STEP
+            if (RLDM_DBG(p, 64)) stamp();
 #undef RLDM_HALO_STEP
             pm_prev = cmain;
             x_ready = (s + 1 < NS) && (ncc <= vis);
@@ -731,6 +748,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         }
     }
     stamp();
+    flush_stamps();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -804,7 +822,7 @@ size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
     const size_t gscratch = p.st0 ? w + ((size_t)2 * (p.C0 + p.C1) + 2 * p.gn_groups) * 8 : 0;
     size_t epi = (size_t)t.BM * (t.BN * 2 + 16) + (size_t)2 * (64 * NW / (t.BN / 8)) * t.BN * 4;
     if (inst && inst->KG == 2) epi = std::max(epi, (size_t)t.BM * t.BN * 4);      // k-group accumulator hand-over
-    return std::max(std::max(main_bytes, gscratch), epi);
+    return std::max(std::max(main_bytes, gscratch), epi) + 512;    // + timeline scratch (ABLATE builds)
 }
 
 template <int NW, int BM, int BN, int WM, int WN, int KG, int CK, int TAPS, int TG, int ACH>
@@ -844,9 +862,11 @@ int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream) {
     const int grid = p.B * (p.Wout / p.TW) * (p.Hout / p.TH) * p.ntile_n * p.ksplit;
     const size_t lds = conv_lds_bytes(t, p);
     RLDM_REQUIRE(lds <= 160 * 1024, "conv: LDS footprint exceeds 160 KiB");
+    ConvParams pp = p;
+    pp.lds_total = (int)lds;
 #define X(nw_, bm_, bn_, wm_, wn_, kg_, ck_, taps_, tg_, ach_)                            \
     if (t.BM == bm_ && t.BN == bn_ && t.CK == ck_ && t.taps == taps_)                     \
-        return launch_inst<nw_, bm_, bn_, wm_, wn_, kg_, ck_, taps_, tg_, ach_>(p, grid, lds, stream);
+        return launch_inst<nw_, bm_, bn_, wm_, wn_, kg_, ck_, taps_, tg_, ach_>(pp, grid, lds, stream);
     RLDM_CONV_INSTANCES(X)
 #undef X
     return 1;

@@ -61,6 +61,7 @@ struct ConvParams {
     int ksplit;             // >= 1
     float* slab;            // [tiles][ksplit][BM*BN] fp32 (ksplit > 1)
     int* ticket;            // [tiles] zero-initialised arrival counters (re-armed by the last arriver)
+    int lds_total;           // dynamic LDS bytes of the launch (set by launch_conv)
     unsigned long long* ts;  // tuning: s_memtime stamps of blocks 0..3, wave 0 ([4][64]) or null
     int dbg;                // tuning ablations (rldm_debug_set_flags): 1 skip stores, 2 skip main loop, 4 skip GN finalize
 };

@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--vae", action="store_true")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--custom", action="append", default=[],
+                    help="extra case B,C0,C1,W,H,Cout,k,stride,up,gn,res,temb (repeatable; replaces the network's list)")
     ap.add_argument("--ts", action="store_true", help="print in-kernel s_memtime stamps (deltas, cycles) of block 0")
     a = ap.parse_args()
     _lib.require_gpu()
@@ -154,6 +156,12 @@ def main():
     cases = unet_cases(a.B)
     if a.vae:
         cases += vae_decoder_cases(a.B)
+    if a.custom:
+        cases = []
+        for spec in a.custom:
+            v = list(map(int, spec.split(",")))
+            cases.append((Case(name="custom", count=0, B=v[0], C0=v[1], C1=v[2], W=v[3], H=v[4], Cout=v[5], k=v[6], stride=v[7],
+                               pad=0, up=v[8], gn=v[9], silu=v[9], res=v[10], temb=v[11]), 1))
     tiles = [tuple(map(int, t.split("x"))) for t in a.tiles.split(",") if t] or [(0, 0, 0)]
     tiles = [t if len(t) == 3 else (t[0], t[1], 0) for t in tiles]
     tot = collections.defaultdict(float)
