@@ -1,0 +1,133 @@
+"""Unconditional sampling driver -- the MI355X counterpart of the reference's `ldm/inference.py:154-183`
+(`accelerate launch ldm/inference.py --cfg configs/RangeLDM.yaml`): one process per GPU, every rank samples
+`eval_batch_size` images per outer iteration, image index = (rank + nproc * i) * B + j, truncation at `--samples`,
+one file per image.
+
+    python -m rangeldm_amd.inference --cfg RangeLDM --samples 64 --out outputs/RangeLDM/generated
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m rangeldm_amd.inference --cfg RangeLDM ...
+
+`--cfg` is a preset name (rangeldm_amd.config.PRESETS) or a reference-style yaml whose `model_config` holds the
+UNet2DModel kwargs (ldm/configs/*.yaml).  Weights: a directory laid out like the reference's output_dir
+(`unet/diffusion_pytorch_model.safetensors`, `vae/diffusion_pytorch_model.safetensors`, diffusers keys) or, when
+none is given, the deterministic synthetic state dict (no checkpoints exist offline).  Output per image: `<idx>.npy`
+(the raw (2, W, H) range image, fp32) and `<idx>_range.png` exactly as ldm/inference.py:181-183 renders it; the point
+cloud / BEV projection of ldm/dataset.py (row f1 of SURVEY.md 8) is not part of this path.
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from . import distributed as D
+from .config import PRESETS, UNetConfig, VAEConfig
+
+
+def plan_iterations(samples, batch_size, world):
+    """Outer-loop length of ldm/inference.py:159 (`samples // B // nproc + 1`: up to one wasted batch per rank)."""
+    return samples // batch_size // world + 1
+
+
+def image_indices(iteration, batch_size, rank, world, samples):
+    """(j, global index) pairs rank `rank` keeps in iteration `iteration` -- ldm/inference.py:174-176."""
+    out = []
+    for j in range(batch_size):
+        idx = (rank + world * iteration) * batch_size + j
+        if idx >= samples:
+            break
+        out.append((j, idx))
+    return out
+
+
+def load_config(cfg):
+    if cfg in PRESETS:
+        return dict(PRESETS[cfg])
+    import yaml
+    with open(cfg) as f:
+        y = yaml.safe_load(f)
+    mc = dict(y["model_config"])
+    mc["sample_size"] = tuple(mc["sample_size"])
+    unet = UNetConfig(**{k: v for k, v in mc.items() if k in UNetConfig.__dataclass_fields__})
+    vae = None
+    if y.get("with_vae", False):
+        f = 4                                   # vae/configs/kitti360.yaml:35-41: ch_mult [1,2,4] -> 4x
+        vae = VAEConfig(sample_size=(unet.sample_size[0] * f, unet.sample_size[1] * f))
+    return dict(unet=unet, vae=vae, pos_encoding=bool(y.get("pos_encoding", False)), cond_channels=0,
+                steps=int(y.get("ddpm_num_inference_steps", 50)), ddim=bool(y.get("ddim", False)),
+                batch=int(y.get("eval_batch_size", 16)))
+
+
+def to_png(img2d):
+    """(W, H) in [0, 1] -> 8-bit grayscale PNG bytes via PIL if present (ldm/inference.py:182), else None."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return None
+    return Image.fromarray((np.clip(img2d, 0, 1) * 255.0).astype(np.uint8), mode="L")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="RangeLDM sampler on MI355X (ldm/inference.py counterpart)")
+    ap.add_argument("--cfg", required=True)
+    ap.add_argument("--batch_size", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--weights", default=None, help="reference-style output_dir with unet/ and vae/ safetensors")
+    ap.add_argument("--seed", type=int, default=20240310)
+    a = ap.parse_args(argv)
+
+    from .params import unet_param_shapes, vae_param_shapes
+    from .pipelines import DDIMPipelineRange, LDMPipelineRange
+    from .schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
+    from .synth import latent_noise, synth_state_dict
+    from .unet import UNet2DModelHIP
+    from .vae import AutoencoderKLHIP
+
+    cfg = load_config(a.cfg)
+    B = a.batch_size or cfg.get("batch", 16)
+    steps = cfg.get("steps", 50)
+    rank, world, local = D.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    out_dir = a.out or os.path.join("outputs", os.path.splitext(os.path.basename(a.cfg))[0], "generated")
+    os.makedirs(out_dir, exist_ok=True)
+
+    def state(sub, shapes, prefix):
+        if a.weights:
+            from safetensors.torch import load_file
+            return load_file(os.path.join(a.weights, sub, "diffusion_pytorch_model.safetensors"))
+        return synth_state_dict(shapes, seed=a.seed, prefix=prefix)
+
+    unet = UNet2DModelHIP(cfg["unet"])
+    unet.load_state_dict(state("unet", unet_param_shapes(cfg["unet"]), ""))
+    if cfg["vae"] is not None:
+        vae = AutoencoderKLHIP(cfg["vae"])
+        vae.load_state_dict(state("vae", vae_param_shapes(cfg["vae"]), "vae."))
+        # ldm/inference.py:131-136: the LDM branch keeps the DDPM scheduler (strided ancestral sampling)
+        pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDPMSchedulerHIP(), pos_encoding=cfg["pos_encoding"])
+    else:
+        pipe = DDIMPipelineRange(unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=cfg["pos_encoding"])
+    lat_shape = (cfg["unet"].out_channels, *cfg["unet"].sample_size)
+
+    for i in range(plan_iterations(a.samples, B, world)):
+        keep = image_indices(i, B, rank, world, a.samples)
+        if not keep:
+            continue
+        # x_T is a function of the GLOBAL image index: any GPU count produces the same images
+        idx = D.global_sample_indices(i, B, rank, world)
+        x_T = torch.from_numpy(np.stack([latent_noise(a.seed, j, lat_shape) for j in idx])).to(dev)
+        gen = torch.Generator().manual_seed(a.seed + 1000 * rank + i)       # DDPM step noise
+        image = pipe(batch_size=B, generator=gen, num_inference_steps=steps, output_type="torch", latents=x_T)
+        host = image.float().cpu().numpy()
+        for j, gidx in keep:
+            np.save(os.path.join(out_dir, f"{gidx}.npy"), host[j])
+            png = to_png(host[j, 0].T)          # ldm/inference.py:182: image[j].permute(2, 1, 0)[..., 0]
+            if png is not None:
+                png.save(os.path.join(out_dir, f"{gidx}_range.png"))
+    D.barrier()
+    if rank == 0:
+        print(f"wrote {a.samples} range images to {out_dir}")
+
+
+if __name__ == "__main__":
+    main()

@@ -105,3 +105,28 @@ def test_randn_tensor_semantics():
     gs = [torch.Generator().manual_seed(i) for i in range(2)]
     b = randn_tensor((2, 3), generator=gs, device="cpu")
     assert torch.equal(b[1:], torch.randn((1, 3), generator=torch.Generator().manual_seed(1)))
+
+
+def test_inference_driver_index_arithmetic():
+    """rangeldm_amd.inference reproduces ldm/inference.py:159,174-176: every image index below `samples` is written by
+    exactly one (rank, iteration, j), for any GPU count."""
+    from rangeldm_amd.inference import image_indices, plan_iterations
+    for samples, B, world in [(1000, 16, 1), (1000, 16, 8), (37, 4, 3), (16, 16, 2), (5, 8, 4)]:
+        seen = []
+        for rank in range(world):
+            for i in range(plan_iterations(samples, B, world)):
+                seen += [g for _, g in image_indices(i, B, rank, world, samples)]
+        assert sorted(seen) == list(range(samples)), (samples, B, world)
+
+
+def test_inference_driver_reads_reference_yaml(tmp_path):
+    from rangeldm_amd.inference import load_config
+    y = tmp_path / "RangeLDM.yaml"
+    y.write_text("eval_batch_size: 16\nddpm_num_inference_steps: 50\nwith_vae: True\npos_encoding: True\n"
+                 "model_config:\n  sample_size: [256, 16]\n  in_channels: 5\n  out_channels: 4\n  layers_per_block: 2\n"
+                 "  block_out_channels: [128, 128, 256, 256]\n"
+                 "  down_block_types: [DownBlock2D, AttnDownBlock2D, AttnDownBlock2D, AttnDownBlock2D]\n"
+                 "  up_block_types: [AttnUpBlock2D, AttnUpBlock2D, AttnUpBlock2D, UpBlock2D]\n")
+    c = load_config(str(y))
+    assert c["unet"].sample_size == (256, 16) and c["unet"].in_channels == 5 and c["vae"].sample_size == (1024, 64)
+    assert c["steps"] == 50 and c["batch"] == 16 and c["pos_encoding"] is True
