@@ -1,0 +1,440 @@
+// Activation-stationary circular 3x3 convolution for the low-resolution UNet levels (gfx950, bf16 MFMA, fp32 accumulate).
+//
+// Same arithmetic as conv_igemm.hip -- conv 3x3 (wrap W / zero H) over an already normalised + activated input, bias + time
+// embedding, shortcut-conv / residual as extra K, per-channel statistics of the output for the next GroupNorm
+// (ldm/utils.py:40-58, vae/sgm/modules/diffusionmodules/model.py:342-362) -- but organised for the levels where an image is only
+// 64..256 pixels (64x4, 32x2 latents).  There a wave issues ~1 instruction per 5 cycles whatever its kind, and the generic
+// kernel's per-chunk work (barrier, weight DMA, halo pipeline: ~300 instructions per 9 MFMAs of a wave) is the whole cost;
+// its GroupNorm prologue is also redone by every channel tile (4-8x).  So here:
+//   * GroupNorm + SiLU run once, in a separate launch (norm.hip: gn_apply_kernel), into one bf16 tensor;
+//   * the whole input tile of the workgroup (all C_in channels of its 64 pixels + halo, 60-150 KB) is copied to LDS ONCE.
+//     A wave owns halo columns; everything per-lane about a piece is loop-invariant, so a piece costs a load, an add and a
+//     store;
+//   * the weights are packed on the host in MFMA fragment order, one contiguous stream per (32-channel tile, k-group), and
+//     go straight from L2 into registers: one global_load (scalar base + lane offset + immediate) per k-step, a ring of
+//     G = 3..12 fragments in flight, exact s_waitcnt counts (the ring is issued in program order, pinned by sched_barrier);
+//   * the pixel operand is one ds_read_b128 per 32 pixels at a per-tap base register + immediate;
+//   * a k-step therefore costs 2 MFMAs + 3 memory instructions; no barrier, no LDS ring, no DMA issue in the K loop;
+//   * 8 waves = NWN 32-channel tiles x KG k-groups.  Within every tap, k-group kg takes the 16-channel groups kg, kg + KG,
+//     ...; the k-groups' fp32 partial tiles meet in LDS, where all 512 threads sum them, round, store 16 bytes each and
+//     keep (sum, sumsq) of the rounded values for the next GroupNorm (conv_igemm.hip's contract).
+#include "kernels.h"
+
+namespace rldm {
+
+__device__ __forceinline__ void lds_barrier_s() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// BM = 64 pixels, BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads
+template <int NWN, int CPT>
+__global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) {
+    constexpr int NT = 512, MI = 2, KG = 8 / NWN, BM = 32 * MI, BN = 32 * NWN;
+    constexpr int CIN = 16 * KG * CPT, C8 = CIN / 8;
+    constexpr int RSM = CIN * 2 + 16;          // image row stride (bytes): C8 + 1 16-byte slots, odd
+    constexpr int TPG = CPT <= 4 ? 3 : 1;      // taps per unrolled group (a tap row, or one tap for the wide inputs)
+    constexpr int G = TPG * CPT;               // k-steps per group = weight fragments in flight per wave
+    constexpr int NGRP = 9 / TPG;
+    constexpr int PFX = (G % 3 == 0) ? 3 : 2;  // pixel fragments read ahead (LDS); divides G
+    constexpr int RMAX = G < 8 ? G : 8;        // residual-phase steps per k-group (<= G: they arrive in the ring)
+    constexpr int AS = 2;                      // accumulator sets: consecutive MFMAs never share an accumulator
+    constexpr int FRS = BN * 4 + 16, NC8 = BN / 8;    // fp32 partial-sum image: [k-group][pixel][FRS bytes]
+    constexpr int LPS = C8 <= 16 ? 16 : (C8 <= 32 ? 32 : 64), SPI = 64 / LPS;   // lanes per halo slot, slots per instruction
+    constexpr int NCW = 5, KB = 4;             // staging batch: columns per wave x row groups in flight
+    static_assert(C8 <= 64 && G % PFX == 0 && 9 % TPG == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NWN, kg = wave / NWN;
+    const int kh = lane >> 5, l31 = lane & 31;
+#ifdef RLDM_ABLATE
+    unsigned long long tsv[8];
+    int tsn = 0;
+#define RLDM_STAMP() tsv[tsn++] = __builtin_amdgcn_s_memtime()
+#else
+#define RLDM_STAMP()
+#endif
+    RLDM_STAMP();
+
+    // ---- which tile ---------------------------------------------------------------------------------------------
+    // grid = (channel tiles, pixel tiles of an image, images).  Workgroups go to the XCDs round-robin in x-fastest order, so
+    // with 4 or 8 channel tiles all blocks that stream the same weight slice share an XCD (one L2 copy of it)
+    const int tiles_h = p.tiles_h, tiles_img = p.tiles_img;       // tiles_h is a power of two
+    const int nt = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
+    const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
+    const int w0 = tw * p.TW, h0 = th * p.TH;
+    const int npx = p.TW * p.TH;               // == BM
+    const int R = p.R0 + p.R1, R8 = R >> 3;
+    const int RSR = R * 2 + 16;                // residual image row stride
+    const int THv = p.TH + 2, TWv = p.TW + 2;
+    const int colb = p.colb;
+    const int abytes = TWv * colb;
+
+    unsigned char* sA = smem;                                   // [TWv][colb]: activated input + halo
+    unsigned char* sR = sA + abytes;                            // [npx][RSR]: raw residual-phase input
+    float* sBias = reinterpret_cast<float*>(sR + npx * RSR);    // BN
+
+    // ---- bias (+ time embedding row): fetched now, parked in LDS after the staging loop ---------------------------------
+    float bias_v = 0.f, temb_v = 0.f;
+    if (tid < BN) {
+        const int ch = nt * BN + tid;
+        bias_v = p.bias[ch];
+        if (p.temb) {
+            const int step = p.step_ptr ? *p.step_ptr : 0;
+            temb_v = p.temb[(size_t)(step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld + ch];
+        }
+    }
+
+    // ---- this wave's weight stream: [9 * CPT main steps (tap-major)][RPT residual steps], 1 KiB each; lane l holds channel
+    // l & 31, k = 8 * (l >> 5) .. + 8 of the step.  The first G fragments are requested before anything else.
+    const int RPT = (R >> 4) / KG;              // residual steps of this k-group (<= RMAX)
+    const int nmine = 9 * CPT + RPT;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wpk) +
+                                 ((size_t)((nt * NWN + wn) * KG + kg) * nmine) * 1024;      // uniform
+    unsigned woff[(G + 7) / 8];                 // lane offsets: immediates of +-4 KiB around them reach 8 fragments each
+#pragma unroll
+    for (int q = 0; q < (G + 7) / 8; ++q) woff[q] = lane * 16 + 4096 + q * 8192;
+    auto w_load = [&](const unsigned char* base, int idx) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(base + woff[idx / 8] + ((idx % 8) * 1024 - 4096));
+    };
+    bf16x8 wr[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        wr[j] = w_load(wbase, j);
+        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the K loop's counted waits rely on it
+    }
+
+    RLDM_STAMP();
+    // ---- the input tile, once: global -> LDS; wrap on W, zeros on H.  Wave w copies halo columns w, w + 8, ...; a wave
+    // instruction moves SPI rows x C8 16-byte pieces of a column, so a lane's row, channel and both offsets never change ----
+    {
+        const int c8 = lane & (LPS - 1), rsub = lane / LPS;
+        const bool laneok = c8 < C8;
+        const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x0);
+        const int KC = (THv + SPI - 1) / SPI;   // instructions per column
+        for (int k0 = 0; k0 < KC; k0 += KB) {
+            uint4 v[KB][NCW];
+            int ldo[KB];
+            bool rowok[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int vhl = (k0 + kb) * SPI + rsub;
+                const int vh = h0 - 1 + vhl;
+                rowok[kb] = laneok && (k0 + kb) < KC && vhl < THv;
+                const bool inimg = rowok[kb] && vh >= 0 && vh < p.Hin;
+                const unsigned goff = (unsigned)(vh * (CIN * 2) + c8 * 16);
+                ldo[kb] = vhl * RSM + c8 * 16;
+#pragma unroll
+                for (int j = 0; j < NCW; ++j) {
+                    const int col = wave + 8 * j;
+                    v[kb][j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (col < TWv && (k0 + kb) < KC) {
+                        int vw = w0 - 1 + col;
+                        vw = vw < 0 ? vw + p.Win : (vw >= p.Win ? vw - p.Win : vw);
+                        const unsigned char* cbase = xg + (size_t)((b * p.Win + vw) * p.Hin) * (CIN * 2);     // uniform
+                        if (inimg) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
+                    }
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int j = 0; j < NCW; ++j) {
+                    const int col = wave + 8 * j;
+                    if (col < TWv && rowok[kb]) *reinterpret_cast<uint4*>(sA + col * colb + ldo[kb]) = v[kb][j];
+                }
+        }
+        // residual-phase input: raw cat[r0, r1], the tile's own pixels only; a wave instruction moves 64 / LPR pixels
+        if (R8 > 0) {
+            const int lgr = R8 <= 16 ? 4 : (R8 <= 32 ? 5 : 6);          // log2(lanes per pixel)
+            const int rc8 = lane & ((1 << lgr) - 1), psub = lane >> lgr;
+            const int ppi = 64 >> lgr;                                   // pixels per instruction
+            const int c = rc8 * 8;
+            const bf16_t* gr0 = p.r0;           // (locals: selecting between fields of `p` by address would copy it to scratch)
+            const bf16_t* gr1 = p.r1;
+            const int nR0 = p.R0, nR1 = p.R1;
+            const bool first = c < nR0;
+            const unsigned char* lbase = reinterpret_cast<const unsigned char*>(first ? gr0 + c : gr1 + (c - nR0));
+            const unsigned ld2 = (unsigned)(first ? nR0 : nR1) * 2u;
+            const int pix0 = (b * p.Win + w0) * p.Hin + h0;
+            constexpr int NBR = 8;              // <= 8 instructions per wave (R <= 512)
+            uint4 rv[NBR];
+#pragma unroll
+            for (int u = 0; u < NBR; ++u) {
+                const int pidx = (wave + 8 * u) * ppi + psub;
+                const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+                rv[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (pidx < npx && rc8 < R8)
+                    rv[u] = *reinterpret_cast<const uint4*>(lbase + (size_t)(unsigned)(pix0 + pw * p.Hin + ph) * ld2);
+            }
+#pragma unroll
+            for (int u = 0; u < NBR; ++u) {
+                const int pidx = (wave + 8 * u) * ppi + psub;
+                if (pidx < npx && rc8 < R8) *reinterpret_cast<uint4*>(sR + pidx * RSR + rc8 * 16) = rv[u];
+            }
+        }
+    }
+    if (tid < BN) sBias[tid] = bias_v + temb_v;
+    lds_barrier_s();
+    RLDM_STAMP();
+
+    // ---- accumulators: k-group 0 carries bias + temb ---------------------------------------------------------------
+    f32x16 acc[AS][MI];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        float4 bv = *reinterpret_cast<const float4*>(sBias + wn * 32 + 8 * r4 + 4 * kh);
+        if (kg != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int a = 0; a < AS; ++a) {
+                const float z = a == 0 ? 1.f : 0.f;
+                acc[a][mi][r4 * 4 + 0] = bv.x * z; acc[a][mi][r4 * 4 + 1] = bv.y * z;
+                acc[a][mi][r4 * 4 + 2] = bv.z * z; acc[a][mi][r4 * 4 + 3] = bv.w * z;
+            }
+    }
+
+    // ---- barrier-free K loop ------------------------------------------------------------------------------------------
+    // NGRP groups of TPG taps; step idx of a group = tap idx / CPT of the group, 16-channel group kg + (idx % CPT) * KG.
+    // Per-lane LDS addresses: xa[mi][t] = pixel (mi, lane) at tap t of the current group, xn = the same for the next group.
+    int xa[MI][TPG], xn[MI][TPG], xres[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int pidx = mi * 32 + l31;
+        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+        const int x0 = pw * colb + ph * RSM + kh * 16 + kg * 32;
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            xa[mi][t] = x0 + t * RSM;                                      // group 0: taps (0, t)
+            xn[mi][t] = TPG == 3 ? x0 + colb + t * RSM : x0 + RSM;         // group 1: taps (1, t) | tap (0, 1)
+        }
+        xres[mi] = abytes + pidx * RSR + kh * 16 + kg * 32;
+    }
+    auto x_read = [&](const int (&base)[MI][TPG], int idx, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + base[mi][idx / CPT] + (idx % CPT) * (KG * 32));
+    };
+    auto x_read_res = [&](int idx, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(smem + xres[mi] + idx * (KG * 32));
+    };
+    bf16x8 xr[PFX][MI];
+#pragma unroll
+    for (int j = 0; j < PFX; ++j) {
+        x_read(xa, j, xr[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned char* wnext = wbase + G * 1024;          // fragments of the next group
+    int tj = 0;                                             // TPG == 1: beam offset of the current tap
+#pragma unroll 1
+    for (int g = 0; g < NGRP - 1; ++g) {
+#pragma unroll
+        for (int idx = 0; idx < G; ++idx) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[idx % AS][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], xr[idx % PFX][mi], acc[idx % AS][mi], 0, 0, 0);
+            wr[idx] = w_load(wnext, idx);
+            if (idx + PFX < G) x_read(xa, idx + PFX, xr[idx % PFX]);
+            else x_read(xn, idx + PFX - G, xr[idx % PFX]);
+            __builtin_amdgcn_sched_barrier(0);  // steps stay in program order: every wait then leaves G - 1 loads in flight
+        }
+        wnext += G * 1024;
+        // next group's addresses
+        if (TPG == 3) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) { xa[mi][t] = xn[mi][t]; xn[mi][t] += colb; }
+        } else {
+            tj = tj == 2 ? 0 : tj + 1;                      // beam offset of the tap that just became current
+            const int d = tj == 2 ? colb - 2 * RSM : RSM;   // ... and the step to the one after it
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) { xa[mi][0] = xn[mi][0]; xn[mi][0] += d; }
+        }
+    }
+    // last main group: its refills are the residual steps (clamped: a k-group without that many re-reads a fragment)
+    {
+        const unsigned char* wres = wbase + 9 * CPT * 1024;
+#pragma unroll
+        for (int idx = 0; idx < G; ++idx) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[idx % AS][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], xr[idx % PFX][mi], acc[idx % AS][mi], 0, 0, 0);
+            if (idx < RMAX) wr[idx] = *reinterpret_cast<const bf16x8*>(wres + (unsigned)(lane * 16 + max(min(idx, RPT - 1), 0) * 1024));
+            if (idx + PFX < G) x_read(xa, idx + PFX, xr[idx % PFX]);
+            else x_read_res(idx + PFX - G, xr[idx % PFX]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int idx = 0; idx < RMAX; ++idx) {
+        if (idx < RPT) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[idx % AS][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[idx], xr[idx % PFX][mi], acc[idx % AS][mi], 0, 0, 0);
+        }
+        x_read_res(idx + PFX, xr[idx % PFX]);
+    }
+#pragma unroll
+    for (int a = 1; a < AS; ++a)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][mi][r] += acc[a][mi][r];
+    RLDM_STAMP();
+    lds_barrier_s();                            // everyone is done with the input images: LDS is reused below
+    RLDM_STAMP();
+
+    // ---- epilogue: every k-group parks its fp32 partial tile in LDS as [k-group][pixel][channel]; then all 512 threads
+    // sum the k-groups for one (pixel, 8 channels) item each, round to bf16, store 16 bytes, and keep (sum, sumsq) of the
+    // ROUNDED values for the next GroupNorm (same contract as conv_igemm.hip's epilogue) -----------------------------
+    unsigned char* sE = smem;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int pidx = mi * 32 + l31;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int chl = wn * 32 + 8 * r4 + 4 * kh;
+            *reinterpret_cast<float4*>(sE + (kg * BM + pidx) * FRS + chl * 4) =
+                make_float4(acc[0][mi][r4 * 4 + 0], acc[0][mi][r4 * 4 + 1], acc[0][mi][r4 * 4 + 2], acc[0][mi][r4 * 4 + 3]);
+        }
+    }
+    lds_barrier_s();
+    RLDM_STAMP();
+    const int c8 = tid % NC8;
+    const int chg = nt * BN + c8 * 8;
+    constexpr int TRS = BN * 2 + 16;            // rounded tile [pixel][channel] bf16, for the statistics
+    unsigned char* sT = sE + KG * BM * FRS;
+    for (int pidx = tid / NC8; pidx < npx; pidx += NT / NC8) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const float4 v0 = *reinterpret_cast<const float4*>(sE + (g * BM + pidx) * FRS + c8 * 32);
+            const float4 v1 = *reinterpret_cast<const float4*>(sE + (g * BM + pidx) * FRS + c8 * 32 + 16);
+            f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
+            f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
+        }
+        uint4 v;
+        v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+        v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+        const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
+        *reinterpret_cast<uint4*>(p.y + pix * p.y_ld + chg) = v;             // N % BN == 0 on this path
+        *reinterpret_cast<uint4*>(sT + pidx * TRS + c8 * 16) = v;
+    }
+    if (p.y_stats) {
+        // (sum, sumsq) of the ROUNDED values per channel: lane = channel pair (conflict-free 4-byte reads down the pixels),
+        // NT / (BN/2) pixel groups; the groups of one wave fold by lane shuffles, the 8 waves through LDS
+        constexpr int NCP = BN / 2, NG = NT / NCP, PPG = BM / NG;
+        float* sS = reinterpret_cast<float*>(sT + BM * TRS);                // [8 waves][2][BN]
+        lds_barrier_s();
+        const int cp = tid % NCP, pg = tid / NCP;
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) {
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sT + (pg * PPG + j) * TRS + cp * 4);
+            const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+            s0 += a0; s1 += a1;
+            q0 += a0 * a0; q1 += a1 * a1;
+        }
+#pragma unroll
+        for (int d = NCP; d < 64; d <<= 1) {
+            s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d);
+            q0 += __shfl_xor(q0, d); q1 += __shfl_xor(q1, d);
+        }
+        if (lane < NCP) {
+            *reinterpret_cast<float2*>(sS + (wave * 2 + 0) * BN + cp * 2) = make_float2(s0, s1);
+            *reinterpret_cast<float2*>(sS + (wave * 2 + 1) * BN + cp * 2) = make_float2(q0, q1);
+        }
+        lds_barrier_s();
+        if (tid < 2 * BN) {
+            const int kind = tid / BN, c = tid - kind * BN;
+            float S = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
+            reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
+        }
+    }
+    RLDM_STAMP();
+#ifdef RLDM_ABLATE
+    if (p.ts && blockIdx.x < 4 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) p.ts[blockIdx.x * 64 + i] = i < tsn ? tsv[i] : 0ull;
+#endif
+#undef RLDM_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+int conv_small_col_bytes(int Cin, int TH) {
+    const int rs = Cin / 8 + 1;                 // 16-byte slots per row (odd)
+    int slots = (TH + 2) * rs;
+    while (slots % 16 != TH % 16) ++slots;      // same conflict-freedom rule as conv_halo_col_bytes
+    return slots * 16;
+}
+
+size_t conv_small_lds_bytes(const ConvParams& p, int BN) {
+    const int BM = 64, KG = 8 / (BN / 32);
+    const int R = p.R0 + p.R1;
+    const size_t a = (size_t)(p.TW + 2) * p.colb;
+    const size_t r = (size_t)p.TW * p.TH * (R * 2 + 16);
+    const size_t main_bytes = a + r + BN * 4 + 3072;            // + read-ahead slack past the residual image
+    const size_t epi = (size_t)KG * BM * (BN * 4 + 16) + (size_t)BM * (BN * 2 + 16) + (size_t)8 * 2 * BN * 4;
+    return std::max(main_bytes, epi);
+}
+
+// k-steps per tap of one k-group, or 0 if the kernel is not instantiated for this (BN, Cin)
+static int small_cpt(int Cin, int BN) {
+    const int KG = 8 / (BN / 32);
+    if (Cin % (16 * KG) != 0 || Cin > 512) return 0;
+    const int cpt = Cin / (16 * KG);
+    return (cpt == 1 || cpt == 2 || cpt == 3 || cpt == 4 || cpt == 6 || cpt == 8) ? cpt : 0;
+}
+
+bool conv_small_supported(const ConvParams& p, int taps, int BN) {
+    const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
+    if (BN != 32 && BN != 64) return false;
+    if (taps != 9 || p.stride != 1 || p.up != 1 || p.pad_lo != 1 || p.y_nchw || p.ksplit > 1) return false;
+    if (p.C1 != 0 || p.st0 != nullptr) return false;            // one pre-activated input tensor
+    const int KG = 8 / (BN / 32), cpt = small_cpt(Cin, BN);
+    if (cpt == 0 || p.N % BN != 0 || R % (16 * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
+    const int G = (cpt <= 4 ? 3 : 1) * cpt;
+    if (R / (16 * KG) > std::min(G, 8)) return false;
+    if (p.TW * p.TH != 64 || p.TH < 2 || p.TW + 2 > 40 || p.Win < 2) return false;
+    if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
+    return conv_small_lds_bytes(p, BN) <= 160 * 1024;
+}
+
+int conv_small_kgroups(int BN) { return 8 / (BN / 32); }
+
+template <int NWN, int CPT>
+static int launch_small_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
+    auto kern = conv_small_kernel<NWN, CPT>;
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.ntile_n, p.tiles_img, p.B), dim3(512), lds, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_conv_small(const ConvParams& p, int BN, hipStream_t stream) {
+    RLDM_REQUIRE(conv_small_supported(p, 9, BN), "conv_small: unsupported shape");
+    const size_t lds = conv_small_lds_bytes(p, BN);
+    const int cpt = small_cpt(p.C0, BN);
+#define RLDM_SMALL(NWN_, CPT_) \
+    if (BN == 32 * NWN_ && cpt == CPT_) return launch_small_inst<NWN_, CPT_>(p, lds, stream);
+    RLDM_SMALL(1, 1) RLDM_SMALL(1, 2) RLDM_SMALL(1, 3) RLDM_SMALL(1, 4)
+    RLDM_SMALL(2, 1) RLDM_SMALL(2, 2) RLDM_SMALL(2, 3) RLDM_SMALL(2, 4) RLDM_SMALL(2, 6) RLDM_SMALL(2, 8)
+#undef RLDM_SMALL
+    RLDM_REQUIRE(false, "conv_small: no instance");
+    return 1;
+}
+
+}  // namespace rldm

@@ -78,6 +78,16 @@ int conv_halo_col_bytes(const ConvTile& t, int TH, int stride);
 int conv_tile_threads(const ConvTile& t);
 int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream);
 
+// Activation-stationary 3x3 / stride 1 variant for 64-pixel tiles (conv_small.hip).  Same ConvParams, with one
+// pre-activated input tensor (C1 == 0, no GroupNorm prologue); wpk is the fragment-ordered image
+// [N/32][k-groups][9*Cin/16/KG + R/16/KG][64 lanes][8 bf16] (ConvLayer::get_fragpacked), colb from conv_small_col_bytes,
+// BN in {32, 64}, KG = conv_small_kgroups(BN).
+int conv_small_kgroups(int BN);
+int conv_small_col_bytes(int Cin, int TH);
+size_t conv_small_lds_bytes(const ConvParams& p, int BN);
+bool conv_small_supported(const ConvParams& p, int taps, int BN);
+int launch_conv_small(const ConvParams& p, int BN, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------------------------
 // Per-channel statistics (norm.hip) for tensors that did not come out of a conv epilogue (tests, external inputs):
 // deterministic partial (sum, sumsq) per (b, pixel chunk p, channel).
@@ -90,6 +100,25 @@ struct GnStatsParams {
     float2* part;           // [B][P][C] per-channel (sum, sumsq)
 };
 int launch_gn_stats(const GnStatsParams& p, hipStream_t stream);
+
+// y = silu?( GroupNorm( cat[x0, x1] ) ) as one bf16 tensor [B][npix][C0 + C1], from the producers' per-channel partials.
+// Used in front of conv_small.hip where every 32/64-channel tile of a conv would otherwise redo the whole activation.
+struct GnApplyParams {
+    const bf16_t* x0;
+    const bf16_t* x1;
+    int C0, C1;
+    const float2* st0;
+    const float2* st1;
+    int P0, P1;
+    int B, npix;
+    int groups;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    int silu;
+    bf16_t* y;
+};
+int launch_gn_apply(const GnApplyParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Multi-head self-attention with head_dim 8 (attention.hip).  qkv: [B][L][3C] (q | k | v, q pre-scaled by

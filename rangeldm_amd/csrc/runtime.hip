@@ -157,6 +157,44 @@ struct ConvLayer {
         packed[key] = std::move(pk);
         return 0;
     }
+
+    // conv_small.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per (32-channel tile, k-group):
+    // [Cout/32][KG][9*CPT main steps (tap-major) + RPT residual steps][64 lanes][8 bf16] + one zero fragment; k-group kg
+    // owns the 16-channel groups kg, kg + KG, ... of every tap; lane l of a step holds channel 32*t + (l & 31), k = 8*(l >> 5) .. +8
+    int get_fragpacked(int Cin_pad, int KG, Packed** out) {
+        auto key = std::make_pair(0, KG);
+        auto it = packed.find(key);
+        if (it != packed.end()) {
+            RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
+            *out = it->second.get();
+            return 0;
+        }
+        RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % (16 * KG) == 0 && R % (16 * KG) == 0,
+                     "conv " + name + ": not fragment-packable");
+        const int CPT = Cin_pad / 16 / KG, RPT = R / 16 / KG, nmine = 9 * CPT + RPT;
+        std::vector<bf16_t> img((size_t)(Cout / 32) * KG * nmine * 512 + 512, 0);
+        auto at = [&](int n, int step, int c16, int k) -> bf16_t& {     // step within the stream of k-group c16 % KG
+            const size_t stream = (size_t)(n / 32) * KG + c16 % KG;
+            return img[((stream * nmine + step) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8];
+        };
+        for (int n = 0; n < Cout; ++n) {
+            for (int c = 0; c < Cin; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    at(n, tap * CPT + (c / 16) / KG, c / 16, c % 16) = f32_to_bf16(w[((size_t)n * Cin + c) * 9 + tap]);
+            for (int c = 0; c < R; ++c) {
+                const float v = sc_identity ? (c == n ? 1.f : 0.f) : sc_w[(size_t)n * R + c];
+                at(n, 9 * CPT + (c / 16) / KG, c / 16, c % 16) = f32_to_bf16(v);
+            }
+        }
+        auto pk = std::make_unique<Packed>();
+        if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(pk->bias, b.data(), b.size() * sizeof(float))) return 1;
+        pk->ntile_n = 0;
+        pk->Cin_pad = Cin_pad;
+        *out = pk.get();
+        packed[key] = std::move(pk);
+        return 0;
+    }
 };
 
 struct ParamStore {
@@ -519,6 +557,143 @@ struct Builder {
         return 0;
     }
 
+    // 3x3 / stride 1 convs over <= 256-pixel images (the 64x4 and 32x2 UNet levels) go to conv_small.hip
+    static void small_tile(int Wout, int Hout, int* tw, int* th) {
+        int h = 1;
+        while (h * 2 <= Hout && h * 2 <= 8 && Hout % (h * 2) == 0) h *= 2;
+        *th = h;
+        *tw = 64 / h;
+    }
+    bool small_route(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout) const {
+        if (g_dbg_flags & 256) return false;
+        if (taps != 9 || a.stride != 1 || a.up != 1 || a.pad_mode != 0 || a.out_f32_nchw) return false;
+        if (Wout * Hout > 256 || a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
+        int tw, th;
+        small_tile(Wout, Hout, &tw, &th);
+        if (Wout % tw != 0 || Hout % th != 0 || Wout < 2) return false;
+        if (!a.gn && a.x1.valid()) return false;
+        const int C0 = Cin_t;                  // the (pre-activated) input is one tensor
+        const int R0 = a.r0.valid() ? a.r0.C : 0;
+        if (Cin_t % 16 || C0 % 16 || R_t % 16 || R0 % 16) return false;
+        ConvParams q;
+        memset(&q, 0, sizeof(q));
+        q.C0 = C0; q.C1 = Cin_t - C0; q.R0 = R0; q.R1 = R_t - R0;
+        q.stride = 1; q.up = 1; q.pad_lo = 1; q.ksplit = 1; q.N = a.layer->Cout; q.Win = a.x0.W;
+        q.TW = tw; q.TH = th;
+        q.colb = conv_small_col_bytes(Cin_t, th);
+        q.gn_groups = a.groups;
+        q.B = a.x0.B;
+        q.tiles_h = Hout / th;
+        q.tiles_img = (Wout / tw) * q.tiles_h;
+        return small_bn(q) != 0;
+    }
+    // 64-channel tiles when they fill the chip, else 32 (twice the blocks, half the weight stream per block)
+    static int small_bn(const ConvParams& q) {
+        const bool ok64 = conv_small_supported(q, 9, 64), ok32 = conv_small_supported(q, 9, 32);
+        if (g_force_bn == 64 && ok64) return 64;
+        if (g_force_bn == 32 && ok32) return 32;
+        if (ok64 && ((long long)q.B * q.tiles_img * (q.N / 64) >= 200 || !ok32)) return 64;
+        return ok32 ? 32 : 0;
+    }
+
+    int conv_small(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
+        ConvLayer* L = a.layer;
+        const int N = L->Cout;
+        const bool preact = a.gn != nullptr;
+        if (a.gn) {
+            RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
+            RLDM_REQUIRE(a.x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
+        }
+        // GroupNorm + SiLU once, ahead of the conv: every channel tile of the conv would otherwise redo it (4-8x at these levels)
+        Tensor act;
+        if (preact) {
+            act = make(a.x0.B, a.x0.W, a.x0.H, Cin_t);
+            ++launches;
+            if (!dry) {
+                GnApplyParams g;
+                memset(&g, 0, sizeof(g));
+                g.x0 = tptr(a.x0); g.x1 = tptr(a.x1);
+                g.C0 = a.x0.C; g.C1 = a.x1.valid() ? a.x1.C : 0;
+                g.st0 = sptr(a.x0); g.st1 = sptr(a.x1);
+                g.P0 = a.x0.P; g.P1 = a.x1.valid() ? a.x1.P : 0;
+                g.B = a.x0.B; g.npix = a.x0.W * a.x0.H;
+                g.groups = a.groups;
+                g.gamma = a.gn->gamma.as<float>(); g.beta = a.gn->beta.as<float>();
+                g.eps = a.eps; g.silu = a.silu;
+                g.y = tptr(act);
+                const double by = (double)g.B * g.npix * Cin_t * 4.0;
+                plan->ops.push_back({[g](hipStream_t s) { return launch_gn_apply(g, s); }, "gn_apply_kernel", 0.0, by});
+            }
+        }
+        const Tensor& x0 = preact ? act : a.x0;
+        ConvParams p;
+        memset(&p, 0, sizeof(p));
+        p.C0 = x0.C;
+        p.C1 = Cin_t - x0.C;
+        p.R0 = a.r0.valid() ? a.r0.C : 0;
+        p.R1 = a.r1.valid() ? a.r1.C : 0;
+        p.B = x0.B; p.Win = x0.W; p.Hin = x0.H;
+        p.up = 1; p.stride = 1; p.pad_lo = 1;
+        p.Wout = Wout; p.Hout = Hout;
+        small_tile(Wout, Hout, &p.TW, &p.TH);
+        p.colb = conv_small_col_bytes(Cin_t, p.TH);
+        p.tiles_h = Hout / p.TH;
+        p.tiles_img = (Wout / p.TW) * p.tiles_h;
+        p.th_shift = 0;
+        while ((1 << p.th_shift) < p.TH) ++p.th_shift;
+        const int thv = p.TH + 2;
+        p.magic_thv = ((1 << 20) + thv - 1) / thv;
+        const int cpg = std::max(1, Cin_t / a.groups);
+        p.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+        p.N = N;
+        p.silu = a.silu;
+        p.gn_eps = a.eps;
+        p.gn_groups = a.groups;
+        p.ksplit = 1;
+        p.dbg = g_dbg_flags;
+        p.ts = g_ts_buf;
+        const int BN = small_bn(p);
+        RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
+        p.ntile_n = N / BN;
+
+        Tensor y = make(x0.B, Wout, Hout, N);
+        if (a.want_stats) add_stats(y, p.tiles_img);
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
+        plan->flops += fl;
+        ++launches;
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_fragpacked(Cin_t, conv_small_kgroups(BN), &pk)) return 1;
+            p.x0 = tptr(x0);
+            p.x1 = nullptr;
+            p.r0 = tptr(a.r0);
+            p.r1 = tptr(a.r1);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            p.y = tptr(y);
+            p.y_ld = N;
+            p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
+            p.temb_ld = temb_ld;
+            Plan* pl = plan;
+            const int temb_off = a.temb_off;
+            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * 9 + L->R) * 2.0 +
+                              (double)x0.B * Wout * Hout * N * 2.0 + (double)x0.B * Wout * Hout * R_t * 2.0;
+            const std::string kname = "conv_small_kernel<64," + std::to_string(BN) + ">";
+            plan->ops.push_back({[p, BN, pl, temb_off](hipStream_t s) mutable {
+                if (temb_off >= 0) {
+                    p.temb = pl->io.temb + temb_off;
+                    p.step_ptr = pl->io.step_ptr;
+                    p.temb_rows_per_step = pl->io.temb_rows_per_step;
+                    p.temb_per_sample = pl->io.temb_per_sample;
+                }
+                return launch_conv_small(p, BN, s);
+            }, kname, fl, by});
+        }
+        if (preact) release(act);
+        *out = y;
+        return 0;
+    }
+
     // y = conv(...) ; consumes nothing (callers release inputs)
     int conv(const ConvArgs& a, Tensor* out) {
         ConvLayer* L = a.layer;
@@ -535,6 +710,7 @@ struct Builder {
         RLDM_REQUIRE(Wv % a.stride == 0 && Hv % a.stride == 0, "conv " + L->name + ": odd size under stride 2");
         RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
+        if (small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, Wout, Hout, out);
         const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, x0.C, R_t, a.r0.valid() ? a.r0.C : 0, taps,
                                           a.out_f32_nchw, a.gn != nullptr);
         const ConvTile tile = tc.tile;
@@ -1892,20 +2068,28 @@ int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int wa
     cc.plan.io.temb_rows_per_step = d->B;
     cc.plan.io.temb_per_sample = 1;
     RLDM_REQUIRE(!cc.plan.ops.empty(), "internal: empty plan");
-    Op& conv_op = cc.plan.ops.back();
+    // the timed unit: the conv launch, plus the GroupNorm+SiLU launch in front of it on the conv_small.hip route
+    size_t first = cc.plan.ops.size() - 1;
+    if (first > 0 && cc.plan.ops[first - 1].name == "gn_apply_kernel") --first;
+    auto run_unit = [&]() {
+        for (size_t o = first; o < cc.plan.ops.size(); ++o)
+            if (cc.plan.ops[o].fn(st)) return 1;
+        return 0;
+    };
     if (kernel_name && name_cap) {
-        strncpy(kernel_name, conv_op.name.c_str(), name_cap - 1);
+        const std::string nm = (first + 1 < cc.plan.ops.size() ? "gn_apply+" : "") + cc.plan.ops.back().name;
+        strncpy(kernel_name, nm.c_str(), name_cap - 1);
         kernel_name[name_cap - 1] = 0;
     }
     if (cc.plan.run(st)) return 1;
     for (int i = 0; i < warmup; ++i)
-        if (conv_op.fn(st)) return 1;
+        if (run_unit()) return 1;
     hipEvent_t e0, e1;
     RLDM_HIP_CHECK(hipEventCreate(&e0));
     RLDM_HIP_CHECK(hipEventCreate(&e1));
     RLDM_HIP_CHECK(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        if (conv_op.fn(st)) return 1;
+        if (run_unit()) return 1;
     RLDM_HIP_CHECK(hipEventRecord(e1, st));
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0.f;

@@ -39,6 +39,11 @@ CONV_CASES = [
     (2, 32, 32, 32, 8, 3, 1, 0, False),        # small-config channels (CK=16 path)
     (2, 32, 64, 8, 1, 3, 1, 0, False),         # H=1 (nuScenes deepest level)
     (1, 64, 64, 1024, 64, 3, 1, 0, False),     # VAE full resolution
+    (2, 512, 256, 32, 2, 3, 1, 0, False),      # conv_small.hip: L3 up-block conv1 (concat width), 32-channel tiles
+    (1, 384, 256, 64, 4, 3, 1, 0, False),      # conv_small.hip: L2, Cin = 256 + 128
+    (16, 256, 256, 64, 4, 3, 1, 0, False),     # conv_small.hip: L2 at the bench batch -> 64-channel tiles
+    (2, 128, 64, 32, 8, 3, 1, 0, False),       # conv_small.hip: 8x8 pixel tiles
+    (3, 64, 64, 16, 4, 3, 1, 0, False),        # conv_small.hip: one 64-pixel image per block, Cin = 64 (64-channel tiles only)
 ]
 
 
@@ -79,9 +84,21 @@ def test_conv_wrap_seam_exact():
     assert y[0, 2].abs().sum() == 0                             # beam -1 does not exist: zero padding
 
 
-@pytest.mark.parametrize("C0,C1,Cout,W,H", [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2),
-                                            (64, 32, 64, 16, 8)])
-def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H):
+GN_CASES = [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
+            (256, 128, 256, 64, 4), (128, 128, 128, 16, 4)]
+
+
+@pytest.fixture(params=[0, 512], ids=["default", "small-fused-gn"])
+def conv_flags(request):
+    """0: conv_small.hip behind a separate GroupNorm+SiLU launch (default); 512: GroupNorm folded into its prologue."""
+    from rangeldm_amd import _lib
+    _lib.lib().rldm_debug_set_flags(request.param)
+    yield request.param
+    _lib.lib().rldm_debug_set_flags(0)
+
+
+@pytest.mark.parametrize("C0,C1,Cout,W,H", GN_CASES)
+def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H, conv_flags):
     """The full ResnetBlock conv1 fusion: GN(32)+SiLU over cat[x0,x1] -> conv3x3 -> +bias +temb[b] (+res)."""
     B = 2
     x0, x1 = _rand(B, C0, W, H, seed=4) * 1.5 + 0.3, _rand(B, C1, W, H, seed=5) * 0.7 - 0.2
@@ -103,7 +120,7 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
-                                                (1, 128, 128, 256, 16, 3)])
+                                                (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3)])
 def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
     the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
