@@ -68,91 +68,123 @@ int launch_gn_stats(const GnStatsParams& p, hipStream_t stream) {
     return 0;
 }
 
-// GroupNorm (+SiLU) of cat[x0, x1] from the producers' per-channel partials -> one activated bf16 tensor.  A block
-// re-derives the per-channel affine of its image (a few KB of partials) and then streams `ppb` pixels: 16 bytes per
-// lane in, 16 bytes out.  The finalize arithmetic is the conv prologue's (conv_igemm.hip), so both routes agree bit for bit.
+// GroupNorm (+SiLU) of cat[x0, x1] from the producers' per-channel partials -> one activated bf16 tensor.
+// A block owns GSL consecutive groups (1/8 of the channels) of `ppb` pixels of one image: it folds just those channels'
+// partials into the affine (a few hundred floats, double accumulation as in the conv prologue of conv_igemm.hip) and then
+// streams its slice: 16 bytes per lane in, 16 bytes out.
 __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, int ppb) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    __shared__ double sD[2 * 128 + 2 * 32];
+    __shared__ __attribute__((aligned(16))) float sGa[128];
+    __shared__ __attribute__((aligned(16))) float sGs[128];
     const int tid = threadIdx.x;
     const int Cin = p.C0 + p.C1;
-    const int b = blockIdx.y;
-    double* sD = reinterpret_cast<double*>(gsm);                 // [2*Cin + 2*groups]
-    float* sGa = reinterpret_cast<float*>(sD + 2 * Cin + 2 * p.groups);
-    float* sGs = sGa + Cin;
+    const int b = blockIdx.z;
     const int cpg = Cin / p.groups;
-    for (int t = tid; t < Cin; t += 256) {
-        const bool first = t < p.C0;
-        const int c = first ? t : t - p.C0;
-        const int C = first ? p.C0 : p.C1;
-        const int P = first ? p.P0 : p.P1;
-        const float2* src = (first ? p.st0 : p.st1) + (size_t)b * P * C + c;
+    const int gsl = (p.groups + gridDim.y - 1) / gridDim.y;        // groups per block
+    const int g0 = blockIdx.y * gsl;
+    const int ng = min(gsl, p.groups - g0);
+    const int c0 = g0 * cpg, nc = ng * cpg;                         // channel slice (<= 128, multiple of 8)
+    const bf16_t* gx0 = p.x0;               // (locals: selecting between fields of `p` by address would copy it to scratch)
+    const bf16_t* gx1 = p.x1;
+    const float2* gs0 = p.st0;
+    const float2* gs1 = p.st1;
+    const int nC0 = p.C0, nC1 = p.C1, nP0 = p.P0, nP1 = p.P1;
+    if (tid < nc) {
+        const int t = c0 + tid;
+        const bool first = t < nC0;
+        const int c = first ? t : t - nC0;
+        const int C = first ? nC0 : nC1;
+        const int P = first ? nP0 : nP1;
+        const float2* src = (first ? gs0 : gs1) + (size_t)b * P * C + c;
         double S = 0.0, SS = 0.0;
         for (int q = 0; q < P; ++q) {
             const float2 v = src[(size_t)q * C];
             S += (double)v.x;
             SS += (double)v.y;
         }
-        sD[t] = S;
-        sD[Cin + t] = SS;
+        sD[tid] = S;
+        sD[128 + tid] = SS;
     }
     __syncthreads();
-    if (tid < p.groups) {
+    if (tid < ng) {
         double S = 0.0, SS = 0.0;
         for (int i = 0; i < cpg; ++i) {
             S += sD[tid * cpg + i];
-            SS += sD[Cin + tid * cpg + i];
+            SS += sD[128 + tid * cpg + i];
         }
         const double inv_n = 1.0 / ((double)p.npix * (double)cpg);
         const double mean = S * inv_n;
         double var = SS * inv_n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        sD[2 * Cin + tid] = mean;
-        sD[2 * Cin + p.groups + tid] = (double)__builtin_amdgcn_rsqf((float)var + p.eps);
+        sD[256 + tid] = mean;
+        sD[256 + 32 + tid] = (double)__builtin_amdgcn_rsqf((float)var + p.eps);
     }
     __syncthreads();
-    for (int t = tid; t < Cin; t += 256) {
-        const int g = t / cpg;
-        const float ga = p.gamma[t] * (float)sD[2 * Cin + p.groups + g];
-        sGa[t] = ga;
-        sGs[t] = p.beta[t] - (float)sD[2 * Cin + g] * ga;
+    if (tid < nc) {
+        const int g = tid / cpg;
+        const float ga = p.gamma[c0 + tid] * (float)sD[256 + 32 + g];
+        sGa[tid] = ga;
+        sGs[tid] = p.beta[c0 + tid] - (float)sD[256 + g] * ga;
     }
     __syncthreads();
-    const int C8 = Cin >> 3;
+    const int n8 = nc >> 3;                  // 16-byte pieces per pixel of the slice
     const int px0 = blockIdx.x * ppb;
-    const int total = min(ppb, p.npix - px0) * C8;
-    for (int q = tid; q < total; q += 256) {
-        const int px = px0 + q / C8, c = (q % C8) * 8;
-        const bool first = c < p.C0;
-        const bf16_t* src = first ? p.x0 + ((size_t)b * p.npix + px) * p.C0 + c
-                                  : p.x1 + ((size_t)b * p.npix + px) * p.C1 + (c - p.C0);
-        const uint4 v = *reinterpret_cast<const uint4*>(src);
-        const float4 a0 = *reinterpret_cast<const float4*>(sGa + c), a1 = *reinterpret_cast<const float4*>(sGa + c + 4);
-        const float4 s0 = *reinterpret_cast<const float4*>(sGs + c), s1 = *reinterpret_cast<const float4*>(sGs + c + 4);
-        float f0 = bf16lo(v.x) * a0.x + s0.x, f1 = bf16hi(v.x) * a0.y + s0.y;
-        float f2 = bf16lo(v.y) * a0.z + s0.z, f3 = bf16hi(v.y) * a0.w + s0.w;
-        float f4 = bf16lo(v.z) * a1.x + s1.x, f5 = bf16hi(v.z) * a1.y + s1.y;
-        float f6 = bf16lo(v.w) * a1.z + s1.z, f7 = bf16hi(v.w) * a1.w + s1.w;
-        if (p.silu) {
-            f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
-            f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+    const int total = min(ppb, p.npix - px0) * n8;
+    constexpr int NB = 4;
+    for (int q0 = tid; q0 < total; q0 += 256 * NB) {
+        uint4 v[NB];
+        int cl[NB];
+        size_t dst[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int q = q0 + j * 256;
+            const int pl = q / n8;
+            cl[j] = (q - pl * n8) * 8;
+            const int c = c0 + cl[j];
+            const size_t pix = (size_t)b * p.npix + px0 + pl;
+            dst[j] = pix * Cin + c;
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < total) {
+                const bool first = c < nC0;
+                v[j] = *reinterpret_cast<const uint4*>(first ? gx0 + pix * nC0 + c : gx1 + pix * nC1 + (c - nC0));
+            }
         }
-        uint4 o;
-        o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
-        o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);
-        *reinterpret_cast<uint4*>(p.y + ((size_t)b * p.npix + px) * Cin + c) = o;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (q0 + j * 256 >= total) continue;
+            const float4 a0 = *reinterpret_cast<const float4*>(sGa + cl[j]), a1 = *reinterpret_cast<const float4*>(sGa + cl[j] + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(sGs + cl[j]), s1 = *reinterpret_cast<const float4*>(sGs + cl[j] + 4);
+            float f0 = bf16lo(v[j].x) * a0.x + s0.x, f1 = bf16hi(v[j].x) * a0.y + s0.y;
+            float f2 = bf16lo(v[j].y) * a0.z + s0.z, f3 = bf16hi(v[j].y) * a0.w + s0.w;
+            float f4 = bf16lo(v[j].z) * a1.x + s1.x, f5 = bf16hi(v[j].z) * a1.y + s1.y;
+            float f6 = bf16lo(v[j].w) * a1.z + s1.z, f7 = bf16hi(v[j].w) * a1.w + s1.w;
+            if (p.silu) {
+                f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
+                f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
+            o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);
+            *reinterpret_cast<uint4*>(p.y + dst[j]) = o;
+        }
     }
 }
 
 int launch_gn_apply(const GnApplyParams& p, hipStream_t stream) {
     const int Cin = p.C0 + p.C1;
-    RLDM_REQUIRE(Cin % 8 == 0 && p.C0 % 8 == 0 && Cin % p.groups == 0 && p.groups <= 256, "gn_apply: unsupported channels");
-    int ppb = std::max(1, 512 / (Cin / 8));                     // ~2 pieces per thread
-    while (ppb > 1 && (long long)p.B * ((p.npix + ppb - 1) / ppb) < 512) ppb >>= 1;
-    const size_t lds = ((size_t)2 * Cin + 2 * p.groups) * 8 + (size_t)Cin * 8;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((p.npix + ppb - 1) / ppb, p.B), dim3(256), lds, stream, p, ppb);
+    RLDM_REQUIRE(Cin % p.groups == 0 && p.C0 % 8 == 0 && p.C1 % 8 == 0, "gn_apply: unsupported channels");
+    const int cpg = Cin / p.groups;
+    // groups per block: ~1/8 of them, widened until the slice is whole 16-byte pieces (<= 128 channels)
+    int gsl = (p.groups + 7) / 8;
+    while ((gsl * cpg) % 8 != 0 && gsl < p.groups) ++gsl;
+    RLDM_REQUIRE((gsl * cpg) % 8 == 0 && gsl * cpg <= 128 && gsl <= 32, "gn_apply: channel slices must be whole 16-byte pieces");
+    const int ny = (p.groups + gsl - 1) / gsl;
+    const int n8 = gsl * cpg / 8;
+    int ppb = std::max(1, 1024 / n8);                           // ~4 pieces per thread
+    while (ppb > 16 && (long long)p.B * ny * ((p.npix + ppb - 1) / ppb) < 256) ppb >>= 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((p.npix + ppb - 1) / ppb, ny, p.B), dim3(256), 0, stream, p, ppb);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
-
 
 }  // namespace rldm
