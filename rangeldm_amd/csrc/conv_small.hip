@@ -27,22 +27,25 @@ __device__ __forceinline__ void lds_barrier_s() {
     __builtin_amdgcn_s_barrier();
 }
 
-// BM = 64 pixels, BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads
-template <int NWN, int CPT>
+// BM = 64 pixels, BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
+// TAPS == 9: 3x3 over a pre-activated input.  TAPS == 1: pointwise (attention q/k/v and output projections); there the
+// GroupNorm affine (no separate launch: one FMA per element while the tile is on its way to LDS) is folded in.
+template <int NWN, int CPT, int TAPS>
 __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) {
     constexpr int NT = 512, MI = 2, KG = 8 / NWN, BM = 32 * MI, BN = 32 * NWN;
     constexpr int CIN = 16 * KG * CPT, C8 = CIN / 8;
     constexpr int RSM = CIN * 2 + 16;          // image row stride (bytes): C8 + 1 16-byte slots, odd
-    constexpr int TPG = CPT <= 4 ? 3 : 1;      // taps per unrolled group (a tap row, or one tap for the wide inputs)
+    constexpr int HALO = TAPS == 9 ? 1 : 0;
+    constexpr int TPG = TAPS == 1 ? 1 : (CPT <= 4 ? 3 : 1);   // taps per unrolled group (a tap row, or one tap for wide inputs)
     constexpr int G = TPG * CPT;               // k-steps per group = weight fragments in flight per wave
-    constexpr int NGRP = 9 / TPG;
+    constexpr int NGRP = TAPS / TPG;
     constexpr int PFX = (G % 3 == 0) ? 3 : 2;  // pixel fragments read ahead (LDS); divides G
     constexpr int RMAX = G < 8 ? G : 8;        // residual-phase steps per k-group (<= G: they arrive in the ring)
     constexpr int AS = 2;                      // accumulator sets: consecutive MFMAs never share an accumulator
     constexpr int FRS = BN * 4 + 16, NC8 = BN / 8;    // fp32 partial-sum image: [k-group][pixel][FRS bytes]
     constexpr int LPS = C8 <= 16 ? 16 : (C8 <= 32 ? 32 : 64), SPI = 64 / LPS;   // lanes per halo slot, slots per instruction
     constexpr int NCW = 5, KB = 4;             // staging batch: columns per wave x row groups in flight
-    static_assert(C8 <= 64 && G % PFX == 0 && 9 % TPG == 0, "shape");
+    static_assert(C8 <= 64 && G % PFX == 0 && TAPS % TPG == 0 && PFX <= G, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +70,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     const int npx = p.TW * p.TH;               // == BM
     const int R = p.R0 + p.R1, R8 = R >> 3;
     const int RSR = R * 2 + 16;                // residual image row stride
-    const int THv = p.TH + 2, TWv = p.TW + 2;
+    const int THv = p.TH + 2 * HALO, TWv = p.TW + 2 * HALO;
     const int colb = p.colb;
     const int abytes = TWv * colb;
 
@@ -86,10 +89,34 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
         }
     }
 
+    // ---- TAPS == 1: the GroupNorm inputs of channel `tid` (statistics partials of the producer, gamma, beta), requested now
+    const bool gn = TAPS == 1 && p.st0 != nullptr;
+    double gS = 0.0, gSS = 0.0;
+    float g_gamma = 0.f, g_beta = 0.f;
+    if (TAPS == 1 && gn && tid < CIN) {
+        const float2* src = p.st0 + (size_t)b * p.P0 * CIN + tid;
+        const int P = p.P0;
+        int q = 0;
+        for (; q + 4 <= P; q += 4) {
+            float2 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = src[(size_t)(q + j) * CIN];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gS += (double)u[j].x; gSS += (double)u[j].y; }
+        }
+        for (; q < P; ++q) {
+            const float2 u = src[(size_t)q * CIN];
+            gS += (double)u.x;
+            gSS += (double)u.y;
+        }
+        g_gamma = p.gn_gamma[tid];
+        g_beta = p.gn_beta[tid];
+    }
+
     // ---- this wave's weight stream: [9 * CPT main steps (tap-major)][RPT residual steps], 1 KiB each; lane l holds channel
     // l & 31, k = 8 * (l >> 5) .. + 8 of the step.  The first G fragments are requested before anything else.
     const int RPT = (R >> 4) / KG;              // residual steps of this k-group (<= RMAX)
-    const int nmine = 9 * CPT + RPT;
+    const int nmine = TAPS * CPT + RPT;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wpk) +
                                  ((size_t)((nt * NWN + wn) * KG + kg) * nmine) * 1024;      // uniform
     unsigned woff[(G + 7) / 8];                 // lane offsets: immediates of +-4 KiB around them reach 8 fragments each
@@ -107,22 +134,25 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
 
     RLDM_STAMP();
     // ---- the input tile, once: global -> LDS; wrap on W, zeros on H.  Wave w copies halo columns w, w + 8, ...; a wave
-    // instruction moves SPI rows x C8 16-byte pieces of a column, so a lane's row, channel and both offsets never change ----
+    // instruction moves SPI rows x C8 16-byte pieces of a column, so a lane's row, channel and both offsets never change.
+    // TAPS == 1 with statistics: the GroupNorm affine of the image is derived while the first loads are in flight and
+    // applied on the way into LDS ----
     {
         const int c8 = lane & (LPS - 1), rsub = lane / LPS;
         const bool laneok = c8 < C8;
         const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x0);
         const int KC = (THv + SPI - 1) / SPI;   // instructions per column
+        float ga[8], gs[8];
         for (int k0 = 0; k0 < KC; k0 += KB) {
             uint4 v[KB][NCW];
             int ldo[KB];
-            bool rowok[KB];
+            bool rowok[KB], inimg[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int vhl = (k0 + kb) * SPI + rsub;
-                const int vh = h0 - 1 + vhl;
+                const int vh = h0 - HALO + vhl;
                 rowok[kb] = laneok && (k0 + kb) < KC && vhl < THv;
-                const bool inimg = rowok[kb] && vh >= 0 && vh < p.Hin;
+                inimg[kb] = rowok[kb] && vh >= 0 && vh < p.Hin;
                 const unsigned goff = (unsigned)(vh * (CIN * 2) + c8 * 16);
                 ldo[kb] = vhl * RSM + c8 * 16;
 #pragma unroll
@@ -130,11 +160,42 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     const int col = wave + 8 * j;
                     v[kb][j] = make_uint4(0u, 0u, 0u, 0u);
                     if (col < TWv && (k0 + kb) < KC) {
-                        int vw = w0 - 1 + col;
+                        int vw = w0 - HALO + col;
                         vw = vw < 0 ? vw + p.Win : (vw >= p.Win ? vw - p.Win : vw);
                         const unsigned char* cbase = xg + (size_t)((b * p.Win + vw) * p.Hin) * (CIN * 2);     // uniform
-                        if (inimg) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
+                        if (inimg[kb]) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
                     }
+                }
+            }
+            if (TAPS == 1 && gn && k0 == 0) {
+                // per-channel sums -> (every channel's thread folds its own group: no serial phase) mean / rstd -> a*x + s
+                double* sD = reinterpret_cast<double*>(smem + abytes + 64);      // [2*CIN], behind the image
+                float* sG = reinterpret_cast<float*>(sD + 2 * CIN);              // [2][CIN]
+                const int cpg = CIN / p.gn_groups;
+                if (tid < CIN) {
+                    sD[tid] = gS;
+                    sD[CIN + tid] = gSS;
+                }
+                __syncthreads();
+                if (tid < CIN) {
+                    const int g0 = ((tid * p.magic_cpg) >> 20) * cpg;
+                    double S = 0.0, SS = 0.0;
+                    for (int i = 0; i < cpg; ++i) {
+                        S += sD[g0 + i];
+                        SS += sD[CIN + g0 + i];
+                    }
+                    const double inv_n = (double)p.gn_inv_n;
+                    const double mean = S * inv_n;
+                    double var = SS * inv_n - mean * mean;
+                    var = var < 0.0 ? 0.0 : var;
+                    const float a = g_gamma * __builtin_amdgcn_rsqf((float)var + p.gn_eps);
+                    sG[tid] = a;
+                    sG[CIN + tid] = g_beta - (float)mean * a;
+                }
+                __syncthreads();
+                if (laneok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ga[e] = sG[c8 * 8 + e]; gs[e] = sG[CIN + c8 * 8 + e]; }
                 }
             }
 #pragma unroll
@@ -142,7 +203,20 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
 #pragma unroll
                 for (int j = 0; j < NCW; ++j) {
                     const int col = wave + 8 * j;
-                    if (col < TWv && rowok[kb]) *reinterpret_cast<uint4*>(sA + col * colb + ldo[kb]) = v[kb][j];
+                    uint4 o = v[kb][j];
+                    if (TAPS == 1 && gn && inimg[kb]) {
+                        float f0 = bf16lo(o.x) * ga[0] + gs[0], f1 = bf16hi(o.x) * ga[1] + gs[1];
+                        float f2 = bf16lo(o.y) * ga[2] + gs[2], f3 = bf16hi(o.y) * ga[3] + gs[3];
+                        float f4 = bf16lo(o.z) * ga[4] + gs[4], f5 = bf16hi(o.z) * ga[5] + gs[5];
+                        float f6 = bf16lo(o.w) * ga[6] + gs[6], f7 = bf16hi(o.w) * ga[7] + gs[7];
+                        if (p.silu) {
+                            f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
+                            f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+                        }
+                        o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
+                        o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);
+                    }
+                    if (col < TWv && rowok[kb]) *reinterpret_cast<uint4*>(sA + col * colb + ldo[kb]) = o;
                 }
         }
         // residual-phase input: raw cat[r0, r1], the tile's own pixels only; a wave instruction moves 64 / LPR pixels
@@ -193,6 +267,19 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                 acc[a][mi][r4 * 4 + 0] = bv.x * z; acc[a][mi][r4 * 4 + 1] = bv.y * z;
                 acc[a][mi][r4 * 4 + 2] = bv.z * z; acc[a][mi][r4 * 4 + 3] = bv.w * z;
             }
+    }
+
+    // ---- identity residual (y = conv + x): fetched now, added in fp32 in the epilogue ------------------------------------
+    constexpr int NPASS = (BM * NC8 + NT - 1) / NT;             // epilogue items (pixel, 8 channels) per thread
+    uint4 resv[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int pidx = tid / NC8 + q * (NT / NC8);
+        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+        resv[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.res && pidx < npx)
+            resv[q] = *reinterpret_cast<const uint4*>(p.res + (((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph)) * p.N +
+                                                      nt * BN + (tid % NC8) * 8);
     }
 
     // ---- barrier-free K loop ------------------------------------------------------------------------------------------
@@ -256,7 +343,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     }
     // last main group: its refills are the residual steps (clamped: a k-group without that many re-reads a fragment)
     {
-        const unsigned char* wres = wbase + 9 * CPT * 1024;
+        const unsigned char* wres = wbase + TAPS * CPT * 1024;
 #pragma unroll
         for (int idx = 0; idx < G; ++idx) {
 #pragma unroll
@@ -307,10 +394,12 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     const int chg = nt * BN + c8 * 8;
     constexpr int TRS = BN * 2 + 16;            // rounded tile [pixel][channel] bf16, for the statistics
     unsigned char* sT = sE + KG * BM * FRS;
-    for (int pidx = tid / NC8; pidx < npx; pidx += NT / NC8) {
-        float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    for (int q = 0; q < NPASS; ++q) {
+        const int pidx = tid / NC8 + q * (NT / NC8);
+        if (pidx >= npx) break;
+        float f[8] = {bf16lo(resv[q].x), bf16hi(resv[q].x), bf16lo(resv[q].y), bf16hi(resv[q].y),
+                      bf16lo(resv[q].z), bf16hi(resv[q].z), bf16lo(resv[q].w), bf16hi(resv[q].w)};
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             const float4 v0 = *reinterpret_cast<const float4*>(sE + (g * BM + pidx) * FRS + c8 * 32);
@@ -370,50 +459,54 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-int conv_small_col_bytes(int Cin, int TH) {
+int conv_small_col_bytes(int Cin, int TH, int taps) {
     const int rs = Cin / 8 + 1;                 // 16-byte slots per row (odd)
-    int slots = (TH + 2) * rs;
+    int slots = (TH + (taps == 9 ? 2 : 0)) * rs;
     while (slots % 16 != TH % 16) ++slots;      // same conflict-freedom rule as conv_halo_col_bytes
     return slots * 16;
 }
 
-size_t conv_small_lds_bytes(const ConvParams& p, int BN) {
-    const int BM = 64, KG = 8 / (BN / 32);
-    const int R = p.R0 + p.R1;
-    const size_t a = (size_t)(p.TW + 2) * p.colb;
+int conv_small_kgroups(int BN) { return 8 / (BN / 32); }
+
+size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN) {
+    const int BM = 64, KG = conv_small_kgroups(BN);
+    const int Cin = p.C0, R = p.R0 + p.R1;
+    const size_t a = (size_t)(p.TW + (taps == 9 ? 2 : 0)) * p.colb;
     const size_t r = (size_t)p.TW * p.TH * (R * 2 + 16);
     const size_t main_bytes = a + r + BN * 4 + 3072;            // + read-ahead slack past the residual image
+    const size_t gn_bytes = a + 64 + (size_t)2 * Cin * 8 + (size_t)2 * Cin * 4;    // GroupNorm scratch behind the image
     const size_t epi = (size_t)KG * BM * (BN * 4 + 16) + (size_t)BM * (BN * 2 + 16) + (size_t)8 * 2 * BN * 4;
-    return std::max(main_bytes, epi);
+    return std::max(std::max(main_bytes, gn_bytes), epi);
 }
 
-// k-steps per tap of one k-group, or 0 if the kernel is not instantiated for this (BN, Cin)
-static int small_cpt(int Cin, int BN) {
-    const int KG = 8 / (BN / 32);
+// k-steps per tap of one k-group, or 0 if the kernel is not instantiated for this (taps, BN, Cin)
+static int small_cpt(int Cin, int taps, int BN) {
+    const int KG = conv_small_kgroups(BN);
     if (Cin % (16 * KG) != 0 || Cin > 512) return 0;
     const int cpt = Cin / (16 * KG);
-    return (cpt == 1 || cpt == 2 || cpt == 3 || cpt == 4 || cpt == 6 || cpt == 8) ? cpt : 0;
+    if (taps == 9) return (BN <= 64 && (cpt == 1 || cpt == 2 || cpt == 3 || cpt == 4 || cpt == 6 || cpt == 8)) ? cpt : 0;
+    return (cpt == 2 || cpt == 4 || cpt == 8) ? cpt : 0;
 }
 
 bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
-    if (BN != 32 && BN != 64) return false;
-    if (taps != 9 || p.stride != 1 || p.up != 1 || p.pad_lo != 1 || p.y_nchw || p.ksplit > 1) return false;
-    if (p.C1 != 0 || p.st0 != nullptr) return false;            // one pre-activated input tensor
-    const int KG = 8 / (BN / 32), cpt = small_cpt(Cin, BN);
+    if (BN != 32 && BN != 64 && BN != 128) return false;
+    if ((taps != 9 && taps != 1) || p.stride != 1 || p.up != 1 || p.pad_lo != (taps == 9 ? 1 : 0) || p.y_nchw || p.ksplit > 1)
+        return false;
+    if (p.C1 != 0) return false;                                // one input tensor
+    if (p.st0 != nullptr && (taps != 1 || p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;   // 3x3: pre-activated input
+    const int KG = conv_small_kgroups(BN), cpt = small_cpt(Cin, taps, BN);
     if (cpt == 0 || p.N % BN != 0 || R % (16 * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
-    const int G = (cpt <= 4 ? 3 : 1) * cpt;
+    const int G = (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;
     if (R / (16 * KG) > std::min(G, 8)) return false;
     if (p.TW * p.TH != 64 || p.TH < 2 || p.TW + 2 > 40 || p.Win < 2) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
-    return conv_small_lds_bytes(p, BN) <= 160 * 1024;
+    return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;
 }
 
-int conv_small_kgroups(int BN) { return 8 / (BN / 32); }
-
-template <int NWN, int CPT>
+template <int NWN, int CPT, int TAPS>
 static int launch_small_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
-    auto kern = conv_small_kernel<NWN, CPT>;
+    auto kern = conv_small_kernel<NWN, CPT, TAPS>;
     static size_t max_set = 0;
     if (lds > max_set) {
         RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -424,14 +517,17 @@ static int launch_small_inst(const ConvParams& p, size_t lds, hipStream_t stream
     return 0;
 }
 
-int launch_conv_small(const ConvParams& p, int BN, hipStream_t stream) {
-    RLDM_REQUIRE(conv_small_supported(p, 9, BN), "conv_small: unsupported shape");
-    const size_t lds = conv_small_lds_bytes(p, BN);
-    const int cpt = small_cpt(p.C0, BN);
-#define RLDM_SMALL(NWN_, CPT_) \
-    if (BN == 32 * NWN_ && cpt == CPT_) return launch_small_inst<NWN_, CPT_>(p, lds, stream);
-    RLDM_SMALL(1, 1) RLDM_SMALL(1, 2) RLDM_SMALL(1, 3) RLDM_SMALL(1, 4)
-    RLDM_SMALL(2, 1) RLDM_SMALL(2, 2) RLDM_SMALL(2, 3) RLDM_SMALL(2, 4) RLDM_SMALL(2, 6) RLDM_SMALL(2, 8)
+int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream) {
+    RLDM_REQUIRE(conv_small_supported(p, taps, BN), "conv_small: unsupported shape");
+    const size_t lds = conv_small_lds_bytes(p, taps, BN);
+    const int cpt = small_cpt(p.C0, taps, BN);
+#define RLDM_SMALL(NWN_, CPT_, TAPS_) \
+    if (BN == 32 * NWN_ && cpt == CPT_ && taps == TAPS_) return launch_small_inst<NWN_, CPT_, TAPS_>(p, lds, stream);
+    RLDM_SMALL(1, 1, 9) RLDM_SMALL(1, 2, 9) RLDM_SMALL(1, 3, 9) RLDM_SMALL(1, 4, 9)
+    RLDM_SMALL(2, 1, 9) RLDM_SMALL(2, 2, 9) RLDM_SMALL(2, 3, 9) RLDM_SMALL(2, 4, 9) RLDM_SMALL(2, 6, 9) RLDM_SMALL(2, 8, 9)
+    RLDM_SMALL(1, 2, 1) RLDM_SMALL(1, 4, 1)
+    RLDM_SMALL(2, 2, 1) RLDM_SMALL(2, 4, 1) RLDM_SMALL(2, 8, 1)
+    RLDM_SMALL(4, 4, 1) RLDM_SMALL(4, 8, 1)
 #undef RLDM_SMALL
     RLDM_REQUIRE(false, "conv_small: no instance");
     return 1;

@@ -62,6 +62,8 @@ struct ConvParams {
     float* slab;            // [tiles][ksplit][BM*BN] fp32 (ksplit > 1)
     int* ticket;            // [tiles] zero-initialised arrival counters (re-armed by the last arriver)
     int lds_total;           // dynamic LDS bytes of the launch (set by launch_conv)
+    float gn_inv_n;          // conv_small.hip: 1 / (pixels per image * channels per group)
+    const bf16_t* res;       // conv_small.hip: identity residual [B][Wout][Hout][N] added in the epilogue (or null)
     unsigned long long* ts;  // tuning: s_memtime stamps of blocks 0..3, wave 0 ([4][64]) or null
     int dbg;                // tuning ablations (rldm_debug_set_flags): 1 skip stores, 2 skip main loop, 4 skip GN finalize
 };
@@ -78,15 +80,16 @@ int conv_halo_col_bytes(const ConvTile& t, int TH, int stride);
 int conv_tile_threads(const ConvTile& t);
 int launch_conv(const ConvTile& t, const ConvParams& p, hipStream_t stream);
 
-// Activation-stationary 3x3 / stride 1 variant for 64-pixel tiles (conv_small.hip).  Same ConvParams, with one
-// pre-activated input tensor (C1 == 0, no GroupNorm prologue); wpk is the fragment-ordered image
+// Activation-stationary stride-1 variant for 64-pixel tiles (conv_small.hip): 3x3 over one pre-activated input tensor
+// (C1 == 0, no GroupNorm prologue) or 1x1 with the GroupNorm affine folded in; an identity residual is added in the
+// epilogue (ConvParams::res).  wpk is the fragment-ordered image
 // [N/32][k-groups][9*Cin/16/KG + R/16/KG][64 lanes][8 bf16] (ConvLayer::get_fragpacked), colb from conv_small_col_bytes,
 // BN in {32, 64}, KG = conv_small_kgroups(BN).
 int conv_small_kgroups(int BN);
-int conv_small_col_bytes(int Cin, int TH);
-size_t conv_small_lds_bytes(const ConvParams& p, int BN);
+int conv_small_col_bytes(int Cin, int TH, int taps);
+size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN);
 bool conv_small_supported(const ConvParams& p, int taps, int BN);
-int launch_conv_small(const ConvParams& p, int BN, hipStream_t stream);
+int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-channel statistics (norm.hip) for tensors that did not come out of a conv epilogue (tests, external inputs):

@@ -159,19 +159,20 @@ struct ConvLayer {
     }
 
     // conv_small.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per (32-channel tile, k-group):
-    // [Cout/32][KG][9*CPT main steps (tap-major) + RPT residual steps][64 lanes][8 bf16] + one zero fragment; k-group kg
-    // owns the 16-channel groups kg, kg + KG, ... of every tap; lane l of a step holds channel 32*t + (l & 31), k = 8*(l >> 5) .. +8
-    int get_fragpacked(int Cin_pad, int KG, Packed** out) {
-        auto key = std::make_pair(0, KG);
+    // [Cout/32][KG][taps*CPT main steps (tap-major) + RPT residual steps][64 lanes][8 bf16] + one zero fragment; k-group kg
+    // owns the 16-channel groups kg, kg + KG, ... of every tap; lane l of a step holds channel 32*t + (l & 31),
+    // k = 8*(l >> 5) .. +8.  `no_res`: the (identity) residual is added by the kernel's epilogue, not multiplied here.
+    int get_fragpacked(int Cin_pad, int KG, bool no_res, Packed** out) {
+        auto key = std::make_pair(no_res ? -1 : 0, KG);
         auto it = packed.find(key);
         if (it != packed.end()) {
             RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
             *out = it->second.get();
             return 0;
         }
-        RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % (16 * KG) == 0 && R % (16 * KG) == 0,
-                     "conv " + name + ": not fragment-packable");
-        const int CPT = Cin_pad / 16 / KG, RPT = R / 16 / KG, nmine = 9 * CPT + RPT;
+        const int taps = ksize * ksize, Rp = no_res ? 0 : R;
+        RLDM_REQUIRE(Cout % 32 == 0 && Cin_pad % (16 * KG) == 0 && Rp % (16 * KG) == 0, "conv " + name + ": not fragment-packable");
+        const int CPT = Cin_pad / 16 / KG, RPT = Rp / 16 / KG, nmine = taps * CPT + RPT;
         std::vector<bf16_t> img((size_t)(Cout / 32) * KG * nmine * 512 + 512, 0);
         auto at = [&](int n, int step, int c16, int k) -> bf16_t& {     // step within the stream of k-group c16 % KG
             const size_t stream = (size_t)(n / 32) * KG + c16 % KG;
@@ -179,11 +180,11 @@ struct ConvLayer {
         };
         for (int n = 0; n < Cout; ++n) {
             for (int c = 0; c < Cin; ++c)
-                for (int tap = 0; tap < 9; ++tap)
-                    at(n, tap * CPT + (c / 16) / KG, c / 16, c % 16) = f32_to_bf16(w[((size_t)n * Cin + c) * 9 + tap]);
-            for (int c = 0; c < R; ++c) {
+                for (int tap = 0; tap < taps; ++tap)
+                    at(n, tap * CPT + (c / 16) / KG, c / 16, c % 16) = f32_to_bf16(w[((size_t)n * Cin + c) * taps + tap]);
+            for (int c = 0; c < Rp; ++c) {
                 const float v = sc_identity ? (c == n ? 1.f : 0.f) : sc_w[(size_t)n * R + c];
-                at(n, 9 * CPT + (c / 16) / KG, c / 16, c % 16) = f32_to_bf16(v);
+                at(n, taps * CPT + (c / 16) / KG, c / 16, c % 16) = f32_to_bf16(v);
             }
         }
         auto pk = std::make_unique<Packed>();
@@ -557,49 +558,79 @@ struct Builder {
         return 0;
     }
 
-    // 3x3 / stride 1 convs over <= 256-pixel images (the 64x4 and 32x2 UNet levels) go to conv_small.hip
+    // conv_small.hip route: 3x3 / stride 1 convs over <= 256-pixel images (the 64x4 and 32x2 UNet levels) and every
+    // pointwise conv with 128..512 input channels (attention q/k/v and output projections)
     static void small_tile(int Wout, int Hout, int* tw, int* th) {
         int h = 1;
         while (h * 2 <= Hout && h * 2 <= 8 && Hout % (h * 2) == 0) h *= 2;
         *th = h;
         *tw = 64 / h;
     }
-    bool small_route(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout) const {
+    // geometry + channel counts of the route; `epi_res`: the identity residual is added in the epilogue instead of the K loop
+    static bool small_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q, bool* epi_res) {
         if (g_dbg_flags & 256) return false;
-        if (taps != 9 || a.stride != 1 || a.up != 1 || a.pad_mode != 0 || a.out_f32_nchw) return false;
-        if (Wout * Hout > 256 || a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
+        if ((taps != 9 && taps != 1) || a.stride != 1 || a.up != 1 || a.out_f32_nchw) return false;
+        if (taps == 9 && (a.pad_mode != 0 || Wout * Hout > 256)) return false;
+        if (taps == 1 && a.x1.valid()) return false;
+        if (!a.gn && a.x1.valid()) return false;
+        if (a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
         int tw, th;
         small_tile(Wout, Hout, &tw, &th);
         if (Wout % tw != 0 || Hout % th != 0 || Wout < 2) return false;
-        if (!a.gn && a.x1.valid()) return false;
-        const int C0 = Cin_t;                  // the (pre-activated) input is one tensor
-        const int R0 = a.r0.valid() ? a.r0.C : 0;
-        if (Cin_t % 16 || C0 % 16 || R_t % 16 || R0 % 16) return false;
-        ConvParams q;
-        memset(&q, 0, sizeof(q));
-        q.C0 = C0; q.C1 = Cin_t - C0; q.R0 = R0; q.R1 = R_t - R0;
-        q.stride = 1; q.up = 1; q.pad_lo = 1; q.ksplit = 1; q.N = a.layer->Cout; q.Win = a.x0.W;
-        q.TW = tw; q.TH = th;
-        q.colb = conv_small_col_bytes(Cin_t, th);
-        q.gn_groups = a.groups;
-        q.B = a.x0.B;
-        q.tiles_h = Hout / th;
-        q.tiles_img = (Wout / tw) * q.tiles_h;
-        return small_bn(q) != 0;
+        *epi_res = a.layer->sc_identity && a.r0.valid() && !a.r1.valid() && a.r0.C == a.layer->Cout;
+        memset(q, 0, sizeof(*q));
+        q->C0 = Cin_t;                          // one input tensor (3x3: pre-activated by gn_apply)
+        q->R0 = *epi_res ? 0 : (a.r0.valid() ? a.r0.C : 0);
+        q->R1 = *epi_res ? 0 : R_t - q->R0;
+        q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
+        q->up = 1; q->stride = 1; q->pad_lo = taps == 9 ? 1 : 0;
+        q->Wout = Wout; q->Hout = Hout;
+        q->TW = tw; q->TH = th;
+        q->colb = conv_small_col_bytes(Cin_t, th, taps);
+        q->tiles_h = Hout / th;
+        q->tiles_img = (Wout / tw) * q->tiles_h;
+        while ((1 << q->th_shift) < th) ++q->th_shift;
+        const int cpg = std::max(1, Cin_t / a.groups);
+        q->magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+        q->gn_inv_n = (float)(1.0 / ((double)a.x0.W * a.x0.H * cpg));
+        q->N = a.layer->Cout;
+        q->silu = a.silu;
+        q->gn_eps = a.eps;
+        q->gn_groups = a.groups;
+        q->ksplit = 1;
+        return true;
     }
-    // 64-channel tiles when they fill the chip, else 32 (twice the blocks, half the weight stream per block)
-    static int small_bn(const ConvParams& q) {
-        const bool ok64 = conv_small_supported(q, 9, 64), ok32 = conv_small_supported(q, 9, 32);
-        if (g_force_bn == 64 && ok64) return 64;
-        if (g_force_bn == 32 && ok32) return 32;
-        if (ok64 && ((long long)q.B * q.tiles_img * (q.N / 64) >= 200 || !ok32)) return 64;
-        return ok32 ? 32 : 0;
+    // channel tile; 0: no instance / not worth it.
+    // 3x3: 64 channels when that fills the chip, else 32 (twice the blocks, half the weight stream per block).
+    // 1x1: the work per block is a few MFMAs and the launch is one latency chain per block, so the route is taken only if
+    // the grid fits one round of 256 workgroups -- with the narrowest tile that does (most blocks); else the generic kernel.
+    static int small_bn(const ConvParams& q, int taps, bool gn_fused) {
+        ConvParams t = q;
+        if (gn_fused) t.st0 = reinterpret_cast<const float2*>(&t);      // (only its presence matters to the shape check)
+        const long long tiles = (long long)q.B * q.tiles_img;
+        if (g_force_bn && conv_small_supported(t, taps, g_force_bn)) return g_force_bn;
+        if (taps == 9) {
+            const bool ok64 = conv_small_supported(t, 9, 64), ok32 = conv_small_supported(t, 9, 32);
+            if (ok64 && (tiles * (q.N / 64) >= 200 || !ok32)) return 64;
+            return ok32 ? 32 : 0;
+        }
+        const int cand[3] = {32, 64, 128};
+        for (int bn : cand)
+            if (conv_small_supported(t, taps, bn) && tiles * (q.N / bn) <= 256) return bn;
+        return 0;
+    }
+    bool small_route(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout) const {
+        ConvParams q;
+        bool epi;
+        if (!small_params(a, Cin_t, R_t, taps, Wout, Hout, &q, &epi)) return false;
+        return small_bn(q, taps, taps == 1 && a.gn != nullptr) != 0;
     }
 
-    int conv_small(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
+    int conv_small(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, Tensor* out) {
         ConvLayer* L = a.layer;
         const int N = L->Cout;
-        const bool preact = a.gn != nullptr;
+        const bool preact = a.gn != nullptr && taps == 9;      // 3x3: GroupNorm + SiLU in their own launch
+        const bool gn_fused = a.gn != nullptr && taps == 1;    // 1x1: folded into the conv's staging
         if (a.gn) {
             RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
             RLDM_REQUIRE(a.x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
@@ -627,66 +658,51 @@ struct Builder {
         }
         const Tensor& x0 = preact ? act : a.x0;
         ConvParams p;
-        memset(&p, 0, sizeof(p));
-        p.C0 = x0.C;
-        p.C1 = Cin_t - x0.C;
-        p.R0 = a.r0.valid() ? a.r0.C : 0;
-        p.R1 = a.r1.valid() ? a.r1.C : 0;
-        p.B = x0.B; p.Win = x0.W; p.Hin = x0.H;
-        p.up = 1; p.stride = 1; p.pad_lo = 1;
-        p.Wout = Wout; p.Hout = Hout;
-        small_tile(Wout, Hout, &p.TW, &p.TH);
-        p.colb = conv_small_col_bytes(Cin_t, p.TH);
-        p.tiles_h = Hout / p.TH;
-        p.tiles_img = (Wout / p.TW) * p.tiles_h;
-        p.th_shift = 0;
-        while ((1 << p.th_shift) < p.TH) ++p.th_shift;
-        const int thv = p.TH + 2;
-        p.magic_thv = ((1 << 20) + thv - 1) / thv;
-        const int cpg = std::max(1, Cin_t / a.groups);
-        p.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
-        p.N = N;
-        p.silu = a.silu;
-        p.gn_eps = a.eps;
-        p.gn_groups = a.groups;
-        p.ksplit = 1;
+        bool epi_res = false;
+        RLDM_REQUIRE(small_params(a, Cin_t, R_t, taps, Wout, Hout, &p, &epi_res), "conv " + L->name + ": conv_small route lost");
         p.dbg = g_dbg_flags;
         p.ts = g_ts_buf;
-        const int BN = small_bn(p);
+        const int BN = small_bn(p, taps, gn_fused);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
         p.ntile_n = N / BN;
 
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img);
-        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
         plan->flops += fl;
         ++launches;
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
-            if (L->get_fragpacked(Cin_t, conv_small_kgroups(BN), &pk)) return 1;
+            if (L->get_fragpacked(Cin_t, conv_small_kgroups(BN), epi_res, &pk)) return 1;
             p.x0 = tptr(x0);
-            p.x1 = nullptr;
-            p.r0 = tptr(a.r0);
-            p.r1 = tptr(a.r1);
+            p.r0 = epi_res ? nullptr : tptr(a.r0);
+            p.r1 = epi_res ? nullptr : tptr(a.r1);
+            p.res = epi_res ? tptr(a.r0) : nullptr;
             p.wpk = pk->w.as<bf16_t>();
             p.bias = pk->bias.as<float>();
+            if (gn_fused) {
+                p.st0 = sptr(a.x0);
+                p.P0 = a.x0.P;
+                p.gn_gamma = a.gn->gamma.as<float>();
+                p.gn_beta = a.gn->beta.as<float>();
+            }
             p.y = tptr(y);
             p.y_ld = N;
             p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
             p.temb_ld = temb_ld;
             Plan* pl = plan;
             const int temb_off = a.temb_off;
-            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * 9 + L->R) * 2.0 +
+            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * taps + L->R) * 2.0 +
                               (double)x0.B * Wout * Hout * N * 2.0 + (double)x0.B * Wout * Hout * R_t * 2.0;
-            const std::string kname = "conv_small_kernel<64," + std::to_string(BN) + ">";
-            plan->ops.push_back({[p, BN, pl, temb_off](hipStream_t s) mutable {
+            const std::string kname = "conv_small_kernel<64," + std::to_string(BN) + ",taps" + std::to_string(taps) + ">";
+            plan->ops.push_back({[p, BN, taps, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;
                     p.step_ptr = pl->io.step_ptr;
                     p.temb_rows_per_step = pl->io.temb_rows_per_step;
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
-                return launch_conv_small(p, BN, s);
+                return launch_conv_small(p, taps, BN, s);
             }, kname, fl, by});
         }
         if (preact) release(act);
@@ -710,7 +726,7 @@ struct Builder {
         RLDM_REQUIRE(Wv % a.stride == 0 && Hv % a.stride == 0, "conv " + L->name + ": odd size under stride 2");
         RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
-        if (small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, Wout, Hout, out);
+        if (small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, taps, Wout, Hout, out);
         const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, x0.C, R_t, a.r0.valid() ? a.r0.C : 0, taps,
                                           a.out_f32_nchw, a.gn != nullptr);
         const ConvTile tile = tc.tile;

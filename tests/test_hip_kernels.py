@@ -120,7 +120,8 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H, conv_flags):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
-                                                (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3)])
+                                                (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3),
+                                                (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1)])
 def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
     the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
@@ -134,6 +135,30 @@ def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     n = W * H
     assert float((st[..., 0].double() - ref_s).abs().max()) < 1e-4 * n
     assert float(((st[..., 1].double() - ref_q).abs() / (ref_q + 1e-6)).max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,C,N,W,H,gn,res", [(2, 256, 768, 32, 2, True, False),     # L3 attention q/k/v (32-channel tiles)
+                                                (16, 128, 384, 128, 8, True, False),   # L1 q/k/v at the bench batch (128-ch tiles)
+                                                (4, 256, 768, 64, 4, True, False),     # L2 q/k/v
+                                                (2, 256, 256, 32, 2, False, True),     # L3 attention output projection + x
+                                                (16, 128, 128, 128, 8, False, True),   # L1 output projection + x
+                                                (3, 512, 256, 16, 4, True, True)])
+def test_conv_pointwise_small_route(B, C, N, W, H, gn, res):
+    """conv_small.hip, taps == 1: GroupNorm affine folded into the staging, identity residual added in the epilogue."""
+    x = _rand(B, C, W, H, seed=40) * 1.7 + 0.4
+    w = _rand(N, C, 1, 1, seed=41, scale=C ** -0.5)
+    b = _rand(N, seed=42, scale=0.1)
+    gamma, beta = (1 + 0.2 * _rand(C, seed=43), 0.2 * _rand(C, seed=44)) if gn else (None, None)
+    r = _rand(B, N, W, H, seed=45) if res else None
+    y = hip_conv(x, w, b, gamma=gamma, beta=beta, silu=False, eps=1e-6, res=r)
+
+    def ref(q):
+        h = q(F.group_norm(q(x), 32, gamma, beta, 1e-6)) if gn else q(x)
+        out = ops.circ_conv2d(h, q(w), b, 1, 0)
+        return out + q(r) if res else out
+
+    assert rel_l2(y, ref(bf16r)) < TOL_Q
+    assert rel_l2(y, ref(lambda t: t)) < TOL_F
 
 
 def test_conv_gn_no_silu_1x1():
