@@ -27,12 +27,12 @@ __device__ __forceinline__ void lds_barrier_s() {
     __builtin_amdgcn_s_barrier();
 }
 
-// BM = 64 pixels, BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
+// BM = 32 * MI pixels (64: the 64x4 / 32x2 levels and the pointwise convs; 128: the 128x8 level), BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
 // TAPS == 9: 3x3 over a pre-activated input.  TAPS == 1: pointwise (attention q/k/v and output projections); there the
 // GroupNorm affine (no separate launch: one FMA per element while the tile is on its way to LDS) is folded in.
-template <int NWN, int CPT, int TAPS>
+template <int NWN, int CPT, int TAPS, int MI>
 __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) {
-    constexpr int NT = 512, MI = 2, KG = 8 / NWN, BM = 32 * MI, BN = 32 * NWN;
+    constexpr int NT = 512, KG = 8 / NWN, BM = 32 * MI, BN = 32 * NWN;
     constexpr int CIN = 16 * KG * CPT, C8 = CIN / 8;
     constexpr int RSM = CIN * 2 + 16;          // image row stride (bytes): C8 + 1 16-byte slots, odd
     constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -41,8 +41,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     constexpr int NGRP = TAPS / TPG;
     constexpr int PFX = (G % 3 == 0) ? 3 : 2;  // pixel fragments read ahead (LDS); divides G
     constexpr int RMAX = G < 8 ? G : 8;        // residual-phase steps per k-group (<= G: they arrive in the ring)
-    constexpr int AS = 2;                      // accumulator sets: consecutive MFMAs never share an accumulator
-    constexpr int FRS = BN * 4 + 16, NC8 = BN / 8;    // fp32 partial-sum image: [k-group][pixel][FRS bytes]
+    constexpr int AS = MI >= 4 ? 1 : 2;        // accumulator sets: consecutive MFMAs never share an accumulator
+    constexpr int HB = 64;                     // epilogue half-tile: pixels exchanged through LDS at a time
+    constexpr int FRS = BN * 4 + 16, NC8 = BN / 8;    // fp32 partial-sum image: [k-group][HB pixels][FRS bytes]
     constexpr int LPS = C8 <= 16 ? 16 : (C8 <= 32 ? 32 : 64), SPI = 64 / LPS;   // lanes per halo slot, slots per instruction
     constexpr int NCW = 5, KB = 4;             // staging batch: columns per wave x row groups in flight
     static_assert(C8 <= 64 && G % PFX == 0 && TAPS % TPG == 0 && PFX <= G, "shape");
@@ -232,20 +233,22 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
             const unsigned char* lbase = reinterpret_cast<const unsigned char*>(first ? gr0 + c : gr1 + (c - nR0));
             const unsigned ld2 = (unsigned)(first ? nR0 : nR1) * 2u;
             const int pix0 = (b * p.Win + w0) * p.Hin + h0;
-            constexpr int NBR = 8;              // <= 8 instructions per wave (R <= 512)
-            uint4 rv[NBR];
+            constexpr int NBR = 8;              // <= 8 instructions per wave and 64 pixels (R <= 512)
+            for (int hp = 0; hp < BM / 64; ++hp) {
+                uint4 rv[NBR];
 #pragma unroll
-            for (int u = 0; u < NBR; ++u) {
-                const int pidx = (wave + 8 * u) * ppi + psub;
-                const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-                rv[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (pidx < npx && rc8 < R8)
-                    rv[u] = *reinterpret_cast<const uint4*>(lbase + (size_t)(unsigned)(pix0 + pw * p.Hin + ph) * ld2);
-            }
+                for (int u = 0; u < NBR; ++u) {
+                    const int pl = (wave + 8 * u) * ppi + psub, pidx = hp * 64 + pl;
+                    const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+                    rv[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (pl < 64 && rc8 < R8)
+                        rv[u] = *reinterpret_cast<const uint4*>(lbase + (size_t)(unsigned)(pix0 + pw * p.Hin + ph) * ld2);
+                }
 #pragma unroll
-            for (int u = 0; u < NBR; ++u) {
-                const int pidx = (wave + 8 * u) * ppi + psub;
-                if (pidx < npx && rc8 < R8) *reinterpret_cast<uint4*>(sR + pidx * RSR + rc8 * 16) = rv[u];
+                for (int u = 0; u < NBR; ++u) {
+                    const int pl = (wave + 8 * u) * ppi + psub, pidx = hp * 64 + pl;
+                    if (pl < 64 && rc8 < R8) *reinterpret_cast<uint4*>(sR + pidx * RSR + rc8 * 16) = rv[u];
+                }
             }
         }
     }
@@ -270,17 +273,20 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     }
 
     // ---- identity residual (y = conv + x): fetched now, added in fp32 in the epilogue ------------------------------------
-    constexpr int NPASS = (BM * NC8 + NT - 1) / NT;             // epilogue items (pixel, 8 channels) per thread
-    uint4 resv[NPASS];
+    constexpr int NHALF = BM / HB;
+    constexpr int NPASS = (HB * NC8 + NT - 1) / NT;             // epilogue items (pixel, 8 channels) per thread and half-tile
+    uint4 resv[NHALF][NPASS];
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q) {
-        const int pidx = tid / NC8 + q * (NT / NC8);
-        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        resv[q] = make_uint4(0u, 0u, 0u, 0u);
-        if (p.res && pidx < npx)
-            resv[q] = *reinterpret_cast<const uint4*>(p.res + (((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph)) * p.N +
-                                                      nt * BN + (tid % NC8) * 8);
-    }
+    for (int hp = 0; hp < NHALF; ++hp)
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int pl = tid / NC8 + q * (NT / NC8), pidx = hp * HB + pl;
+            const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+            resv[hp][q] = make_uint4(0u, 0u, 0u, 0u);
+            if (p.res && pl < HB)
+                resv[hp][q] = *reinterpret_cast<const uint4*>(
+                    p.res + (((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph)) * p.N + nt * BN + (tid % NC8) * 8);
+        }
 
     // ---- barrier-free K loop ------------------------------------------------------------------------------------------
     // NGRP groups of TPG taps; step idx of a group = tap idx / CPT of the group, 16-channel group kg + (idx % CPT) * KG.
@@ -374,62 +380,69 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     lds_barrier_s();                            // everyone is done with the input images: LDS is reused below
     RLDM_STAMP();
 
-    // ---- epilogue: every k-group parks its fp32 partial tile in LDS as [k-group][pixel][channel]; then all 512 threads
-    // sum the k-groups for one (pixel, 8 channels) item each, round to bf16, store 16 bytes, and keep (sum, sumsq) of the
-    // ROUNDED values for the next GroupNorm (same contract as conv_igemm.hip's epilogue) -----------------------------
+    // ---- epilogue, 64 pixels at a time: every k-group parks its fp32 partial half-tile in LDS as [k-group][pixel][channel];
+    // then all 512 threads sum the k-groups for one (pixel, 8 channels) item each, round to bf16, store 16 bytes, and keep
+    // (sum, sumsq) of the ROUNDED values for the next GroupNorm (same contract as conv_igemm.hip's epilogue) ------------
     unsigned char* sE = smem;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int pidx = mi * 32 + l31;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int chl = wn * 32 + 8 * r4 + 4 * kh;
-            *reinterpret_cast<float4*>(sE + (kg * BM + pidx) * FRS + chl * 4) =
-                make_float4(acc[0][mi][r4 * 4 + 0], acc[0][mi][r4 * 4 + 1], acc[0][mi][r4 * 4 + 2], acc[0][mi][r4 * 4 + 3]);
-        }
-    }
-    lds_barrier_s();
-    RLDM_STAMP();
+    constexpr int TRS = BN * 2 + 16;            // rounded half-tile [pixel][channel] bf16, for the statistics
+    unsigned char* sT = sE + KG * HB * FRS;
     const int c8 = tid % NC8;
     const int chg = nt * BN + c8 * 8;
-    constexpr int TRS = BN * 2 + 16;            // rounded tile [pixel][channel] bf16, for the statistics
-    unsigned char* sT = sE + KG * BM * FRS;
+    // statistics: lane = channel pair (conflict-free 4-byte reads down the pixels), NT / (BN/2) pixel groups
+    constexpr int NCP = BN / 2, NG = NT / NCP, PPG = HB / NG;
+    const int cp = tid % NCP, pg = tid / NCP;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q) {
-        const int pidx = tid / NC8 + q * (NT / NC8);
-        if (pidx >= npx) break;
-        float f[8] = {bf16lo(resv[q].x), bf16hi(resv[q].x), bf16lo(resv[q].y), bf16hi(resv[q].y),
-                      bf16lo(resv[q].z), bf16hi(resv[q].z), bf16lo(resv[q].w), bf16hi(resv[q].w)};
+    for (int hp = 0; hp < NHALF; ++hp) {
+        if (hp > 0) lds_barrier_s();            // the previous half-tile has been consumed
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            const float4 v0 = *reinterpret_cast<const float4*>(sE + (g * BM + pidx) * FRS + c8 * 32);
-            const float4 v1 = *reinterpret_cast<const float4*>(sE + (g * BM + pidx) * FRS + c8 * 32 + 16);
-            f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
-            f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
+        for (int m2 = 0; m2 < 2; ++m2) {
+            const int mi = hp * 2 + m2, pl = m2 * 32 + l31;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int chl = wn * 32 + 8 * r4 + 4 * kh;
+                *reinterpret_cast<float4*>(sE + (kg * HB + pl) * FRS + chl * 4) =
+                    make_float4(acc[0][mi][r4 * 4 + 0], acc[0][mi][r4 * 4 + 1], acc[0][mi][r4 * 4 + 2], acc[0][mi][r4 * 4 + 3]);
+            }
         }
-        uint4 v;
-        v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
-        v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
-        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
-        *reinterpret_cast<uint4*>(p.y + pix * p.y_ld + chg) = v;             // N % BN == 0 on this path
-        *reinterpret_cast<uint4*>(sT + pidx * TRS + c8 * 16) = v;
+        lds_barrier_s();
+        if (hp == 0) { RLDM_STAMP(); }
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int pl = tid / NC8 + q * (NT / NC8), pidx = hp * HB + pl;
+            if (pl >= HB) break;
+            const uint4 rq = resv[hp][q];
+            float f[8] = {bf16lo(rq.x), bf16hi(rq.x), bf16lo(rq.y), bf16hi(rq.y),
+                          bf16lo(rq.z), bf16hi(rq.z), bf16lo(rq.w), bf16hi(rq.w)};
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sE + (g * HB + pl) * FRS + c8 * 32);
+                const float4 v1 = *reinterpret_cast<const float4*>(sE + (g * HB + pl) * FRS + c8 * 32 + 16);
+                f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
+                f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
+            }
+            uint4 v;
+            v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+            v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+            const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+            const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
+            *reinterpret_cast<uint4*>(p.y + pix * p.y_ld + chg) = v;             // N % BN == 0 on this path
+            *reinterpret_cast<uint4*>(sT + pl * TRS + c8 * 16) = v;
+        }
+        if (p.y_stats) {
+            lds_barrier_s();
+#pragma unroll
+            for (int j = 0; j < PPG; ++j) {
+                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sT + (pg * PPG + j) * TRS + cp * 4);
+                const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+                s0 += a0; s1 += a1;
+                q0 += a0 * a0; q1 += a1 * a1;
+            }
+        }
     }
     if (p.y_stats) {
-        // (sum, sumsq) of the ROUNDED values per channel: lane = channel pair (conflict-free 4-byte reads down the pixels),
-        // NT / (BN/2) pixel groups; the groups of one wave fold by lane shuffles, the 8 waves through LDS
-        constexpr int NCP = BN / 2, NG = NT / NCP, PPG = BM / NG;
-        float* sS = reinterpret_cast<float*>(sT + BM * TRS);                // [8 waves][2][BN]
-        lds_barrier_s();
-        const int cp = tid % NCP, pg = tid / NCP;
-        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < PPG; ++j) {
-            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sT + (pg * PPG + j) * TRS + cp * 4);
-            const float a0 = bf16lo(w2), a1 = bf16hi(w2);
-            s0 += a0; s1 += a1;
-            q0 += a0 * a0; q1 += a1 * a1;
-        }
+        // the pixel groups of one wave fold by lane shuffles, the 8 waves through LDS
+        float* sS = reinterpret_cast<float*>(sT + HB * TRS);                // [8 waves][2][BN]
 #pragma unroll
         for (int d = NCP; d < 64; d <<= 1) {
             s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d);
@@ -469,7 +482,7 @@ int conv_small_col_bytes(int Cin, int TH, int taps) {
 int conv_small_kgroups(int BN) { return 8 / (BN / 32); }
 
 size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN) {
-    const int BM = 64, KG = conv_small_kgroups(BN);
+    const int BM = 64, KG = conv_small_kgroups(BN);             // (epilogue: 64-pixel half-tiles)
     const int Cin = p.C0, R = p.R0 + p.R1;
     const size_t a = (size_t)(p.TW + (taps == 9 ? 2 : 0)) * p.colb;
     const size_t r = (size_t)p.TW * p.TH * (R * 2 + 16);
@@ -499,14 +512,16 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     if (cpt == 0 || p.N % BN != 0 || R % (16 * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
     const int G = (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;
     if (R / (16 * KG) > std::min(G, 8)) return false;
-    if (p.TW * p.TH != 64 || p.TH < 2 || p.TW + 2 > 40 || p.Win < 2) return false;
+    const int BMpx = p.TW * p.TH;
+    if ((BMpx != 64 && BMpx != 128) || p.TH < 2 || p.TW + 2 > 40 || p.Win < 2) return false;
+    if (BMpx == 128 && (taps != 9 || BN != 64 || (cpt != 2 && cpt != 4 && cpt != 6))) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
     return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;
 }
 
-template <int NWN, int CPT, int TAPS>
+template <int NWN, int CPT, int TAPS, int MI>
 static int launch_small_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
-    auto kern = conv_small_kernel<NWN, CPT, TAPS>;
+    auto kern = conv_small_kernel<NWN, CPT, TAPS, MI>;
     static size_t max_set = 0;
     if (lds > max_set) {
         RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -521,14 +536,18 @@ int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream)
     RLDM_REQUIRE(conv_small_supported(p, taps, BN), "conv_small: unsupported shape");
     const size_t lds = conv_small_lds_bytes(p, taps, BN);
     const int cpt = small_cpt(p.C0, taps, BN);
-#define RLDM_SMALL(NWN_, CPT_, TAPS_) \
-    if (BN == 32 * NWN_ && cpt == CPT_ && taps == TAPS_) return launch_small_inst<NWN_, CPT_, TAPS_>(p, lds, stream);
+    const int mi = p.TW * p.TH / 32;
+#define RLDM_SMALL4(NWN_, CPT_, TAPS_, MI_) \
+    if (BN == 32 * NWN_ && cpt == CPT_ && taps == TAPS_ && mi == MI_) return launch_small_inst<NWN_, CPT_, TAPS_, MI_>(p, lds, stream);
+#define RLDM_SMALL(NWN_, CPT_, TAPS_) RLDM_SMALL4(NWN_, CPT_, TAPS_, 2)
     RLDM_SMALL(1, 1, 9) RLDM_SMALL(1, 2, 9) RLDM_SMALL(1, 3, 9) RLDM_SMALL(1, 4, 9)
     RLDM_SMALL(2, 1, 9) RLDM_SMALL(2, 2, 9) RLDM_SMALL(2, 3, 9) RLDM_SMALL(2, 4, 9) RLDM_SMALL(2, 6, 9) RLDM_SMALL(2, 8, 9)
     RLDM_SMALL(1, 2, 1) RLDM_SMALL(1, 4, 1)
     RLDM_SMALL(2, 2, 1) RLDM_SMALL(2, 4, 1) RLDM_SMALL(2, 8, 1)
     RLDM_SMALL(4, 4, 1) RLDM_SMALL(4, 8, 1)
+    RLDM_SMALL4(2, 2, 9, 4) RLDM_SMALL4(2, 4, 9, 4) RLDM_SMALL4(2, 6, 9, 4)
 #undef RLDM_SMALL
+#undef RLDM_SMALL4
     RLDM_REQUIRE(false, "conv_small: no instance");
     return 1;
 }

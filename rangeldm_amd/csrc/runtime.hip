@@ -560,22 +560,26 @@ struct Builder {
 
     // conv_small.hip route: 3x3 / stride 1 convs over <= 256-pixel images (the 64x4 and 32x2 UNet levels) and every
     // pointwise conv with 128..512 input channels (attention q/k/v and output projections)
-    static void small_tile(int Wout, int Hout, int* tw, int* th) {
+    static void small_tile(int bm, int Wout, int Hout, int* tw, int* th) {
         int h = 1;
         while (h * 2 <= Hout && h * 2 <= 8 && Hout % (h * 2) == 0) h *= 2;
         *th = h;
-        *tw = 64 / h;
+        *tw = bm / h;
     }
     // geometry + channel counts of the route; `epi_res`: the identity residual is added in the epilogue instead of the K loop
     static bool small_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q, bool* epi_res) {
         if (g_dbg_flags & 256) return false;
         if ((taps != 9 && taps != 1) || a.stride != 1 || a.up != 1 || a.out_f32_nchw) return false;
-        if (taps == 9 && (a.pad_mode != 0 || Wout * Hout > 256)) return false;
+        // (128-pixel tiles for the 128x8 level are built and tested but lose to the generic kernel there: the separate
+        //  GroupNorm pass over a 12 MB tensor costs more than the faster K loop wins; rldm_debug_set_flags(1024) routes them)
+        if (taps == 9 && (a.pad_mode != 0 || Wout * Hout > ((g_dbg_flags & 1024) ? 1024 : 256))) return false;
+        // pixel tile: 64; 128 for the 3x3 convs of the 128x8 level (each weight fragment then feeds 4 MFMAs)
+        const int bm = (taps == 9 && Wout * Hout > 256) ? 128 : 64;
         if (taps == 1 && a.x1.valid()) return false;
         if (!a.gn && a.x1.valid()) return false;
         if (a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
         int tw, th;
-        small_tile(Wout, Hout, &tw, &th);
+        small_tile(bm, Wout, Hout, &tw, &th);
         if (Wout % tw != 0 || Hout % th != 0 || Wout < 2) return false;
         *epi_res = a.layer->sc_identity && a.r0.valid() && !a.r1.valid() && a.r0.C == a.layer->Cout;
         memset(q, 0, sizeof(*q));
@@ -609,6 +613,8 @@ struct Builder {
         if (gn_fused) t.st0 = reinterpret_cast<const float2*>(&t);      // (only its presence matters to the shape check)
         const long long tiles = (long long)q.B * q.tiles_img;
         if (g_force_bn && conv_small_supported(t, taps, g_force_bn)) return g_force_bn;
+        if (taps == 9 && q.TW * q.TH == 128)    // one round of workgroups, or the generic kernel
+            return (conv_small_supported(t, 9, 64) && tiles * (q.N / 64) <= 256) ? 64 : 0;
         if (taps == 9) {
             const bool ok64 = conv_small_supported(t, 9, 64), ok32 = conv_small_supported(t, 9, 32);
             if (ok64 && (tiles * (q.N / 64) >= 200 || !ok32)) return 64;
@@ -694,7 +700,7 @@ struct Builder {
             const int temb_off = a.temb_off;
             const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * taps + L->R) * 2.0 +
                               (double)x0.B * Wout * Hout * N * 2.0 + (double)x0.B * Wout * Hout * R_t * 2.0;
-            const std::string kname = "conv_small_kernel<64," + std::to_string(BN) + ",taps" + std::to_string(taps) + ">";
+            const std::string kname = "conv_small_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(BN) + ",taps" + std::to_string(taps) + ">";
             plan->ops.push_back({[p, BN, taps, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;

@@ -44,11 +44,14 @@ CONV_CASES = [
     (16, 256, 256, 64, 4, 3, 1, 0, False),     # conv_small.hip: L2 at the bench batch -> 64-channel tiles
     (2, 128, 64, 32, 8, 3, 1, 0, False),       # conv_small.hip: 8x8 pixel tiles
     (3, 64, 64, 16, 4, 3, 1, 0, False),        # conv_small.hip: one 64-pixel image per block, Cin = 64 (64-channel tiles only)
+    (2, 128, 128, 128, 8, 3, 1, 0, False),     # conv_small.hip: L1, 128-pixel tiles (16x8)
+    (16, 256, 128, 128, 8, 3, 1, 0, False),    # conv_small.hip: L1 at the bench batch (one full round of workgroups)
+    (1, 384, 128, 128, 8, 3, 1, 0, False),     # conv_small.hip: L1 up-block width 256 + 128
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_geometry(case):
+def test_conv_geometry(case, conv_flags):
     B, Cin, Cout, W, H, k, s, pm, up = case
     x = _rand(B, Cin, W, H, seed=1)
     w = _rand(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
@@ -85,12 +88,13 @@ def test_conv_wrap_seam_exact():
 
 
 GN_CASES = [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
-            (256, 128, 256, 64, 4), (128, 128, 128, 16, 4)]
+            (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8)]
 
 
-@pytest.fixture(params=[0, 512], ids=["default", "small-fused-gn"])
+@pytest.fixture(params=[0, 1024, 256], ids=["default", "small-128px-tiles", "generic-only"])
 def conv_flags(request):
-    """0: conv_small.hip behind a separate GroupNorm+SiLU launch (default); 512: GroupNorm folded into its prologue."""
+    """Routing of the conv launches: 0 default; 1024 also sends the 128x8 level to conv_small.hip (128-pixel tiles);
+    256 keeps everything on the generic implicit-GEMM kernel."""
     from rangeldm_amd import _lib
     _lib.lib().rldm_debug_set_flags(request.param)
     yield request.param
@@ -121,7 +125,7 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H, conv_flags):
 
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
                                                 (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3),
-                                                (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1)])
+                                                (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1), (2, 128, 128, 128, 8, 3)])
 def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
     the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
