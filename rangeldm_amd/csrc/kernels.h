@@ -120,6 +120,7 @@ struct GnApplyParams {
     float eps;
     int silu;
     bf16_t* y;
+    float inv_n;            // 1 / (npix * channels per group) (set by launch_gn_apply)
 };
 int launch_gn_apply(const GnApplyParams& p, hipStream_t stream);
 

@@ -73,7 +73,7 @@ int launch_gn_stats(const GnStatsParams& p, hipStream_t stream) {
 // partials into the affine (a few hundred floats, double accumulation as in the conv prologue of conv_igemm.hip) and then
 // streams its slice: 16 bytes per lane in, 16 bytes out.
 __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, int ppb) {
-    __shared__ double sD[2 * 128 + 2 * 32];
+    __shared__ double sD[2 * 128];
     __shared__ __attribute__((aligned(16))) float sGa[128];
     __shared__ __attribute__((aligned(16))) float sGs[128];
     const int tid = threadIdx.x;
@@ -89,52 +89,19 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
     const float2* gs0 = p.st0;
     const float2* gs1 = p.st1;
     const int nC0 = p.C0, nC1 = p.C1, nP0 = p.P0, nP1 = p.P1;
-    if (tid < nc) {
-        const int t = c0 + tid;
-        const bool first = t < nC0;
-        const int c = first ? t : t - nC0;
-        const int C = first ? nC0 : nC1;
-        const int P = first ? nP0 : nP1;
-        const float2* src = (first ? gs0 : gs1) + (size_t)b * P * C + c;
-        double S = 0.0, SS = 0.0;
-        for (int q = 0; q < P; ++q) {
-            const float2 v = src[(size_t)q * C];
-            S += (double)v.x;
-            SS += (double)v.y;
-        }
-        sD[tid] = S;
-        sD[128 + tid] = SS;
-    }
-    __syncthreads();
-    if (tid < ng) {
-        double S = 0.0, SS = 0.0;
-        for (int i = 0; i < cpg; ++i) {
-            S += sD[tid * cpg + i];
-            SS += sD[128 + tid * cpg + i];
-        }
-        const double inv_n = 1.0 / ((double)p.npix * (double)cpg);
-        const double mean = S * inv_n;
-        double var = SS * inv_n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        sD[256 + tid] = mean;
-        sD[256 + 32 + tid] = (double)__builtin_amdgcn_rsqf((float)var + p.eps);
-    }
-    __syncthreads();
-    if (tid < nc) {
-        const int g = tid / cpg;
-        const float ga = p.gamma[c0 + tid] * (float)sD[256 + 32 + g];
-        sGa[tid] = ga;
-        sGs[tid] = p.beta[c0 + tid] - (float)sD[256 + g] * ga;
-    }
-    __syncthreads();
+
+    // everything the block reads is requested up front (one memory round trip): its channels' statistics, gamma / beta,
+    // and the first pieces of its slice
+    double S = 0.0, SS = 0.0;
+    float gam = 0.f, bet = 0.f;
     const int n8 = nc >> 3;                  // 16-byte pieces per pixel of the slice
     const int px0 = blockIdx.x * ppb;
     const int total = min(ppb, p.npix - px0) * n8;
     constexpr int NB = 4;
-    for (int q0 = tid; q0 < total; q0 += 256 * NB) {
-        uint4 v[NB];
-        int cl[NB];
-        size_t dst[NB];
+    uint4 v[NB];
+    int cl[NB];
+    size_t dst[NB];
+    auto load_batch = [&](int q0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int q = q0 + j * 256;
@@ -149,6 +116,54 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
                 v[j] = *reinterpret_cast<const uint4*>(first ? gx0 + pix * nC0 + c : gx1 + pix * nC1 + (c - nC0));
             }
         }
+    };
+    if (tid < nc) {
+        const int t = c0 + tid;
+        const bool first = t < nC0;
+        const int c = first ? t : t - nC0;
+        const int C = first ? nC0 : nC1;
+        const int P = first ? nP0 : nP1;
+        const float2* src = (first ? gs0 : gs1) + (size_t)b * P * C + c;
+        int q = 0;
+        for (; q + 4 <= P; q += 4) {
+            float2 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = src[(size_t)(q + j) * C];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { S += (double)u[j].x; SS += (double)u[j].y; }
+        }
+        for (; q < P; ++q) {
+            const float2 u = src[(size_t)q * C];
+            S += (double)u.x;
+            SS += (double)u.y;
+        }
+        gam = p.gamma[t];
+        bet = p.beta[t];
+    }
+    load_batch(tid);
+    if (tid < nc) {
+        sD[tid] = S;
+        sD[128 + tid] = SS;
+    }
+    __syncthreads();
+    if (tid < nc) {                          // every channel's thread folds its own group (no serial phase)
+        const int gb = (tid / cpg) * cpg;
+        double GS = 0.0, GSS = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+            GS += sD[gb + i];
+            GSS += sD[128 + gb + i];
+        }
+        const double inv_n = (double)p.inv_n;
+        const double mean = GS * inv_n;
+        double var = GSS * inv_n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float a = gam * __builtin_amdgcn_rsqf((float)var + p.eps);
+        sGa[tid] = a;
+        sGs[tid] = bet - (float)mean * a;
+    }
+    __syncthreads();
+    for (int q0 = tid; q0 < total; q0 += 256 * NB) {
+        if (q0 != tid) load_batch(q0);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (q0 + j * 256 >= total) continue;
@@ -182,7 +197,9 @@ int launch_gn_apply(const GnApplyParams& p, hipStream_t stream) {
     const int n8 = gsl * cpg / 8;
     int ppb = std::max(1, 1024 / n8);                           // ~4 pieces per thread
     while (ppb > 16 && (long long)p.B * ny * ((p.npix + ppb - 1) / ppb) < 256) ppb >>= 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((p.npix + ppb - 1) / ppb, ny, p.B), dim3(256), 0, stream, p, ppb);
+    GnApplyParams q = p;
+    q.inv_n = (float)(1.0 / ((double)p.npix * cpg));
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((p.npix + ppb - 1) / ppb, ny, p.B), dim3(256), 0, stream, q, ppb);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
