@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     constexpr int HB = 64;                     // epilogue half-tile: pixels exchanged through LDS at a time
     constexpr int FRS = BN * 4 + 16, NC8 = BN / 8;    // fp32 partial-sum image: [k-group][HB pixels][FRS bytes]
     constexpr int LPS = C8 <= 16 ? 16 : (C8 <= 32 ? 32 : 64), SPI = 64 / LPS;   // lanes per halo slot, slots per instruction
-    constexpr int NCW = 5, KB = 4;             // staging batch: columns per wave x row groups in flight
+    // staging batch: columns per wave x row groups in flight (128-pixel tiles are 16 wide: 18 halo columns, 3 per wave,
+    // and all of a wave's pieces are requested before the first is stored)
+    constexpr int NCW = MI >= 4 ? 3 : 5, KB = MI >= 4 ? (10 + SPI - 1) / SPI : 4;
     static_assert(C8 <= 64 && G % PFX == 0 && TAPS % TPG == 0 && PFX <= G, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -514,7 +516,7 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     if (R / (16 * KG) > std::min(G, 8)) return false;
     const int BMpx = p.TW * p.TH;
     if ((BMpx != 64 && BMpx != 128) || p.TH < 2 || p.TW + 2 > 40 || p.Win < 2) return false;
-    if (BMpx == 128 && (taps != 9 || BN != 64 || (cpt != 2 && cpt != 4 && cpt != 6))) return false;
+    if (BMpx == 128 && (taps != 9 || BN != 64 || p.TW + 2 > 24 || (cpt != 2 && cpt != 4 && cpt != 6))) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
     return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;
 }
