@@ -1,0 +1,439 @@
+// Weight-streaming circular 3x3 convolution for the full-resolution levels (UNet 256x16, VAE decoder) on gfx950:
+// bf16 MFMA 32x32x16, fp32 accumulate, 256 pixels x 128 channels per workgroup.
+//
+// Same fused unit as conv_igemm.hip -- GroupNorm + SiLU of cat[x0, x1] on the way into LDS, conv 3x3 (wrap W / zero H,
+// optional nearest-x2 folded into the indexing), bias + time embedding, shortcut-conv / residual as extra K over the raw
+// block input, per-channel statistics of the output for the next GroupNorm (ldm/utils.py:40-58,107-116;
+// vae/sgm/modules/diffusionmodules/model.py:93-125,342-362) -- with a different division of labour between LDS and L2:
+//   * only the ACTIVATIONS go through LDS: per 64-channel chunk the halo of the 32x8 pixel tile (34x10 positions) is
+//     double-buffered, chunk c+1 is fetched and normalised while chunk c computes, and the workgroup meets at ONE barrier
+//     per chunk (conv_igemm.hip: one per tap, because its weight ring lives in LDS too);
+//   * the WEIGHTS are packed on the host in MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per 32-channel
+//     tile, and every wave loads its own fragments straight from L2 into registers: a ring of 12 fragments (one row of
+//     taps) in flight, refilled in program order so the compiler's s_waitcnt counts are exact; the stream never stops at
+//     a barrier;
+//   * 8 waves = 2 pixel halves x 4 channel tiles; a wave owns 128 pixels x 32 channels (4 MFMAs per fragment), so each
+//     fragment is requested by two waves (the second hit is an L1 hit) and the LDS feeds 4 pixel fragments per k-step;
+//   * waves 0-3 normalise their share of the next chunk after the first row of taps, waves 4-7 after the second, so the
+//     VALU work (GroupNorm affine + SiLU) of one half runs under the other half's MFMAs: the two waves of a SIMD are never
+//     both in it.
+#include "kernels.h"
+
+namespace rldm {
+
+#ifdef RLDM_ABLATE
+#define RLDM_TDBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define RLDM_TDBG(p, bit) false
+#endif
+
+namespace {
+__device__ __forceinline__ void lds_barrier_b() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+}  // namespace
+
+__global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p) {
+    constexpr int NT = 512, BM = 256, BN = 128, CK = 64, WM = 2, MI = 4;
+    constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
+    constexpr int C8 = CK / 8;
+    constexpr int ACH = 6;                     // 16-byte halo pieces per thread and chunk (34 x 10 x 8 <= 6 * 512)
+    constexpr int G = 12;                      // weight fragments in flight per wave = k-steps of one row of taps
+    constexpr int PFX = 2;                     // pixel fragments read ahead (8 MFMAs of cover)
+    constexpr int ERS = BN * 2 + 16, NC8 = BN / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 4, wn = wave % 4;    // waves 0-3: pixels 0..127, waves 4-7: pixels 128..255
+    const int kh = lane >> 5, l31 = lane & 31;
+#ifdef RLDM_ABLATE
+    unsigned long long tsv[12];
+    int tsn = 0;
+#define RLDM_STAMP() if (tsn < 12) tsv[tsn++] = __builtin_amdgcn_s_memtime()
+#else
+#define RLDM_STAMP()
+#endif
+    RLDM_STAMP();
+
+    // ---- which tile: grid = (channel tiles, pixel tiles of an image, images) -------------------------------------------
+    const int tiles_h = p.tiles_h, tiles_img = p.tiles_img;       // tiles_h is a power of two
+    const int nt = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
+    const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
+    const int w0 = tw * p.TW, h0 = th * p.TH;
+
+    // the sampler's step index selects the time-embedding row: requested first, used after everything else is in flight
+    const int temb_step = (p.temb && p.step_ptr) ? *p.step_ptr : 0;
+
+    const int Cin = p.C0 + p.C1;
+    const int NCC = Cin / CK;                  // main-phase chunks: 9 taps x 4 k-steps
+    const int NCB = (p.R0 + p.R1) / CK;        // residual-phase chunks: centre tap, 4 k-steps, raw input
+    const int NCT = NCC + NCB;
+    const int THv = p.TH + 2, TWv = p.TW + 2;
+    const int colb = p.colb;
+    const int abytes = TWv * colb;
+    const int Wv = p.Win * p.up, Hv = p.Hin * p.up;
+    const int upshift = p.up - 1;
+
+    unsigned char* sA = smem;                                  // 2 * abytes
+    float* sGa = reinterpret_cast<float*>(sA + 2 * abytes);    // Cin
+    float* sGs = sGa + Cin;
+    float* sBias = sGs + Cin;                                  // BN
+
+    // ---- this wave's weight stream (channel tile 4*nt + wn): [NCC][9 taps][4 k-steps] then [NCB][4 k-steps], 1 KiB each ----
+    const int nsteps = NCC * 36 + NCB * 4;
+    const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)(nt * 4 + wn) * nsteps * 1024;
+    const unsigned woff = lane * 16 + 4096;     // lane offset: immediates of +-4 KiB around it reach 8 fragments
+    auto w_load = [&](const unsigned char* base, int idx) __attribute__((always_inline)) {      // fragment idx in [0, 16)
+        return *reinterpret_cast<const bf16x8*>(base + (idx / 8) * 8192 + woff + ((idx % 8) * 1024 - 4096));
+    };
+    bf16x8 wr[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        wr[j] = w_load(wptr, j);
+        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the counted waits below rely on it
+    }
+    wptr += G * 1024;                           // -> the fragments the first row of taps refills
+
+    RLDM_STAMP();
+    // ---- halo staging: thread-constant source pixel of each of its ACH 16-byte pieces ---------------------------------
+    const int atotal = TWv * THv * C8;
+    int apix[ACH];
+    const int my_c8 = (tid % C8) * 8;
+    uint4 areg[ACH];
+    const bool gn = p.st0 != nullptr;
+    const bf16_t* const gx0 = p.x0;             // (locals: selecting between fields of `p` by address would copy it to scratch)
+    const bf16_t* const gx1 = p.x1;
+    const bf16_t* const gr0 = p.r0;
+    const bf16_t* const gr1 = p.r1;
+    const int nC0 = p.C0, nC1 = p.C1, nR0 = p.R0, nR1 = p.R1;
+    auto load_a = [&](int cs) __attribute__((always_inline)) {                  // chunk cs of the sequence main, residual
+        const bool main_phase = cs < NCC;
+        const int c = (main_phase ? cs : cs - NCC) * CK + my_c8;
+        const int split = main_phase ? nC0 : nR0;
+        const bool first = c < split;
+        const bf16_t* t0 = main_phase ? gx0 : gr0;
+        const bf16_t* t1 = main_phase ? gx1 : gr1;
+        const bf16_t* base = first ? t0 + c : t1 + (c - split);
+        const int ld = first ? split : (main_phase ? nC1 : nR1);
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int pix = apix[i] < 0 ? 0 : apix[i];
+            areg[i] = *reinterpret_cast<const uint4*>(base + (size_t)pix * ld);
+        }
+    };
+    auto store_a = [&](int cs) __attribute__((always_inline)) {                 // GroupNorm + SiLU (main phase) -> LDS
+        unsigned char* dstbuf = sA + (cs & 1) * abytes;
+        const bool anorm = gn && cs < NCC;
+        float4 ga0, ga1, gs0, gs1;
+        if (anorm) {
+            const int c = cs * CK + my_c8;
+            ga0 = *reinterpret_cast<const float4*>(sGa + c);
+            ga1 = *reinterpret_cast<const float4*>(sGa + c + 4);
+            gs0 = *reinterpret_cast<const float4*>(sGs + c);
+            gs1 = *reinterpret_cast<const float4*>(sGs + c + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            uint4 v = areg[i];
+            if (apix[i] < 0) {
+                v = make_uint4(0u, 0u, 0u, 0u);
+            } else if (anorm) {
+                float f0 = bf16lo(v.x) * ga0.x + gs0.x, f1 = bf16hi(v.x) * ga0.y + gs0.y;
+                float f2 = bf16lo(v.y) * ga0.z + gs0.z, f3 = bf16hi(v.y) * ga0.w + gs0.w;
+                float f4 = bf16lo(v.z) * ga1.x + gs1.x, f5 = bf16hi(v.z) * ga1.y + gs1.y;
+                float f6 = bf16lo(v.w) * ga1.z + gs1.z, f7 = bf16hi(v.w) * ga1.w + gs1.w;
+                if (p.silu) {
+                    f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
+                    f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+                }
+                v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
+                v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);
+            }
+            const int q = tid + i * NT;
+            const int slot = q / C8, c8 = q - slot * C8;
+            const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
+            if (q < atotal) *reinterpret_cast<uint4*>(dstbuf + vwl * colb + vhl * RS + c8 * 16) = v;
+        }
+    };
+    RLDM_STAMP();
+    // ---- GroupNorm: the statistics partials of channel `tid`, gamma and beta are requested first, then the first halo
+    // chunk; the fold runs while they are all in flight.  Every channel's thread folds its own group (no serial phase).
+    double gS = 0.0, gSS = 0.0;
+    float g_gamma = 0.f, g_beta = 0.f;
+    if (gn && tid < Cin) {
+        const float2* const gs0p = p.st0;
+        const float2* const gs1p = p.st1;
+        const int nP0 = p.P0, nP1 = p.P1;
+        const bool first = tid < nC0;
+        const int c = first ? tid : tid - nC0;
+        const int C = first ? nC0 : nC1;
+        const int P = first ? nP0 : nP1;
+        const float2* src = (first ? gs0p : gs1p) + (size_t)b * P * C + c;
+        g_gamma = p.gn_gamma[tid];
+        g_beta = p.gn_beta[tid];
+        int q = 0;
+        for (; q + 16 <= P; q += 16) {          // 16 partials per round trip (P = pixel tiles per image of the producer)
+            float2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(q + j) * C];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { gS += (double)v[j].x; gSS += (double)v[j].y; }
+        }
+        for (; q + 4 <= P; q += 4) {
+            float2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = src[(size_t)(q + j) * C];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gS += (double)v[j].x; gSS += (double)v[j].y; }
+        }
+        for (; q < P; ++q) {
+            const float2 v = src[(size_t)q * C];
+            gS += (double)v.x;
+            gSS += (double)v.y;
+        }
+    }
+    float bias_v = 0.f;
+    if (tid < BN) bias_v = p.bias[nt * BN + tid];
+    RLDM_STAMP();
+    // (address arithmetic of the halo pieces: integer multiplies, done while the requests above are in flight)
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int q = tid + i * NT;
+        const int slot = q / C8;
+        const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
+        const int vh = h0 - 1 + vhl;
+        int vw = w0 - 1 + vwl;
+        vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
+        const bool ok = q < atotal && vh >= 0 && vh < Hv;
+        apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
+    }
+    if (NCT > 0) load_a(0);
+    if (p.temb && tid < BN)
+        bias_v += p.temb[(size_t)(temb_step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld + nt * BN + tid];
+    if (gn) {
+        double* sD = reinterpret_cast<double*>(sA);             // scratch: [2][Cin] doubles (the halo is not written yet)
+        const int cpg = Cin / p.gn_groups;
+        if (tid < Cin) {
+            sD[tid] = gS;
+            sD[Cin + tid] = gSS;
+        }
+        __syncthreads();
+        float ga = 0.f, gs = 0.f;               // Cin <= NT
+        if (tid < Cin) {
+            const int g0 = ((tid * p.magic_cpg) >> 20) * cpg;
+            double S = 0.0, SS = 0.0;
+            for (int i = 0; i < cpg; ++i) {
+                S += sD[g0 + i];
+                SS += sD[Cin + g0 + i];
+            }
+            const double inv_n = (double)p.gn_inv_n;
+            const double mean = S * inv_n;
+            double var = SS * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            ga = g_gamma * __builtin_amdgcn_rsqf((float)var + p.gn_eps);
+            gs = g_beta - (float)mean * ga;
+            sGa[tid] = ga;                      // (sGa / sGs sit behind both halo buffers: disjoint from the scratch)
+            sGs[tid] = gs;
+        }
+        __syncthreads();                        // affine visible; sD fully consumed before the halo is written
+    }
+    RLDM_STAMP();
+    if (tid < BN) sBias[tid] = bias_v;
+    if (NCT > 0) store_a(0);
+    RLDM_STAMP();
+
+    // ---- per-lane LDS offsets of the pixel fragments; accumulators start at bias + temb ---------------------------------
+    int xoff[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int pidx = wm * (MI * 32) + mi * 32 + l31;
+        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+        xoff[mi] = pw * colb + ph * RS + kh * 16;
+    }
+    lds_barrier_b();                            // sBias and halo chunk 0 are written
+    f32x16 acc[MI];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 bv = *reinterpret_cast<const float4*>(sBias + wn * 32 + 8 * r4 + 4 * kh);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            acc[mi][r4 * 4 + 0] = bv.x; acc[mi][r4 * 4 + 1] = bv.y;
+            acc[mi][r4 * 4 + 2] = bv.z; acc[mi][r4 * 4 + 3] = bv.w;
+        }
+    }
+
+    // ---- K loop ----------------------------------------------------------------------------------------------------------
+    // one row of taps (ti): 12 k-steps j = 4*tj + ks; the fragment of step j sits in ring slot j and is refilled with the
+    // fragment 12 steps ahead (next row, next chunk or residual phase: the stream is linear) right after its MFMAs
+    bf16x8 xr[PFX][MI];
+    auto x_read = [&](const int (&base)[MI], int j, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + base[mi] + (j / 4) * RS + (j % 4) * 32);
+    };
+    // LAST: the row is the last one before a barrier (no read-ahead into an image that may still be written)
+    auto tap_row = [&](const int (&xa)[MI], const int (&xn)[MI], bool last) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[j], xr[j % PFX][mi], acc[mi], 0, 0, 0);
+            wr[j] = w_load(wptr, j);
+            if (j + PFX < G) x_read(xa, j + PFX, xr[j % PFX]);
+            else if (!last) x_read(xn, j + PFX - G, xr[j % PFX]);
+            __builtin_amdgcn_sched_barrier(0);  // steps stay in program order: every wait then leaves G - 1 loads in flight
+        }
+        wptr += G * 1024;
+    };
+    RLDM_STAMP();
+    for (int cs = 0; cs < NCC; ++cs) {
+        if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_a(cs + 1);       // next chunk (main or first residual): requested now, written below
+        int xa[MI], xn[MI];
+        const int boff = (cs & 1) * abytes;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { xa[mi] = xoff[mi] + boff; xn[mi] = xa[mi] + colb; }
+#pragma unroll
+        for (int j = 0; j < PFX; ++j) {
+            x_read(xa, j, xr[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tap_row(xa, xn, false);
+        if (wm == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { xa[mi] = xn[mi]; xn[mi] += colb; }
+        tap_row(xa, xn, false);
+        if (wm == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xa[mi] = xn[mi];
+        tap_row(xa, xn, true);
+        lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
+    }
+    // residual phase: centre tap of the raw block input, 4 k-steps per chunk; ring slots continue (36 = 3 * 12)
+    for (int rc0 = 0; rc0 < NCB; rc0 += 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int rc = rc0 + r;
+            if (rc < NCB) {
+                const int cs = NCC + rc;
+                if (cs + 1 < NCT) load_a(cs + 1);
+                int xc[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) xc[mi] = xoff[mi] + (cs & 1) * abytes + colb + RS;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 xf[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(smem + xc[mi] + ks * 32);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[r * 4 + ks], xf[mi], acc[mi], 0, 0, 0);
+                    wr[r * 4 + ks] = w_load(wptr, r * 4 + ks);
+                }
+                if (cs + 1 < NCT) store_a(cs + 1);
+                lds_barrier_b();
+            }
+        }
+        wptr += G * 1024;
+    }
+    RLDM_STAMP();
+
+    // ---- epilogue (conv_igemm.hip's): bf16 -> LDS [pixel][channel] -> 16-byte coalesced stores + statistics -----------------
+    unsigned char* sE = smem;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int pidx = wm * (MI * 32) + mi * 32 + l31;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int chl = wn * 32 + 8 * r4 + 4 * kh;
+            uint2 o;
+            o.x = pack_bf16x2(acc[mi][r4 * 4 + 0], acc[mi][r4 * 4 + 1]);
+            o.y = pack_bf16x2(acc[mi][r4 * 4 + 2], acc[mi][r4 * 4 + 3]);
+            *reinterpret_cast<uint2*>(sE + pidx * ERS + chl * 2) = o;
+        }
+    }
+    lds_barrier_b();
+    RLDM_STAMP();
+    // thread (g = tid / 16, c8 = tid % 16) stores 16 bytes of pixels g, g + 32, ... (4 halo columns apart: a constant
+    // address step), then the statistics of the ROUNDED tile: lane = channel pair, 8 pixel groups, LDS fold over the waves
+    const int c8 = tid % NC8;
+    const int chg = nt * BN + c8 * 8;
+    {
+        const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7)
+        bf16_t* yp = p.y + (((size_t)b * p.Wout + w0 + (g >> 3)) * p.Hout + h0 + (g & 7)) * p.y_ld + chg;
+        const size_t ystep = (size_t)4 * p.Hout * p.y_ld;
+#pragma unroll
+        for (int i = 0; i < BM / (NT / NC8); ++i) {
+            *reinterpret_cast<uint4*>(yp) = *reinterpret_cast<const uint4*>(sE + (g + i * (NT / NC8)) * ERS + c8 * 16);
+            yp += ystep;
+        }
+    }
+    if (p.y_stats) {
+        constexpr int NCP = BN / 2, NG = NT / NCP, PPG = BM / NG;          // 64 channel pairs x 8 pixel groups of 32
+        const int cp = tid % NCP, pg = tid / NCP;
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < PPG; ++j) {
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sE + (pg * PPG + j) * ERS + cp * 4);
+            const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+            s0 += a0; s1 += a1;
+            q0 += a0 * a0; q1 += a1 * a1;
+        }
+        float* sS = reinterpret_cast<float*>(sE + BM * ERS);                // [8 waves][2][BN]
+        *reinterpret_cast<float2*>(sS + (wave * 2 + 0) * BN + cp * 2) = make_float2(s0, s1);
+        *reinterpret_cast<float2*>(sS + (wave * 2 + 1) * BN + cp * 2) = make_float2(q0, q1);
+        lds_barrier_b();
+        if (tid < 2 * BN) {
+            const int kind = tid / BN, c = tid - kind * BN;
+            float S = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
+            reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
+        }
+    }
+    RLDM_STAMP();
+#ifdef RLDM_ABLATE
+    if (p.ts && blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z == 0 && tid == 0)
+        for (int i = 0; i < 12; ++i) p.ts[blockIdx.y * 64 + i] = i < tsn ? tsv[i] : 0ull;
+#endif
+#undef RLDM_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+size_t conv_stream_lds_bytes(const ConvParams& p) {
+    const size_t a = (size_t)(p.TW + 2) * p.colb;
+    const size_t main_bytes = 2 * a + (size_t)(p.C0 + p.C1) * 8 + 128 * 4;
+    const size_t gscratch = p.st0 ? (size_t)2 * (p.C0 + p.C1) * 8 : 0;
+    const size_t epi = (size_t)256 * (128 * 2 + 16) + (size_t)8 * 2 * 128 * 4;
+    return std::max(std::max(main_bytes, gscratch), epi);
+}
+
+bool conv_stream_supported(const ConvParams& p, int taps) {
+    const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
+    if (taps != 9 || p.stride != 1 || p.pad_lo != 1 || (p.up != 1 && p.up != 2) || p.y_nchw || p.ksplit > 1) return false;
+    if (Cin % 64 != 0 || (p.C1 != 0 && p.C0 % 64 != 0) || R % 64 != 0 || (p.R1 != 0 && p.R0 % 64 != 0)) return false;
+    if (R != 0 && p.up != 1) return false;
+    if (p.N % 128 != 0 || Cin > 512) return false;
+    if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
+    if (p.TW != 32 || p.TH != 8 || p.Win * p.up < 2) return false;
+    if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
+    return conv_stream_lds_bytes(p) <= 160 * 1024;
+}
+
+int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(conv_stream_supported(p, 9), "conv_stream: unsupported shape");
+    const size_t lds = conv_stream_lds_bytes(p);
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stream_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(conv_stream_kernel, dim3(p.N / 128, p.tiles_img, p.B), dim3(512), lds, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rldm

@@ -158,6 +158,42 @@ struct ConvLayer {
         return 0;
     }
 
+    // conv_stream.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per 32-channel tile:
+    // [Cout/32][Cin_pad/64 chunks x 9 taps x 4 k-steps, then R/64 chunks x 4 k-steps][64 lanes][8 bf16] + 16 KiB of zeros
+    // (the ring's read-ahead past the last stream); lane l holds channel 32*t + (l & 31), k = 8*(l >> 5) .. +8 of the step
+    int get_streampacked(int Cin_pad, Packed** out) {
+        auto key = std::make_pair(-2, 64);
+        auto it = packed.find(key);
+        if (it != packed.end()) {
+            RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
+            *out = it->second.get();
+            return 0;
+        }
+        RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % 64 == 0 && R % 64 == 0, "conv " + name + ": not stream-packable");
+        const int NCC = Cin_pad / 64, NCB = R / 64, nsteps = NCC * 36 + NCB * 4;
+        std::vector<bf16_t> img((size_t)(Cout / 32) * nsteps * 512 + 8192, 0);
+        auto at = [&](int n, int step, int k) -> bf16_t& {
+            return img[(((size_t)(n / 32) * nsteps + step) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8];
+        };
+        for (int n = 0; n < Cout; ++n) {
+            for (int c = 0; c < Cin; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    at(n, (c / 64) * 36 + tap * 4 + (c % 64) / 16, c % 16) = f32_to_bf16(w[((size_t)n * Cin + c) * 9 + tap]);
+            for (int c = 0; c < R; ++c) {
+                const float v = sc_identity ? (c == n ? 1.f : 0.f) : sc_w[(size_t)n * R + c];
+                at(n, NCC * 36 + (c / 64) * 4 + (c % 64) / 16, c % 16) = f32_to_bf16(v);
+            }
+        }
+        auto pk = std::make_unique<Packed>();
+        if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(pk->bias, b.data(), b.size() * sizeof(float))) return 1;
+        pk->ntile_n = 0;
+        pk->Cin_pad = Cin_pad;
+        *out = pk.get();
+        packed[key] = std::move(pk);
+        return 0;
+    }
+
     // conv_small.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per (32-channel tile, k-group):
     // [Cout/32][KG][taps*CPT main steps (tap-major) + RPT residual steps][64 lanes][8 bf16] + one zero fragment; k-group kg
     // owns the 16-channel groups kg, kg + KG, ... of every tap; lane l of a step holds channel 32*t + (l & 31),
@@ -198,6 +234,7 @@ struct ConvLayer {
     }
 };
 
+// (ConvLayer::get_streampacked is defined with the struct above)
 struct ParamStore {
     std::map<std::string, std::vector<float>> host;
     std::map<std::string, int64_t> expected;    // name -> numel
@@ -390,7 +427,8 @@ struct ConvArgs {
     bool out_f32_nchw = false;     // conv_out: write plan->io.out
 };
 
-static int g_dbg_flags = 0;
+// routing / ablation switches (rldm_debug_set_flags); RLDM_DBG_FLAGS seeds them for A/B runs of unmodified drivers
+static int g_dbg_flags = getenv("RLDM_DBG_FLAGS") ? atoi(getenv("RLDM_DBG_FLAGS")) : 0;
 static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
@@ -716,6 +754,98 @@ struct Builder {
         return 0;
     }
 
+    // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels
+    static bool stream_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+        if (g_dbg_flags & 2048) return false;
+        if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
+        if (Wout % 32 != 0 || Hout % 8 != 0 || a.layer->Cout % 128 != 0) return false;
+        memset(q, 0, sizeof(*q));
+        q->C0 = a.x0.C;
+        q->C1 = Cin_t - a.x0.C;
+        q->R0 = a.r0.valid() ? a.r0.C : 0;
+        q->R1 = R_t - q->R0;
+        q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
+        q->up = a.up; q->stride = 1; q->pad_lo = 1;
+        q->Wout = Wout; q->Hout = Hout;
+        q->TW = 32; q->TH = 8; q->th_shift = 3;
+        ConvTile t;
+        t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
+        q->colb = conv_halo_col_bytes(t, 8, 1);
+        q->tiles_h = Hout / 8;
+        q->tiles_img = (Wout / 32) * q->tiles_h;
+        q->magic_thv = ((1 << 20) + 10 - 1) / 10;
+        const int cpg = std::max(1, Cin_t / a.groups);
+        q->magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+        q->gn_inv_n = (float)(1.0 / ((double)a.x0.W * a.x0.H * cpg));
+        q->N = a.layer->Cout;
+        q->silu = a.silu;
+        q->gn_eps = a.eps;
+        q->gn_groups = a.groups;
+        q->ksplit = 1;
+        if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only its presence matters to the shape check)
+        const bool ok = conv_stream_supported(*q, 9) &&
+                        ((g_dbg_flags & 4096) || (long long)q->B * q->tiles_img * (q->N / 128) >= 128);
+        q->st0 = nullptr;
+        return ok;
+    }
+
+    int conv_stream(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
+        ConvLayer* L = a.layer;
+        const int N = L->Cout;
+        const Tensor& x0 = a.x0;
+        ConvParams p;
+        RLDM_REQUIRE(stream_params(a, Cin_t, R_t, 9, Wout, Hout, &p), "conv " + L->name + ": conv_stream route lost");
+        if (a.gn) {
+            RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
+            RLDM_REQUIRE(x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
+        }
+        p.dbg = g_dbg_flags;
+        p.ts = g_ts_buf;
+        p.ntile_n = N / 128;
+        Tensor y = make(x0.B, Wout, Hout, N);
+        if (a.want_stats) add_stats(y, p.tiles_img);
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
+        plan->flops += fl;
+        ++launches;
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_streampacked(Cin_t, &pk)) return 1;
+            p.x0 = tptr(x0);
+            p.x1 = tptr(a.x1);
+            p.r0 = tptr(a.r0);
+            p.r1 = tptr(a.r1);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            if (a.gn) {
+                p.st0 = sptr(x0);
+                p.st1 = sptr(a.x1);
+                p.P0 = x0.P;
+                p.P1 = a.x1.valid() ? a.x1.P : 0;
+                p.gn_gamma = a.gn->gamma.as<float>();
+                p.gn_beta = a.gn->beta.as<float>();
+            }
+            p.y = tptr(y);
+            p.y_ld = N;
+            p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
+            p.temb_ld = temb_ld;
+            Plan* pl = plan;
+            const int temb_off = a.temb_off;
+            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * 9 + L->R) * 2.0 +
+                              (double)x0.B * Wout * Hout * N * 2.0 + (double)x0.B * Wout * Hout * R_t * 2.0;
+            plan->ops.push_back({[p, pl, temb_off](hipStream_t s) mutable {
+                if (temb_off >= 0) {
+                    p.temb = pl->io.temb + temb_off;
+                    p.step_ptr = pl->io.step_ptr;
+                    p.temb_rows_per_step = pl->io.temb_rows_per_step;
+                    p.temb_per_sample = pl->io.temb_per_sample;
+                }
+                return launch_conv_stream(p, s);
+            }, "conv_stream_kernel<256,128,CK64,taps9>", fl, by});
+        }
+        *out = y;
+        return 0;
+    }
+
     // y = conv(...) ; consumes nothing (callers release inputs)
     int conv(const ConvArgs& a, Tensor* out) {
         ConvLayer* L = a.layer;
@@ -733,6 +863,10 @@ struct Builder {
         RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
         if (small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, taps, Wout, Hout, out);
+        {
+            ConvParams q;
+            if (stream_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_stream(a, Cin_t, R_t, Wout, Hout, out);
+        }
         const TileChoice tc = choose_tile(x0.B, Wout, Hout, a.stride, N, Cin_t, x0.C, R_t, a.r0.valid() ? a.r0.C : 0, taps,
                                           a.out_f32_nchw, a.gn != nullptr);
         const ConvTile tile = tc.tile;

@@ -47,6 +47,10 @@ CONV_CASES = [
     (2, 128, 128, 128, 8, 3, 1, 0, False),     # conv_small.hip: L1, 128-pixel tiles (16x8)
     (16, 256, 128, 128, 8, 3, 1, 0, False),    # conv_small.hip: L1 at the bench batch (one full round of workgroups)
     (1, 384, 128, 128, 8, 3, 1, 0, False),     # conv_small.hip: L1 up-block width 256 + 128
+    (16, 128, 128, 256, 16, 3, 1, 0, False),   # conv_stream.hip: L0 at the bench batch (256 workgroups)
+    (1, 256, 256, 64, 16, 3, 1, 0, False),     # conv_stream.hip (flag): 4 chunks, two channel tiles
+    (1, 64, 128, 32, 8, 3, 1, 0, False),       # conv_stream.hip (flag): a single chunk, a single tile
+    (1, 128, 128, 32, 16, 3, 1, 0, True),      # conv_stream.hip (flag): nearest x2 folded (64x32 output)
 ]
 
 
@@ -88,13 +92,15 @@ def test_conv_wrap_seam_exact():
 
 
 GN_CASES = [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
-            (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8)]
+            (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8),
+            (128, 64, 128, 64, 16), (64, 64, 256, 32, 8)]
 
 
-@pytest.fixture(params=[0, 1024, 256], ids=["default", "small-128px-tiles", "generic-only"])
+@pytest.fixture(params=[0, 1024, 4096, 256 + 2048], ids=["default", "small-128px-tiles", "stream-any-grid", "generic-only"])
 def conv_flags(request):
     """Routing of the conv launches: 0 default; 1024 also sends the 128x8 level to conv_small.hip (128-pixel tiles);
-    256 keeps everything on the generic implicit-GEMM kernel."""
+    4096 sends every eligible 3x3 to conv_stream.hip regardless of the grid size (by default it needs >= 128 workgroups);
+    256 + 2048 keeps everything on the generic implicit-GEMM kernel."""
     from rangeldm_amd import _lib
     _lib.lib().rldm_debug_set_flags(request.param)
     yield request.param
