@@ -175,7 +175,9 @@ int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int wa
                     char* kernel_name, size_t name_cap, void* stream);
 int rldm_debug_force_tile(int BM, int BN, int ksplit);
 int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
-int rldm_debug_set_flags(int flags);   /* kernel ablation switches, see ConvParams::dbg */
+int rldm_debug_set_flags(int flags);
+/* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
+int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */
 /* statistics side-output of the conv epilogue (feeds the next GroupNorm): stats device fp32 [B][Cout][2] = per-image
  * (sum, sum of squares) of the bf16 outputs of conv(x0); plain single-input conv only. */
 int rldm_test_conv_stats(const rldm_conv_desc* d, const float* x0, const float* weight, const float* bias, float* stats,

@@ -187,6 +187,16 @@ int launch_diag_gaussian(const float* moments, const float* noise, float scale, 
 __global__ void step_counter_kernel(int* p, int set_to, int inc) {
     if (threadIdx.x == 0) *p = (inc ? *p + inc : set_to);
 }
+// in-graph timeline (tools/graph_trace.py): one thread writes the constant-rate (100 MHz) real-time counter
+__global__ void stamp_kernel(unsigned long long* slot) {
+    if (threadIdx.x == 0) *slot = wall_clock64();
+}
+int launch_stamp(unsigned long long* slot, hipStream_t stream) {
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, stream, slot);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_step_counter(int* step_ptr, int set_to, int increment, hipStream_t stream) {
     hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, step_ptr, set_to, increment);
     RLDM_HIP_CHECK(hipGetLastError());

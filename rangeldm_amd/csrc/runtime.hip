@@ -338,6 +338,16 @@ struct Plan {
             if (o.fn(s)) return 1;
         return 0;
     }
+    // same, with a timestamp launch around every op (rldm_debug_graph_trace: the timeline of the ops as they run
+    // back to back inside the captured graph, which a host-side profiler cannot see without spacing them out)
+    int run_stamped(hipStream_t s, unsigned long long* slots, int cap) {
+        if (launch_stamp(slots, s)) return 1;
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (ops[i].fn(s)) return 1;
+            if ((int)i + 1 < cap && launch_stamp(slots + i + 1, s)) return 1;
+        }
+        return 0;
+    }
     // eager pass with a HIP event pair around every launch on `s` (the stream the kernels run on)
     int run_profiled(hipStream_t s, std::map<std::string, KernelStat>& stats) {
         std::vector<hipEvent_t> ev(ops.size() + 1);
@@ -1622,8 +1632,18 @@ struct rldm_sampler {
     }
 };
 
+static DevBuf g_trace;                 // rldm_debug_graph_trace: 4096 timestamps
+static Plan* g_trace_plan = nullptr;
+
 static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* noise, hipStream_t st) {
-    if (ln->uplan->run(st)) return 1;
+    if (g_dbg_flags & 8192) {
+        if (!g_trace.p) {
+            if (g_trace.alloc(4096 * 8)) return 1;
+            RLDM_HIP_CHECK(hipMemset(g_trace.p, 0, 4096 * 8));
+        }
+        g_trace_plan = ln->uplan.get();
+        if (ln->uplan->run_stamped(st, g_trace.as<unsigned long long>(), 4096)) return 1;
+    } else if (ln->uplan->run(st)) return 1;
     SchedParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
@@ -2184,6 +2204,23 @@ int rldm_debug_timestamps(unsigned long long* host_out) {
         RLDM_HIP_CHECK(hipMemset(g_ts_buf, 0, 256 * 8));
     }
     return 0;
+}
+
+// timeline of the UNet ops inside the sampler's captured step graph (flag 8192 at sampler creation): stamps[i] =
+// 100 MHz counter before op i (stamps[n] after the last), names = op kernel names joined by '\n'.  Returns the op count.
+int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap) {
+    if (!g_trace.p || !g_trace_plan) return 0;
+    (void)hipDeviceSynchronize();
+    const int n = (int)g_trace_plan->ops.size();
+    const int m = std::min(cap, n + 1);
+    if (stamps && m > 0 && hipMemcpy(stamps, g_trace.p, (size_t)m * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (names && names_cap) {
+        std::string all;
+        for (auto& o : g_trace_plan->ops) all += o.name + "\n";
+        strncpy(names, all.c_str(), names_cap - 1);
+        names[names_cap - 1] = 0;
+    }
+    return n;
 }
 
 int rldm_debug_force_tile(int BM, int BN, int ksplit) {
