@@ -282,69 +282,82 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         for (int i = 0; i < ACH; ++i) store_piece(cc, i);
     };
     stamp();
-    if (NS > 0) load_a(cbeg);                 // in flight while the GroupNorm statistics are folded
-    if (tid < BN) sBias[tid] = bias_v;         // visible after the barriers below
-
-    // ---- GroupNorm finalize: per-channel partial (sum, sumsq) of the producers -> per-channel affine a*x + s --------
+    // ---- GroupNorm finalize: per-channel partial (sum, sumsq) of the producers -> per-channel affine a*x + s.  The
+    // statistics, gamma and beta of this thread's channels are requested first, then the first halo chunk: one memory
+    // round trip; every channel's thread folds its own group (no serial phase) --------------------------------------------
+    double gS[2] = {0.0, 0.0}, gSS[2] = {0.0, 0.0};           // Cin <= 2 * NT
+    float g_gamma[2] = {0.f, 0.f}, g_beta[2] = {0.f, 0.f};
     if (gn) {
-        double* sD = reinterpret_cast<double*>(sA);           // scratch: [2][Cin] doubles + [2][groups] (halo not yet written)
-        const int cpg = Cin / p.gn_groups;
-        for (int t = tid; t < Cin; t += NT) {
-            const bool first = t < p.C0;
-            const int c = first ? t : t - p.C0;
-            const int C = first ? p.C0 : p.C1;
-            const int P = first ? p.P0 : p.P1;
-            const float2* src = (first ? p.st0 : p.st1) + (size_t)b * P * C + c;
-            double S = 0.0, SS = 0.0;
-            int q = 0;
-            for (; q + 16 <= P; q += 16) {
-                float2 v[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(q + j) * C];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
-            }
-            for (; q + 4 <= P; q += 4) {
-                float2 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = src[(size_t)(q + j) * C];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
-            }
-            for (; q < P; ++q) {
-                const float2 v = src[(size_t)q * C];
-                S += (double)v.x;
-                SS += (double)v.y;
-            }
-            sD[t] = S;
-            sD[Cin + t] = SS;
-        }
-        __syncthreads();
-        if (tid < p.gn_groups) {
-            double S = 0.0, SS = 0.0;
-            for (int i = 0; i < cpg; ++i) {
-                S += sD[tid * cpg + i];
-                SS += sD[Cin + tid * cpg + i];
-            }
-            const double inv_n = 1.0 / ((double)p.Win * (double)p.Hin * (double)cpg);
-            const double mean = S * inv_n;
-            double var = SS * inv_n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            sD[2 * Cin + tid] = mean;
-            sD[2 * Cin + p.gn_groups + tid] = (double)__builtin_amdgcn_rsqf((float)var + p.gn_eps);   // hardware rsqrt, 1 ulp
-        }
-        __syncthreads();
-        float ga[2], gs[2];                     // Cin <= 2 * NT
+        const float2* const gs0p = p.st0;
+        const float2* const gs1p = p.st1;
+        const int nP0 = p.P0, nP1 = p.P1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int t = tid + j * NT;
             if (t < Cin) {
-                const int g = (t * p.magic_cpg) >> 20;
-                ga[j] = p.gn_gamma[t] * (float)sD[2 * Cin + p.gn_groups + g];
-                gs[j] = p.gn_beta[t] - (float)sD[2 * Cin + g] * ga[j];
+                const bool first = t < nC0;
+                const int c = first ? t : t - nC0;
+                const int C = first ? nC0 : nC1;
+                const int P = first ? nP0 : nP1;
+                const float2* src = (first ? gs0p : gs1p) + (size_t)b * P * C + c;
+                g_gamma[j] = p.gn_gamma[t];
+                g_beta[j] = p.gn_beta[t];
+                double S = 0.0, SS = 0.0;
+                int q = 0;
+                for (; q + 16 <= P; q += 16) {
+                    float2 v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = src[(size_t)(q + i) * C];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { S += (double)v[i].x; SS += (double)v[i].y; }
+                }
+                for (; q + 4 <= P; q += 4) {
+                    float2 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = src[(size_t)(q + i) * C];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { S += (double)v[i].x; SS += (double)v[i].y; }
+                }
+                for (; q < P; ++q) {
+                    const float2 v = src[(size_t)q * C];
+                    S += (double)v.x;
+                    SS += (double)v.y;
+                }
+                gS[j] = S;
+                gSS[j] = SS;
             }
         }
-        __syncthreads();                       // sD fully consumed before sGa/sGs and the halo are written
+    }
+    if (NS > 0) load_a(cbeg);                 // in flight while the GroupNorm statistics are folded
+    if (gn) {
+        double* sD = reinterpret_cast<double*>(sA);           // scratch: [2][Cin] doubles (halo not yet written)
+        const int cpg = Cin / p.gn_groups;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = tid + j * NT;
+            if (t < Cin) { sD[t] = gS[j]; sD[Cin + t] = gSS[j]; }
+        }
+        __syncthreads();
+        float ga[2], gs[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = tid + j * NT;
+            if (t < Cin) {
+                const int g0 = ((t * p.magic_cpg) >> 20) * cpg;
+                double S = 0.0, SS = 0.0;
+                for (int i = 0; i < cpg; ++i) {
+                    S += sD[g0 + i];
+                    SS += sD[Cin + g0 + i];
+                }
+                const double inv_n = (double)p.gn_inv_n;
+                const double mean = S * inv_n;
+                double var = SS * inv_n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                ga[j] = g_gamma[j] * __builtin_amdgcn_rsqf((float)var + p.gn_eps);      // hardware rsqrt, 1 ulp
+                gs[j] = g_beta[j] - (float)mean * ga[j];
+            }
+        }
+        __syncthreads();                       // sD fully consumed before sGa/sGs (which may overlap it) and the halo are written
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int t = tid + j * NT;
@@ -352,6 +365,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
         }
         __syncthreads();
     }
+    if (tid < BN) sBias[tid] = bias_v;         // (after the GroupNorm scratch is dead) visible after the main loop's barriers
     stamp();
     int loaded = cbeg, stored = cbeg;          // halo chunks whose loads were issued / whose LDS image is complete
     if (NS > 0) {
@@ -819,7 +833,7 @@ size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
     const size_t w = (size_t)(TG == 9 ? 2 : 3) * TG * t.BN * RS;
     size_t main_bytes = w + 2 * a + g;
     // GroupNorm finalize scratch lives in the (not yet written) halo buffers: 2*Cin + 2*groups doubles
-    const size_t gscratch = p.st0 ? w + ((size_t)2 * (p.C0 + p.C1) + 2 * p.gn_groups) * 8 : 0;
+    const size_t gscratch = p.st0 ? w + (size_t)2 * (p.C0 + p.C1) * 8 : 0;
     size_t epi = (size_t)t.BM * (t.BN * 2 + 16) + (size_t)2 * (64 * NW / (t.BN / 8)) * t.BN * 4;
     if (inst && inst->KG == 2) epi = std::max(epi, (size_t)t.BM * t.BN * 4);      // k-group accumulator hand-over
     return std::max(std::max(main_bytes, gscratch), epi) + 512;    // + timeline scratch (ABLATE builds)

@@ -904,6 +904,7 @@ struct Builder {
             p.magic_thv = ((1 << 20) + thv - 1) / thv;
             const int cpg = std::max(1, Cin_t / a.groups);
             p.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+            p.gn_inv_n = (float)(1.0 / ((double)x0.W * x0.H * cpg));
         }
         RLDM_REQUIRE(Wout % p.TW == 0 && Hout % p.TH == 0, "conv " + L->name + ": size not tileable (powers of two expected)");
         p.N = N;
