@@ -17,6 +17,9 @@
 //   * waves 0-3 normalise their share of the next chunk after the first row of taps, waves 4-7 after the second, so the
 //     VALU work (GroupNorm affine + SiLU) of one half runs under the other half's MFMAs: the two waves of a SIMD are never
 //     both in it.
+// Second instance for the 128x8 level (too few 256-pixel tiles to fill the chip): 128 pixels x 64 channels per workgroup,
+// 8 waves = 2 channel tiles x 4 k-groups (k-group kg owns the kg-th 16-channel group of every tap of a chunk: one k-step
+// per tap, ring = the 9 steps of a chunk); the k-groups' fp32 partial tiles meet in LDS for the epilogue (conv_small.hip's).
 #include "kernels.h"
 
 namespace rldm {
@@ -34,18 +37,27 @@ __device__ __forceinline__ void lds_barrier_b() {
 }
 }  // namespace
 
+// WM pixel parts (128 pixels each) x WN 32-channel tiles x KG k-groups = 8 waves
+template <int WM, int WN>
 __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p) {
-    constexpr int NT = 512, BM = 256, BN = 128, CK = 64, WM = 2, MI = 4;
+    constexpr int NT = 512, CK = 64, MI = 4, KG = 8 / (WM * WN);
+    constexpr int BM = 128 * WM, BN = 32 * WN;
     constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
     constexpr int C8 = CK / 8;
-    constexpr int ACH = 6;                     // 16-byte halo pieces per thread and chunk (34 x 10 x 8 <= 6 * 512)
-    constexpr int G = 12;                      // weight fragments in flight per wave = k-steps of one row of taps
-    constexpr int PFX = 2;                     // pixel fragments read ahead (8 MFMAs of cover)
+    constexpr int ACH = ((BM / 8 + 2) * 10 * C8 + NT - 1) / NT;    // 16-byte halo pieces per thread and chunk (6 | 3)
+    constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
+    constexpr int ROW = 3 * SPT;               // ... per row of taps
+    constexpr int CST = 9 * SPT;               // ... per chunk
+    constexpr int G = KG == 1 ? ROW : CST;     // weight fragments in flight per wave (ring): a row of taps | a chunk
+    constexpr int PFX = KG == 1 ? 2 : 3;       // pixel fragments read ahead; divides CST
     constexpr int ERS = BN * 2 + 16, NC8 = BN / 8;
+    static_assert(WM * WN * KG == 8 && (KG == 1 || WM == 1) && CST % PFX == 0 && G <= 16, "wave grid");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / 4, wn = wave % 4;    // waves 0-3: pixels 0..127, waves 4-7: pixels 128..255
+    const int kg = wave / (WM * WN);
+    const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
+    const int grp = wave >> 2;                 // the two waves of a SIMD are in different halves of the workgroup
     const int kh = lane >> 5, l31 = lane & 31;
 #ifdef RLDM_ABLATE
     unsigned long long tsv[12];
@@ -80,9 +92,10 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     float* sGs = sGa + Cin;
     float* sBias = sGs + Cin;                                  // BN
 
-    // ---- this wave's weight stream (channel tile 4*nt + wn): [NCC][9 taps][4 k-steps] then [NCB][4 k-steps], 1 KiB each ----
-    const int nsteps = NCC * 36 + NCB * 4;
-    const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)(nt * 4 + wn) * nsteps * 1024;
+    // ---- this wave's weight stream (channel tile WN*nt + wn, k-group kg): [NCC][9 taps][SPT k-steps] then [NCB][SPT], 1 KiB each
+    const int nsteps = NCC * CST + NCB * SPT;
+    const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk) +
+                                (size_t)((nt * WN + wn) * KG + kg) * nsteps * 1024;
     const unsigned woff = lane * 16 + 4096;     // lane offset: immediates of +-4 KiB around it reach 8 fragments
     auto w_load = [&](const unsigned char* base, int idx) __attribute__((always_inline)) {      // fragment idx in [0, 16)
         return *reinterpret_cast<const bf16x8*>(base + (idx / 8) * 8192 + woff + ((idx % 8) * 1024 - 4096));
@@ -249,13 +262,14 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     for (int mi = 0; mi < MI; ++mi) {
         const int pidx = wm * (MI * 32) + mi * 32 + l31;
         const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        xoff[mi] = pw * colb + ph * RS + kh * 16;
+        xoff[mi] = pw * colb + ph * RS + kh * 16 + kg * (SPT * 32);
     }
     lds_barrier_b();                            // sBias and halo chunk 0 are written
     f32x16 acc[MI];
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 bv = *reinterpret_cast<const float4*>(sBias + wn * 32 + 8 * r4 + 4 * kh);
+        float4 bv = *reinterpret_cast<const float4*>(sBias + wn * 32 + 8 * r4 + 4 * kh);
+        if (kg != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             acc[mi][r4 * 4 + 0] = bv.x; acc[mi][r4 * 4 + 1] = bv.y;
@@ -264,55 +278,53 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     }
 
     // ---- K loop ----------------------------------------------------------------------------------------------------------
-    // one row of taps (ti): 12 k-steps j = 4*tj + ks; the fragment of step j sits in ring slot j and is refilled with the
-    // fragment 12 steps ahead (next row, next chunk or residual phase: the stream is linear) right after its MFMAs
+    // chunk step c = ROW * ti + SPT * tj + ks; its fragment sits in ring slot c % G and is refilled with the fragment G
+    // steps ahead (next row / next chunk / residual phase: the stream is linear) right after its MFMAs
     bf16x8 xr[PFX][MI];
-    auto x_read = [&](const int (&base)[MI], int j, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
+    auto x_read = [&](const int (&rows)[3][MI], int c, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + base[mi] + (j / 4) * RS + (j % 4) * 32);
+            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + rows[c / ROW][mi] + ((c % ROW) / SPT) * RS + (c % SPT) * 32);
     };
-    // LAST: the row is the last one before a barrier (no read-ahead into an image that may still be written)
-    auto tap_row = [&](const int (&xa)[MI], const int (&xn)[MI], bool last) __attribute__((always_inline)) {
+    auto tap_row = [&](const int (&rows)[3][MI], int ti) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
+        for (int j = 0; j < ROW; ++j) {
+            const int c = ti * ROW + j, slot = c % G;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[j], xr[j % PFX][mi], acc[mi], 0, 0, 0);
-            wr[j] = w_load(wptr, j);
-            if (j + PFX < G) x_read(xa, j + PFX, xr[j % PFX]);
-            else if (!last) x_read(xn, j + PFX - G, xr[j % PFX]);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xr[c % PFX][mi], acc[mi], 0, 0, 0);
+            wr[slot] = w_load(wptr, slot);
+            if (c + PFX < CST) x_read(rows, c + PFX, xr[c % PFX]);      // (no read-ahead across the chunk's barrier)
             __builtin_amdgcn_sched_barrier(0);  // steps stay in program order: every wait then leaves G - 1 loads in flight
         }
-        wptr += G * 1024;
+        if ((ti * ROW + ROW) % G == 0) wptr += G * 1024;
     };
     RLDM_STAMP();
     for (int cs = 0; cs < NCC; ++cs) {
         if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_a(cs + 1);       // next chunk (main or first residual): requested now, written below
-        int xa[MI], xn[MI];
+        int rows[3][MI];
         const int boff = (cs & 1) * abytes;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) { xa[mi] = xoff[mi] + boff; xn[mi] = xa[mi] + colb; }
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) rows[ti][mi] = xoff[mi] + boff + ti * colb;
 #pragma unroll
         for (int j = 0; j < PFX; ++j) {
-            x_read(xa, j, xr[j]);
+            x_read(rows, j, xr[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        tap_row(xa, xn, false);
-        if (wm == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) { xa[mi] = xn[mi]; xn[mi] += colb; }
-        tap_row(xa, xn, false);
-        if (wm == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) xa[mi] = xn[mi];
-        tap_row(xa, xn, true);
+        tap_row(rows, 0);
+        if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
+        tap_row(rows, 1);
+        if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
+        tap_row(rows, 2);
         lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
     }
-    // residual phase: centre tap of the raw block input, 4 k-steps per chunk; ring slots continue (36 = 3 * 12)
-    for (int rc0 = 0; rc0 < NCB; rc0 += 3) {
+    // residual phase: centre tap of the raw block input, SPT k-steps per chunk; ring slots continue (CST % G == 0)
+    constexpr int RCR = G / SPT;                // residual chunks per ring revolution
+    for (int rc0 = 0; rc0 < NCB; rc0 += RCR) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < RCR; ++r) {
             const int rc = rc0 + r;
             if (rc < NCB) {
                 const int cs = NCC + rc;
@@ -321,14 +333,14 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) xc[mi] = xoff[mi] + (cs & 1) * abytes + colb + RS;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < SPT; ++ks) {
                     bf16x8 xf[MI];
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(smem + xc[mi] + ks * 32);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[r * 4 + ks], xf[mi], acc[mi], 0, 0, 0);
-                    wr[r * 4 + ks] = w_load(wptr, r * 4 + ks);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[r * SPT + ks], xf[mi], acc[mi], 0, 0, 0);
+                    wr[r * SPT + ks] = w_load(wptr, r * SPT + ks);
                 }
                 if (cs + 1 < NCT) store_a(cs + 1);
                 lds_barrier_b();
@@ -338,6 +350,84 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     }
     RLDM_STAMP();
 
+    if constexpr (KG > 1) {
+    // ---- epilogue of the k-group instance (conv_small.hip's), 64 pixels at a time: fp32 partials [k-group][pixel][channel] in
+    // LDS -> all threads sum the k-groups of one (pixel, 8 channels) item each, round, store 16 bytes, statistics ----------
+    constexpr int HB = 64, NHALF = BM / HB, FRS = BN * 4 + 16, TRS = BN * 2 + 16;
+    constexpr int NPASS = (HB * NC8 + NT - 1) / NT;
+    unsigned char* sE = smem;
+    unsigned char* sT = sE + KG * HB * FRS;
+    const int c8 = tid % NC8;
+    const int chg = nt * BN + c8 * 8;
+    constexpr int NCP = BN / 2, NG = NT / NCP, PPG = HB / NG;
+    const int cp = tid % NCP, pg = tid / NCP;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int hp = 0; hp < NHALF; ++hp) {
+        if (hp > 0) lds_barrier_b();            // the previous half-tile has been consumed
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+            const int mi = hp * 2 + m2, pl = m2 * 32 + l31;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int chl = wn * 32 + 8 * r4 + 4 * kh;
+                *reinterpret_cast<float4*>(sE + (kg * HB + pl) * FRS + chl * 4) =
+                    make_float4(acc[mi][r4 * 4 + 0], acc[mi][r4 * 4 + 1], acc[mi][r4 * 4 + 2], acc[mi][r4 * 4 + 3]);
+            }
+        }
+        lds_barrier_b();
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int pl = tid / NC8 + q * (NT / NC8), pidx = hp * HB + pl;
+            if (pl >= HB) break;
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sE + (g * HB + pl) * FRS + c8 * 32);
+                const float4 v1 = *reinterpret_cast<const float4*>(sE + (g * HB + pl) * FRS + c8 * 32 + 16);
+                f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
+                f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
+            }
+            uint4 v;
+            v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+            v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+            const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+            const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
+            *reinterpret_cast<uint4*>(p.y + pix * p.y_ld + chg) = v;
+            *reinterpret_cast<uint4*>(sT + pl * TRS + c8 * 16) = v;
+        }
+        if (p.y_stats) {
+            lds_barrier_b();
+#pragma unroll
+            for (int j = 0; j < PPG; ++j) {
+                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sT + (pg * PPG + j) * TRS + cp * 4);
+                const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+                s0 += a0; s1 += a1;
+                q0 += a0 * a0; q1 += a1 * a1;
+            }
+        }
+    }
+    if (p.y_stats) {
+        float* sS = reinterpret_cast<float*>(sT + HB * TRS);                // [8 waves][2][BN]
+#pragma unroll
+        for (int d = NCP; d < 64; d <<= 1) {
+            s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d);
+            q0 += __shfl_xor(q0, d); q1 += __shfl_xor(q1, d);
+        }
+        if (lane < NCP) {
+            *reinterpret_cast<float2*>(sS + (wave * 2 + 0) * BN + cp * 2) = make_float2(s0, s1);
+            *reinterpret_cast<float2*>(sS + (wave * 2 + 1) * BN + cp * 2) = make_float2(q0, q1);
+        }
+        lds_barrier_b();
+        if (tid < 2 * BN) {
+            const int kind = tid / BN, c = tid - kind * BN;
+            float S = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
+            reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
+        }
+    }
+    } else {
     // ---- epilogue (conv_igemm.hip's): bf16 -> LDS [pixel][channel] -> 16-byte coalesced stores + statistics -----------------
     unsigned char* sE = smem;
 #pragma unroll
@@ -391,6 +481,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
             reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
         }
     }
+    }
     RLDM_STAMP();
 #ifdef RLDM_ABLATE
     if (p.ts && blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z == 0 && tid == 0)
@@ -402,11 +493,17 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
+// the instance is chosen by the pixel tile: 32 x 8 -> 256 px x 128 ch (one k-group), 16 x 8 -> 128 px x 64 ch (4 k-groups)
+int conv_stream_bn(const ConvParams& p) { return p.TW == 32 ? 128 : 64; }
+int conv_stream_kgroups(const ConvParams& p) { return p.TW == 32 ? 1 : 4; }
+
 size_t conv_stream_lds_bytes(const ConvParams& p) {
+    const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * 8;
     const size_t a = (size_t)(p.TW + 2) * p.colb;
-    const size_t main_bytes = 2 * a + (size_t)(p.C0 + p.C1) * 8 + 128 * 4;
+    const size_t main_bytes = 2 * a + (size_t)(p.C0 + p.C1) * 8 + BN * 4;
     const size_t gscratch = p.st0 ? (size_t)2 * (p.C0 + p.C1) * 8 : 0;
-    const size_t epi = (size_t)256 * (128 * 2 + 16) + (size_t)8 * 2 * 128 * 4;
+    const size_t epi = KG == 1 ? (size_t)BM * (BN * 2 + 16) + (size_t)8 * 2 * BN * 4
+                               : (size_t)KG * 64 * (BN * 4 + 16) + (size_t)64 * (BN * 2 + 16) + (size_t)8 * 2 * BN * 4;
     return std::max(std::max(main_bytes, gscratch), epi);
 }
 
@@ -415,25 +512,30 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     if (taps != 9 || p.stride != 1 || p.pad_lo != 1 || (p.up != 1 && p.up != 2) || p.y_nchw || p.ksplit > 1) return false;
     if (Cin % 64 != 0 || (p.C1 != 0 && p.C0 % 64 != 0) || R % 64 != 0 || (p.R1 != 0 && p.R0 % 64 != 0)) return false;
     if (R != 0 && p.up != 1) return false;
-    if (p.N % 128 != 0 || Cin > 512) return false;
+    if ((p.TW != 32 && p.TW != 16) || p.TH != 8 || p.Win * p.up < 2) return false;
+    if (p.N % conv_stream_bn(p) != 0 || Cin > 512) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
-    if (p.TW != 32 || p.TH != 8 || p.Win * p.up < 2) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
     return conv_stream_lds_bytes(p) <= 160 * 1024;
+}
+
+template <int WM, int WN>
+static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
+    auto kern = conv_stream_kernel<WM, WN>;
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.N / (32 * WN), p.tiles_img, p.B), dim3(512), lds, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(conv_stream_supported(p, 9), "conv_stream: unsupported shape");
     const size_t lds = conv_stream_lds_bytes(p);
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stream_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        max_set = lds;
-    }
-    hipLaunchKernelGGL(conv_stream_kernel, dim3(p.N / 128, p.tiles_img, p.B), dim3(512), lds, stream, p);
-    RLDM_HIP_CHECK(hipGetLastError());
-    return 0;
+    return p.TW == 32 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<1, 2>(p, lds, stream);
 }
 
 }  // namespace rldm

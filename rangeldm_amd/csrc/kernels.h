@@ -91,9 +91,12 @@ size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN);
 bool conv_small_supported(const ConvParams& p, int taps, int BN);
 int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream);
 
-// Weight-streaming 3x3 / stride 1 variant for the full-resolution levels (conv_stream.hip): 256 pixels (32 x 8) x 128
-// channels per workgroup, 64-channel chunks.  Same ConvParams (colb = conv_halo_col_bytes of a CK = 64 tile); wpk is the
-// fragment-ordered image [N/32][Cin/64 * 36 + R/64 * 4 k-steps][64 lanes][8 bf16] (ConvLayer::get_streampacked).
+// Weight-streaming 3x3 / stride 1 variant (conv_stream.hip): 256 pixels (32 x 8) x 128 channels per workgroup for the
+// full-resolution levels, 128 pixels (16 x 8) x 64 channels with 4 k-groups for the 128x8 level; 64-channel chunks.  Same
+// ConvParams (colb = conv_halo_col_bytes of a CK = 64 tile); wpk is the fragment-ordered image
+// [N/32][KG][(Cin/64 * 9 + R/64) * 4/KG k-steps][64 lanes][8 bf16] (ConvLayer::get_streampacked).
+int conv_stream_bn(const ConvParams& p);          // 128 (TW = 32) | 64 (TW = 16: the 4-k-group instance)
+int conv_stream_kgroups(const ConvParams& p);
 size_t conv_stream_lds_bytes(const ConvParams& p);
 bool conv_stream_supported(const ConvParams& p, int taps);
 int launch_conv_stream(const ConvParams& p, hipStream_t stream);

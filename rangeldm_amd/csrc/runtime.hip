@@ -158,11 +158,12 @@ struct ConvLayer {
         return 0;
     }
 
-    // conv_stream.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per 32-channel tile:
-    // [Cout/32][Cin_pad/64 chunks x 9 taps x 4 k-steps, then R/64 chunks x 4 k-steps][64 lanes][8 bf16] + 16 KiB of zeros
-    // (the ring's read-ahead past the last stream); lane l holds channel 32*t + (l & 31), k = 8*(l >> 5) .. +8 of the step
-    int get_streampacked(int Cin_pad, Packed** out) {
-        auto key = std::make_pair(-2, 64);
+    // conv_stream.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per (32-channel tile, k-group):
+    // [Cout/32][KG][Cin_pad/64 chunks x 9 taps x 4/KG k-steps, then R/64 chunks x 4/KG k-steps][64 lanes][8 bf16] + 16 KiB
+    // of zeros (the ring's read-ahead past the last stream); k-group kg owns the k-steps [kg*4/KG, (kg+1)*4/KG) of every
+    // tap of a chunk; lane l holds channel 32*t + (l & 31), k = 8*(l >> 5) .. +8 of the step
+    int get_streampacked(int Cin_pad, int KG, Packed** out) {
+        auto key = std::make_pair(-2, KG);
         auto it = packed.find(key);
         if (it != packed.end()) {
             RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
@@ -170,18 +171,19 @@ struct ConvLayer {
             return 0;
         }
         RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % 64 == 0 && R % 64 == 0, "conv " + name + ": not stream-packable");
-        const int NCC = Cin_pad / 64, NCB = R / 64, nsteps = NCC * 36 + NCB * 4;
-        std::vector<bf16_t> img((size_t)(Cout / 32) * nsteps * 512 + 8192, 0);
-        auto at = [&](int n, int step, int k) -> bf16_t& {
-            return img[(((size_t)(n / 32) * nsteps + step) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8];
+        const int SPT = 4 / KG, NCC = Cin_pad / 64, NCB = R / 64, nsteps = (NCC * 9 + NCB) * SPT;
+        std::vector<bf16_t> img((size_t)(Cout / 32) * KG * nsteps * 512 + 8192, 0);
+        auto at = [&](int n, int ks, int step, int k) -> bf16_t& {      // ks: 16-channel group within the 64-channel chunk
+            const size_t stream = (size_t)(n / 32) * KG + ks / SPT;
+            return img[((stream * nsteps + step + ks % SPT) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8];
         };
         for (int n = 0; n < Cout; ++n) {
             for (int c = 0; c < Cin; ++c)
                 for (int tap = 0; tap < 9; ++tap)
-                    at(n, (c / 64) * 36 + tap * 4 + (c % 64) / 16, c % 16) = f32_to_bf16(w[((size_t)n * Cin + c) * 9 + tap]);
+                    at(n, (c % 64) / 16, ((c / 64) * 9 + tap) * SPT, c % 16) = f32_to_bf16(w[((size_t)n * Cin + c) * 9 + tap]);
             for (int c = 0; c < R; ++c) {
                 const float v = sc_identity ? (c == n ? 1.f : 0.f) : sc_w[(size_t)n * R + c];
-                at(n, NCC * 36 + (c / 64) * 4 + (c % 64) / 16, c % 16) = f32_to_bf16(v);
+                at(n, (c % 64) / 16, (NCC * 9 + c / 64) * SPT, c % 16) = f32_to_bf16(v);
             }
         }
         auto pk = std::make_unique<Packed>();
@@ -764,11 +766,12 @@ struct Builder {
         return 0;
     }
 
-    // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels
-    static bool stream_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+    // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels, or
+    // (the 128x8 level) of 16 x 8 pixels x 64 channels
+    static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, ConvParams* q) {
         if (g_dbg_flags & 2048) return false;
         if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
-        if (Wout % 32 != 0 || Hout % 8 != 0 || a.layer->Cout % 128 != 0) return false;
+        if (Wout % TW != 0 || Hout % 8 != 0) return false;
         memset(q, 0, sizeof(*q));
         q->C0 = a.x0.C;
         q->C1 = Cin_t - a.x0.C;
@@ -777,12 +780,12 @@ struct Builder {
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
         q->up = a.up; q->stride = 1; q->pad_lo = 1;
         q->Wout = Wout; q->Hout = Hout;
-        q->TW = 32; q->TH = 8; q->th_shift = 3;
+        q->TW = TW; q->TH = 8; q->th_shift = 3;
         ConvTile t;
         t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
         q->colb = conv_halo_col_bytes(t, 8, 1);
         q->tiles_h = Hout / 8;
-        q->tiles_img = (Wout / 32) * q->tiles_h;
+        q->tiles_img = (Wout / TW) * q->tiles_h;
         q->magic_thv = ((1 << 20) + 10 - 1) / 10;
         const int cpg = std::max(1, Cin_t / a.groups);
         q->magic_cpg = ((1 << 20) + cpg - 1) / cpg;
@@ -793,10 +796,17 @@ struct Builder {
         q->gn_groups = a.groups;
         q->ksplit = 1;
         if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only its presence matters to the shape check)
+        const long long blocks = (long long)q->B * q->tiles_img * (q->N / conv_stream_bn(*q));
+        // the 4-k-group instance re-streams the weights per 128 pixels: only where the grid is about one round
         const bool ok = conv_stream_supported(*q, 9) &&
-                        ((g_dbg_flags & 4096) || (long long)q->B * q->tiles_img * (q->N / 128) >= 128);
+                        ((g_dbg_flags & 4096) || (blocks >= 128 && (TW == 32 || blocks <= 512)));
         q->st0 = nullptr;
         return ok;
+    }
+    static bool stream_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+        if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, q)) return true;
+        if (g_dbg_flags & 16384) return false;                        // (A/B: no 128-pixel instance)
+        return stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, q);
     }
 
     int conv_stream(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
@@ -811,7 +821,7 @@ struct Builder {
         }
         p.dbg = g_dbg_flags;
         p.ts = g_ts_buf;
-        p.ntile_n = N / 128;
+        p.ntile_n = N / conv_stream_bn(p);
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img);
         const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
@@ -819,7 +829,7 @@ struct Builder {
         ++launches;
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
-            if (L->get_streampacked(Cin_t, &pk)) return 1;
+            if (L->get_streampacked(Cin_t, conv_stream_kgroups(p), &pk)) return 1;
             p.x0 = tptr(x0);
             p.x1 = tptr(a.x1);
             p.r0 = tptr(a.r0);
@@ -850,7 +860,7 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_stream(p, s);
-            }, "conv_stream_kernel<256,128,CK64,taps9>", fl, by});
+            }, p.TW == 32 ? "conv_stream_kernel<256,128,CK64,taps9>" : "conv_stream_kernel<128,64,CK64,taps9>", fl, by});
         }
         *out = y;
         return 0;

@@ -93,7 +93,7 @@ def test_conv_wrap_seam_exact():
 
 GN_CASES = [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
             (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8),
-            (128, 64, 128, 64, 16), (64, 64, 256, 32, 8)]
+            (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16)]
 
 
 @pytest.fixture(params=[0, 1024, 4096, 256 + 2048], ids=["default", "small-128px-tiles", "stream-any-grid", "generic-only"])

@@ -25,8 +25,10 @@ def op_name(k):
     if m:
         nwn, _, taps, mi = map(int, m.groups())
         return f"conv_small_kernel<{32 * mi},{32 * nwn},taps{taps}>"
-    if k.startswith("conv_stream_kernel"):
-        return "conv_stream_kernel<256,128,CK64,taps9>"
+    m = re.match(r"conv_stream_kernel<(\d+), (\d+)>", k)
+    if m:
+        wm, wn = map(int, m.groups())
+        return f"conv_stream_kernel<{128 * wm},{32 * wn},CK64,taps9>"
     return re.sub(r"\(.*$", "", k)
 
 
