@@ -281,12 +281,13 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     // chunk step c = ROW * ti + SPT * tj + ks; its fragment sits in ring slot c % G and is refilled with the fragment G
     // steps ahead (next row / next chunk / residual phase: the stream is linear) right after its MFMAs
     bf16x8 xr[PFX][MI];
-    auto x_read = [&](const int (&rows)[3][MI], int c, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
+    // cur / nxt: per-lane LDS addresses of the pixel at tap (ti, 0) / (ti + 1, 0); r = step within the row (may run into the next)
+    auto x_read = [&](const int (&cur)[MI], const int (&nxt)[MI], int r, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + rows[c / ROW][mi] + ((c % ROW) / SPT) * RS + (c % SPT) * 32);
+            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + (r < ROW ? cur[mi] : nxt[mi]) + ((r % ROW) / SPT) * RS + (r % SPT) * 32);
     };
-    auto tap_row = [&](const int (&rows)[3][MI], int ti) __attribute__((always_inline)) {
+    auto tap_row = [&](const int (&cur)[MI], const int (&nxt)[MI], int ti) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < ROW; ++j) {
             const int c = ti * ROW + j, slot = c % G;
@@ -294,30 +295,33 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
             for (int mi = 0; mi < MI; ++mi)
                 acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xr[c % PFX][mi], acc[mi], 0, 0, 0);
             wr[slot] = w_load(wptr, slot);
-            if (c + PFX < CST) x_read(rows, c + PFX, xr[c % PFX]);      // (no read-ahead across the chunk's barrier)
+            if (c + PFX < CST) x_read(cur, nxt, j + PFX, xr[c % PFX]);   // (no read-ahead across the chunk's barrier)
             __builtin_amdgcn_sched_barrier(0);  // steps stay in program order: every wait then leaves G - 1 loads in flight
         }
         if ((ti * ROW + ROW) % G == 0) wptr += G * 1024;
     };
+    static_assert(PFX <= ROW, "the read-ahead reaches at most into the next row of taps");
     RLDM_STAMP();
     for (int cs = 0; cs < NCC; ++cs) {
         if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_a(cs + 1);       // next chunk (main or first residual): requested now, written below
-        int rows[3][MI];
+        int cur[MI], nxt[MI];
         const int boff = (cs & 1) * abytes;
 #pragma unroll
-        for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) rows[ti][mi] = xoff[mi] + boff + ti * colb;
+        for (int mi = 0; mi < MI; ++mi) { cur[mi] = xoff[mi] + boff; nxt[mi] = cur[mi] + colb; }
 #pragma unroll
         for (int j = 0; j < PFX; ++j) {
-            x_read(rows, j, xr[j]);
+            x_read(cur, nxt, j, xr[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        tap_row(rows, 0);
+        tap_row(cur, nxt, 0);
         if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
-        tap_row(rows, 1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { cur[mi] = nxt[mi]; nxt[mi] += colb; }
+        tap_row(cur, nxt, 1);
         if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
-        tap_row(rows, 2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) cur[mi] = nxt[mi];
+        tap_row(cur, nxt, 2);
         lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
     }
     // residual phase: centre tap of the raw block input, SPT k-steps per chunk; ring slots continue (CST % G == 0)
