@@ -507,7 +507,9 @@ static TileChoice choose_tile(long long B, int Wout, int Hout, int stride, int N
                 ConvTile u;
                 int tw, th;
                 if (!pick(bms[bi], bns[ni], &u, &tw, &th)) continue;
-                if (pass == 0 && tw * th * 2 <= u.BM && bi < 2) continue;   // more than half empty: try a smaller BM first
+                // more than half empty: try a smaller BM first -- except under stride 2, where the halo capacity shrinks the
+                // pixel tile of every instance and the 256-pixel one-tap pipeline still wins when it fills the chip (measured)
+                if (pass == 0 && tw * th * 2 <= u.BM && bi < 2 && !(stride == 2 && bi == 0)) continue;
                 const long long nb = blocks(u, tw, th);
                 if (nb > best_blocks) {
                     best_blocks = nb;
