@@ -770,7 +770,8 @@ struct Builder {
 
     // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels, or
     // (the 128x8 level) of 16 x 8 pixels x 64 channels
-    static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, ConvParams* q) {
+    static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, long long min_blocks,
+                                 long long max_blocks, ConvParams* q) {
         if (g_dbg_flags & 2048) return false;
         if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
         if (Wout % TW != 0 || Hout % 8 != 0) return false;
@@ -799,16 +800,16 @@ struct Builder {
         q->ksplit = 1;
         if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only its presence matters to the shape check)
         const long long blocks = (long long)q->B * q->tiles_img * (q->N / conv_stream_bn(*q));
-        // the 4-k-group instance re-streams the weights per 128 pixels: only where the grid is about one round
-        const bool ok = conv_stream_supported(*q, 9) &&
-                        ((g_dbg_flags & 4096) || (blocks >= 128 && (TW == 32 || blocks <= 512)));
+        const bool ok = conv_stream_supported(*q, 9) && ((g_dbg_flags & 4096) || (blocks >= min_blocks && blocks <= max_blocks));
         q->st0 = nullptr;
         return ok;
     }
     static bool stream_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
-        if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, q)) return true;
-        if (g_dbg_flags & 16384) return false;                        // (A/B: no 128-pixel instance)
-        return stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, q);
+        // 256-pixel tiles when they fill the chip; else the 4-k-group instance (it re-streams the weights per 128 pixels:
+        // only where its grid is about one or two rounds); else 256-pixel tiles on at least half the chip
+        if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
+        if (!(g_dbg_flags & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
+        return stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 128, 1ll << 40, q);
     }
 
     int conv_stream(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
