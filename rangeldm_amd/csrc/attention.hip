@@ -20,6 +20,86 @@
 
 namespace rldm {
 
+// One 32-query tile against all Lp keys staged in LDS (sK rows, sVt = V^T in consumption order + ones + zero rows).
+// qf: B operand of S^T for lane (query l31, half hh) = q[query][4*hh .. 4*hh+3] (pre-scaled by log2(e)/sqrt(8)).
+__device__ __forceinline__ void attention_tile(const bf16_t* sK, const bf16_t* sVt, int vst, int L, int Lp, int C, int q0,
+                                               s16x4 qf, bf16_t* out_bh, int l31, int hh) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+
+    // A operand rows of the PV MFMA: row l31 < 8 -> V^T[d = l31], row 8 -> ones, rows 9..31 -> the zero row (one address)
+    const bf16_t* vrow_ptr = sVt + min(l31, 9) * vst + 8 * hh;
+    const bf16_t* krow_ptr = sK + l31 * 8 + 4 * hh;
+    const bool ragged = (L & 31) != 0;
+
+    // Running maximum m of the query (log2 units), kept as the MFMA's C operand: s = k.q - m comes out of the matrix core.
+    // m is exact after the first tile and afterwards only raised when some score of the wave exceeds it by more than 8
+    // (p <= 2^8 then: harmless in fp32 / bf16), so the rescale of o, the subtraction and the refresh of C are rare.
+    f32x16 cn;
+    {
+        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, s, 0, 0, 0);
+        if (ragged && 32 > L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -1e30f;
+        }
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
+        tmax = fmaxf(tmax, s[15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cn[r] = -tmax;
+    }
+
+    for (int k0 = 0; k0 < Lp; k0 += 32) {
+        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr + k0 * 8);
+        const uint4 v0 = *reinterpret_cast<const uint4*>(vrow_ptr + k0);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(vrow_ptr + k0 + 16);
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, cn, 0, 0, 0);
+        // lane (query l31, half hh), register r <-> key k0 + (r&3) + 8*(r>>2) + 4*hh ; scores are in log2 units, relative to m
+        if (ragged && k0 + 32 > L) {                        // last tile: keys >= L get -inf scores
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -1e30f;
+        }
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
+        tmax = fmaxf(tmax, s[15]);
+        if (__builtin_amdgcn_ballot_w64(tmax > 8.0f) != 0ull) {
+            // raise m (both halves of a query agree on it), rescale what has been accumulated
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float d = fmaxf(tmax, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] -= d; cn[r] -= d; }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) o[r] *= alpha;      // rows 0..8 only: V rows and the ones row (others stay 0)
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1]));
+        // PV: MFMA t (t = 0, 1) contracts over the 16 keys {k0 + 16t + 4hh' + (e&3) + 8(e>>2)}, e = 0..7, hh' = 0, 1
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0),
+                                                    __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])), o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1),
+                                                    __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7])), o, 0, 0, 0);
+    }
+    // o rows: reg r of half hh <-> row (r&3) + 8*(r>>2) + 4*hh.  d = 4*hh + r for r < 4; denominator = row 8 = reg 4 of hh 0
+    float denom = __shfl(o[4], l31);
+    const float inv = 1.0f / denom;
+    uint2 ov;
+    ov.x = pack_bf16x2(o[0] * inv, o[1] * inv);
+    ov.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+    if (q0 + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0 + l31) * C + 4 * hh) = ov;
+}
+
 __global__ void __launch_bounds__(512) attention_d8_kernel(const AttnParams p, const int waves_per_block, const int Lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,80 +146,163 @@ __global__ void __launch_bounds__(512) attention_d8_kernel(const AttnParams p, c
     const int qrow = min(q0 + l31, p.L - 1);              // rows past L are computed on a clamped row, never stored
     const s16x4 qf = *reinterpret_cast<const s16x4*>(qbase + (size_t)qrow * ld + 4 * hh);
 
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    attention_tile(sK, sVt, vst, p.L, Lp, p.C, q0, qf, p.out + ((size_t)b * p.L) * p.C + h * 8, l31, hh);
+}
 
-    // A operand rows of the PV MFMA: row l31 < 8 -> V^T[d = l31], row 8 -> ones, rows 9..31 -> the zero row (one address)
-    const bf16_t* vrow_ptr = sVt + min(l31, 9) * vst + 8 * hh;
-    const bf16_t* krow_ptr = sK + l31 * 8 + 4 * hh;
-    const bool ragged = (p.L & 31) != 0;
+// Fused GroupNorm -> q/k/v projection -> attention for one (image, head): the three Linear(C, C) maps split perfectly by
+// head (head h needs rows 8h..8h+7 of each), so the workgroup projects its own 24 rows itself and the [B][L][3C] q/k/v
+// tensor never exists: D[32 rows][32 pixels] = W_h[32][C] * xn[C][32 pixels] on v_mfma_f32_32x32x16_bf16, W_h streamed in
+// A-fragment order from L2 (one 1 KiB fragment per 16 input channels, shared by all tiles), xn = the GroupNorm affine applied
+// to 16-byte pieces of x on their way into the B operand.  In the result layout lane (pixel l31, half hh) holds
+// q[4hh..4hh+3], k[4hh..4hh+3], v[4hh..4hh+3] of its pixel: q is already the S^T MFMA's B operand, k goes to its LDS row
+// with one 8-byte store, v to the transposed image.  Every wave projects the pixel tiles it will later own as queries.
+// (diffusers Attention: group_norm -> to_q / to_k / to_v -> softmax(q k^T / sqrt(8)) v; to_out stays a conv launch.)
+__global__ void __launch_bounds__(512) attention_qkv_d8_kernel(const AttnQkvParams p, const int waves, const int Lp) {
+    constexpr int TPW = 4;                                // query tiles per wave (L <= 1024)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = waves * 64;
+    const int heads = p.C >> 3;
+    const int h = blockIdx.x % heads, b = blockIdx.x / heads;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int C = p.C, L = p.L;
+    const int vst = Lp + 8;
+    const int ntiles = Lp >> 5;
 
-    // Running maximum m of the query (log2 units), kept as the MFMA's C operand: s = k.q - m comes out of the matrix core.
-    // m is exact after the first tile and afterwards only raised when some score of the wave exceeds it by more than 8
-    // (p <= 2^8 then: harmless in fp32 / bf16), so the rescale of o, the subtraction and the refresh of C are rare.
-    f32x16 cn;
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);         // [Lp][8]
+    bf16_t* sVt = sK + (size_t)Lp * 8;                    // [10][vst]
+    float* sGa = reinterpret_cast<float*>(sVt + 10 * vst);         // [C]
+    float* sGs = sGa + C;
+    double* sD = reinterpret_cast<double*>(sGs + C);      // [2][C] scratch
+
+    // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic) ----------------------------------------------------
     {
-        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr);
-        f32x16 s;
+        const int cpg = C / p.groups;
+        for (int t = tid; t < C; t += NT) {
+            const float2* src = p.st + (size_t)b * p.P * C + t;
+            double S = 0.0, SS = 0.0;
+            int q = 0;
+            for (; q + 8 <= p.P; q += 8) {
+                float2 v[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, s, 0, 0, 0);
-        if (ragged && 32 > p.L) {
+                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(q + j) * C];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * hh >= p.L) s[r] = -1e30f;
+                for (int j = 0; j < 8; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
+            }
+            for (; q < p.P; ++q) {
+                const float2 v = src[(size_t)q * C];
+                S += (double)v.x;
+                SS += (double)v.y;
+            }
+            sD[t] = S;
+            sD[C + t] = SS;
         }
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cn[r] = -tmax;
+        __syncthreads();
+        for (int t = tid; t < C; t += NT) {
+            const int g0 = ((t * p.magic_cpg) >> 20) * cpg;
+            double S = 0.0, SS = 0.0;
+            for (int i = 0; i < cpg; ++i) {
+                S += sD[g0 + i];
+                SS += sD[C + g0 + i];
+            }
+            const double mean = S * (double)p.inv_n;
+            double var = SS * (double)p.inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const float a = p.gamma[t] * __builtin_amdgcn_rsqf((float)var + p.eps);
+            sGa[t] = a;
+            sGs[t] = p.beta[t] - (float)mean * a;
+        }
+        __syncthreads();
     }
 
-    for (int k0 = 0; k0 < Lp; k0 += 32) {
-        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr + k0 * 8);
-        const uint4 v0 = *reinterpret_cast<const uint4*>(vrow_ptr + k0);
-        const uint4 v1 = *reinterpret_cast<const uint4*>(vrow_ptr + k0 + 16);
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, cn, 0, 0, 0);
-        // lane (query l31, half hh), register r <-> key k0 + (r&3) + 8*(r>>2) + 4*hh ; scores are in log2 units, relative to m
-        if (ragged && k0 + 32 > p.L) {                        // last tile: keys >= L get -inf scores
+    // ---- projection of this wave's pixel tiles T = wave, wave + waves, ... -----------------------------------------------
+    f32x16 acc[TPW];
+    const float* bh = p.bias + h * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= p.L) s[r] = -1e30f;
-        }
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        if (__builtin_amdgcn_ballot_w64(tmax > 8.0f) != 0ull) {
-            // raise m (both halves of a query agree on it), rescale what has been accumulated
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float d = fmaxf(tmax, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-d);
+        for (int r = 0; r < 16; ++r) acc[ti][r] = (r < 12) ? bh[8 * (r >> 2) + 4 * hh + (r & 3)] : 0.f;
+    const bf16_t* xrow[TPW];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] -= d; cn[r] -= d; }
-#pragma unroll
-            for (int r = 0; r < 5; ++r) o[r] *= alpha;      // rows 0..8 only: V rows and the ones row (others stay 0)
-        }
-        uint32_t pk[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1]));
-        // PV: MFMA t (t = 0, 1) contracts over the 16 keys {k0 + 16t + 4hh' + (e&3) + 8(e>>2)}, e = 0..7, hh' = 0, 1
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0),
-                                                    __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])), o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1),
-                                                    __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7])), o, 0, 0, 0);
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int px = min((wave + ti * waves) * 32 + l31, L - 1);          // keys / queries past L: a clamped row, masked later
+        xrow[ti] = p.x + ((size_t)b * L + px) * C + 8 * hh;
     }
-    // o rows: reg r of half hh <-> row (r&3) + 8*(r>>2) + 4*hh.  d = 4*hh + r for r < 4; denominator = row 8 = reg 4 of hh 0
-    float denom = __shfl(o[4], l31);
-    const float inv = 1.0f / denom;
-    uint2 ov;
-    ov.x = pack_bf16x2(o[0] * inv, o[1] * inv);
-    ov.y = pack_bf16x2(o[2] * inv, o[3] * inv);
-    if (q0 + l31 < p.L) *reinterpret_cast<uint2*>(p.out + ((size_t)b * p.L + q0 + l31) * p.C + h * 8 + 4 * hh) = ov;
+    const bf16_t* wf_ptr = p.wfrag + ((size_t)h * (C >> 4) * 64 + lane) * 8;
+    const int nks = C >> 4;
+    for (int ks = 0; ks < nks; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wf_ptr + (size_t)ks * 512);
+        uint4 xv[TPW];
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti)
+            if (wave + ti * waves < ntiles) xv[ti] = *reinterpret_cast<const uint4*>(xrow[ti] + ks * 16);
+        const int c0 = ks * 16 + 8 * hh;
+        const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+            if (wave + ti * waves >= ntiles) continue;
+            const uint4 v = xv[ti];
+            uint4 n;
+            n.x = pack_bf16x2(bf16lo(v.x) * a0.x + s0.x, bf16hi(v.x) * a0.y + s0.y);
+            n.y = pack_bf16x2(bf16lo(v.y) * a0.z + s0.z, bf16hi(v.y) * a0.w + s0.w);
+            n.z = pack_bf16x2(bf16lo(v.z) * a1.x + s1.x, bf16hi(v.z) * a1.y + s1.y);
+            n.w = pack_bf16x2(bf16lo(v.w) * a1.z + s1.z, bf16hi(v.w) * a1.w + s1.w);
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, n), acc[ti], 0, 0, 0);
+        }
+    }
+    // q stays in registers (the S^T MFMA's B operand), k / v go to LDS
+    s16x4 qf[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int T = wave + ti * waves;
+        uint2 qp, kp, vp;
+        qp.x = pack_bf16x2(acc[ti][0], acc[ti][1]); qp.y = pack_bf16x2(acc[ti][2], acc[ti][3]);
+        kp.x = pack_bf16x2(acc[ti][4], acc[ti][5]); kp.y = pack_bf16x2(acc[ti][6], acc[ti][7]);
+        vp.x = pack_bf16x2(acc[ti][8], acc[ti][9]); vp.y = pack_bf16x2(acc[ti][10], acc[ti][11]);
+        qf[ti] = __builtin_bit_cast(s16x4, qp);
+        if (T < ntiles) {
+            const int key = T * 32 + l31;
+            *reinterpret_cast<uint2*>(sK + (size_t)key * 8 + 4 * hh) = kp;
+            const int j = key & 15;
+            const int pos = (key & ~15) + 8 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);
+            bf16_t* vcol = sVt + pos;
+            vcol[(4 * hh + 0) * vst] = (bf16_t)(vp.x & 0xffffu);
+            vcol[(4 * hh + 1) * vst] = (bf16_t)(vp.x >> 16);
+            vcol[(4 * hh + 2) * vst] = (bf16_t)(vp.y & 0xffffu);
+            vcol[(4 * hh + 3) * vst] = (bf16_t)(vp.y >> 16);
+            if (hh == 0) {
+                vcol[8 * vst] = (bf16_t)0x3f80;           // 1.0: the PV MFMA's row 8 accumulates the softmax denominator
+                vcol[9 * vst] = (bf16_t)0;
+            }
+        }
+    }
+    __syncthreads();
+    bf16_t* out_bh = p.out + ((size_t)b * L) * C + h * 8;
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int q0 = (wave + ti * waves) * 32;
+        if (q0 < L) attention_tile(sK, sVt, vst, L, Lp, C, q0, qf[ti], out_bh, l31, hh);
+    }
+}
+
+int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(p.L >= 1 && p.L <= 1024, "attention_qkv: token count must be in [1, 1024]");
+    RLDM_REQUIRE(p.C % 16 == 0 && p.C <= 512 && p.C % p.groups == 0, "attention_qkv: channels must be a multiple of 16, <= 512");
+    const int Lp = (p.L + 31) / 32 * 32;
+    const int ntiles = Lp / 32;
+    const int waves = ntiles < 8 ? ntiles : 8;
+    const size_t lds = (size_t)Lp * 16 + (size_t)10 * (Lp + 8) * 2 + (size_t)p.C * 8 + (size_t)2 * p.C * 8;
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qkv_d8_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(attention_qkv_d8_kernel, dim3(p.B * (p.C / 8)), dim3(64 * waves), lds, stream, p, waves, Lp);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_attention(const AttnParams& p, hipStream_t stream) {

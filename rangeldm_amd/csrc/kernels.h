@@ -145,6 +145,26 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
 
+// Fused GroupNorm -> q/k/v projection -> attention (attention.hip): x is the block input with its statistics partials;
+// wfrag = per-head MFMA A fragments [heads][C/16][64 lanes][8 bf16] (rows 0-7 q pre-scaled by log2(e)/sqrt(8), 8-15 k,
+// 16-23 v, 24-31 zero), bias [heads][32] fp32.  out: [B][L][C].
+struct AttnQkvParams {
+    const bf16_t* x;
+    const float2* st;
+    int P;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    int groups;
+    float inv_n;
+    int magic_cpg;
+    const bf16_t* wfrag;
+    const float* bias;
+    bf16_t* out;
+    int B, L, C;
+};
+int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------------------------
 // Small kernels (elementwise.hip)
 // ---------------------------------------------------------------------------------------------------------------

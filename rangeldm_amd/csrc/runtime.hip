@@ -1065,7 +1065,78 @@ struct NetCommon {
 
     // diffusers Attention (+x residual): qkv = GN + Linear(C, 3C); softmax(q k^T / sqrt(8)) v per head; to_out + x.
     // Releases one reference of x.
+    // per-head q/k/v fragments for attention_qkv_d8_kernel, built once per layer from the merged qkv Linear
+    struct AttnFused {
+        DevBuf w, bias;
+    };
+    std::map<std::string, std::unique_ptr<AttnFused>> attn_fused;
+    int get_attn_fused(const std::string& p, int C, AttnFused** out) {
+        auto it = attn_fused.find(p);
+        if (it != attn_fused.end()) {
+            *out = it->second.get();
+            return 0;
+        }
+        ConvLayer* L = layers.get_conv(p + ".qkv");
+        RLDM_REQUIRE(L && L->Cin == C && L->Cout == 3 * C, "attention " + p + ": unexpected q/k/v shapes");
+        const int heads = C / 8, nks = C / 16;
+        std::vector<bf16_t> img((size_t)heads * nks * 512, 0);
+        std::vector<float> bias((size_t)heads * 32, 0.f);
+        for (int h = 0; h < heads; ++h)
+            for (int row = 0; row < 24; ++row) {
+                const int src = (row / 8) * C + h * 8 + row % 8;            // q | k | v rows of the merged Linear
+                bias[(size_t)h * 32 + row] = L->b[src];
+                for (int c = 0; c < C; ++c)
+                    img[(((size_t)h * nks + c / 16) * 64 + ((c % 16) / 8) * 32 + row) * 8 + c % 8] = f32_to_bf16(L->w[(size_t)src * C + c]);
+            }
+        auto f = std::make_unique<AttnFused>();
+        if (upload(f->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(f->bias, bias.data(), bias.size() * sizeof(float))) return 1;
+        *out = f.get();
+        attn_fused[p] = std::move(f);
+        return 0;
+    }
+
     int attention(Builder& b, const std::string& p, Tensor x, Tensor* out) {
+        const int Lt = x.W * x.H;
+        if (!(g_dbg_flags & 32768) && x.C % 16 == 0 && x.C <= 512 && Lt <= 1024 && x.P > 0 && x.C % groups == 0) {
+            // GroupNorm + q/k/v projection inside the attention launch: no [B][L][3C] tensor, one launch less
+            Tensor o = b.make(x.B, x.W, x.H, x.C);
+            const double fl = 4.0 * (double)x.B * (x.C / 8) * (double)Lt * Lt * 8 + 2.0 * (double)x.B * Lt * 3.0 * x.C * x.C;
+            b.plan->flops += fl;
+            ++b.launches;
+            if (!b.dry) {
+                AttnFused* f = nullptr;
+                if (get_attn_fused(p, x.C, &f)) return 1;
+                NormParams* gnp = layers.get_norm(p + ".group_norm");
+                AttnQkvParams ap;
+                memset(&ap, 0, sizeof(ap));
+                ap.x = b.tptr(x);
+                ap.st = b.sptr(x);
+                ap.P = x.P;
+                ap.gamma = gnp->gamma.as<float>();
+                ap.beta = gnp->beta.as<float>();
+                ap.eps = eps;
+                ap.groups = groups;
+                const int cpg = x.C / groups;
+                ap.inv_n = (float)(1.0 / ((double)Lt * cpg));
+                ap.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+                ap.wfrag = f->w.as<bf16_t>();
+                ap.bias = f->bias.as<float>();
+                ap.out = b.tptr(o);
+                ap.B = x.B; ap.L = Lt; ap.C = x.C;
+                b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl,
+                                       (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0});
+            }
+            ConvArgs co;
+            co.layer = layers.get_conv(p + ".to_out.0");
+            co.x0 = o;
+            co.r0 = x;
+            co.want_stats = true;
+            if (b.conv(co, out)) return 1;
+            b.release(o);
+            b.release(x);
+            return 0;
+        }
         ConvArgs cq;
         cq.layer = layers.get_conv(p + ".qkv");
         cq.x0 = x;
