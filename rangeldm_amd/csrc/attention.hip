@@ -216,66 +216,67 @@ __global__ void __launch_bounds__(512) attention_qkv_d8_kernel(const AttnQkvPara
         __syncthreads();
     }
 
-    // ---- projection of this wave's pixel tiles T = wave, wave + waves, ... -----------------------------------------------
-    f32x16 acc[TPW];
+    // ---- projection of this wave's pixel tiles T = wave, wave + waves, ...: one tile at a time, its rows of x requested
+    // whole (a lane's 16-byte pieces of one 128-byte line are issued back to back: every line is fetched once) ------------
     const float* bh = p.bias + h * 32;
+    float binit[12];
 #pragma unroll
-    for (int ti = 0; ti < TPW; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ti][r] = (r < 12) ? bh[8 * (r >> 2) + 4 * hh + (r & 3)] : 0.f;
-    const bf16_t* xrow[TPW];
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int px = min((wave + ti * waves) * 32 + l31, L - 1);          // keys / queries past L: a clamped row, masked later
-        xrow[ti] = p.x + ((size_t)b * L + px) * C + 8 * hh;
-    }
+    for (int r = 0; r < 12; ++r) binit[r] = bh[8 * (r >> 2) + 4 * hh + (r & 3)];
     const bf16_t* wf_ptr = p.wfrag + ((size_t)h * (C >> 4) * 64 + lane) * 8;
     const int nks = C >> 4;
-    for (int ks = 0; ks < nks; ++ks) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wf_ptr + (size_t)ks * 512);
-        uint4 xv[TPW];
-#pragma unroll
-        for (int ti = 0; ti < TPW; ++ti)
-            if (wave + ti * waves < ntiles) xv[ti] = *reinterpret_cast<const uint4*>(xrow[ti] + ks * 16);
-        const int c0 = ks * 16 + 8 * hh;
-        const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
-        const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
-#pragma unroll
-        for (int ti = 0; ti < TPW; ++ti) {
-            if (wave + ti * waves >= ntiles) continue;
-            const uint4 v = xv[ti];
-            uint4 n;
-            n.x = pack_bf16x2(bf16lo(v.x) * a0.x + s0.x, bf16hi(v.x) * a0.y + s0.y);
-            n.y = pack_bf16x2(bf16lo(v.y) * a0.z + s0.z, bf16hi(v.y) * a0.w + s0.w);
-            n.z = pack_bf16x2(bf16lo(v.z) * a1.x + s1.x, bf16hi(v.z) * a1.y + s1.y);
-            n.w = pack_bf16x2(bf16lo(v.w) * a1.z + s1.z, bf16hi(v.w) * a1.w + s1.w);
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, n), acc[ti], 0, 0, 0);
-        }
-    }
-    // q stays in registers (the S^T MFMA's B operand), k / v go to LDS
     s16x4 qf[TPW];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
         const int T = wave + ti * waves;
-        uint2 qp, kp, vp;
-        qp.x = pack_bf16x2(acc[ti][0], acc[ti][1]); qp.y = pack_bf16x2(acc[ti][2], acc[ti][3]);
-        kp.x = pack_bf16x2(acc[ti][4], acc[ti][5]); kp.y = pack_bf16x2(acc[ti][6], acc[ti][7]);
-        vp.x = pack_bf16x2(acc[ti][8], acc[ti][9]); vp.y = pack_bf16x2(acc[ti][10], acc[ti][11]);
-        qf[ti] = __builtin_bit_cast(s16x4, qp);
-        if (T < ntiles) {
-            const int key = T * 32 + l31;
-            *reinterpret_cast<uint2*>(sK + (size_t)key * 8 + 4 * hh) = kp;
-            const int j = key & 15;
-            const int pos = (key & ~15) + 8 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);
-            bf16_t* vcol = sVt + pos;
-            vcol[(4 * hh + 0) * vst] = (bf16_t)(vp.x & 0xffffu);
-            vcol[(4 * hh + 1) * vst] = (bf16_t)(vp.x >> 16);
-            vcol[(4 * hh + 2) * vst] = (bf16_t)(vp.y & 0xffffu);
-            vcol[(4 * hh + 3) * vst] = (bf16_t)(vp.y >> 16);
-            if (hh == 0) {
-                vcol[8 * vst] = (bf16_t)0x3f80;           // 1.0: the PV MFMA's row 8 accumulates the softmax denominator
-                vcol[9 * vst] = (bf16_t)0;
+        if (T >= ntiles) continue;
+        const int px = min(T * 32 + l31, L - 1);          // keys / queries past L: a clamped row, masked later
+        const bf16_t* xrow = p.x + ((size_t)b * L + px) * C + 8 * hh;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = r < 12 ? binit[r] : 0.f;
+        constexpr int KB = 8;                             // k-steps (16 channels each) per batch of loads
+        for (int k0 = 0; k0 < nks; k0 += KB) {
+            uint4 xv[KB];
+            bf16x8 wf[KB];
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                if (k0 + j < nks) {
+                    xv[j] = *reinterpret_cast<const uint4*>(xrow + (k0 + j) * 16);
+                    wf[j] = *reinterpret_cast<const bf16x8*>(wf_ptr + (size_t)(k0 + j) * 512);
+                }
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                if (k0 + j >= nks) break;
+                const int c0 = (k0 + j) * 16 + 8 * hh;
+                const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
+                const uint4 v = xv[j];
+                uint4 n;
+                n.x = pack_bf16x2(bf16lo(v.x) * a0.x + s0.x, bf16hi(v.x) * a0.y + s0.y);
+                n.y = pack_bf16x2(bf16lo(v.y) * a0.z + s0.z, bf16hi(v.y) * a0.w + s0.w);
+                n.z = pack_bf16x2(bf16lo(v.z) * a1.x + s1.x, bf16hi(v.z) * a1.y + s1.y);
+                n.w = pack_bf16x2(bf16lo(v.w) * a1.z + s1.z, bf16hi(v.w) * a1.w + s1.w);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], __builtin_bit_cast(bf16x8, n), acc, 0, 0, 0);
             }
+        }
+        // q stays in registers (the S^T MFMA's B operand), k / v go to LDS
+        uint2 qp, kp, vp;
+        qp.x = pack_bf16x2(acc[0], acc[1]); qp.y = pack_bf16x2(acc[2], acc[3]);
+        kp.x = pack_bf16x2(acc[4], acc[5]); kp.y = pack_bf16x2(acc[6], acc[7]);
+        vp.x = pack_bf16x2(acc[8], acc[9]); vp.y = pack_bf16x2(acc[10], acc[11]);
+        qf[ti] = __builtin_bit_cast(s16x4, qp);
+        const int key = T * 32 + l31;
+        *reinterpret_cast<uint2*>(sK + (size_t)key * 8 + 4 * hh) = kp;
+        const int j16 = key & 15;
+        const int pos = (key & ~15) + 8 * ((j16 >> 2) & 1) + (j16 & 3) + 4 * (j16 >> 3);
+        bf16_t* vcol = sVt + pos;
+        vcol[(4 * hh + 0) * vst] = (bf16_t)(vp.x & 0xffffu);
+        vcol[(4 * hh + 1) * vst] = (bf16_t)(vp.x >> 16);
+        vcol[(4 * hh + 2) * vst] = (bf16_t)(vp.y & 0xffffu);
+        vcol[(4 * hh + 3) * vst] = (bf16_t)(vp.y >> 16);
+        if (hh == 0) {
+            vcol[8 * vst] = (bf16_t)0x3f80;               // 1.0: the PV MFMA's row 8 accumulates the softmax denominator
+            vcol[9 * vst] = (bf16_t)0;
         }
     }
     __syncthreads();
