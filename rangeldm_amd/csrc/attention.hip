@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(512) attention_d8_kernel(const AttnParams p, c
 // q[4hh..4hh+3], k[4hh..4hh+3], v[4hh..4hh+3] of its pixel: q is already the S^T MFMA's B operand, k goes to its LDS row
 // with one 8-byte store, v to the transposed image.  Every wave projects the pixel tiles it will later own as queries.
 // (diffusers Attention: group_norm -> to_q / to_k / to_v -> softmax(q k^T / sqrt(8)) v; to_out stays a conv launch.)
-__global__ void __launch_bounds__(512) attention_qkv_d8_kernel(const AttnQkvParams p, const int waves, const int Lp) {
+__global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvParams p, const int waves, const int Lp) {
     constexpr int TPW = 4;                                // query tiles per wave (L <= 1024)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(512) attention_qkv_d8_kernel(const AttnQkvPara
     float* sGa = reinterpret_cast<float*>(sVt + 10 * vst);         // [C]
     float* sGs = sGa + C;
     double* sD = reinterpret_cast<double*>(sGs + C);      // [2][C] scratch
+    bf16_t* sW = reinterpret_cast<bf16_t*>(sD + 2 * C);   // [C/16][64 lanes][8]: this image's W_h * diag(a)
+    float* sBp = reinterpret_cast<float*>(sW + (size_t)(C >> 4) * 512);    // [32]: b_h + W_h * s
 
     // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic) ----------------------------------------------------
     {
@@ -216,14 +218,38 @@ __global__ void __launch_bounds__(512) attention_qkv_d8_kernel(const AttnQkvPara
         __syncthreads();
     }
 
+    // ---- the GroupNorm affine folded into the head's weights: W' = W_h * diag(a) (bf16, A-fragment order, LDS),
+    // b' = b_h + W_h * s -- the pixel fragments then go from global memory into the MFMA untouched -----------------------
+    const int nks = C >> 4;
+    const bf16_t* wf_ptr = p.wfrag + (size_t)h * nks * 512;
+    for (int q = tid; q < nks * 64; q += NT) {            // piece q = (k-step, lane): row q & 31, channels 16*ks + 8*(lane >> 5) ..
+        const int c0 = (q >> 6) * 16 + ((q >> 5) & 1) * 8;
+        const uint4 w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);
+        const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
+        uint4 n;
+        n.x = pack_bf16x2(bf16lo(w.x) * a0.x, bf16hi(w.x) * a0.y);
+        n.y = pack_bf16x2(bf16lo(w.y) * a0.z, bf16hi(w.y) * a0.w);
+        n.z = pack_bf16x2(bf16lo(w.z) * a1.x, bf16hi(w.z) * a1.y);
+        n.w = pack_bf16x2(bf16lo(w.w) * a1.z, bf16hi(w.w) * a1.w);
+        *reinterpret_cast<uint4*>(sW + (size_t)q * 8) = n;
+        // partial of W_h * s for row q & 31 over these 8 channels -> scratch [piece]
+        reinterpret_cast<float*>(sD)[q] = bf16lo(w.x) * s0.x + bf16hi(w.x) * s0.y + bf16lo(w.y) * s0.z + bf16hi(w.y) * s0.w +
+                                          bf16lo(w.z) * s1.x + bf16hi(w.z) * s1.y + bf16lo(w.w) * s1.z + bf16hi(w.w) * s1.w;
+    }
+    __syncthreads();
+    if (tid < 32) {                                       // fixed summation order
+        float acc_b = tid < 24 ? p.bias[h * 32 + tid] : 0.f;
+        for (int j = 0; j < 2 * nks; ++j) acc_b += reinterpret_cast<float*>(sD)[j * 32 + tid];
+        sBp[tid] = acc_b;
+    }
+    __syncthreads();
+
     // ---- projection of this wave's pixel tiles T = wave, wave + waves, ...: one tile at a time, its rows of x requested
     // whole (a lane's 16-byte pieces of one 128-byte line are issued back to back: every line is fetched once) ------------
-    const float* bh = p.bias + h * 32;
     float binit[12];
 #pragma unroll
-    for (int r = 0; r < 12; ++r) binit[r] = bh[8 * (r >> 2) + 4 * hh + (r & 3)];
-    const bf16_t* wf_ptr = p.wfrag + ((size_t)h * (C >> 4) * 64 + lane) * 8;
-    const int nks = C >> 4;
+    for (int r = 0; r < 12; ++r) binit[r] = sBp[8 * (r >> 2) + 4 * hh + (r & 3)];
     s16x4 qf[TPW];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
@@ -234,29 +260,17 @@ __global__ void __launch_bounds__(512) attention_qkv_d8_kernel(const AttnQkvPara
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = r < 12 ? binit[r] : 0.f;
-        constexpr int KB = 8;                             // k-steps (16 channels each) per batch of loads
+        constexpr int KB = 16;                            // k-steps (16 channels each) per batch of loads
         for (int k0 = 0; k0 < nks; k0 += KB) {
-            uint4 xv[KB];
-            bf16x8 wf[KB];
+            bf16x8 xv[KB];
 #pragma unroll
             for (int j = 0; j < KB; ++j)
-                if (k0 + j < nks) {
-                    xv[j] = *reinterpret_cast<const uint4*>(xrow + (k0 + j) * 16);
-                    wf[j] = *reinterpret_cast<const bf16x8*>(wf_ptr + (size_t)(k0 + j) * 512);
-                }
+                if (k0 + j < nks) xv[j] = *reinterpret_cast<const bf16x8*>(xrow + (k0 + j) * 16);
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 if (k0 + j >= nks) break;
-                const int c0 = (k0 + j) * 16 + 8 * hh;
-                const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
-                const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
-                const uint4 v = xv[j];
-                uint4 n;
-                n.x = pack_bf16x2(bf16lo(v.x) * a0.x + s0.x, bf16hi(v.x) * a0.y + s0.y);
-                n.y = pack_bf16x2(bf16lo(v.y) * a0.z + s0.z, bf16hi(v.y) * a0.w + s0.w);
-                n.z = pack_bf16x2(bf16lo(v.z) * a1.x + s1.x, bf16hi(v.z) * a1.y + s1.y);
-                n.w = pack_bf16x2(bf16lo(v.w) * a1.z + s1.z, bf16hi(v.w) * a1.w + s1.w);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], __builtin_bit_cast(bf16x8, n), acc, 0, 0, 0);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + ((size_t)(k0 + j) * 64 + lane) * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xv[j], acc, 0, 0, 0);
             }
         }
         // q stays in registers (the S^T MFMA's B operand), k / v go to LDS
@@ -293,8 +307,9 @@ int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(p.C % 16 == 0 && p.C <= 512 && p.C % p.groups == 0, "attention_qkv: channels must be a multiple of 16, <= 512");
     const int Lp = (p.L + 31) / 32 * 32;
     const int ntiles = Lp / 32;
-    const int waves = ntiles < 8 ? ntiles : 8;
-    const size_t lds = (size_t)Lp * 16 + (size_t)10 * (Lp + 8) * 2 + (size_t)p.C * 8 + (size_t)2 * p.C * 8;
+    // up to 16 waves per (image, head): with 1024 tokens that is 4 waves per SIMD on one workgroup per CU
+    const int waves = ntiles <= 4 ? 4 : (ntiles <= 8 ? ntiles : 16);       // (>= 4: the affine / weight fold uses every thread)
+    const size_t lds = (size_t)Lp * 16 + (size_t)10 * (Lp + 8) * 2 + (size_t)p.C * 8 + (size_t)2 * p.C * 8 + (size_t)p.C * 64 + 128;
     static size_t max_set = 0;
     if (lds > max_set) {
         RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qkv_d8_kernel),
