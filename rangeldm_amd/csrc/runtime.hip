@@ -1693,6 +1693,7 @@ struct SamplerLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_out = nullptr;
     hipGraphExec_t step_graph = nullptr, decode_graph = nullptr;
+    int graph_steps = 1;                            // sampler steps captured in step_graph
     const float* captured_noise = nullptr;
     long long n_latent = 0, n_image = 0, n_cond = 0;
     ~SamplerLane() {
@@ -2082,7 +2083,17 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             RLDM_HIP_CHECK(hipStreamSynchronize(st));
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
             if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
-            if (capture(st, [&]() { return sampler_enqueue_step(s, ln, noise, st); }, &ln->step_graph)) return 1;
+            // the graph holds `gs` consecutive steps (the step index lives on the device, so the steps are identical launches):
+            // fewer, longer graphs keep the queue fed across step boundaries
+            int gs = getenv("RLDM_GRAPH_STEPS") ? atoi(getenv("RLDM_GRAPH_STEPS")) : 10;
+            gs = std::max(1, std::min(gs, s->cfg.num_steps));
+            while (s->cfg.num_steps % gs != 0) --gs;
+            ln->graph_steps = gs;
+            if (capture(st, [&]() {
+                    for (int k = 0; k < gs; ++k)
+                        if (sampler_enqueue_step(s, ln, noise, st)) return 1;
+                    return 0;
+                }, &ln->step_graph)) return 1;
             ln->captured_noise = noise;
         }
         if (images && s->vae && !ln->decode_graph) {
@@ -2094,7 +2105,7 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
         }
     }
     // the chains: step-major so every stream always has work queued
-    for (int i = 0; i < s->cfg.num_steps; ++i)
+    for (int i = 0; i < s->cfg.num_steps; i += s->lanes[0]->graph_steps)
         for (auto& lnp : s->lanes) RLDM_HIP_CHECK(hipGraphLaunch(lnp->step_graph, lnp->stream));
     for (auto& lnp : s->lanes) {
         SamplerLane* ln = lnp.get();
