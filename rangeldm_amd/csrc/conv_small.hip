@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
         const bool laneok = c8 < C8;
         const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x0);
         const int KC = (THv + SPI - 1) / SPI;   // instructions per column
+        const int ups = p.up - 1;               // nearest x2 folded into the source indexing
         float ga[8], gs[8];
         for (int k0 = 0; k0 < KC; k0 += KB) {
             uint4 v[KB][NCW];
@@ -153,10 +154,10 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int vhl = (k0 + kb) * SPI + rsub;
-                const int vh = h0 - HALO + vhl;
+                const int vh = h0 - HALO + vhl;                 // row / column of the (nearest-x2: virtual) input image
                 rowok[kb] = laneok && (k0 + kb) < KC && vhl < THv;
-                inimg[kb] = rowok[kb] && vh >= 0 && vh < p.Hin;
-                const unsigned goff = (unsigned)(vh * (CIN * 2) + c8 * 16);
+                inimg[kb] = rowok[kb] && vh >= 0 && vh < (p.Hin << ups);
+                const unsigned goff = (unsigned)((vh >> ups) * (CIN * 2) + c8 * 16);
                 ldo[kb] = vhl * RSM + c8 * 16;
 #pragma unroll
                 for (int j = 0; j < NCW; ++j) {
@@ -164,8 +165,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     v[kb][j] = make_uint4(0u, 0u, 0u, 0u);
                     if (col < TWv && (k0 + kb) < KC) {
                         int vw = w0 - HALO + col;
-                        vw = vw < 0 ? vw + p.Win : (vw >= p.Win ? vw - p.Win : vw);
-                        const unsigned char* cbase = xg + (size_t)((b * p.Win + vw) * p.Hin) * (CIN * 2);     // uniform
+                        const int Wv = p.Win << ups;
+                        vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
+                        const unsigned char* cbase = xg + (size_t)((b * p.Win + (vw >> ups)) * p.Hin) * (CIN * 2);     // uniform
                         if (inimg[kb]) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
                     }
                 }
@@ -506,7 +508,8 @@ static int small_cpt(int Cin, int taps, int BN) {
 bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
     if (BN != 32 && BN != 64 && BN != 128) return false;
-    if ((taps != 9 && taps != 1) || p.stride != 1 || p.up != 1 || p.pad_lo != (taps == 9 ? 1 : 0) || p.y_nchw || p.ksplit > 1)
+    if ((taps != 9 && taps != 1) || p.stride != 1 || (p.up != 1 && !(p.up == 2 && taps == 9 && p.R0 + p.R1 == 0 && !p.res)) ||
+        p.pad_lo != (taps == 9 ? 1 : 0) || p.y_nchw || p.ksplit > 1)
         return false;
     if (p.C1 != 0) return false;                                // one input tensor
     if (p.st0 != nullptr && (taps != 1 || p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;   // 3x3: pre-activated input
@@ -515,7 +518,7 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     const int G = (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;
     if (R / (16 * KG) > std::min(G, 8)) return false;
     const int BMpx = p.TW * p.TH;
-    if ((BMpx != 64 && BMpx != 128) || p.TH < 2 || p.TW + 2 > 40 || p.Win < 2) return false;
+    if ((BMpx != 64 && BMpx != 128) || p.TH < 2 || p.TW + 2 > 40 || p.Win * p.up < 2) return false;
     if (BMpx == 128 && (taps != 9 || BN != 64 || p.TW + 2 > 24 || (cpt != 2 && cpt != 4 && cpt != 6))) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
     return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;

@@ -621,7 +621,8 @@ struct Builder {
     // geometry + channel counts of the route; `epi_res`: the identity residual is added in the epilogue instead of the K loop
     static bool small_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q, bool* epi_res) {
         if (g_dbg_flags & 256) return false;
-        if ((taps != 9 && taps != 1) || a.stride != 1 || a.up != 1 || a.out_f32_nchw) return false;
+        if ((taps != 9 && taps != 1) || a.stride != 1 || (a.up != 1 && !(a.up == 2 && taps == 9 && !a.gn && R_t == 0)) || a.out_f32_nchw)
+            return false;
         // (128-pixel tiles for the 128x8 level are built and tested but lose to the generic kernel there: the separate
         //  GroupNorm pass over a 12 MB tensor costs more than the faster K loop wins; rldm_debug_set_flags(1024) routes them)
         if (taps == 9 && (a.pad_mode != 0 || Wout * Hout > ((g_dbg_flags & 1024) ? 1024 : 256))) return false;
@@ -639,7 +640,7 @@ struct Builder {
         q->R0 = *epi_res ? 0 : (a.r0.valid() ? a.r0.C : 0);
         q->R1 = *epi_res ? 0 : R_t - q->R0;
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
-        q->up = 1; q->stride = 1; q->pad_lo = taps == 9 ? 1 : 0;
+        q->up = a.up; q->stride = 1; q->pad_lo = taps == 9 ? 1 : 0;
         q->Wout = Wout; q->Hout = Hout;
         q->TW = tw; q->TH = th;
         q->colb = conv_small_col_bytes(Cin_t, th, taps);

@@ -47,6 +47,7 @@ CONV_CASES = [
     (2, 128, 128, 128, 8, 3, 1, 0, False),     # conv_small.hip: L1, 128-pixel tiles (16x8)
     (16, 256, 128, 128, 8, 3, 1, 0, False),    # conv_small.hip: L1 at the bench batch (one full round of workgroups)
     (1, 384, 128, 128, 8, 3, 1, 0, False),     # conv_small.hip: L1 up-block width 256 + 128
+    (3, 256, 256, 32, 2, 3, 1, 0, True),       # conv_small.hip: nearest x2 folded into the staging (L3 upsample)
     (16, 128, 128, 256, 16, 3, 1, 0, False),   # conv_stream.hip: L0 at the bench batch (256 workgroups)
     (1, 256, 256, 64, 16, 3, 1, 0, False),     # conv_stream.hip (flag): 4 chunks, two channel tiles
     (1, 64, 128, 32, 8, 3, 1, 0, False),       # conv_stream.hip (flag): a single chunk, a single tile
