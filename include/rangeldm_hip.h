@@ -138,6 +138,47 @@ void rldm_sampler_destroy(rldm_sampler* s);
 int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, const float* cond, float* images,
                 float* latents_out, void* stream);
 
+/* ---- range image <-> point cloud (rangeldm_amd/csrc/lidar.hip) ------------------------- */
+typedef struct rldm_lidar rldm_lidar;     /* point_cloud_to_range_image replacement, ldm/dataset.py:135-294 */
+
+/* point_cloud_to_range_image.__init__ (ldm/dataset.py:136-154); per-beam tables of the sensor subclasses
+ * (ldm/kitti360_range_image.py:19-48, ldm/nuscenes_range_image.py:20-35) are passed to rldm_lidar_create. */
+typedef struct rldm_lidar_config {
+    int32_t beams;                      /* H = len(incl)                                            */
+    int32_t width;                      /* azimuth bins of the projection (`width`, 1024)           */
+    int32_t mode;                       /* 0: (r - mean) / std, 1: log2(r + 1) / 6, 2: 1 / r        */
+    float mean, std;                    /* 20, 40                                                   */
+    float range_fill, intensity_fill;   /* range_fill_value = [100, 0]                              */
+    int32_t grid[3];                    /* grid_sizes = [D, H, W] of the BEV volume ([1, 1024, 1024]) */
+    float pc_range[6];                  /* [-25.6, -25.6, -3, 25.6, 25.6, 1]                        */
+    int32_t normalize_volume_densities; /* log(density + 1)                                         */
+} rldm_lidar_config;
+
+int rldm_lidar_create(const rldm_lidar_config* cfg, const float* incl /*host [beams]*/, const float* height /*host*/,
+                      rldm_lidar** out);
+void rldm_lidar_destroy(rldm_lidar* l);
+/* to_pc_torch (ldm/dataset.py:228-278): range_images device fp32 (B, C, W, beams) -> points device fp32
+ * [B][W*beams][C > 1 ? 4 : 3] = (x, y, z[, remission]); point index = w * beams + h.  The input is not modified. */
+int rldm_lidar_to_points(rldm_lidar* l, const float* range_images, int B, int C, int W, float* points, void* stream);
+/* to_voxel (ldm/dataset.py:280-294 over _splat_points_to_volumes :13-132): -> voxel device fp32 (B, 2*D, H, W):
+ * D planes of [log(1 +)] vote density, then D planes of density-normalised remission.  C >= 2. */
+int rldm_lidar_to_voxel(rldm_lidar* l, const float* range_images, int B, int C, int W, float* voxel, void* stream);
+/* `pc[np.linalg.norm(pc[:, :3], 2, axis=1) < max_depth]` per image, order preserved (ldm/inference.py:177-179):
+ * points [B][N][cols] -> out [B][N][cols] (first counts[b] rows valid), counts device int32 [B]. cols = 3 or 4. */
+int rldm_lidar_filter_points(rldm_lidar* l, const float* points, int B, int N, int cols, float max_depth, float* out,
+                             int32_t* counts, void* stream);
+/* `(x[b].permute(2, 1, 0).clip(0, 1) * 255).astype(uint8)[:, :, channel]` (ldm/inference.py:180-183):
+ * src device fp32 (B, C, W, H) -> dst device bytes [B][H][W] (the pixels of the 8-bit range / BEV PNG). */
+int rldm_render_u8(const float* src, int B, int C, int W, int H, int channel, uint8_t* dst, void* stream);
+/* point_cloud_to_range_image.__call__ + process_miss_value + normalize + the (2,1,0) permute of
+ * RangeDataset.__getitem__ (ldm/dataset.py:159-226, 320-333): one sweep `points` device fp32 [n_points][stride]
+ * (x, y, z, intensity, ...) -> image device fp32 (2, width, beams), mask / car_window_mask device bytes
+ * (width, beams).  rows: device int32 [n_points] beam index per return, or NULL = nearest inclination
+ * (ldm/kitti360_range_image.py:51-61).  min_depth > 0 drops returns with |xyz| <= min_depth
+ * (ldm/nuscenes_range_image.py:37-41).  `points` is not modified. */
+int rldm_lidar_project(rldm_lidar* l, const float* points, int n_points, int stride, const int32_t* rows, float min_depth,
+                       float* image, uint8_t* mask, uint8_t* car_window_mask, void* stream);
+
 /* ---- introspection used by bench.py / tests ----------------------------------------------------------------- */
 /* algorithmic FLOPs (2*MACs of conv/linear/QK^T/PV) of one UNet forward / VAE decode / encode for batch B */
 double rldm_unet_flops(rldm_unet* m, int B);

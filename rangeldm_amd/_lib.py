@@ -35,6 +35,12 @@ class ConvDescC(C.Structure):
                 ("upsample", C.c_int32), ("gn", C.c_int32), ("silu", C.c_int32), ("eps", C.c_float)]
 
 
+class LidarConfigC(C.Structure):
+    _fields_ = [("beams", C.c_int32), ("width", C.c_int32), ("mode", C.c_int32), ("mean", C.c_float), ("std", C.c_float),
+                ("range_fill", C.c_float), ("intensity_fill", C.c_float), ("grid", C.c_int32 * 3),
+                ("pc_range", C.c_float * 6), ("normalize_volume_densities", C.c_int32)]
+
+
 _P = C.c_void_p
 # every symbol declared in include/rangeldm_hip.h: name -> (restype, argtypes)
 PROTOTYPES = {
@@ -58,6 +64,13 @@ PROTOTYPES = {
     "rldm_sampler_create": (C.c_int, [_P, _P, C.POINTER(SamplerConfigC), C.POINTER(_P)]),
     "rldm_sampler_destroy": (None, [_P]),
     "rldm_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rldm_lidar_create": (C.c_int, [C.POINTER(LidarConfigC), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_P)]),
+    "rldm_lidar_destroy": (None, [_P]),
+    "rldm_lidar_to_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_lidar_to_voxel": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_lidar_filter_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
+    "rldm_render_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_lidar_project": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
     "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),

@@ -9,9 +9,11 @@ one file per image.
 `--cfg` is a preset name (rangeldm_amd.config.PRESETS) or a reference-style yaml whose `model_config` holds the
 UNet2DModel kwargs (ldm/configs/*.yaml).  Weights: a directory laid out like the reference's output_dir
 (`unet/diffusion_pytorch_model.safetensors`, `vae/diffusion_pytorch_model.safetensors`, diffusers keys) or, when
-none is given, the deterministic synthetic state dict (no checkpoints exist offline).  Output per image: `<idx>.npy`
-(the raw (2, W, H) range image, fp32) and `<idx>_range.png` exactly as ldm/inference.py:181-183 renders it; the point
-cloud / BEV projection of ldm/dataset.py (row f1 of SURVEY.md 8) is not part of this path.
+none is given, the deterministic synthetic state dict (no checkpoints exist offline).  Output per image, as
+ldm/inference.py:171-183 writes it: `<idx>.bin` (float32 [N, 4] x, y, z, remission of the returns closer than 90 m),
+`<idx>.png` (8-bit BEV density) and `<idx>_range.png` (8-bit range channel) -- the point cloud, the BEV volume, the depth
+filter and the 8-bit rendering all run on the GPU (rangeldm_amd.range_image); only finished bytes cross PCIe.
+`--save-npy` adds `<idx>.npy`, the raw (2, W, H) fp32 range image.
 """
 import argparse
 import os
@@ -57,13 +59,48 @@ def load_config(cfg):
                 batch=int(y.get("eval_batch_size", 16)))
 
 
-def to_png(img2d):
-    """(W, H) in [0, 1] -> 8-bit grayscale PNG bytes via PIL if present (ldm/inference.py:182), else None."""
+def save_png(pixels_u8, path):
+    """(rows, cols) uint8 -> 8-bit grayscale PNG (ldm/inference.py:180-183 uses PIL; without it a minimal encoder)."""
     try:
         from PIL import Image
+        Image.fromarray(pixels_u8, mode="L").save(path)
+        return
     except ImportError:
-        return None
-    return Image.fromarray((np.clip(img2d, 0, 1) * 255.0).astype(np.uint8), mode="L")
+        pass
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xffffffff)
+
+    h, w = pixels_u8.shape
+    raw = b"".join(b"\x00" + pixels_u8[r].tobytes() for r in range(h))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def sensor_for(beams, **kw):
+    """ldm/inference.py:60-70 picks the projection class from the config; here: by the number of beams."""
+    from .range_image import point_cloud_to_range_image_KITTI, point_cloud_to_range_image_nuScenes
+    if beams == 64:
+        return point_cloud_to_range_image_KITTI(**kw)
+    if beams == 32:
+        return point_cloud_to_range_image_nuScenes(**kw)
+    raise ValueError(f"no sensor table for {beams} beams (64: KITTI-360, 32: nuScenes)")
+
+
+def postprocess(to_range, image, max_depth=90.0):
+    """The per-batch tail of ldm/inference.py:171-183 on the device.  image: (B, 2, W, H) fp32 cuda.
+    Returns host arrays: points (B, N, 4), counts (B,), bev_u8 (B, gx, gy), range_u8 (B, H, W)."""
+    from .range_image import render_u8
+    pc_all = to_range.to_pc_torch(image)
+    bev_out_all = to_range.to_voxel(image)
+    kept, counts = to_range.filter_points(pc_all, max_depth)
+    bev_u8 = render_u8(bev_out_all)
+    range_u8 = render_u8(image)
+    return kept.cpu().numpy(), counts.cpu().numpy(), bev_u8.cpu().numpy(), range_u8.cpu().numpy()
 
 
 def main(argv=None):
@@ -74,6 +111,7 @@ def main(argv=None):
     ap.add_argument("--out", default=None)
     ap.add_argument("--weights", default=None, help="reference-style output_dir with unet/ and vae/ safetensors")
     ap.add_argument("--seed", type=int, default=20240310)
+    ap.add_argument("--save-npy", action="store_true", help="also write the raw (2, W, H) fp32 range image")
     a = ap.parse_args(argv)
 
     from .params import unet_param_shapes, vae_param_shapes
@@ -108,6 +146,7 @@ def main(argv=None):
     else:
         pipe = DDIMPipelineRange(unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=cfg["pos_encoding"])
     lat_shape = (cfg["unet"].out_channels, *cfg["unet"].sample_size)
+    to_range = None
 
     for i in range(plan_iterations(a.samples, B, world)):
         keep = image_indices(i, B, rank, world, a.samples)
@@ -118,12 +157,16 @@ def main(argv=None):
         x_T = torch.from_numpy(np.stack([latent_noise(a.seed, j, lat_shape) for j in idx])).to(dev)
         gen = torch.Generator().manual_seed(a.seed + 1000 * rank + i)       # DDPM step noise
         image = pipe(batch_size=B, generator=gen, num_inference_steps=steps, output_type="torch", latents=x_T)
-        host = image.float().cpu().numpy()
+        if to_range is None:
+            to_range = sensor_for(image.shape[3])
+        points, counts, bev_u8, range_u8 = postprocess(to_range, image)
+        host = image.float().cpu().numpy() if a.save_npy else None
         for j, gidx in keep:
-            np.save(os.path.join(out_dir, f"{gidx}.npy"), host[j])
-            png = to_png(host[j, 0].T)          # ldm/inference.py:182: image[j].permute(2, 1, 0)[..., 0]
-            if png is not None:
-                png.save(os.path.join(out_dir, f"{gidx}_range.png"))
+            points[j, :counts[j]].tofile(os.path.join(out_dir, f"{gidx}.bin"))          # ldm/inference.py:177-179
+            save_png(bev_u8[j], os.path.join(out_dir, f"{gidx}.png"))                   # :180-181
+            save_png(range_u8[j], os.path.join(out_dir, f"{gidx}_range.png"))           # :182-183
+            if host is not None:
+                np.save(os.path.join(out_dir, f"{gidx}.npy"), host[j])
     D.barrier()
     if rank == 0:
         print(f"wrote {a.samples} range images to {out_dir}")
