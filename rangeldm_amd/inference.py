@@ -111,6 +111,7 @@ def main(argv=None):
     ap.add_argument("--out", default=None)
     ap.add_argument("--weights", default=None, help="reference-style output_dir with unet/ and vae/ safetensors")
     ap.add_argument("--seed", type=int, default=20240310)
+    ap.add_argument("--ema", action="store_true", help="read <weights>/unet_ema instead of <weights>/unet")
     ap.add_argument("--save-npy", action="store_true", help="also write the raw (2, W, H) fp32 range image")
     a = ap.parse_args(argv)
 
@@ -130,21 +131,28 @@ def main(argv=None):
     out_dir = a.out or os.path.join("outputs", os.path.splitext(os.path.basename(a.cfg))[0], "generated")
     os.makedirs(out_dir, exist_ok=True)
 
-    def state(sub, shapes, prefix):
-        if a.weights:
-            from safetensors.torch import load_file
-            return load_file(os.path.join(a.weights, sub, "diffusion_pytorch_model.safetensors"))
-        return synth_state_dict(shapes, seed=a.seed, prefix=prefix)
-
+    sched_cfg = None
+    if a.weights:
+        # ldm/inference.py:46-52,84-127: configs and weights come from the training run's output_dir
+        from .checkpoint import load_output_dir
+        ck = load_output_dir(a.weights, with_vae=cfg["vae"] is not None, ema=a.ema)
+        cfg["unet"], usd, sched_cfg = ck["unet_config"], ck["unet"], ck["scheduler_config"]
+        if cfg["vae"] is not None:
+            cfg["vae"], vsd = ck["vae_config"], ck["vae"]
+    else:
+        usd = synth_state_dict(unet_param_shapes(cfg["unet"]), seed=a.seed, prefix="")
+        if cfg["vae"] is not None:
+            vsd = synth_state_dict(vae_param_shapes(cfg["vae"]), seed=a.seed, prefix="vae.")
     unet = UNet2DModelHIP(cfg["unet"])
-    unet.load_state_dict(state("unet", unet_param_shapes(cfg["unet"]), ""))
+    unet.load_state_dict(usd)
     if cfg["vae"] is not None:
         vae = AutoencoderKLHIP(cfg["vae"])
-        vae.load_state_dict(state("vae", vae_param_shapes(cfg["vae"]), "vae."))
+        vae.load_state_dict(vsd)
         # ldm/inference.py:131-136: the LDM branch keeps the DDPM scheduler (strided ancestral sampling)
-        pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDPMSchedulerHIP(), pos_encoding=cfg["pos_encoding"])
+        pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDPMSchedulerHIP(sched_cfg),
+                                pos_encoding=cfg["pos_encoding"])
     else:
-        pipe = DDIMPipelineRange(unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=cfg["pos_encoding"])
+        pipe = DDIMPipelineRange(unet=unet, scheduler=DDIMSchedulerHIP(sched_cfg), pos_encoding=cfg["pos_encoding"])
     lat_shape = (cfg["unet"].out_channels, *cfg["unet"].sample_size)
     to_range = None
 

@@ -87,6 +87,23 @@ class _PipelineBase:
     def to(self, device=None, *a, **k):
         return self
 
+    def save_pretrained(self, output_dir):
+        """`pipeline.save_pretrained(args.output_dir)` (ldm/train_unconditional.py:675): unet/, vae/, scheduler/ and
+        model_index.json in the layout ldm/inference.py:46-52 reads back."""
+        import os
+        self.unet.save_pretrained(os.path.join(output_dir, "unet"))
+        vae = getattr(self, "vae", None)
+        if vae is not None:
+            vae.save_pretrained(os.path.join(output_dir, "vae"))
+        self.scheduler.save_pretrained(os.path.join(output_dir, "scheduler"))
+        import json
+        index = {"_class_name": type(self).__name__, "_diffusers_version": "0.21.0",
+                 "unet": ["diffusers", "UNet2DModel"], "scheduler": ["diffusers", "DDPMScheduler"]}
+        if vae is not None:
+            index["vae"] = ["diffusers", "AutoencoderKL"]
+        with open(os.path.join(output_dir, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2, sort_keys=True)
+
     def set_progress_bar_config(self, **kw):
         self._progress = kw
 

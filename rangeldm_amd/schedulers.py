@@ -65,6 +65,32 @@ class _SchedulerBase:
     def from_config(cls, config, **kw):
         return cls(config, **kw)
 
+    @classmethod
+    def load_config(cls, path, subfolder=None):
+        """`DDPMScheduler.load_config(args.scheduler_config)` (ldm/inference.py:126): json path or directory."""
+        import json
+        import os
+        from .checkpoint import SCHEDULER_CONFIG_NAME, scheduler_config_from_diffusers
+        if subfolder:
+            path = os.path.join(path, subfolder)
+        if os.path.isdir(path):
+            path = os.path.join(path, SCHEDULER_CONFIG_NAME)
+        with open(path) as f:
+            return scheduler_config_from_diffusers(json.load(f))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **kw):
+        return cls(cls.load_config(path, subfolder), **kw)
+
+    def save_pretrained(self, path):
+        import json
+        import os
+        from .checkpoint import SCHEDULER_CONFIG_NAME, scheduler_config_to_diffusers
+        os.makedirs(path, exist_ok=True)
+        name = "DDIMScheduler" if type(self).__name__.startswith("DDIM") else "DDPMScheduler"
+        with open(os.path.join(path, SCHEDULER_CONFIG_NAME), "w") as f:
+            json.dump(scheduler_config_to_diffusers(self._cfg, name), f, indent=2, sort_keys=True)
+
     def set_timesteps(self, num_inference_steps, device=None):
         c = self._cfg
         if num_inference_steps > c.num_train_timesteps:

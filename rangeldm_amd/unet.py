@@ -67,6 +67,34 @@ class UNet2DModelHIP:
     def from_config(cls, config, **kw):
         return cls(config, **kw)
 
+    @classmethod
+    def load_config(cls, path, subfolder=None):
+        """`UNet2DModel.load_config(args.unet_config)` (ldm/inference.py:84): a config.json path or its directory."""
+        import json
+        import os
+        from .checkpoint import CONFIG_NAME, unet_config_from_diffusers
+        if subfolder:
+            path = os.path.join(path, subfolder)
+        if os.path.isdir(path):
+            path = os.path.join(path, CONFIG_NAME)
+        with open(path) as f:
+            return unet_config_from_diffusers(json.load(f))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **kw):
+        """`UNet2DModel.from_pretrained(input_dir, subfolder="unet")` (ldm/train_unconditional.py:169)."""
+        import os
+        from .checkpoint import load_unet_dir
+        cfg, sd = load_unet_dir(os.path.join(path, subfolder) if subfolder else path)
+        m = cls(cfg, **kw)
+        m.load_state_dict(sd)
+        return m
+
+    def save_pretrained(self, path):
+        """`model.save_pretrained(os.path.join(output_dir, "unet"))` (ldm/train_unconditional.py:152)."""
+        from .checkpoint import save_model_dir, unet_config_to_diffusers
+        save_model_dir(path, unet_config_to_diffusers(self._cfg), self._state)
+
     # -- weights ------------------------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
         missing = [k for k in self._shapes if k not in state_dict]

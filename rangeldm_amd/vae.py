@@ -73,6 +73,45 @@ class AutoencoderKLHIP:
         self._state = {}
         self._finalized = False
 
+    @classmethod
+    def from_config(cls, config, **kw):
+        return cls(config, **kw)
+
+    @classmethod
+    def load_config(cls, path, subfolder=None):
+        """`AutoencoderKL.load_config(args.vae_config)` (ldm/inference.py:86)."""
+        import json
+        import os
+        from .checkpoint import CONFIG_NAME, vae_config_from_diffusers
+        if subfolder:
+            path = os.path.join(path, subfolder)
+        if os.path.isdir(path):
+            path = os.path.join(path, CONFIG_NAME)
+        with open(path) as f:
+            return vae_config_from_diffusers(json.load(f))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **kw):
+        import os
+        from .checkpoint import load_vae_dir
+        cfg, sd = load_vae_dir(os.path.join(path, subfolder) if subfolder else path)
+        m = cls(cfg, **kw)
+        m.load_state_dict(sd)
+        return m
+
+    @classmethod
+    def from_sgm_checkpoint(cls, ckpt_path, yaml_path=None, image_size=None, **kw):
+        """ldm/convert_vae.py:149-189: an sgm AutoencodingEngine `.ckpt` (+ its yaml) straight into the HIP VAE."""
+        from .checkpoint import load_sgm_vae_checkpoint
+        cfg, sd = load_sgm_vae_checkpoint(ckpt_path, yaml_path, image_size)
+        m = cls(cfg, **kw)
+        m.load_state_dict(sd)
+        return m
+
+    def save_pretrained(self, path):
+        from .checkpoint import save_model_dir, vae_config_to_diffusers
+        save_model_dir(path, vae_config_to_diffusers(self._cfg), self._state)
+
     def load_state_dict(self, state_dict, strict=True):
         sd = {}
         for k, v in state_dict.items():
