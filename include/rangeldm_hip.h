@@ -179,6 +179,25 @@ int rldm_render_u8(const float* src, int B, int C, int W, int H, int channel, ui
 int rldm_lidar_project(rldm_lidar* l, const float* points, int n_points, int stride, const int32_t* rows, float min_depth,
                        float* image, uint8_t* mask, uint8_t* car_window_mask, void* stream);
 
+/* ---- BEV-histogram evaluation (rangeldm_amd/csrc/metrics.hip) ------------------------------ */
+/* load_point_cloud_xyz depth mask (metrics/metrics/histogram/mmd.py:39-44: min_depth < |xyz| < max_depth) +
+ * point_cloud_to_histogram(field_size, bins, pc)[0] (histogram.py:4-18, np.histogramdd over +-field_size/2) for a ragged
+ * batch: sample s = points[offsets[s] .. offsets[s+1]) (device fp32 [n][stride], device int32 [num_samples + 1])
+ * -> hist device uint32 [num_samples][bins][bins] (x bin major).  Counts are exact. */
+int rldm_bev_histogram(const float* points, const int32_t* offsets, int num_samples, int stride, float field_size, int bins,
+                       float min_depth, float max_depth, uint32_t* hist, void* stream);
+/* jsd_2d(sum(hx) / total, sum(hy) / total) (metrics/metrics/histogram/jsd.py:14-16,90-101; scipy jensenshannon, base e).
+ * hx / hy device uint32 [n][bins][bins]; *jsd is a HOST double (the call synchronises the stream). */
+int rldm_hist_jsd(const uint32_t* hx, int nx, const uint32_t* hy, int ny, int bins, double* jsd, void* stream);
+/* np.linalg.norm(x_i / sum(x_i) - y_j / sum(y_j), 2) ** 2 for every pair -- the SPECTRAL norm the `gaussian` kernel of
+ * metrics/metrics/histogram/dist_helper.py:84-104 takes of two 2-D pmfs.  lambda device fp32 [nx][ny]; symmetric = 1
+ * (hx == hy): only j > i is written, the rest is 0.  bins <= 104, multiple of 4. */
+int rldm_hist_spectral_sq(const uint32_t* hx, int nx, const uint32_t* hy, int ny, int bins, int symmetric, float* lambda,
+                          void* stream);
+/* compute_mmd(samples1, samples2, gaussian, is_hist=True) (dist_helper.py:156-172) with sigma (0.5):
+ * out4 HOST doubles = {s1, s2, cross, s1 + s2 - 2 cross} (the call synchronises the stream). */
+int rldm_hist_mmd(const uint32_t* hx, int nx, const uint32_t* hy, int ny, int bins, float sigma, double* out4, void* stream);
+
 /* ---- introspection used by bench.py / tests ----------------------------------------------------------------- */
 /* algorithmic FLOPs (2*MACs of conv/linear/QK^T/PV) of one UNet forward / VAE decode / encode for batch B */
 double rldm_unet_flops(rldm_unet* m, int B);

@@ -71,6 +71,10 @@ PROTOTYPES = {
     "rldm_lidar_filter_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
     "rldm_render_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_lidar_project": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
+    "rldm_bev_histogram": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, _P, _P]),
+    "rldm_hist_jsd": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
+    "rldm_hist_spectral_sq": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_hist_mmd": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), _P]),
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
     "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),

@@ -6,7 +6,9 @@
 // 64..256 pixels (64x4, 32x2 latents).  There a wave issues ~1 instruction per 5 cycles whatever its kind, and the generic
 // kernel's per-chunk work (barrier, weight DMA, halo pipeline: ~300 instructions per 9 MFMAs of a wave) is the whole cost;
 // its GroupNorm prologue is also redone by every channel tile (4-8x).  So here:
-//   * GroupNorm + SiLU run once, in a separate launch (norm.hip: gn_apply_kernel), into one bf16 tensor;
+//   * GroupNorm + SiLU of a single-tensor input are applied while the tile is on its way into LDS (the statistics fold of
+//     the image overlaps the first loads; ~50 elements per thread, against a 7 us launch of its own); a concatenated
+//     input (up-block conv1) is normalised once by a separate launch (norm.hip: gn_apply_kernel) into one bf16 tensor;
 //   * the whole input tile of the workgroup (all C_in channels of its 64 pixels + halo, 60-150 KB) is copied to LDS ONCE.
 //     A wave owns halo columns; everything per-lane about a piece is loop-invariant, so a piece costs a load, an add and a
 //     store;
@@ -93,10 +95,10 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     }
 
     // ---- TAPS == 1: the GroupNorm inputs of channel `tid` (statistics partials of the producer, gamma, beta), requested now
-    const bool gn = TAPS == 1 && p.st0 != nullptr;
+    const bool gn = p.st0 != nullptr;       // (3x3: single-input convs only; concatenated inputs come pre-activated)
     double gS = 0.0, gSS = 0.0;
     float g_gamma = 0.f, g_beta = 0.f;
-    if (TAPS == 1 && gn && tid < CIN) {
+    if (gn && tid < CIN) {
         const float2* src = p.st0 + (size_t)b * p.P0 * CIN + tid;
         const int P = p.P0;
         int q = 0;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     }
                 }
             }
-            if (TAPS == 1 && gn && k0 == 0) {
+            if (gn && k0 == 0) {
                 // per-channel sums -> (every channel's thread folds its own group: no serial phase) mean / rstd -> a*x + s
                 double* sD = reinterpret_cast<double*>(smem + abytes + 64);      // [2*CIN], behind the image
                 float* sG = reinterpret_cast<float*>(sD + 2 * CIN);              // [2][CIN]
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                 for (int j = 0; j < NCW; ++j) {
                     const int col = wave + 8 * j;
                     uint4 o = v[kb][j];
-                    if (TAPS == 1 && gn && inimg[kb]) {
+                    if (gn && inimg[kb]) {
                         float f0 = bf16lo(o.x) * ga[0] + gs[0], f1 = bf16hi(o.x) * ga[1] + gs[1];
                         float f2 = bf16lo(o.y) * ga[2] + gs[2], f3 = bf16hi(o.y) * ga[3] + gs[3];
                         float f4 = bf16lo(o.z) * ga[4] + gs[4], f5 = bf16hi(o.z) * ga[5] + gs[5];
@@ -512,7 +514,7 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
         p.pad_lo != (taps == 9 ? 1 : 0) || p.y_nchw || p.ksplit > 1)
         return false;
     if (p.C1 != 0) return false;                                // one input tensor
-    if (p.st0 != nullptr && (taps != 1 || p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;   // 3x3: pre-activated input
+    if (p.st0 != nullptr && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;   // GroupNorm (+ SiLU) folded into the staging
     const int KG = conv_small_kgroups(BN), cpt = small_cpt(Cin, taps, BN);
     if (cpt == 0 || p.N % BN != 0 || R % (16 * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
     const int G = (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;

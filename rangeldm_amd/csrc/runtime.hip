@@ -625,9 +625,12 @@ struct Builder {
             return false;
         // (128-pixel tiles for the 128x8 level are built and tested but lose to the generic kernel there: the separate
         //  GroupNorm pass over a 12 MB tensor costs more than the faster K loop wins; rldm_debug_set_flags(1024) routes them)
-        if (taps == 9 && (a.pad_mode != 0 || Wout * Hout > ((g_dbg_flags & 1024) ? 1024 : 256))) return false;
+        // small images (C2: the 64x4 / 32x2 levels at batch 16), or few pixels in the whole batch (C1 / C3: 128x8 at batch 1,
+        // 128x4 at batch 4): the same 64-pixel tiles, more of them per image
+        const bool few_px = (long long)a.x0.B * Wout * Hout <= 4096 && !(g_dbg_flags & 65536);
+        if (taps == 9 && (a.pad_mode != 0 || (Wout * Hout > ((g_dbg_flags & 1024) ? 1024 : 256) && !few_px))) return false;
         // pixel tile: 64; 128 for the 3x3 convs of the 128x8 level (each weight fragment then feeds 4 MFMAs)
-        const int bm = (taps == 9 && Wout * Hout > 256) ? 128 : 64;
+        const int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : 64;
         if (taps == 1 && a.x1.valid()) return false;
         if (!a.gn && a.x1.valid()) return false;
         if (a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
@@ -678,18 +681,23 @@ struct Builder {
             if (conv_small_supported(t, taps, bn) && tiles * (q.N / bn) <= 256) return bn;
         return 0;
     }
+    // GroupNorm (+ SiLU) folded into the conv's staging: every 1x1, and the 3x3 convs over ONE input tensor (a concatenated
+    // input keeps the separate gn_apply launch; rldm_debug_set_flags(131072) keeps it for every 3x3: A/B runs)
+    static bool small_gn_fused(const ConvArgs& a, int taps) {
+        return a.gn != nullptr && (taps == 1 || (!a.x1.valid() && !(g_dbg_flags & 131072)));
+    }
     bool small_route(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout) const {
         ConvParams q;
         bool epi;
         if (!small_params(a, Cin_t, R_t, taps, Wout, Hout, &q, &epi)) return false;
-        return small_bn(q, taps, taps == 1 && a.gn != nullptr) != 0;
+        return small_bn(q, taps, small_gn_fused(a, taps)) != 0;
     }
 
     int conv_small(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, Tensor* out) {
         ConvLayer* L = a.layer;
         const int N = L->Cout;
-        const bool preact = a.gn != nullptr && taps == 9;      // 3x3: GroupNorm + SiLU in their own launch
-        const bool gn_fused = a.gn != nullptr && taps == 1;    // 1x1: folded into the conv's staging
+        const bool gn_fused = small_gn_fused(a, taps);         // folded into the conv's staging
+        const bool preact = a.gn != nullptr && !gn_fused;      // concatenated 3x3 input: GroupNorm + SiLU in their own launch
         if (a.gn) {
             RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
             RLDM_REQUIRE(a.x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");

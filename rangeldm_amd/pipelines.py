@@ -170,7 +170,8 @@ class DDIMPipelineRange(_PipelineBase):
 
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, eta=0.0, num_inference_steps=50, use_clipped_model_output=None,
-                 output_type="torch", return_dict=True, fused=True):
+                 output_type="torch", return_dict=True, fused=True, latents=None):
+        """`latents` (not in the reference signature): x_T already resident on the device, instead of drawing it."""
         cfg = self.unet.config
         ss = cfg.sample_size if not isinstance(cfg.sample_size, int) else (cfg.sample_size, cfg.sample_size)
         shape = (batch_size, cfg.out_channels, *ss)
@@ -178,7 +179,12 @@ class DDIMPipelineRange(_PipelineBase):
             raise ValueError(
                 f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
                 f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
-        image = randn_tensor(shape, generator=generator, device=self._execution_device, dtype=self.unet.dtype)
+        if latents is not None:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"latents shape {tuple(latents.shape)} != {shape}")
+            image = latents.to(device=self._execution_device, dtype=self.unet.dtype)
+        else:
+            image = randn_tensor(shape, generator=generator, device=self._execution_device, dtype=self.unet.dtype)
         self.scheduler.set_timesteps(num_inference_steps)
         if fused and eta == 0.0:
             h = self._fused.get(self.unet, None, self.scheduler, batch_size, num_inference_steps, 0,
