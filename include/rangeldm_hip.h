@@ -198,6 +198,64 @@ int rldm_hist_spectral_sq(const uint32_t* hx, int nx, const uint32_t* hy, int ny
  * out4 HOST doubles = {s1, s2, cross, s1 + s2 - 2 cross} (the call synchronises the stream). */
 int rldm_hist_mmd(const uint32_t* hx, int nx, const uint32_t* hy, int ny, int bins, float sigma, double* out4, void* stream);
 
+/* ---- UNet training step (rangeldm_amd/csrc/train.hip; ldm/train_unconditional.py:466-558) ----
+ * Op-level entry points driven by rangeldm_amd/training.py (the autograd tape is host-side).  Every tensor is device
+ * fp32, activations / gradients channels-last [B][W][H][C] (W wraps, H zero-pads); GEMM operands are rounded to bf16 into
+ * the MFMA with fp32 accumulation (the reference's `mixed_precision: bf16`). */
+typedef struct rldm_train_conv_desc {
+    int32_t B, Win, Hin, Cin;   /* input tensor                                                                    */
+    int32_t N;                  /* output channels                                                                 */
+    int32_t taps;               /* 9: 3x3 pad 1 (ldm/utils.py:40-55), 1: 1x1 / Linear                             */
+    int32_t stride;             /* 1 | 2 (Downsample2D, ldm/utils.py:107-116)                                      */
+    int32_t mode;               /* 0 plain, 1 nearest-x2 of the input first (Upsample2D), 2 zero insertion (data
+                                   gradient of a stride-2 conv); output = (Win << (mode != 0)) / stride            */
+} rldm_train_conv_desc;
+/* y = conv(x) + bias + rowadd[b] + res (each optional); w_packed = bf16 [N][taps][ceil16(Cin)] from
+ * rldm_train_pack_weights (forward copy, or the transposed copy with Cin/N swapped for the data gradient). */
+int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* rowadd,
+                    int rowadd_ld, const float* res, float* y, int accumulate, void* stream);
+/* dw[N][Cin][taps] += sum over pixels of dy (x) x  (torch weight layout; dw must be zeroed by the caller). */
+int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, void* stream);
+/* rows[b][n] (+)= sum over image b's pixels of dy[p][n] (time-embedding row gradient); total[n] += over all images (bias). */
+int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int rows_ld, int rows_accumulate, float* total,
+                      void* stream);
+/* GroupNorm (+ SiLU): stats [B][groups][2] = (mean, rstd) are written by forward and read by backward. */
+int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, float eps, const float* gamma, const float* beta,
+                          int silu, float* stats, float* y, void* stream);
+int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, int B, int npix, int C, int groups,
+                           const float* gamma, const float* beta, int silu, float* scratch /*[B][groups][2]*/, float* dx,
+                           int accumulate, float* dgamma, float* dbeta, void* stream);
+/* softmax(q k^T / sqrt(8)) v per head of 8 channels; q, k, v, o [B][L][C]; lse / delta [B][C/8][L]. */
+int rldm_train_attention_forward(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse,
+                                 void* stream);
+int rldm_train_attention_backward(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
+                                  int B, int L, int C, float* delta, float* dq, float* dk, float* dv, void* stream);
+int rldm_train_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+int rldm_train_copy_channels(const float* src, int src_ld, int src_off, float* dst, int dst_ld, int dst_off, int ncopy,
+                             int64_t npix, int accumulate, void* stream);
+int rldm_train_sum2x2(const float* du, int B, int W, int H, int C, float* dx, void* stream);       /* nearest-x2 backward */
+int rldm_train_silu(const float* x, const float* dy, float* y, int64_t n, int backward, int accumulate, void* stream);
+int rldm_train_timestep_embedding(const int64_t* timesteps /*device*/, int B, int dim, float* out, void* stream);
+/* (B, C, W, H) fp32 + optional pos-encoding channel (ldm/train_unconditional.py:455-463,500-501) -> [B][W][H][C(+1)] */
+int rldm_train_pack_input(const float* x, int B, int C, int W, int H, int pos_encoding, float* y, void* stream);
+int rldm_train_unpack_output(const float* x, int B, int C, int W, int H, float* y, void* stream);
+/* F.mse_loss(model_output, target) with optional per-sample weights (min-SNR, :529-543): pred [B][W][H][C], target
+ * (B, C, W, H); dpred [B][W][H][C]; *loss device double. */
+int rldm_train_mse(const float* pred, const float* target, const float* weight, int B, int C, int W, int H, float* dpred,
+                   double* loss, void* stream);
+int rldm_train_sqnorm(const float* g, int64_t n, double* out /*device*/, void* stream);
+typedef struct rldm_adamw_config {
+    float lr, beta1, beta2, eps, weight_decay;  /* torch.optim.AdamW, ldm/train_unconditional.py:357-363           */
+    float max_grad_norm;                        /* clip_grad_norm_ (:548); <= 0: off; uses *sqnorm                 */
+    float ema_decay;                            /* EMAModel.step (:556); used when ema != NULL                     */
+    int32_t step;                               /* 1-based optimizer step (bias corrections)                       */
+} rldm_adamw_config;
+int rldm_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
+                     int64_t n, const rldm_adamw_config* c, void* stream);
+/* master fp32 [N][Cin][taps] -> bf16 [N][taps][ceil16(Cin)] (forward) and bf16 [Cin][taps][ceil16(N)] (flipped / transposed:
+ * data gradient; may be NULL). */
+int rldm_train_pack_weights(const float* w, int N, int Cin, int taps, void* w_forward, void* w_transposed, void* stream);
+
 /* ---- introspection used by bench.py / tests ----------------------------------------------------------------- */
 /* algorithmic FLOPs (2*MACs of conv/linear/QK^T/PV) of one UNet forward / VAE decode / encode for batch B */
 double rldm_unet_flops(rldm_unet* m, int B);

@@ -41,6 +41,16 @@ class LidarConfigC(C.Structure):
                 ("pc_range", C.c_float * 6), ("normalize_volume_densities", C.c_int32)]
 
 
+class TrainConvDescC(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Win", C.c_int32), ("Hin", C.c_int32), ("Cin", C.c_int32), ("N", C.c_int32),
+                ("taps", C.c_int32), ("stride", C.c_int32), ("mode", C.c_int32)]
+
+
+class AdamWConfigC(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("ema_decay", C.c_float), ("step", C.c_int32)]
+
+
 _P = C.c_void_p
 # every symbol declared in include/rangeldm_hip.h: name -> (restype, argtypes)
 PROTOTYPES = {
@@ -75,6 +85,25 @@ PROTOTYPES = {
     "rldm_hist_jsd": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "rldm_hist_spectral_sq": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_hist_mmd": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), _P]),
+    "rldm_train_conv": (C.c_int, [C.POINTER(TrainConvDescC), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "rldm_train_wgrad": (C.c_int, [C.POINTER(TrainConvDescC), _P, _P, _P, _P]),
+    "rldm_train_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_gn_forward": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P]),
+    "rldm_train_gn_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int,
+                                         _P, _P, _P]),
+    "rldm_train_attention_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "rldm_train_attention_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "rldm_train_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "rldm_train_copy_channels": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
+    "rldm_train_sum2x2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_silu": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "rldm_train_timestep_embedding": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_pack_input": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_unpack_output": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_mse": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "rldm_train_sqnorm": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "rldm_train_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(AdamWConfigC), _P]),
+    "rldm_train_pack_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
     "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),

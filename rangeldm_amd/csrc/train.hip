@@ -1,0 +1,790 @@
+// train.hip -- kernels of the UNet training step (ldm/train_unconditional.py:466-558) for gfx950.
+//
+// First correct version: self-contained and deliberately simple.  Activations and gradients are fp32 channels-last
+// [B][W][H][C] (W = azimuth wraps, H = beams zero-padded); GEMM operands are rounded to bf16 on their way into
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (what `mixed_precision: bf16` autocast does to conv / linear), everything
+// else is fp32.  Master weights stay in the torch layout [N][Cin][3][3] (fp32, flat buffer shared with AdamW / EMA); the
+// convolutions read bf16 copies [N][tap][Cin] (forward) and [Cin][8 - tap][N] (data gradient) refreshed after every
+// optimizer step.
+//
+//   tr_conv_kernel        conv 3x3 / 1x1 (circular W, zero H; stride 1 | 2; nearest-x2 or zero-insertion of the input)
+//                         + bias + per-sample row (time embedding) + residual.  Forward, data gradient (flipped /
+//                         transposed weights; stride-2 convs through zero insertion) and every Linear (W = H = 1).
+//   tr_wgrad_kernel       dW[n][c][tap] = sum_p dy[p][n] * x[src(p, tap)][c]: pixels are the contraction index, split over
+//                         workgroups and waves, fp32 atomics into the zeroed gradient.
+//   tr_colsum_kernel      bias / time-embedding-row gradients: per-image column sums of dy.
+//   tr_gn_*               GroupNorm(32) statistics, forward (+ SiLU), backward (reduce + apply, d gamma / d beta).
+//   tr_attn_*             head_dim 8 softmax attention, forward (+ log-sum-exp) and backward (dq ; dk, dv): one thread per
+//                         query / key against the head's K, V (or Q, dO) staged in LDS; no atomics, deterministic.
+//   elementwise           add, channel copy (concat / split), 2x2 sum (nearest-x2 backward), SiLU, sinusoidal timestep
+//                         embedding, input packing, MSE loss + gradient, sum of squares, AdamW (+ clip scale + EMA),
+//                         weight repacking.
+#include "common.h"
+#include "../../include/rangeldm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+// source pixel of output pixel (b, wo, ho) under tap (dw, dh): index into the input's pixel array, or -1 for a zero.
+// mode 0: plain; 1: nearest x2 (virtual input is twice as large); 2: zero insertion (virtual odd coordinates are zeros)
+__device__ inline int src_pixel(int b, int wo, int ho, int dw, int dh, int stride, int mode, int Win, int Hin) {
+    const int sh = mode ? 1 : 0;
+    const int Wv = Win << sh, Hv = Hin << sh;
+    int vw = wo * stride + dw, vh = ho * stride + dh;
+    if (vh < 0 || vh >= Hv) return -1;
+    vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
+    if (mode == 2 && ((vw | vh) & 1)) return -1;
+    return (b * Win + (vw >> sh)) * Hin + (vh >> sh);
+}
+
+// 8 consecutive fp32 -> bf16x8; `valid` elements exist (the rest are zeros); vec: the row is 16-byte aligned
+__device__ inline bf16x8 load_bf16x8_from_f32(const float* p, int valid, bool vec) {
+    float f[8];
+    if (vec && valid >= 8) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = e < valid ? p[e] : 0.f;
+    }
+    uint4 u;
+    u.x = rldm::pack_bf16x2(f[0], f[1]); u.y = rldm::pack_bf16x2(f[2], f[3]);
+    u.z = rldm::pack_bf16x2(f[4], f[5]); u.w = rldm::pack_bf16x2(f[6], f[7]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// ---- convolution / linear (forward and data gradient) ---------------------------------------------------------------
+struct TrConv {
+    const float* x; const bf16_t* w; const float* bias; const float* rowadd; const float* res; float* y;
+    int B, Win, Hin, Cin, Cin_pad, Wout, Hout, N, taps, stride, mode, rowadd_ld, accumulate;
+};
+
+// D[channel][pixel]: lane (pixel l & 31, half l >> 5) holds channels (r & 3) + 8 (r >> 2) + 4 half of its pixel.
+__global__ __launch_bounds__(256) void tr_conv_kernel(const TrConv p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int P = p.B * p.Wout * p.Hout;
+    const int px = blockIdx.x * 64 + (wave & 1) * 32 + l31;
+    const int n0 = blockIdx.y * 64 + (wave >> 1) * 32;
+    if (n0 >= p.N) return;
+    const bool pxok = px < P;
+    const int pc = pxok ? px : 0;
+    const int ho = pc % p.Hout, t1 = pc / p.Hout, wo = t1 % p.Wout, b = t1 / p.Wout;
+    const int nrow = n0 + l31;                                        // this lane's weight row (A operand)
+    const bool rowok = nrow < p.N;
+    const bf16_t* wrow = p.w + (size_t)(rowok ? nrow : 0) * p.taps * p.Cin_pad + 8 * kg;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < p.taps; ++t) {
+        const int dw = p.taps == 9 ? t / 3 - 1 : 0, dh = p.taps == 9 ? t % 3 - 1 : 0;
+        const int sp = pxok ? src_pixel(b, wo, ho, dw, dh, p.stride, p.mode, p.Win, p.Hin) : -1;
+        const float* xrow = p.x + (size_t)(sp < 0 ? 0 : sp) * p.Cin + 8 * kg;
+        const bf16_t* wt = wrow + (size_t)t * p.Cin_pad;
+        for (int c0 = 0; c0 < p.Cin_pad; c0 += 16) {
+            uint4 a = make_uint4(0u, 0u, 0u, 0u);
+            if (rowok) a = *reinterpret_cast<const uint4*>(wt + c0);
+            const int valid = sp < 0 ? 0 : p.Cin - (c0 + 8 * kg);
+            const bf16x8 bv = load_bf16x8_from_f32(xrow + c0, valid, (p.Cin & 3) == 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bv, acc, 0, 0, 0);
+        }
+    }
+    if (!pxok) return;
+    float* yrow = p.y + (size_t)px * p.N;
+    const float* rrow = p.res ? p.res + (size_t)px * p.N : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = n0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (ch >= p.N) continue;
+        float v = acc[r];
+        if (p.bias) v += p.bias[ch];
+        if (p.rowadd) v += p.rowadd[(size_t)b * p.rowadd_ld + ch];
+        if (rrow) v += rrow[ch];
+        if (p.accumulate) v += yrow[ch];
+        yrow[ch] = v;
+    }
+}
+
+// ---- weight gradient --------------------------------------------------------------------------------------------------
+struct TrWgrad {
+    const float* dy; const float* x; float* dw;
+    int B, Win, Hin, Cin, Wout, Hout, N, taps, stride, mode, chunk;      // chunk: pixels per wave (multiple of 16)
+};
+
+// grid (n tiles * c tiles, taps, K splits), 4 waves: wave v contracts pixels [((z * 4 + v) * chunk), + chunk).
+// D[n][c] += A[n][k] B[k][c], k = pixel: both operands are gathered (channels are the contiguous index in memory): a load
+// instruction reads 32 consecutive channels of two pixels.
+__global__ __launch_bounds__(256) void tr_wgrad_kernel(const TrWgrad p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int ct = (p.Cin + 31) / 32;
+    const int n0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+    const int t = blockIdx.y;
+    const int dw = p.taps == 9 ? t / 3 - 1 : 0, dh = p.taps == 9 ? t % 3 - 1 : 0;
+    const int P = p.B * p.Wout * p.Hout;
+    const int kbeg = (blockIdx.z * 4 + wave) * p.chunk;
+    const int kend = min(kbeg + p.chunk, P);
+    const int n = n0 + l31, c = c0 + l31;
+    const bool nok = n < p.N, cok = c < p.Cin;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = k0 + 8 * kg + j;
+            av[j] = 0.f;
+            bv[j] = 0.f;
+            if (px < kend) {
+                if (nok) av[j] = p.dy[(size_t)px * p.N + n];
+                if (cok) {
+                    const int ho = px % p.Hout, t1 = px / p.Hout, wo = t1 % p.Wout, b = t1 / p.Wout;
+                    const int sp = src_pixel(b, wo, ho, dw, dh, p.stride, p.mode, p.Win, p.Hin);
+                    if (sp >= 0) bv[j] = p.x[(size_t)sp * p.Cin + c];
+                }
+            }
+        }
+        uint4 a, bb;
+        a.x = rldm::pack_bf16x2(av[0], av[1]); a.y = rldm::pack_bf16x2(av[2], av[3]);
+        a.z = rldm::pack_bf16x2(av[4], av[5]); a.w = rldm::pack_bf16x2(av[6], av[7]);
+        bb.x = rldm::pack_bf16x2(bv[0], bv[1]); bb.y = rldm::pack_bf16x2(bv[2], bv[3]);
+        bb.z = rldm::pack_bf16x2(bv[4], bv[5]); bb.w = rldm::pack_bf16x2(bv[6], bv[7]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), acc, 0, 0, 0);
+    }
+    if (kbeg >= kend || !cok) return;
+    // lane (column c, half kg) holds rows n0 + (r & 3) + 8 (r >> 2) + 4 kg
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (nn < p.N) unsafeAtomicAdd(p.dw + ((size_t)nn * p.Cin + c) * p.taps + t, acc[r]);
+    }
+}
+
+// rows[b][n] (+)= sum over the pixels of image b of dy[p][n]; total[n] += the same over all images (atomics over b)
+__global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict__ dy, int npix, int N, float* __restrict__ rows,
+                                                        int rows_ld, int rows_acc, float* __restrict__ total) {
+    __shared__ float sh[4][64];
+    const int b = blockIdx.y, ch = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (ch < N)
+        for (int px = q; px < npix; px += 4) acc += dy[((size_t)b * npix + px) * N + ch];
+    sh[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && ch < N) {
+        const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        if (rows) {
+            float* r = rows + (size_t)b * rows_ld + ch;
+            *r = rows_acc ? *r + v : v;
+        }
+        if (total) unsafeAtomicAdd(total + ch, v);
+    }
+}
+
+// ---- GroupNorm ----------------------------------------------------------------------------------------------------------
+__device__ inline double block_sum_d(double v, double* sh) {
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;
+}
+
+// grid (groups, B): stats[b][g] = (mean, rstd) over npix x cpg values
+__global__ __launch_bounds__(256) void tr_gn_stats_kernel(const float* __restrict__ x, int npix, int C, int groups, float eps,
+                                                          float2* __restrict__ stats) {
+    __shared__ double sh[4];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups;
+    const float* base = x + (size_t)b * npix * C + g * cpg;
+    double s = 0.0, ss = 0.0;
+    for (int e = threadIdx.x; e < npix * cpg; e += 256) {
+        const float v = base[(size_t)(e / cpg) * C + (e % cpg)];
+        s += v;
+        ss += (double)v * v;
+    }
+    s = block_sum_d(s, sh);
+    ss = block_sum_d(ss, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)npix * cpg, mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        stats[b * groups + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
+}
+
+__device__ inline float sigmoid_f(float z) { return 1.f / (1.f + __expf(-z)); }
+
+__global__ __launch_bounds__(256) void tr_gn_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int npix,
+                                                        int C, int groups, int silu, size_t total, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((size_t)npix * C));
+    const float2 st = stats[b * groups + c / (C / groups)];
+    const float z = (x[i] - st.x) * st.y * gamma[c] + beta[c];
+    y[i] = silu ? z * sigmoid_f(z) : z;
+}
+
+// grid (groups, B): sums[b][g] = (sum dz gamma, sum dz gamma xhat); dgamma[c] += sum dz xhat, dbeta[c] += sum dz
+// (dz = dy * act'(z)); the first T = 256 - 256 % cpg threads stride by T, so thread t always meets channel t % cpg
+__global__ __launch_bounds__(256) void tr_gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int npix, int C, int groups, int silu,
+                                                               float2* __restrict__ sums, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ double sh[4];
+    __shared__ float shg[256], shb[256];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups;
+    const float2 st = stats[b * groups + g];
+    const size_t base = (size_t)b * npix * C + g * cpg;
+    const int ci = threadIdx.x % cpg, c = g * cpg + ci;
+    const int TT = 256 - 256 % cpg;
+    const float ga = gamma[c], be = beta[c];
+    double s1 = 0.0, s2 = 0.0;
+    float dg = 0.f, db = 0.f;
+    for (int e = threadIdx.x < TT ? threadIdx.x : npix * cpg; e < npix * cpg; e += TT) {
+        const size_t idx = base + (size_t)(e / cpg) * C + ci;
+        const float xh = (x[idx] - st.x) * st.y;
+        float dz = dy[idx];
+        if (silu) {
+            const float z = xh * ga + be, sg = sigmoid_f(z);
+            dz *= sg * (1.f + z * (1.f - sg));
+        }
+        s1 += (double)(dz * ga);
+        s2 += (double)(dz * ga * xh);
+        dg += dz * xh;
+        db += dz;
+    }
+    s1 = block_sum_d(s1, sh);
+    s2 = block_sum_d(s2, sh);
+    shg[threadIdx.x] = dg;
+    shb[threadIdx.x] = db;
+    __syncthreads();
+    if (threadIdx.x < cpg) {
+        float tg = 0.f, tb = 0.f;
+        for (int t = threadIdx.x; t < TT; t += cpg) { tg += shg[t]; tb += shb[t]; }
+        unsafeAtomicAdd(dgamma + g * cpg + threadIdx.x, tg);
+        unsafeAtomicAdd(dbeta + g * cpg + threadIdx.x, tb);
+    }
+    if (threadIdx.x == 0) sums[b * groups + g] = make_float2((float)s1, (float)s2);
+}
+
+__global__ __launch_bounds__(256) void tr_gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float2* __restrict__ stats, const float2* __restrict__ sums,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int npix, int C, int groups, int silu, int accumulate, size_t total,
+                                                              float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C), cpg = C / groups;
+    const int b = (int)(i / ((size_t)npix * C));
+    const int sg_i = b * groups + c / cpg;
+    const float2 st = stats[sg_i], sm = sums[sg_i];
+    const float xh = (x[i] - st.x) * st.y;
+    float dz = dy[i];
+    if (silu) {
+        const float z = xh * gamma[c] + beta[c], sg = sigmoid_f(z);
+        dz *= sg * (1.f + z * (1.f - sg));
+    }
+    const float inv_n = 1.f / ((float)npix * cpg);
+    const float v = st.y * (dz * gamma[c] - sm.x * inv_n - xh * sm.y * inv_n);
+    dx[i] = accumulate ? dx[i] + v : v;
+}
+
+// ---- attention, head_dim 8 -----------------------------------------------------------------------------------------------
+// q, k, v, o: [B][L][C] fp32, head h = channels 8h .. 8h + 8.  grid (ceil(L / 128), heads, B), 128 threads = 128 queries.
+__global__ __launch_bounds__(128) void tr_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, int L, int C, float scale,
+                                                          float* __restrict__ o, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sK = sm;
+    float* sV = sm + (size_t)L * 8;
+    const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+    const size_t base = (size_t)b * L * C + h * 8;
+    for (int e = threadIdx.x; e < L * 8; e += 128) {
+        sK[e] = k[base + (size_t)(e >> 3) * C + (e & 7)];
+        sV[e] = v[base + (size_t)(e >> 3) * C + (e & 7)];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= L) return;
+    float qi[8], acc[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { qi[d] = q[base + (size_t)i * C + d] * scale; acc[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < L; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s += qi[d] * sK[j * 8 + d];
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn), pj = __expf(s - mn);
+        l = l * corr + pj;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[d] = acc[d] * corr + pj * sV[j * 8 + d];
+        m = mn;
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[base + (size_t)i * C + d] = acc[d] * inv;
+    lse[((size_t)b * heads + h) * L + i] = m + __logf(l);
+}
+
+// dq and delta_i = dO_i . O_i ; one thread per query
+__global__ __launch_bounds__(128) void tr_attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, const float* __restrict__ o,
+                                                             const float* __restrict__ dO, const float* __restrict__ lse, int L, int C,
+                                                             float scale, float* __restrict__ dq, float* __restrict__ delta) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sK = sm;
+    float* sV = sm + (size_t)L * 8;
+    const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+    const size_t base = (size_t)b * L * C + h * 8;
+    for (int e = threadIdx.x; e < L * 8; e += 128) {
+        sK[e] = k[base + (size_t)(e >> 3) * C + (e & 7)];
+        sV[e] = v[base + (size_t)(e >> 3) * C + (e & 7)];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= L) return;
+    float qi[8], doi[8], acc[8];
+    float D = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        qi[d] = q[base + (size_t)i * C + d] * scale;
+        doi[d] = dO[base + (size_t)i * C + d];
+        D += doi[d] * o[base + (size_t)i * C + d];
+        acc[d] = 0.f;
+    }
+    const float li = lse[((size_t)b * heads + h) * L + i];
+    for (int j = 0; j < L; ++j) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { s += qi[d] * sK[j * 8 + d]; dp += doi[d] * sV[j * 8 + d]; }
+        const float ds = __expf(s - li) * (dp - D);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[d] += ds * sK[j * 8 + d];
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dq[base + (size_t)i * C + d] = acc[d] * scale;
+    delta[((size_t)b * heads + h) * L + i] = D;
+}
+
+// dk, dv: one thread per key against all queries (Q * scale, dO, lse, delta staged in LDS)
+__global__ __launch_bounds__(128) void tr_attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ dO,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta, int L,
+                                                              int C, float scale, float* __restrict__ dk, float* __restrict__ dv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sQ = sm;
+    float* sDO = sm + (size_t)L * 8;
+    float* sL = sDO + (size_t)L * 8;
+    float* sD = sL + L;
+    const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+    const size_t base = (size_t)b * L * C + h * 8;
+    for (int e = threadIdx.x; e < L * 8; e += 128) {
+        sQ[e] = q[base + (size_t)(e >> 3) * C + (e & 7)] * scale;
+        sDO[e] = dO[base + (size_t)(e >> 3) * C + (e & 7)];
+    }
+    for (int e = threadIdx.x; e < L; e += 128) {
+        sL[e] = lse[((size_t)b * heads + h) * L + e];
+        sD[e] = delta[((size_t)b * heads + h) * L + e];
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= L) return;
+    float kj[8], vj[8], ak[8], av[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        kj[d] = k[base + (size_t)j * C + d];
+        vj[d] = v[base + (size_t)j * C + d];
+        ak[d] = 0.f;
+        av[d] = 0.f;
+    }
+    for (int i = 0; i < L; ++i) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { s += sQ[i * 8 + d] * kj[d]; dp += sDO[i * 8 + d] * vj[d]; }
+        const float pij = __expf(s - sL[i]);
+        const float ds = pij * (dp - sD[i]);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { av[d] += pij * sDO[i * 8 + d]; ak[d] += ds * sQ[i * 8 + d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        dk[base + (size_t)j * C + d] = ak[d];          // sQ already carries the scale
+        dv[base + (size_t)j * C + d] = av[d];
+    }
+}
+
+// ---- elementwise ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tr_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                     size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+
+// dst[p][dst_off + c] (+)= src[p][src_off + c], c < ncopy  (concat, split, accumulate a gradient slice)
+__global__ __launch_bounds__(256) void tr_copy_channels_kernel(const float* __restrict__ src, int src_ld, int src_off,
+                                                               float* __restrict__ dst, int dst_ld, int dst_off, int ncopy,
+                                                               size_t npix, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * ncopy) return;
+    const size_t px = i / ncopy;
+    const int c = (int)(i % ncopy);
+    float* d = dst + px * dst_ld + dst_off + c;
+    const float v = src[px * src_ld + src_off + c];
+    *d = accumulate ? *d + v : v;
+}
+
+// nearest-x2 backward: dx[b][w][h][c] = sum of the 2 x 2 block of du[b][2w..][2h..][c]
+__global__ __launch_bounds__(256) void tr_sum2x2_kernel(const float* __restrict__ du, int B, int W, int H, int C,
+                                                        float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * W * H * C) return;
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int h = (int)(t % H);
+    t /= H;
+    const int w = (int)(t % W), b = (int)(t / W);
+    const size_t r0 = (((size_t)b * 2 * W + 2 * w) * 2 * H + 2 * h) * C + c, r1 = r0 + (size_t)2 * H * C;
+    dx[i] = (du[r0] + du[r0 + C]) + (du[r1] + du[r1 + C]);
+}
+
+__global__ __launch_bounds__(256) void tr_silu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ y,
+                                                      size_t n, int backward, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float z = x[i], sg = sigmoid_f(z);
+    float v = backward ? dy[i] * sg * (1.f + z * (1.f - sg)) : z * sg;
+    if (accumulate) v += y[i];
+    y[i] = v;
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0): e = [cos(t f_i), sin(t f_i)], f_i = exp(-ln(1e4) i / half)
+__global__ __launch_bounds__(256) void tr_timestep_embed_kernel(const long long* __restrict__ t, int B, int dim, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i % dim, half = dim / 2;
+    const float f = expf(-9.210340371976184f * (float)(j % half) / (float)half);
+    const float a = (float)t[b] * f;
+    out[i] = j < half ? cosf(a) : sinf(a);
+}
+
+// NCHW latents (+ constant pos-encoding channel: 1 at azimuth 0) -> NHWC [B][W][H][C + pos]
+__global__ __launch_bounds__(256) void tr_pack_input_kernel(const float* __restrict__ x, int B, int C, int W, int H, int pos,
+                                                            float* __restrict__ y) {
+    const int Co = C + pos;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * W * H * Co) return;
+    const int c = (int)(i % Co);
+    size_t t = i / Co;
+    const int h = (int)(t % H);
+    t /= H;
+    const int w = (int)(t % W), b = (int)(t / W);
+    y[i] = c < C ? x[(((size_t)b * C + c) * W + w) * H + h] : (w == 0 ? 1.f : 0.f);
+}
+
+// NHWC -> NCHW (model_output for the caller)
+__global__ __launch_bounds__(256) void tr_unpack_kernel(const float* __restrict__ x, int B, int C, int W, int H, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * W * H * C) return;
+    const int h = (int)(i % H);
+    size_t t = i / H;
+    const int w = (int)(t % W);
+    t /= W;
+    const int c = (int)(t % C), b = (int)(t / C);
+    y[i] = x[(((size_t)b * W + w) * H + h) * C + c];
+}
+
+// loss = mean_b( weight[b] * mean_{c,w,h} (pred - target)^2 ); dpred = weight[b] * 2 (pred - target) / (B * C * W * H)
+// pred NHWC, target NCHW; loss accumulated in fp64
+__global__ __launch_bounds__(256) void tr_mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                     const float* __restrict__ weight, int B, int C, int W, int H,
+                                                     float* __restrict__ dpred, double* __restrict__ loss) {
+    __shared__ double sh[4];
+    const size_t total = (size_t)B * W * H * C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double part = 0.0;
+    if (i < total) {
+        const int c = (int)(i % C);
+        size_t t = i / C;
+        const int h = (int)(t % H);
+        t /= H;
+        const int w = (int)(t % W), b = (int)(t / W);
+        const float d = pred[i] - target[(((size_t)b * C + c) * W + w) * H + h];
+        const float wb = weight ? weight[b] : 1.f;
+        dpred[i] = wb * 2.f * d / (float)total;
+        part = (double)wb * (double)d * (double)d / (double)total;
+    }
+    part = block_sum_d(part, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, part);
+}
+
+__global__ __launch_bounds__(256) void tr_sqnorm_kernel(const float* __restrict__ g, size_t n, double* __restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += (double)g[i] * g[i];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
+}
+
+// torch.optim.AdamW step on flat buffers with the clip_grad_norm_ coefficient folded in, then diffusers EMAModel.step
+struct TrAdam {
+    float* p; const float* g; float* m; float* v; float* ema; const double* sqnorm;
+    size_t n; float lr, b1, b2, eps, wd, bc1, bc2, max_norm, ema_decay;
+};
+__global__ __launch_bounds__(256) void tr_adamw_kernel(const TrAdam a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    float coef = 1.f;
+    if (a.sqnorm && a.max_norm > 0.f) {
+        const float tn = (float)sqrt(*a.sqnorm);
+        coef = fminf(a.max_norm / (tn + 1e-6f), 1.f);
+    }
+    const float g = a.g[i] * coef;
+    float w = a.p[i] * (1.f - a.lr * a.wd);
+    const float m = a.b1 * a.m[i] + (1.f - a.b1) * g;
+    const float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
+    w -= (a.lr / a.bc1) * (m / denom);
+    a.p[i] = w;
+    if (a.ema) a.ema[i] -= (1.f - a.ema_decay) * (a.ema[i] - w);
+}
+
+// master fp32 [N][Cin][taps] -> forward copy bf16 [N][taps][Cin_pad] and data-gradient copy bf16 [Cin][taps][N_pad]
+// (tap flipped: 8 - t; 1x1: plain transpose); pads are zero
+__global__ __launch_bounds__(256) void tr_pack_weights_kernel(const float* __restrict__ w, int N, int Cin, int taps, int Cin_pad,
+                                                              int N_pad, bf16_t* __restrict__ wf, bf16_t* __restrict__ wt) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nf = (size_t)N * taps * Cin_pad, nt = (size_t)Cin * taps * N_pad;
+    if (i < nf) {
+        const int c = (int)(i % Cin_pad);
+        const int t = (int)((i / Cin_pad) % taps), n = (int)(i / ((size_t)Cin_pad * taps));
+        wf[i] = c < Cin ? rldm::f32_to_bf16(w[((size_t)n * Cin + c) * taps + t]) : (bf16_t)0;
+    }
+    if (wt && i < nt) {
+        const int n = (int)(i % N_pad);
+        const int t = (int)((i / N_pad) % taps), c = (int)(i / ((size_t)N_pad * taps));
+        wt[i] = n < N ? rldm::f32_to_bf16(w[((size_t)n * Cin + c) * taps + (taps - 1 - t)]) : (bf16_t)0;
+    }
+}
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+#define TR_LAUNCH_CHECK() RLDM_HIP_CHECK(hipGetLastError())
+
+extern "C" {
+
+int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* rowadd,
+                    int rowadd_ld, const float* res, float* y, int accumulate, void* stream) {
+    RLDM_REQUIRE(d && x && w_packed && y, "null argument");
+    RLDM_REQUIRE((d->taps == 1 || d->taps == 9) && (d->stride == 1 || d->stride == 2) && d->mode >= 0 && d->mode <= 2, "bad conv desc");
+    RLDM_REQUIRE(d->B > 0 && d->Win > 0 && d->Hin > 0 && d->Cin > 0 && d->N > 0, "bad shape");
+    TrConv p;
+    p.x = x; p.w = static_cast<const bf16_t*>(w_packed); p.bias = bias; p.rowadd = rowadd; p.res = res; p.y = y;
+    p.B = d->B; p.Win = d->Win; p.Hin = d->Hin; p.Cin = d->Cin; p.Cin_pad = (d->Cin + 15) / 16 * 16;
+    const int sh = d->mode ? 1 : 0;
+    p.Wout = (d->Win << sh) / d->stride; p.Hout = (d->Hin << sh) / d->stride;
+    RLDM_REQUIRE(p.Wout > 0 && p.Hout > 0, "empty output");
+    p.N = d->N; p.taps = d->taps; p.stride = d->stride; p.mode = d->mode; p.rowadd_ld = rowadd_ld; p.accumulate = accumulate;
+    const int P = p.B * p.Wout * p.Hout;
+    tr_conv_kernel<<<dim3((P + 63) / 64, (p.N + 63) / 64), 256, 0, (hipStream_t)stream>>>(p);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, void* stream) {
+    RLDM_REQUIRE(d && dy && x && dw, "null argument");
+    RLDM_REQUIRE((d->taps == 1 || d->taps == 9) && (d->stride == 1 || d->stride == 2) && d->mode >= 0 && d->mode <= 2, "bad conv desc");
+    TrWgrad p;
+    p.dy = dy; p.x = x; p.dw = dw;
+    p.B = d->B; p.Win = d->Win; p.Hin = d->Hin; p.Cin = d->Cin; p.N = d->N; p.taps = d->taps; p.stride = d->stride; p.mode = d->mode;
+    const int sh = d->mode ? 1 : 0;
+    p.Wout = (d->Win << sh) / d->stride; p.Hout = (d->Hin << sh) / d->stride;
+    const int P = p.B * p.Wout * p.Hout;
+    const int tiles = ((p.N + 31) / 32) * ((p.Cin + 31) / 32) * p.taps;
+    int splits = 1;
+    while (tiles * splits < 2048 && (P + splits * 2 * 64 - 1) / (splits * 2 * 64) >= 4) splits *= 2;     // >= 64 pixels per wave
+    p.chunk = ((P + splits * 4 - 1) / (splits * 4) + 15) / 16 * 16;
+    tr_wgrad_kernel<<<dim3(((p.N + 31) / 32) * ((p.Cin + 31) / 32), p.taps, splits), 256, 0, (hipStream_t)stream>>>(p);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int rows_ld, int rows_accumulate, float* total,
+                      void* stream) {
+    RLDM_REQUIRE(dy && (rows || total), "null argument");
+    tr_colsum_kernel<<<dim3((N + 63) / 64, B), 256, 0, (hipStream_t)stream>>>(dy, npix, N, rows, rows_ld, rows_accumulate, total);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, float eps, const float* gamma, const float* beta,
+                          int silu, float* stats, float* y, void* stream) {
+    RLDM_REQUIRE(x && gamma && beta && stats && y, "null argument");
+    RLDM_REQUIRE(C % groups == 0, "channels must be a multiple of the group count");
+    hipStream_t st = (hipStream_t)stream;
+    tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
+    const size_t total = (size_t)B * npix * C;
+    tr_gn_fwd_kernel<<<nblk(total), 256, 0, st>>>(x, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C, groups, silu, total, y);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, int B, int npix, int C, int groups,
+                           const float* gamma, const float* beta, int silu, float* scratch, float* dx, int accumulate,
+                           float* dgamma, float* dbeta, void* stream) {
+    RLDM_REQUIRE(x && dy && stats && gamma && beta && scratch && dx && dgamma && dbeta, "null argument");
+    RLDM_REQUIRE(C % groups == 0 && C / groups <= 256, "channels per group must be <= 256");
+    hipStream_t st = (hipStream_t)stream;
+    tr_gn_bwd_reduce_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
+                                                             groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
+    const size_t total = (size_t)B * npix * C;
+    tr_gn_bwd_apply_kernel<<<nblk(total), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats),
+                                                        reinterpret_cast<const float2*>(scratch), gamma, beta, npix, C, groups, silu,
+                                                        accumulate, total, dx);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+static int attn_lds(const void* fn, size_t bytes) {
+    RLDM_REQUIRE(bytes <= 160 * 1024, "attention: sequence too long for the LDS-resident head (L <= 2048)");
+    RLDM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+int rldm_train_attention_forward(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse,
+                                 void* stream) {
+    RLDM_REQUIRE(q && k && v && o && lse, "null argument");
+    RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
+    const size_t lds = (size_t)L * 16 * sizeof(float);
+    if (attn_lds(reinterpret_cast<const void*>(tr_attn_fwd_kernel), lds)) return 1;
+    tr_attn_fwd_kernel<<<dim3((L + 127) / 128, C / 8, B), 128, lds, (hipStream_t)stream>>>(q, k, v, L, C, 0.35355339059327373f, o, lse);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_attention_backward(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
+                                  int B, int L, int C, float* delta, float* dq, float* dk, float* dv, void* stream) {
+    RLDM_REQUIRE(q && k && v && o && dO && lse && delta && dq && dk && dv, "null argument");
+    RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 0.35355339059327373f;
+    const size_t lds1 = (size_t)L * 16 * sizeof(float), lds2 = (size_t)L * 18 * sizeof(float);
+    if (attn_lds(reinterpret_cast<const void*>(tr_attn_bwd_dq_kernel), lds1)) return 1;
+    if (attn_lds(reinterpret_cast<const void*>(tr_attn_bwd_dkv_kernel), lds2)) return 1;
+    const dim3 grid((L + 127) / 128, C / 8, B);
+    tr_attn_bwd_dq_kernel<<<grid, 128, lds1, st>>>(q, k, v, o, dO, lse, L, C, scale, dq, delta);
+    tr_attn_bwd_dkv_kernel<<<grid, 128, lds2, st>>>(q, k, v, dO, lse, delta, L, C, scale, dk, dv);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    RLDM_REQUIRE(a && b && y && n >= 0, "null argument");
+    if (n) tr_add_kernel<<<nblk((size_t)n), 256, 0, (hipStream_t)stream>>>(a, b, y, (size_t)n);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_copy_channels(const float* src, int src_ld, int src_off, float* dst, int dst_ld, int dst_off, int ncopy,
+                             int64_t npix, int accumulate, void* stream) {
+    RLDM_REQUIRE(src && dst && ncopy > 0 && npix >= 0, "null argument");
+    RLDM_REQUIRE(src_off + ncopy <= src_ld && dst_off + ncopy <= dst_ld, "channel slice out of range");
+    if (npix) tr_copy_channels_kernel<<<nblk((size_t)npix * ncopy), 256, 0, (hipStream_t)stream>>>(src, src_ld, src_off, dst, dst_ld,
+                                                                                                   dst_off, ncopy, (size_t)npix, accumulate);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_sum2x2(const float* du, int B, int W, int H, int C, float* dx, void* stream) {
+    RLDM_REQUIRE(du && dx, "null argument");
+    tr_sum2x2_kernel<<<nblk((size_t)B * W * H * C), 256, 0, (hipStream_t)stream>>>(du, B, W, H, C, dx);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_silu(const float* x, const float* dy, float* y, int64_t n, int backward, int accumulate, void* stream) {
+    RLDM_REQUIRE(x && y && (!backward || dy), "null argument");
+    if (n) tr_silu_kernel<<<nblk((size_t)n), 256, 0, (hipStream_t)stream>>>(x, dy, y, (size_t)n, backward, accumulate);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_timestep_embedding(const int64_t* timesteps, int B, int dim, float* out, void* stream) {
+    RLDM_REQUIRE(timesteps && out && dim % 2 == 0, "null argument");
+    tr_timestep_embed_kernel<<<nblk((size_t)B * dim), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const long long*>(timesteps), B,
+                                                                                   dim, out);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_pack_input(const float* x, int B, int C, int W, int H, int pos_encoding, float* y, void* stream) {
+    RLDM_REQUIRE(x && y, "null argument");
+    tr_pack_input_kernel<<<nblk((size_t)B * W * H * (C + (pos_encoding ? 1 : 0))), 256, 0, (hipStream_t)stream>>>(
+        x, B, C, W, H, pos_encoding ? 1 : 0, y);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_unpack_output(const float* x, int B, int C, int W, int H, float* y, void* stream) {
+    RLDM_REQUIRE(x && y, "null argument");
+    tr_unpack_kernel<<<nblk((size_t)B * W * H * C), 256, 0, (hipStream_t)stream>>>(x, B, C, W, H, y);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_mse(const float* pred, const float* target, const float* weight, int B, int C, int W, int H, float* dpred,
+                   double* loss, void* stream) {
+    RLDM_REQUIRE(pred && target && dpred && loss, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    RLDM_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(double), st));
+    tr_mse_kernel<<<nblk((size_t)B * W * H * C), 256, 0, st>>>(pred, target, weight, B, C, W, H, dpred, loss);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_sqnorm(const float* g, int64_t n, double* out, void* stream) {
+    RLDM_REQUIRE(g && out && n >= 0, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    RLDM_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), st));
+    if (n) tr_sqnorm_kernel<<<std::min<unsigned>(nblk((size_t)n), 2048u), 256, 0, st>>>(g, (size_t)n, out);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
+                     int64_t n, const rldm_adamw_config* c, void* stream) {
+    RLDM_REQUIRE(params && grads && exp_avg && exp_avg_sq && c && n >= 0, "null argument");
+    RLDM_REQUIRE(c->step >= 1, "step counts from 1 (torch.optim.AdamW)");
+    TrAdam a;
+    a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.ema = ema; a.sqnorm = sqnorm; a.n = (size_t)n;
+    a.lr = c->lr; a.b1 = c->beta1; a.b2 = c->beta2; a.eps = c->eps; a.wd = c->weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)c->beta1, (double)c->step));
+    a.bc2 = (float)(1.0 - pow((double)c->beta2, (double)c->step));
+    a.max_norm = c->max_grad_norm; a.ema_decay = c->ema_decay;
+    if (n) tr_adamw_kernel<<<nblk((size_t)n), 256, 0, (hipStream_t)stream>>>(a);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_pack_weights(const float* w, int N, int Cin, int taps, void* w_forward, void* w_transposed, void* stream) {
+    RLDM_REQUIRE(w && w_forward && (taps == 1 || taps == 9), "null argument");
+    const int Cin_pad = (Cin + 15) / 16 * 16, N_pad = (N + 15) / 16 * 16;
+    const size_t n = std::max((size_t)N * taps * Cin_pad, w_transposed ? (size_t)Cin * taps * N_pad : (size_t)0);
+    tr_pack_weights_kernel<<<nblk(n), 256, 0, (hipStream_t)stream>>>(w, N, Cin, taps, Cin_pad, N_pad, static_cast<bf16_t*>(w_forward),
+                                                                    static_cast<bf16_t*>(w_transposed));
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""Thin wrappers over the op-level training entry points of librangeldm_hip (rangeldm_amd/csrc/train.hip).
+
+Tensors are device fp32, activations / gradients channels-last (B, W, H, C).  torch is used for allocation and streams
+only; every arithmetic operation below is a HIP kernel behind the C ABI.  No CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _s(t):
+    return _lib.stream_ptr(t.device)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+def empty(shape, like=None, device=None):
+    return torch.empty(shape, dtype=torch.float32, device=like.device if like is not None else device)
+
+
+def conv_desc(x, N, taps, stride=1, mode=0):
+    d = _lib.TrainConvDescC()
+    d.B, d.Win, d.Hin, d.Cin = x.shape
+    d.N, d.taps, d.stride, d.mode = N, taps, stride, mode
+    return d
+
+
+def out_size(W, H, stride, mode):
+    sh = 1 if mode else 0
+    return (W << sh) // stride, (H << sh) // stride
+
+
+def pack_weights(w, taps, want_transposed=True):
+    """master fp32 (N, Cin, k, k) or (N, Cin) -> (bf16 [N][taps][ceil16 Cin], bf16 [Cin][taps][ceil16 N] flipped)"""
+    N, Cin = w.shape[0], w.shape[1]
+    cp, npad = (Cin + 15) // 16 * 16, (N + 15) // 16 * 16
+    wf = torch.empty((N, taps, cp), dtype=torch.bfloat16, device=w.device)
+    wt = torch.empty((Cin, taps, npad), dtype=torch.bfloat16, device=w.device) if want_transposed else None
+    _chk(_lib.lib().rldm_train_pack_weights(_p(w), N, Cin, taps, _p(wf), _p(wt), _s(w)), "rldm_train_pack_weights")
+    return wf, wt
+
+
+def conv(x, w_packed, N, taps, stride=1, mode=0, bias=None, rowadd=None, res=None, out=None, accumulate=False):
+    """y = conv(x) + bias + rowadd[b] + res.  x (B, W, H, Cin) -> (B, Wo, Ho, N)."""
+    d = conv_desc(x, N, taps, stride, mode)
+    Wo, Ho = out_size(x.shape[1], x.shape[2], stride, mode)
+    y = out if out is not None else empty((x.shape[0], Wo, Ho, N), x)
+    _chk(_lib.lib().rldm_train_conv(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(rowadd),
+                                    0 if rowadd is None else rowadd.shape[1], _p(res), _p(y), 1 if accumulate else 0, _s(x)),
+         "rldm_train_conv")
+    return y
+
+
+def wgrad(dy, x, dw, taps, stride=1, mode=0):
+    """dw (N, Cin, k, k) += dy (x) x  (dw is a view into the zeroed flat gradient buffer)."""
+    d = conv_desc(x, dy.shape[3], taps, stride, mode)
+    _chk(_lib.lib().rldm_train_wgrad(C.byref(d), _p(dy), _p(x), _p(dw), _s(x)), "rldm_train_wgrad")
+
+
+def colsum(dy, rows=None, total=None, rows_accumulate=False):
+    B, W, H, N = dy.shape
+    _chk(_lib.lib().rldm_train_colsum(_p(dy), B, W * H, N, _p(rows), 0 if rows is None else rows.shape[1],
+                                      1 if rows_accumulate else 0, _p(total), _s(dy)), "rldm_train_colsum")
+
+
+def gn_forward(x, gamma, beta, groups, eps, silu):
+    B, W, H, Cc = x.shape
+    stats = empty((B, groups, 2), x)
+    y = torch.empty_like(x)
+    _chk(_lib.lib().rldm_train_gn_forward(_p(x), B, W * H, Cc, groups, float(eps), _p(gamma), _p(beta), 1 if silu else 0,
+                                          _p(stats), _p(y), _s(x)), "rldm_train_gn_forward")
+    return y, stats
+
+
+def gn_backward(x, dy, stats, gamma, beta, groups, silu, dgamma, dbeta, dx=None, accumulate=False):
+    B, W, H, Cc = x.shape
+    scratch = empty((B, groups, 2), x)
+    dx = dx if dx is not None else torch.empty_like(x)
+    _chk(_lib.lib().rldm_train_gn_backward(_p(x), _p(dy), _p(stats), B, W * H, Cc, groups, _p(gamma), _p(beta),
+                                           1 if silu else 0, _p(scratch), _p(dx), 1 if accumulate else 0, _p(dgamma),
+                                           _p(dbeta), _s(x)), "rldm_train_gn_backward")
+    return dx
+
+
+def attention_forward(q, k, v):
+    """q, k, v (B, L, C) -> o (B, L, C), lse (B, C/8, L)"""
+    B, L, Cc = q.shape
+    o = torch.empty_like(q)
+    lse = empty((B, Cc // 8, L), q)
+    _chk(_lib.lib().rldm_train_attention_forward(_p(q), _p(k), _p(v), B, L, Cc, _p(o), _p(lse), _s(q)),
+         "rldm_train_attention_forward")
+    return o, lse
+
+
+def attention_backward(q, k, v, o, dO, lse):
+    B, L, Cc = q.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    delta = torch.empty_like(lse)
+    _chk(_lib.lib().rldm_train_attention_backward(_p(q), _p(k), _p(v), _p(o), _p(dO), _p(lse), B, L, Cc, _p(delta), _p(dq),
+                                                  _p(dk), _p(dv), _s(q)), "rldm_train_attention_backward")
+    return dq, dk, dv
+
+
+def add(a, b, out=None):
+    y = out if out is not None else torch.empty_like(a)
+    _chk(_lib.lib().rldm_train_add(_p(a), _p(b), _p(y), a.numel(), _s(a)), "rldm_train_add")
+    return y
+
+
+def copy_channels(src, src_off, dst, dst_off, ncopy, accumulate=False):
+    npix = src.numel() // src.shape[-1]
+    _chk(_lib.lib().rldm_train_copy_channels(_p(src), src.shape[-1], src_off, _p(dst), dst.shape[-1], dst_off, ncopy, npix,
+                                             1 if accumulate else 0, _s(src)), "rldm_train_copy_channels")
+
+
+def concat(a, b):
+    y = empty((*a.shape[:-1], a.shape[-1] + b.shape[-1]), a)
+    copy_channels(a, 0, y, 0, a.shape[-1])
+    copy_channels(b, 0, y, a.shape[-1], b.shape[-1])
+    return y
+
+
+def sum2x2(du):
+    B, W2, H2, Cc = du.shape
+    dx = empty((B, W2 // 2, H2 // 2, Cc), du)
+    _chk(_lib.lib().rldm_train_sum2x2(_p(du), B, W2 // 2, H2 // 2, Cc, _p(dx), _s(du)), "rldm_train_sum2x2")
+    return dx
+
+
+def silu(x):
+    y = torch.empty_like(x)
+    _chk(_lib.lib().rldm_train_silu(_p(x), None, _p(y), x.numel(), 0, 0, _s(x)), "rldm_train_silu")
+    return y
+
+
+def silu_backward(x, dy, out=None, accumulate=False):
+    y = out if out is not None else torch.empty_like(x)
+    _chk(_lib.lib().rldm_train_silu(_p(x), _p(dy), _p(y), x.numel(), 1, 1 if accumulate else 0, _s(x)), "rldm_train_silu")
+    return y
+
+
+def timestep_embedding(timesteps, dim):
+    t = timesteps.to(torch.int64).contiguous()
+    out = empty((t.shape[0], dim), t)
+    _chk(_lib.lib().rldm_train_timestep_embedding(_p(t), t.shape[0], dim, _p(out), _s(t)), "rldm_train_timestep_embedding")
+    return out
+
+
+def pack_input(x_nchw, pos_encoding):
+    B, Cc, W, H = x_nchw.shape
+    y = empty((B, W, H, Cc + (1 if pos_encoding else 0)), x_nchw)
+    _chk(_lib.lib().rldm_train_pack_input(_p(x_nchw), B, Cc, W, H, 1 if pos_encoding else 0, _p(y), _s(x_nchw)),
+         "rldm_train_pack_input")
+    return y
+
+
+def unpack_output(y_nhwc):
+    B, W, H, Cc = y_nhwc.shape
+    out = empty((B, Cc, W, H), y_nhwc)
+    _chk(_lib.lib().rldm_train_unpack_output(_p(y_nhwc), B, Cc, W, H, _p(out), _s(y_nhwc)), "rldm_train_unpack_output")
+    return out
+
+
+def mse(pred_nhwc, target_nchw, weight=None):
+    """-> (loss: 0-d float64 device tensor, dpred (B, W, H, C))"""
+    B, W, H, Cc = pred_nhwc.shape
+    dpred = torch.empty_like(pred_nhwc)
+    loss = torch.empty((), dtype=torch.float64, device=pred_nhwc.device)
+    _chk(_lib.lib().rldm_train_mse(_p(pred_nhwc), _p(target_nchw), _p(weight), B, Cc, W, H, _p(dpred), _p(loss),
+                                   _s(pred_nhwc)), "rldm_train_mse")
+    return loss, dpred
+
+
+def sqnorm(g):
+    out = torch.empty((), dtype=torch.float64, device=g.device)
+    _chk(_lib.lib().rldm_train_sqnorm(_p(g), g.numel(), _p(out), _s(g)), "rldm_train_sqnorm")
+    return out
+
+
+def adamw(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, ema=None,
+          ema_decay=0.0, sqnorm_dev=None, max_grad_norm=0.0):
+    c = _lib.AdamWConfigC()
+    c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+    c.max_grad_norm, c.ema_decay, c.step = float(max_grad_norm), float(ema_decay), int(step)
+    _chk(_lib.lib().rldm_train_adamw(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(ema), _p(sqnorm_dev),
+                                     params.numel(), C.byref(c), _s(params)), "rldm_train_adamw")

@@ -1,0 +1,401 @@
+"""UNet training step on MI355X: the counterpart of ldm/train_unconditional.py:466-558.
+
+`UNetTrainer` owns flat fp32 buffers (parameters, gradients, AdamW moments, EMA copy; state-dict views into them) and
+drives the op-level HIP kernels of rangeldm_amd/csrc/train.hip through a host-side tape: `forward` records one backward
+closure per op (conv / linear, GroupNorm(+SiLU), head_dim-8 attention, concat, nearest-x2, stride-2), `backward` replays
+them in reverse.  Data parallelism = one process per GPU; gradients are averaged with RCCL all-reduce over a few large
+buckets of the flat gradient buffer, each launched as soon as backward has finished the bucket's parameters
+(bucket boundaries: rangeldm_amd.training.plan_buckets).  No torch autograd, no torch compute ops on the path (torch
+allocates and zeroes buffers and runs the collectives); no CPU fallback.
+
+Parity: tests/test_training.py compares every parameter gradient of a small UNet, and the parameters after optimizer
+steps, with torch autograd / torch.optim.AdamW on the oracle (oracle/unet.py).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import train_ops as T
+from .config import UNetConfig
+from .params import unet_param_shapes
+
+
+def plan_buckets(sizes, target_elems):
+    """Contiguous buckets over the flat gradient buffer, in parameter order: [(first_param, end_param, offset, numel)].
+    Backward finishes parameters in REVERSE order, so the last bucket is reduced first."""
+    out, start, off, acc, pos = [], 0, 0, 0, 0
+    for i, n in enumerate(sizes):
+        acc += n
+        pos += n
+        if acc >= target_elems or i == len(sizes) - 1:
+            out.append((start, i + 1, off, acc))
+            start, off, acc = i + 1, pos, 0
+    return out
+
+
+def cosine_lr(step, base_lr, warmup, total):
+    """diffusers get_scheduler("cosine", num_warmup_steps, num_training_steps) (ldm/train_unconditional.py:394-399)."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    progress = (step - warmup) / max(1, total - warmup)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+def ema_decay(optimization_step, max_decay=0.9999, inv_gamma=1.0, power=0.75, min_decay=0.0):
+    """diffusers EMAModel.get_decay with use_ema_warmup=True (ldm/train_unconditional.py:320-329)."""
+    step = max(0, optimization_step - 1)
+    if step <= 0:
+        return 0.0
+    return max(min(1.0 - (1.0 + step / inv_gamma) ** -power, max_decay), min_decay)
+
+
+def snr_weights(alphas_cumprod, timesteps, snr_gamma):
+    """min(SNR, gamma) / SNR (ldm/train_unconditional.py:529-538, epsilon prediction)."""
+    ac = alphas_cumprod[timesteps.cpu()].double()
+    snr = ac / (1.0 - ac)
+    return (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).float()
+
+
+class UNetTrainer:
+    def __init__(self, config, state_dict, device="cuda", lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8,
+                 max_grad_norm=1.0, use_ema=True, ema_max_decay=0.9999, ema_inv_gamma=1.0, ema_power=0.75,
+                 lr_warmup_steps=500, total_steps=100000, bucket_mb=32):
+        self.cfg = config if isinstance(config, UNetConfig) else UNetConfig(**config)
+        _lib.require_gpu()
+        self.device = torch.device(device)
+        self.shapes = unet_param_shapes(self.cfg)
+        self.names = list(self.shapes)
+        sizes = [int(np.prod(self.shapes[n])) for n in self.names]
+        self.offsets = dict(zip(self.names, np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()))
+        self.sizes = dict(zip(self.names, sizes))
+        self.numel = int(sum(sizes))
+        z = lambda: torch.zeros(self.numel, dtype=torch.float32, device=self.device)      # noqa: E731
+        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+        self.ema = z() if use_ema else None
+        host = np.empty(self.numel, np.float32)
+        for n in self.names:
+            a = state_dict[n]
+            a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            if tuple(a.shape) != tuple(self.shapes[n]):
+                raise RuntimeError(f"size mismatch for {n}: {tuple(a.shape)} vs {tuple(self.shapes[n])}")
+            host[self.offsets[n]:self.offsets[n] + self.sizes[n]] = a.reshape(-1)
+        self.params.copy_(torch.from_numpy(host))
+        if self.ema is not None:
+            self.ema.copy_(self.params)
+        self.p = {n: self._view(self.params, n) for n in self.names}
+        self.g = {n: self._view(self.grads, n) for n in self.names}
+        # bf16 operand copies of every conv / linear weight: forward [N][taps][Cin], data gradient [Cin][taps][N]
+        self.wf, self.wt = {}, {}
+        for n in self.names:
+            if n.endswith(".weight") and len(self.shapes[n]) >= 2:
+                N, Cin = self.shapes[n][:2]
+                taps = 9 if len(self.shapes[n]) == 4 and self.shapes[n][2] == 3 else 1
+                self.wf[n] = torch.empty((N, taps, (Cin + 15) // 16 * 16), dtype=torch.bfloat16, device=self.device)
+                need_t = n not in ("conv_in.weight", "time_embedding.linear_1.weight")
+                self.wt[n] = torch.empty((Cin, taps, (N + 15) // 16 * 16), dtype=torch.bfloat16, device=self.device) if need_t else None
+        self.repack()
+        self.hp = dict(lr=lr, betas=betas, weight_decay=weight_decay, eps=eps, max_grad_norm=max_grad_norm,
+                       ema_max_decay=ema_max_decay, ema_inv_gamma=ema_inv_gamma, ema_power=ema_power,
+                       lr_warmup_steps=lr_warmup_steps, total_steps=total_steps)
+        self.global_step = 0
+        self.buckets = plan_buckets([self.sizes[n] for n in self.names], bucket_mb * (1 << 20) // 4)
+        self._tape, self._grad, self._keep = [], {}, []
+        self._pending, self._ready = [], None
+        self.last_grad_norm = None
+
+    # ---- parameters -------------------------------------------------------------------------------------------
+    def _view(self, flat, n):
+        return flat[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(self.shapes[n])
+
+    def repack(self):
+        import ctypes as C
+        L = _lib.lib()
+        for n, wf in self.wf.items():
+            N, Cin = self.shapes[n][:2]
+            wt = self.wt[n]
+            _lib.check(L.rldm_train_pack_weights(C.c_void_p(self.p[n].data_ptr()), N, Cin, wf.shape[1], C.c_void_p(wf.data_ptr()),
+                                                 C.c_void_p(wt.data_ptr()) if wt is not None else None,
+                                                 _lib.stream_ptr(self.device)), "rldm_train_pack_weights")
+
+    def state_dict(self, ema=False):
+        flat = (self.ema if ema else self.params).cpu()
+        return OrderedDict((n, flat[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(self.shapes[n]).clone())
+                           for n in self.names)
+
+    def save_pretrained(self, output_dir):
+        """`unet/` (+ `unet_ema/`) in the layout of the reference's save hook (ldm/train_unconditional.py:148-153)."""
+        import os
+        from .checkpoint import save_model_dir, unet_config_to_diffusers
+        save_model_dir(os.path.join(output_dir, "unet"), unet_config_to_diffusers(self.cfg), self.state_dict())
+        if self.ema is not None:
+            save_model_dir(os.path.join(output_dir, "unet_ema"), unet_config_to_diffusers(self.cfg), self.state_dict(ema=True))
+
+    # ---- tape -------------------------------------------------------------------------------------------------
+    def _acc(self, t, g, owned):
+        """Add gradient g to tensor t's slot; `owned`: g is a fresh buffer nobody else reads."""
+        if t is None:
+            return
+        k = id(t)
+        if k not in self._grad:
+            self._grad[k] = (g, owned)
+        else:
+            cur, cur_owned = self._grad[k]
+            self._grad[k] = (T.add(cur, g, out=cur), True) if cur_owned else (T.add(cur, g), True)
+
+    def _pop(self, t):
+        g = self._grad.pop(id(t), None)
+        return None if g is None else g[0]
+
+    def _done(self, *names):
+        """The gradients of these parameters are final: launch the all-reduce of every bucket that just completed."""
+        if self._ready is None:
+            return
+        for n in names:
+            i = self._pidx[n]
+            for b, (lo, hi, off, cnt) in enumerate(self.buckets):
+                if lo <= i < hi:
+                    self._ready[b] -= 1
+                    if self._ready[b] == 0:
+                        seg = self.grads[off:off + cnt]
+                        self._pending.append(torch.distributed.all_reduce(seg, op=self._reduce_op, async_op=True))
+
+    # ---- ops --------------------------------------------------------------------------------------------------
+    def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True):
+        w = name + ".weight"
+        N = self.shapes[w][0]
+        taps = self.wf[w].shape[1]
+        y = T.conv(x, self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], rowadd=rowadd, res=res)
+
+        def bwd():
+            dy = self._pop(y)
+            T.wgrad(dy, x, self.g[w], taps, stride, mode)
+            drow = None
+            if rowadd is not None:
+                drow = T.empty(rowadd.shape, rowadd)
+            T.colsum(dy, rows=drow, total=self.g[name + ".bias"])
+            self._done(w, name + ".bias")
+            if rowadd is not None:
+                self._acc(rowadd, drow, True)
+            if res is not None:
+                self._acc(res, dy, False)
+            if need_dx:
+                wt = self.wt[w]
+                Cin = x.shape[3]
+                if stride == 2:
+                    dx = T.conv(dy, wt, Cin, taps, 1, 2)
+                elif mode == 1:
+                    dx = T.sum2x2(T.conv(dy, wt, Cin, taps, 1, 0))
+                else:
+                    dx = T.conv(dy, wt, Cin, taps, 1, 0)
+                self._acc(x, dx, True)
+        self._tape.append(bwd)
+        return y
+
+    def _linear(self, x2d, name, need_dx=True):
+        """x2d (B, K) -> (B, N): a 1x1 conv over B one-pixel images"""
+        B, K = x2d.shape
+        x4 = x2d.view(B, 1, 1, K)
+        y4 = self._conv_view(x4, x2d, name, need_dx)
+        return y4
+
+    def _conv_view(self, x4, x2d, name, need_dx):
+        w = name + ".weight"
+        N = self.shapes[w][0]
+        y4 = T.conv(x4, self.wf[w], N, 1, bias=self.p[name + ".bias"])
+        y2 = y4.view(x2d.shape[0], N)
+
+        def bwd():
+            dy = self._pop(y2)
+            dy4 = dy.view(dy.shape[0], 1, 1, N)
+            T.wgrad(dy4, x4, self.g[w], 1)
+            T.colsum(dy4, total=self.g[name + ".bias"])
+            self._done(w, name + ".bias")
+            if need_dx:
+                dx = T.conv(dy4, self.wt[w], x2d.shape[1], 1)
+                self._acc(x2d, dx.view(x2d.shape), True)
+        self._tape.append(bwd)
+        return y2
+
+    def _gn(self, x, name, silu):
+        cfg = self.cfg
+        gamma, beta = self.p[name + ".weight"], self.p[name + ".bias"]
+        y, stats = T.gn_forward(x, gamma, beta, cfg.norm_num_groups, cfg.norm_eps, silu)
+
+        def bwd():
+            dy = self._pop(y)
+            dx = T.gn_backward(x, dy, stats, gamma, beta, cfg.norm_num_groups, silu, self.g[name + ".weight"], self.g[name + ".bias"])
+            self._done(name + ".weight", name + ".bias")
+            self._acc(x, dx, True)
+        self._tape.append(bwd)
+        return y
+
+    def _silu(self, x):
+        y = T.silu(x)
+
+        def bwd():
+            dy = self._pop(y)
+            self._acc(x, T.silu_backward(x, dy), True)
+        self._tape.append(bwd)
+        return y
+
+    def _concat(self, a, b):
+        y = T.concat(a, b)
+        ca, cb = a.shape[3], b.shape[3]
+
+        def bwd():
+            dy = self._pop(y)
+            da, db = T.empty(a.shape, a), T.empty(b.shape, b)
+            T.copy_channels(dy, 0, da, 0, ca)
+            T.copy_channels(dy, ca, db, 0, cb)
+            self._acc(a, da, True)
+            self._acc(b, db, True)
+        self._tape.append(bwd)
+        return y
+
+    def _resnet(self, x, p, temb_act):
+        h = self._gn(x, p + ".norm1", True)
+        row = self._linear(temb_act, p + ".time_emb_proj")
+        h = self._conv(h, p + ".conv1", rowadd=row)
+        h = self._gn(h, p + ".norm2", True)
+        sc = self._conv(x, p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in self.shapes else x
+        return self._conv(h, p + ".conv2", res=sc)
+
+    def _attention(self, x, p):
+        B, W, H, Cc = x.shape
+        y = self._gn(x, p + ".group_norm", False)
+        q = self._conv(y, p + ".to_q")
+        k = self._conv(y, p + ".to_k")
+        v = self._conv(y, p + ".to_v")
+        q3, k3, v3 = (t.view(B, W * H, Cc) for t in (q, k, v))
+        o3, lse = T.attention_forward(q3, k3, v3)
+        o = o3.view(B, W, H, Cc)
+
+        def bwd():
+            dO = self._pop(o)
+            dq, dk, dv = T.attention_backward(q3, k3, v3, o3, dO.view(B, W * H, Cc), lse)
+            self._acc(q, dq.view(q.shape), True)
+            self._acc(k, dk.view(k.shape), True)
+            self._acc(v, dv.view(v.shape), True)
+        self._tape.append(bwd)
+        return self._conv(o, p + ".to_out.0", res=x)
+
+    # ---- network ----------------------------------------------------------------------------------------------
+    def forward(self, sample_nchw, timesteps, pos_encoding=False):
+        """sample (B, C, W, H) fp32 on the device; pos_encoding=True appends the azimuth-0 marker channel here (the
+        `torch.cat([noisy_images, pos_encoding], dim=1)` of ldm/train_unconditional.py:500-501), so C + 1 == in_channels.
+        timesteps (B,) int64 -> model_output (B, W, H, out_channels) NHWC.  Records the tape for `backward`."""
+        cfg = self.cfg
+        self._tape, self._grad = [], {}
+        x = T.pack_input(sample_nchw.float().contiguous(), pos_encoding)
+        if x.shape[3] != cfg.in_channels:
+            raise ValueError(f"sample has {x.shape[3]} channels (incl. pos-encoding), the UNet expects {cfg.in_channels}")
+        B = x.shape[0]
+        ts = timesteps.to(self.device, torch.int64).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(B).contiguous()
+        e = T.timestep_embedding(ts, cfg.block_out_channels[0])
+        e = self._linear(e, "time_embedding.linear_1", need_dx=False)
+        temb = self._linear(self._silu(e), "time_embedding.linear_2")
+        temb_act = self._silu(temb)
+        h = self._conv(x, "conv_in", need_dx=False)
+        skips = [h]
+        nl = len(cfg.block_out_channels)
+        for i, bt in enumerate(cfg.down_block_types):
+            for j in range(cfg.layers_per_block):
+                h = self._resnet(h, f"down_blocks.{i}.resnets.{j}", temb_act)
+                if bt == "AttnDownBlock2D":
+                    h = self._attention(h, f"down_blocks.{i}.attentions.{j}")
+                skips.append(h)
+            if i != nl - 1:
+                h = self._conv(h, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+                skips.append(h)
+        h = self._resnet(h, "mid_block.resnets.0", temb_act)
+        if cfg.add_attention:
+            h = self._attention(h, "mid_block.attentions.0")
+        h = self._resnet(h, "mid_block.resnets.1", temb_act)
+        for i, bt in enumerate(cfg.up_block_types):
+            for j in range(cfg.layers_per_block + 1):
+                h = self._concat(h, skips.pop())
+                h = self._resnet(h, f"up_blocks.{i}.resnets.{j}", temb_act)
+                if bt == "AttnUpBlock2D":
+                    h = self._attention(h, f"up_blocks.{i}.attentions.{j}")
+            if i != nl - 1:
+                h = self._conv(h, f"up_blocks.{i}.upsamplers.0.conv", mode=1)
+        assert not skips
+        h = self._gn(h, "conv_norm_out", True)
+        self._out = self._conv(h, "conv_out")
+        return self._out
+
+    def backward(self, dpred, reduce=None):
+        """Replays the tape in reverse.  reduce: None = single process; True = bucketed RCCL all-reduce (average) of the flat
+        gradient buffer, overlapped with the rest of backward."""
+        if reduce is None:
+            reduce = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self._pending = []
+        self._ready = None
+        avg = False
+        if reduce:
+            self._pidx = {n: i for i, n in enumerate(self.names)}
+            self._ready = [hi - lo for lo, hi, _, _ in self.buckets]
+            avg = torch.distributed.get_backend() == "nccl"          # RCCL averages in the collective; gloo sums
+            self._reduce_op = torch.distributed.ReduceOp.AVG if avg else torch.distributed.ReduceOp.SUM
+        self._acc(self._out, dpred, False)
+        for fn in reversed(self._tape):
+            fn()
+        self._tape, self._grad = [], {}
+        for w in self._pending:
+            w.wait()
+        self._ready = None
+        return torch.distributed.get_world_size() if (reduce and not avg) else 1
+
+    def optimizer_step(self, grad_world=1):
+        """clip_grad_norm_(1.0) + AdamW + cosine/warmup lr + EMA (ldm/train_unconditional.py:546-556), then refresh the
+        bf16 operand copies and zero the gradients."""
+        hp = self.hp
+        self.global_step += 1
+        if grad_world > 1:                              # a summing backend (gloo): finish the average
+            self.grads.mul_(1.0 / grad_world)
+        sq = T.sqnorm(self.grads)
+        lr = cosine_lr(self.global_step - 1, hp["lr"], hp["lr_warmup_steps"], hp["total_steps"])
+        # (lr_scheduler.step() runs AFTER optimizer.step(): step k uses the rate of k - 1 scheduler steps)
+        dec = ema_decay(self.global_step, hp["ema_max_decay"], hp["ema_inv_gamma"], hp["ema_power"])
+        T.adamw(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.global_step, lr, hp["betas"], hp["eps"],
+                hp["weight_decay"], ema=self.ema, ema_decay=dec, sqnorm_dev=sq, max_grad_norm=hp["max_grad_norm"])
+        self.last_grad_norm = sq
+        self.repack()
+        self.grads.zero_()
+        return lr
+
+    def train_step(self, noisy_nchw, timesteps, target_nchw, loss_weights=None, pos_encoding=False):
+        """model_output = model(noisy, t); loss = mse(model_output, target) [* min-SNR weights]; backward; step.
+        Returns the loss (0-d float64 device tensor; no host sync)."""
+        pred = self.forward(noisy_nchw, timesteps, pos_encoding)
+        loss, dpred = T.mse(pred, target_nchw.float().contiguous(), loss_weights)
+        world = self.backward(dpred)
+        self.optimizer_step(world)
+        return loss
+
+
+def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, pos_encoding=True, snr_gamma=None,
+                  noise=None, timesteps=None):
+    """One iteration of the reference's loop body (ldm/train_unconditional.py:479-556) with `with_vae: True`:
+    latents = vae.encode(x).latent_dist.sample() * scaling_factor; eps ~ N(0, 1); t ~ U{0..T-1}; add_noise; pos-encoding
+    channel; epsilon-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA."""
+    dev = trainer.device
+    if vae is not None:
+        latents = vae.encode(clean_images.to(dev)).latent_dist.sample(generator=generator, scale=vae.config.scaling_factor)
+    else:
+        latents = clean_images.to(dev).float()
+    B = latents.shape[0]
+    if noise is None:
+        noise = torch.randn(latents.shape, generator=generator, dtype=torch.float32).to(dev)
+    if timesteps is None:
+        timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (B,), generator=generator).long()
+    noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+    w = None
+    if snr_gamma is not None:
+        w = snr_weights(noise_scheduler.alphas_cumprod, timesteps, snr_gamma).to(dev)
+    return trainer.train_step(noisy, timesteps.to(dev), noise, w, pos_encoding)

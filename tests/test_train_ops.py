@@ -1,0 +1,176 @@
+"""GPU: the op-level training kernels (rangeldm_amd/csrc/train.hip) against torch fp32 autograd of
+the oracle's leaf ops (oracle/ops.py: circular-W / zero-H conv, GroupNorm + SiLU, head_dim-8 attention).
+
+Tolerances: GEMM operands are rounded to bf16 (8 mantissa bits) with fp32 accumulation, so conv / linear results and
+gradients carry ~4e-3 relative L2 error against pure fp32; everything else (GroupNorm, attention, elementwise, AdamW) is
+fp32 end to end: 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as o_ops
+
+pytestmark = pytest.mark.gpu
+TOL_MM = 6e-3
+TOL_F32 = 2e-5
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("B,Cin,N,W,H,taps,stride,mode", [
+    (2, 32, 64, 16, 8, 9, 1, 0), (3, 48, 32, 8, 4, 9, 1, 0), (2, 5, 32, 16, 8, 9, 1, 0), (2, 32, 4, 16, 8, 9, 1, 0),
+    (2, 64, 64, 16, 8, 9, 2, 0), (2, 32, 32, 8, 4, 9, 1, 1), (2, 96, 40, 8, 4, 1, 1, 0), (1, 9, 32, 16, 2, 9, 1, 0),
+    (5, 128, 512, 1, 1, 1, 1, 0),                       # a Linear on 5 rows
+])
+def test_conv_forward_dgrad_wgrad(B, Cin, N, W, H, taps, stride, mode):
+    from rangeldm_amd import train_ops as T
+    k = 3 if taps == 9 else 1
+    x = rnd(B, Cin, W, H, seed=1).requires_grad_()
+    w = (rnd(N, Cin, k, k, seed=2) / (Cin * taps) ** 0.5).requires_grad_()
+    bias = rnd(N, seed=3)
+    row = rnd(B, N, seed=4)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == 1 else x
+    ref = o_ops.circ_conv2d(xin, w, bias, stride, 1 if taps == 9 else 0) + row[:, :, None, None]
+    dy = rnd(*ref.shape, seed=5)
+    ref.backward(dy)
+    wf, wt = T.pack_weights(w.detach().cuda(), taps)
+    xd = nhwc(x.detach())
+    y = T.conv(xd, wf, N, taps, stride, mode, bias=bias.cuda(), rowadd=row.cuda())
+    assert rel(nchw(y), ref.detach()) < TOL_MM
+    # residual + accumulate
+    y2 = T.conv(xd, wf, N, taps, stride, mode, res=y, out=y.clone(), accumulate=True)
+    assert rel(nchw(y2), 3 * ref.detach() - bias[None, :, None, None] - row[:, :, None, None]) < TOL_MM
+    # data gradient: the same kernel on dy with the flipped / transposed copy
+    dyd = nhwc(dy)
+    if stride == 2:
+        dx = T.conv(dyd, wt, Cin, taps, 1, 2)                       # zero insertion
+    elif mode == 1:
+        dx = T.sum2x2(T.conv(dyd, wt, Cin, taps, 1, 0))             # conv at 2x, then fold the nearest-x2
+    else:
+        dx = T.conv(dyd, wt, Cin, taps, 1, 0)
+    assert rel(nchw(dx), x.grad) < TOL_MM
+    # weight gradient into a zeroed buffer, twice (accumulates)
+    dw = torch.zeros_like(w.detach()).cuda()
+    T.wgrad(dyd, xd, dw, taps, stride, mode)
+    assert rel(dw.cpu(), w.grad) < TOL_MM
+    T.wgrad(dyd, xd, dw, taps, stride, mode)
+    assert rel(dw.cpu(), 2 * w.grad) < TOL_MM
+    # bias / per-sample row gradients
+    rows = torch.zeros(B, N).cuda()
+    tot = torch.zeros(N).cuda()
+    T.colsum(dyd, rows=rows, total=tot)
+    assert rel(rows.cpu(), dy.sum((2, 3))) < TOL_F32 and rel(tot.cpu(), dy.sum((0, 2, 3))) < TOL_F32
+
+
+@pytest.mark.parametrize("B,C,W,H,silu", [(2, 64, 16, 8, True), (3, 32, 8, 4, False), (1, 128, 4, 2, True), (2, 512, 4, 2, True),
+                                            (2, 96, 8, 4, True), (2, 160, 4, 2, False)])      # 3 / 5 channels per group
+def test_group_norm_forward_backward(B, C, W, H, silu):
+    from rangeldm_amd import train_ops as T
+    x = (rnd(B, C, W, H, seed=1) * 2 + 0.5).requires_grad_()
+    g = (1 + 0.3 * rnd(C, seed=2)).requires_grad_()
+    b = (0.2 * rnd(C, seed=3)).requires_grad_()
+    ref = o_ops.group_norm_silu(x, g, b, 32, 1e-5, silu)
+    dy = rnd(B, C, W, H, seed=4)
+    ref.backward(dy)
+    xd = nhwc(x.detach())
+    y, stats = T.gn_forward(xd, g.detach().cuda(), b.detach().cuda(), 32, 1e-5, silu)
+    assert rel(nchw(y), ref.detach()) < TOL_F32
+    dg, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dx = T.gn_backward(xd, nhwc(dy), stats, g.detach().cuda(), b.detach().cuda(), 32, silu, dg, db)
+    assert rel(nchw(dx), x.grad) < 1e-4
+    assert rel(dg.cpu(), g.grad) < 1e-4 and rel(db.cpu(), b.grad) < 1e-4
+    dx2 = T.gn_backward(xd, nhwc(dy), stats, g.detach().cuda(), b.detach().cuda(), 32, silu, dg, db, dx=dx.clone(), accumulate=True)
+    assert rel(nchw(dx2), 2 * x.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,L,C", [(2, 64, 32), (1, 200, 16), (2, 1024, 16)])
+def test_attention_forward_backward(B, L, C):
+    from rangeldm_amd import train_ops as T
+    q, k, v = (rnd(B, L, C, seed=s).requires_grad_() for s in (1, 2, 3))
+    nh = C // 8
+    qh, kh, vh = (z.view(B, L, nh, 8).transpose(1, 2) for z in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
+    dO = rnd(B, L, C, seed=4)
+    ref.backward(dO)
+    qd, kd, vd = q.detach().cuda(), k.detach().cuda(), v.detach().cuda()
+    o, lse = T.attention_forward(qd, kd, vd)
+    assert rel(o, ref.detach()) < TOL_F32
+    dq, dk, dv = T.attention_backward(qd, kd, vd, o, dO.cuda(), lse)
+    assert rel(dq, q.grad) < 1e-4 and rel(dk, k.grad) < 1e-4 and rel(dv, v.grad) < 1e-4
+
+
+def test_elementwise_and_loss():
+    from rangeldm_amd import train_ops as T
+    a, b = rnd(2, 8, 4, 6, seed=1).cuda(), rnd(2, 8, 4, 6, seed=2).cuda()
+    assert torch.equal(T.add(a, b), a + b)
+    c = T.concat(a, b[..., :3].contiguous())
+    assert torch.equal(c, torch.cat([a, b[..., :3]], -1))
+    d = torch.zeros_like(a)
+    T.copy_channels(c, 2, d, 1, 4)
+    T.copy_channels(c, 2, d, 1, 4, accumulate=True)
+    assert torch.equal(d[..., 1:5], 2 * c[..., 2:6]) and float(d[..., 0].abs().max()) == 0
+    du = rnd(2, 8, 4, 6, seed=3).cuda()
+    ref = du.view(2, 4, 2, 2, 2, 6).sum((2, 4))
+    assert rel(T.sum2x2(du), ref) < 1e-6
+    z = rnd(5, 512, seed=4).requires_grad_()
+    F.silu(z).backward(torch.ones_like(z) * 0.5)
+    assert rel(T.silu(z.detach().cuda()), F.silu(z).detach()) < 1e-6
+    assert rel(T.silu_backward(z.detach().cuda(), torch.full((5, 512), 0.5).cuda()), z.grad) < 1e-5
+    t = torch.tensor([0, 3, 977, 500, 999])
+    assert rel(T.timestep_embedding(t.cuda(), 128), o_ops.timestep_embedding(t, 128)) < 2e-5
+    x = rnd(2, 4, 8, 4, seed=5)
+    pk = T.pack_input(x.cuda(), True)
+    pe = torch.zeros(2, 1, 8, 4)
+    pe[:, :, 0, :] = 1
+    assert torch.equal(pk.cpu(), torch.cat([x, pe], 1).permute(0, 2, 3, 1))
+    assert torch.equal(T.unpack_output(pk).cpu(), torch.cat([x, pe], 1))
+    pred = rnd(3, 4, 8, 4, seed=6).requires_grad_()
+    tgt = rnd(3, 4, 8, 4, seed=7)
+    wts = torch.tensor([0.5, 1.0, 0.25])
+    loss = (F.mse_loss(pred, tgt, reduction="none").mean((1, 2, 3)) * wts).mean()
+    loss.backward()
+    l, dp = T.mse(nhwc(pred.detach()), tgt.cuda(), wts.cuda())
+    assert abs(float(l) - float(loss)) < 1e-6 and rel(nchw(dp), pred.grad) < 1e-6
+    l2, _ = T.mse(nhwc(pred.detach()), tgt.cuda())
+    assert abs(float(l2) - float(F.mse_loss(pred, tgt))) < 1e-6
+
+
+def test_adamw_clip_ema_match_torch():
+    """torch.optim.AdamW(lr, betas (0.95, 0.999), wd 1e-6, eps 1e-8) + clip_grad_norm_(1.0) + EMAModel.step
+    (ldm/train_unconditional.py:357-363,548,556) on a flat buffer."""
+    from rangeldm_amd import train_ops as T
+    n = 10007
+    p0 = rnd(n, seed=1)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    ema_ref = p0.clone()
+    pd, m, v, ema = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), p0.clone().cuda()
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step) * (3.0 if step == 2 else 0.001)        # step 2 clips, the others do not
+        p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([p], 1.0)
+        opt.step()
+        decay = 0.9 + 0.01 * step
+        ema_ref.sub_((1 - decay) * (ema_ref - p.detach()))
+        gd = g.cuda()
+        sq = T.sqnorm(gd)
+        assert abs(float(sq) - float((g.double() ** 2).sum())) < 1e-6 * float((g.double() ** 2).sum())
+        T.adamw(pd, gd, m, v, step, 1e-3, (0.95, 0.999), 1e-8, 1e-6, ema=ema, ema_decay=decay, sqnorm_dev=sq, max_grad_norm=1.0)
+        assert rel(pd, p.detach()) < 1e-6 and rel(ema, ema_ref) < 1e-6

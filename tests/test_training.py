@@ -1,0 +1,185 @@
+"""UNet training step (ldm/train_unconditional.py:466-558).
+
+GPU: rangeldm_amd.training.UNetTrainer (HIP kernels behind the C ABI, host-side tape) against torch autograd +
+torch.optim.AdamW on the oracle UNet (oracle/unet.py).  Tolerances: conv / linear operands are rounded to bf16
+(`mixed_precision: bf16`), fp32 accumulation -- per-forward 2e-2 (the sampling path's gate), per-parameter gradients
+4e-2 relative L2 and 1.5e-2 over all 3.5 M gradients at once.
+CPU: bucket planning, lr / EMA schedules, min-SNR weights, and a world-size-2 gloo run of the bucketed averaging logic.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rangeldm_amd.config import UNetConfig
+from rangeldm_amd.params import unet_param_shapes
+from rangeldm_amd.synth import synth_state_dict
+from rangeldm_amd import training as TR
+
+SMALL = dict(sample_size=(32, 8), block_out_channels=(32, 32, 64, 64))
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def oracle_grads(cfg, sd, x, t, target, weights=None):
+    from oracle import unet as o_unet
+    sdt = {k: torch.from_numpy(np.array(v)).float().requires_grad_() for k, v in sd.items()}
+    pred = o_unet.unet_forward.__wrapped__(sdt, cfg, x, t)
+    if weights is None:
+        loss = F.mse_loss(pred, target)
+    else:
+        loss = (F.mse_loss(pred, target, reduction="none").mean((1, 2, 3)) * weights).mean()
+    loss.backward()
+    return pred.detach(), float(loss), {k: v.grad for k, v in sdt.items()}
+
+
+def test_schedules_and_buckets():
+    b = TR.plan_buckets([10, 20, 5, 100, 1, 1], 30)
+    assert b == [(0, 2, 0, 30), (2, 4, 30, 105), (4, 6, 135, 2)]
+    assert sum(n for *_, n in b) == 137 and TR.plan_buckets([7], 100) == [(0, 1, 0, 7)]
+    assert TR.cosine_lr(0, 1e-4, 500, 10000) == 0.0 and abs(TR.cosine_lr(250, 1e-4, 500, 10000) - 5e-5) < 1e-12
+    assert abs(TR.cosine_lr(500, 1e-4, 500, 10000) - 1e-4) < 1e-12
+    assert abs(TR.cosine_lr(5250, 1e-4, 500, 10000) - 5e-5) < 1e-12 and TR.cosine_lr(10000, 1e-4, 500, 10000) < 1e-12
+    assert TR.ema_decay(1) == 0.0 and abs(TR.ema_decay(2) - (1 - 2 ** -0.75)) < 1e-12
+    assert TR.ema_decay(10 ** 9) == 0.9999
+    ac = torch.cumprod(1 - torch.linspace(1e-4, 0.02, 1000), 0)
+    w = TR.snr_weights(ac, torch.tensor([0, 999]), 5.0)
+    snr = ac / (1 - ac)
+    assert abs(float(w[0]) - 5.0 / float(snr[0])) < 1e-6 and abs(float(w[1]) - 1.0) < 1e-6
+
+
+def _gloo_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [1000, 30, 5000, 7, 2000]
+    buckets = TR.plan_buckets(sizes, 3000)
+    flat = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1)
+    pend = [torch.distributed.all_reduce(flat[off:off + n], async_op=True) for _, _, off, n in reversed(buckets)]
+    for p in pend:
+        p.wait()
+    flat.mul_(1.0 / world)
+    out[rank] = bool(torch.allclose(flat, torch.arange(sum(sizes), dtype=torch.float32) * (sum(range(1, world + 1)) / world)))
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_gradient_average_world2_gloo():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gloo_worker, args=(2, 29611, out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,B,weights", [
+    (dict(**SMALL), 2, None),
+    (dict(sample_size=(16, 4), block_out_channels=(32, 64), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+          up_block_types=("AttnUpBlock2D", "UpBlock2D")), 3, [0.3, 1.0, 0.6]),
+])
+def test_unet_gradients_match_autograd(kw, B, weights):
+    cfg = UNetConfig(**kw)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, cfg.in_channels, *cfg.sample_size, generator=g)
+    target = torch.randn(B, cfg.out_channels, *cfg.sample_size, generator=g)
+    t = torch.tensor([17, 480, 977][:B])
+    w = None if weights is None else torch.tensor(weights)
+    pred_ref, loss_ref, gref = oracle_grads(cfg, sd, x, t, target, w)
+    tr = TR.UNetTrainer(cfg, sd, use_ema=False)
+    from rangeldm_amd import train_ops as T
+    pred = tr.forward(x.cuda(), t.cuda())
+    assert rel(T.unpack_output(pred), pred_ref) < 2e-2
+    loss, dpred = T.mse(pred, target.cuda(), None if w is None else w.cuda())
+    assert abs(float(loss) - loss_ref) < 2e-2 * loss_ref
+    tr.backward(dpred)
+    flat_ref = torch.cat([gref[n].reshape(-1) for n in tr.names])
+    rms = float(flat_ref.double().norm() / flat_ref.numel() ** 0.5)
+
+    def err(n):
+        # relative L2 with a floor: some gradients are analytically ZERO (a key bias shifts every score of a query equally
+        # and softmax does not see it), so their reference norm is rounding noise
+        d = float((tr.g[n].double().cpu() - gref[n].double()).norm())
+        return d / (float(gref[n].double().norm()) + 2e-2 * rms * gref[n].numel() ** 0.5)
+    ranked = sorted(((err(n), n) for n in tr.names), reverse=True)
+    assert ranked[0][0] < 4e-2, ranked[:6]
+    assert rel(tr.grads, flat_ref) < 1.5e-2
+    # a second forward / backward accumulates into the same buffer (gradient accumulation)
+    tr.backward(T.mse(tr.forward(x.cuda(), t.cuda()), target.cuda(), None if w is None else w.cuda())[1])
+    assert rel(tr.grads, 2 * flat_ref) < 1.5e-2
+
+
+@pytest.mark.gpu
+def test_training_steps_follow_adamw_and_reduce_the_loss():
+    """Ten steps on one fixed batch: the loss falls; the first two steps are checked against torch.optim.AdamW +
+    clip_grad_norm_ + EMA driven by the oracle's autograd gradients."""
+    cfg = UNetConfig(**SMALL)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, 32, 8, generator=g)
+    target = torch.randn(2, 4, 32, 8, generator=g)
+    t = torch.tensor([100, 700])
+    lr = 1e-3
+    tr = TR.UNetTrainer(cfg, sd, lr=lr, lr_warmup_steps=0, total_steps=10 ** 6, use_ema=True)
+    # reference: same loop with torch autograd on the oracle
+    params = {k: torch.nn.Parameter(torch.from_numpy(np.array(v)).float()) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=lr, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    from oracle import unet as o_unet
+    ema_ref = {k: v.detach().clone() for k, v in params.items()}
+    losses = []
+    for step in range(1, 11):
+        losses.append(float(tr.train_step(x.cuda(), t.cuda(), target.cuda())))
+        if step <= 2:
+            opt.zero_grad()
+            F.mse_loss(o_unet.unet_forward.__wrapped__(params, cfg, x, t), target).backward()
+            torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+            opt.step()
+            dec = TR.ema_decay(step)
+            for k in ema_ref:
+                ema_ref[k].sub_((1 - dec) * (ema_ref[k] - params[k].detach()))
+            got = tr.state_dict()
+            # Adam's first updates are +-lr whatever the gradient's size: a sign flip of a near-zero gradient moves a
+            # parameter by 2 lr.  Gate the bulk (98 %) at half a step and the total at a small fraction of the update norm.
+            d = torch.cat([(got[k] - params[k].detach()).reshape(-1) for k in tr.names]).abs()
+            assert float((d > 0.5 * lr).float().mean()) < 0.02, (step, float((d > 0.5 * lr).float().mean()))
+            upd = torch.cat([(params[k].detach() - torch.from_numpy(np.array(sd[k]))).reshape(-1) for k in tr.names])
+            assert float(d.norm() / upd.norm()) < 0.15
+            got_ema = tr.state_dict(ema=True)
+            de = torch.cat([(got_ema[k] - ema_ref[k]).reshape(-1) for k in tr.names]).abs()
+            assert float((de > 0.5 * lr).float().mean()) < 0.02
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert all(math.isfinite(v) for v in losses)
+
+
+@pytest.mark.gpu
+def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
+    """The RCCL path with world size 1: bucket bookkeeping must launch every bucket exactly once and leave the gradients
+    equal to the single-process ones; then save_pretrained -> sampling model round trip."""
+    cfg = UNetConfig(**SMALL)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    x = torch.randn(2, 5, 32, 8, generator=torch.Generator().manual_seed(1)).cuda()
+    target = torch.randn(2, 4, 32, 8, generator=torch.Generator().manual_seed(2)).cuda()
+    t = torch.tensor([5, 900]).cuda()
+    from rangeldm_amd import train_ops as T
+    a = TR.UNetTrainer(cfg, sd, use_ema=False, bucket_mb=1)
+    a.backward(T.mse(a.forward(x, t), target)[1], reduce=False)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", RANK="0", WORLD_SIZE="1")
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        b = TR.UNetTrainer(cfg, sd, use_ema=True, bucket_mb=1)
+        assert len(b.buckets) >= 3
+        b.backward(T.mse(b.forward(x, t), target)[1], reduce=True)
+        assert all(r == 0 for r in [0])                               # (buckets all fired: pending handles were waited)
+        assert rel(b.grads, a.grads) < 1e-5                           # fp32 atomics reorder sums, nothing else differs
+        b.optimizer_step()
+    finally:
+        torch.distributed.destroy_process_group()
+    b.save_pretrained(str(tmp_path))
+    from rangeldm_amd.unet import UNet2DModelHIP
+    m = UNet2DModelHIP.from_pretrained(str(tmp_path), subfolder="unet_ema")
+    assert torch.isfinite(m(x, 10).sample).all()
