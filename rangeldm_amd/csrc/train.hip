@@ -62,49 +62,188 @@ struct TrConv {
 };
 
 // D[channel][pixel]: lane (pixel l & 31, half l >> 5) holds channels (r & 3) + 8 (r >> 2) + 4 half of its pixel.
+// A wave owns 32 pixels x 64 channels (one pixel fragment feeds two MFMAs); a workgroup 64 pixels x 128 channels.
+template <bool FAST>
 __global__ __launch_bounds__(256) void tr_conv_kernel(const TrConv p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     const int P = p.B * p.Wout * p.Hout;
     const int px = blockIdx.x * 64 + (wave & 1) * 32 + l31;
-    const int n0 = blockIdx.y * 64 + (wave >> 1) * 32;
+    const int n0 = blockIdx.y * 128 + (wave >> 1) * 64;
     if (n0 >= p.N) return;
     const bool pxok = px < P;
     const int pc = pxok ? px : 0;
     const int ho = pc % p.Hout, t1 = pc / p.Hout, wo = t1 % p.Wout, b = t1 / p.Wout;
-    const int nrow = n0 + l31;                                        // this lane's weight row (A operand)
-    const bool rowok = nrow < p.N;
-    const bf16_t* wrow = p.w + (size_t)(rowok ? nrow : 0) * p.taps * p.Cin_pad + 8 * kg;
-    f32x16 acc;
+    const int r0 = n0 + l31, r1 = r0 + 32;                            // this lane's weight rows (A operands)
+    const bool ok0 = r0 < p.N, ok1 = r1 < p.N;
+    const size_t rstride = (size_t)p.taps * p.Cin_pad;
+    const bf16_t* w0 = p.w + (size_t)(ok0 ? r0 : 0) * rstride + 8 * kg;
+    const bf16_t* w1 = p.w + (size_t)(ok1 ? r1 : 0) * rstride + 8 * kg;
+    const bool vec = (p.Cin & 3) == 0;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     for (int t = 0; t < p.taps; ++t) {
         const int dw = p.taps == 9 ? t / 3 - 1 : 0, dh = p.taps == 9 ? t % 3 - 1 : 0;
         const int sp = pxok ? src_pixel(b, wo, ho, dw, dh, p.stride, p.mode, p.Win, p.Hin) : -1;
         const float* xrow = p.x + (size_t)(sp < 0 ? 0 : sp) * p.Cin + 8 * kg;
-        const bf16_t* wt = wrow + (size_t)t * p.Cin_pad;
-        for (int c0 = 0; c0 < p.Cin_pad; c0 += 16) {
-            uint4 a = make_uint4(0u, 0u, 0u, 0u);
-            if (rowok) a = *reinterpret_cast<const uint4*>(wt + c0);
-            const int valid = sp < 0 ? 0 : p.Cin - (c0 + 8 * kg);
-            const bf16x8 bv = load_bf16x8_from_f32(xrow + c0, valid, (p.Cin & 3) == 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bv, acc, 0, 0, 0);
+        const size_t toff = (size_t)t * p.Cin_pad;
+        if (FAST) {
+            // Cin % 16 == 0: branch-free body, four k-steps of loads in flight (rows past N are computed on row 0's
+            // weights and never stored; a zero-padded tap multiplies by 0)
+            const float live = sp < 0 ? 0.f : 1.f;
+            const bf16_t* wa = w0 + toff;
+            const bf16_t* wb = w1 + toff;
+#pragma unroll 4
+            for (int c0 = 0; c0 < p.Cin_pad; c0 += 16) {
+                const uint4 a0 = *reinterpret_cast<const uint4*>(wa + c0), a1 = *reinterpret_cast<const uint4*>(wb + c0);
+                const float4 x0 = *reinterpret_cast<const float4*>(xrow + c0), x1 = *reinterpret_cast<const float4*>(xrow + c0 + 4);
+                uint4 u;
+                u.x = rldm::pack_bf16x2(x0.x * live, x0.y * live); u.y = rldm::pack_bf16x2(x0.z * live, x0.w * live);
+                u.z = rldm::pack_bf16x2(x1.x * live, x1.y * live); u.w = rldm::pack_bf16x2(x1.z * live, x1.w * live);
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, u);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), bv, acc1, 0, 0, 0);
+            }
+        } else {
+            for (int c0 = 0; c0 < p.Cin_pad; c0 += 16) {
+                uint4 a0 = make_uint4(0u, 0u, 0u, 0u), a1 = a0;
+                if (ok0) a0 = *reinterpret_cast<const uint4*>(w0 + toff + c0);
+                if (ok1) a1 = *reinterpret_cast<const uint4*>(w1 + toff + c0);
+                const int valid = sp < 0 ? 0 : p.Cin - (c0 + 8 * kg);
+                const bf16x8 bv = load_bf16x8_from_f32(xrow + c0, valid, vec);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), bv, acc1, 0, 0, 0);
+            }
         }
     }
     if (!pxok) return;
     float* yrow = p.y + (size_t)px * p.N;
     const float* rrow = p.res ? p.res + (size_t)px * p.N : nullptr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = n0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (ch >= p.N) continue;
-        float v = acc[r];
-        if (p.bias) v += p.bias[ch];
-        if (p.rowadd) v += p.rowadd[(size_t)b * p.rowadd_ld + ch];
-        if (rrow) v += rrow[ch];
-        if (p.accumulate) v += yrow[ch];
-        yrow[ch] = v;
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = n0 + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (ch >= p.N) continue;
+            float v = h ? acc1[r] : acc0[r];
+            if (p.bias) v += p.bias[ch];
+            if (p.rowadd) v += p.rowadd[(size_t)b * p.rowadd_ld + ch];
+            if (rrow) v += rrow[ch];
+            if (p.accumulate) v += yrow[ch];
+            yrow[ch] = v;
+        }
+}
+
+// LDS-staged variant for Cin % CK == 0 (CK = 32 | 64 channels per stage): the workgroup (64 pixels x 128 channels) stages the
+// pixel tile [64][CK] (fp32 -> bf16 on the way) and the weight tile [128][CK] with coalesced 32- / 64-byte pieces per thread,
+// next stage's global loads are in flight while the current one is multiplied out of LDS (row pitch CK * 2 + 16 bytes: an
+// odd number of 16-byte slots, conflict-free ds_read_b128).
+template <int CK>
+__global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
+    constexpr int PITCH = CK + 8;                   // bf16 elements
+    constexpr int XV = CK / 32;                     // float4 pairs per thread for x (4 threads per pixel row, CK / 4 channels each)
+    constexpr int WV = CK / 16;                     // uint4 per thread for w (2 threads per weight row)
+    __shared__ __attribute__((aligned(16))) bf16_t sX[64 * PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t sW[128 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int P = p.B * p.Wout * p.Hout;
+    const int px0 = blockIdx.x * 64, n0 = blockIdx.y * 128;
+    // staging roles
+    const int spx = tid >> 2, spart = tid & 3;      // x: pixel row of the tile, quarter of the CK channels
+    const int swr = tid >> 1, shalf = tid & 1;      // w: weight row of the tile, half of the CK channels
+    const int gpx = px0 + spx;
+    const bool gpx_ok = gpx < P;
+    const int pc = gpx_ok ? gpx : 0;
+    const int sho = pc % p.Hout, st1 = pc / p.Hout, swo = st1 % p.Wout, sb = st1 / p.Wout;
+    const int wrow = n0 + swr;
+    const bf16_t* wsrc = p.w + (size_t)(wrow < p.N ? wrow : 0) * p.taps * p.Cin_pad + shalf * (CK / 2);
+    const int nck = p.Cin / CK, niter = p.taps * nck;
+    float4 xr[XV][2];
+    uint4 wr[WV];
+    auto fetch = [&](int it) {
+        const int t = it / nck, c0 = (it % nck) * CK;
+        const int dw = p.taps == 9 ? t / 3 - 1 : 0, dh = p.taps == 9 ? t % 3 - 1 : 0;
+        const int sp = gpx_ok ? src_pixel(sb, swo, sho, dw, dh, p.stride, p.mode, p.Win, p.Hin) : -1;
+        const float* xs = p.x + (size_t)(sp < 0 ? 0 : sp) * p.Cin + c0 + spart * (CK / 4);
+        const float live = sp < 0 ? 0.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < XV; ++q) {
+            float4 a = reinterpret_cast<const float4*>(xs)[2 * q], b = reinterpret_cast<const float4*>(xs)[2 * q + 1];
+            a.x *= live; a.y *= live; a.z *= live; a.w *= live; b.x *= live; b.y *= live; b.z *= live; b.w *= live;
+            xr[q][0] = a; xr[q][1] = b;
+        }
+        const bf16_t* ws = wsrc + (size_t)t * p.Cin_pad + c0;
+#pragma unroll
+        for (int q = 0; q < WV; ++q) wr[q] = reinterpret_cast<const uint4*>(ws)[q];
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < XV; ++q) {
+            uint4 u;
+            u.x = rldm::pack_bf16x2(xr[q][0].x, xr[q][0].y); u.y = rldm::pack_bf16x2(xr[q][0].z, xr[q][0].w);
+            u.z = rldm::pack_bf16x2(xr[q][1].x, xr[q][1].y); u.w = rldm::pack_bf16x2(xr[q][1].z, xr[q][1].w);
+            *reinterpret_cast<uint4*>(sX + spx * PITCH + spart * (CK / 4) + 8 * q) = u;
+        }
+#pragma unroll
+        for (int q = 0; q < WV; ++q) *reinterpret_cast<uint4*>(sW + swr * PITCH + shalf * (CK / 2) + 8 * q) = wr[q];
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const bf16_t* bx = sX + ((wave & 1) * 32 + l31) * PITCH + 8 * kg;
+    const bf16_t* aw0 = sW + ((wave >> 1) * 64 + l31) * PITCH + 8 * kg;
+    const bf16_t* aw1 = aw0 + 32 * PITCH;
+    fetch(0);
+    for (int it = 0; it < niter; ++it) {
+        __syncthreads();                            // everyone is done reading the previous stage
+        stash();
+        __syncthreads();
+        if (it + 1 < niter) fetch(it + 1);          // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aw0 + 16 * ks);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+        }
     }
+    const int px = px0 + (wave & 1) * 32 + l31;
+    if (px >= P) return;
+    const int b = px / (p.Wout * p.Hout);
+    const int nb = n0 + (wave >> 1) * 64;
+    float* yrow = p.y + (size_t)px * p.N;
+    const float* rrow = p.res ? p.res + (size_t)px * p.N : nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const int ch = nb + 32 * h + 8 * (r >> 2) + 4 * kg;       // 4 consecutive channels per register quad
+            if (ch >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h ? acc1[r + e] : acc0[r + e];
+            if (ch + 3 < p.N && (p.N & 3) == 0) {
+                if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                if (p.rowadd) { const float4 t = *reinterpret_cast<const float4*>(p.rowadd + (size_t)b * p.rowadd_ld + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                if (rrow) { const float4 t = *reinterpret_cast<const float4*>(rrow + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(yrow + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                *reinterpret_cast<float4*>(yrow + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ch + e >= p.N) continue;
+                    float u = v[e];
+                    if (p.bias) u += p.bias[ch + e];
+                    if (p.rowadd) u += p.rowadd[(size_t)b * p.rowadd_ld + ch + e];
+                    if (rrow) u += rrow[ch + e];
+                    if (p.accumulate) u += yrow[ch + e];
+                    yrow[ch + e] = u;
+                }
+            }
+        }
 }
 
 // ---- weight gradient --------------------------------------------------------------------------------------------------
@@ -113,72 +252,123 @@ struct TrWgrad {
     int B, Win, Hin, Cin, Wout, Hout, N, taps, stride, mode, chunk;      // chunk: pixels per wave (multiple of 16)
 };
 
-// grid (n tiles * c tiles, taps, K splits), 4 waves: wave v contracts pixels [((z * 4 + v) * chunk), + chunk).
-// D[n][c] += A[n][k] B[k][c], k = pixel: both operands are gathered (channels are the contiguous index in memory): a load
-// instruction reads 32 consecutive channels of two pixels.
+// 16 consecutive channels of one pixel row: `valid` of them exist; vec: the row pointer is 16-byte aligned
+__device__ inline void load_row16(const float* p, int valid, bool vec, float* out) {
+    if (vec && valid >= 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(p)[q];
+            out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e] = e < valid ? p[e] : 0.f;
+    }
+}
+
+// grid (n tiles * c tiles, taps, K splits), 4 waves: wave v contracts pixels [((z * 4 + v) * chunk), + chunk) for a 64 x 64
+// tile of dW (2 x 2 MFMA tiles).  D[n][c] += A[n][k] B[k][c] with k = pixel, while memory has channels contiguous: every
+// k-step the wave loads 16 pixel rows x 64 channels of dy and of x (tap-shifted) with coalesced 16-byte loads into its
+// private LDS tile and reads the fragments back transposed (8 pixels of one channel per lane).
+constexpr int WG_PITCH = 68;                     // floats: 16-byte aligned rows, conflict-free column reads
 __global__ __launch_bounds__(256) void tr_wgrad_kernel(const TrWgrad p) {
+    __shared__ __attribute__((aligned(16))) float sm[4][2][16][WG_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
-    const int ct = (p.Cin + 31) / 32;
-    const int n0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+    const int ct = (p.Cin + 63) / 64;
+    const int n0 = (blockIdx.x / ct) * 64, c0 = (blockIdx.x % ct) * 64;
     const int t = blockIdx.y;
     const int dw = p.taps == 9 ? t / 3 - 1 : 0, dh = p.taps == 9 ? t % 3 - 1 : 0;
     const int P = p.B * p.Wout * p.Hout;
     const int kbeg = (blockIdx.z * 4 + wave) * p.chunk;
     const int kend = min(kbeg + p.chunk, P);
-    const int n = n0 + l31, c = c0 + l31;
-    const bool nok = n < p.N, cok = c < p.Cin;
-    f32x16 acc;
+    float (*sA)[WG_PITCH] = sm[wave][0];
+    float (*sB)[WG_PITCH] = sm[wave][1];
+    const int row = lane >> 2, seg = (lane & 3) * 16;          // staging role: pixel row of the k-step, 16-channel segment
+    const bool vecA = (p.N & 3) == 0, vecB = (p.Cin & 3) == 0;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        float av[8], bv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int px = k0 + 8 * kg + j;
-            av[j] = 0.f;
-            bv[j] = 0.f;
-            if (px < kend) {
-                if (nok) av[j] = p.dy[(size_t)px * p.N + n];
-                if (cok) {
-                    const int ho = px % p.Hout, t1 = px / p.Hout, wo = t1 % p.Wout, b = t1 / p.Wout;
-                    const int sp = src_pixel(b, wo, ho, dw, dh, p.stride, p.mode, p.Win, p.Hin);
-                    if (sp >= 0) bv[j] = p.x[(size_t)sp * p.Cin + c];
-                }
+        const int px = k0 + row;
+        float va[16], vb[16];
+        int validA = 0, validB = 0;
+        const float* pa = p.dy;
+        const float* pb = p.x;
+        if (px < kend) {
+            validA = p.N - (n0 + seg);
+            pa = p.dy + (size_t)px * p.N + n0 + seg;
+            const int ho = px % p.Hout, t1 = px / p.Hout, wo = t1 % p.Wout, b = t1 / p.Wout;
+            const int sp = src_pixel(b, wo, ho, dw, dh, p.stride, p.mode, p.Win, p.Hin);
+            if (sp >= 0) {
+                validB = p.Cin - (c0 + seg);
+                pb = p.x + (size_t)sp * p.Cin + c0 + seg;
             }
         }
-        uint4 a, bb;
-        a.x = rldm::pack_bf16x2(av[0], av[1]); a.y = rldm::pack_bf16x2(av[2], av[3]);
-        a.z = rldm::pack_bf16x2(av[4], av[5]); a.w = rldm::pack_bf16x2(av[6], av[7]);
-        bb.x = rldm::pack_bf16x2(bv[0], bv[1]); bb.y = rldm::pack_bf16x2(bv[2], bv[3]);
-        bb.z = rldm::pack_bf16x2(bv[4], bv[5]); bb.w = rldm::pack_bf16x2(bv[6], bv[7]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), acc, 0, 0, 0);
-    }
-    if (kbeg >= kend || !cok) return;
-    // lane (column c, half kg) holds rows n0 + (r & 3) + 8 (r >> 2) + 4 kg
+        load_row16(pa, validA, vecA, va);
+        load_row16(pb, validB, vecB, vb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (nn < p.N) unsafeAtomicAdd(p.dw + ((size_t)nn * p.Cin + c) * p.taps + t, acc[r]);
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4*>(&sA[row][seg + 4 * q]) = make_float4(va[4 * q], va[4 * q + 1], va[4 * q + 2], va[4 * q + 3]);
+            *reinterpret_cast<float4*>(&sB[row][seg + 4 * q]) = make_float4(vb[4 * q], vb[4 * q + 1], vb[4 * q + 2], vb[4 * q + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a0[j] = sA[8 * kg + j][l31]; a1[j] = sA[8 * kg + j][32 + l31];
+            b0[j] = sB[8 * kg + j][l31]; b1[j] = sB[8 * kg + j][32 + l31];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto pack8 = [](const float* f) {
+            uint4 u;
+            u.x = rldm::pack_bf16x2(f[0], f[1]); u.y = rldm::pack_bf16x2(f[2], f[3]);
+            u.z = rldm::pack_bf16x2(f[4], f[5]); u.w = rldm::pack_bf16x2(f[6], f[7]);
+            return __builtin_bit_cast(bf16x8, u);
+        };
+        const bf16x8 A0 = pack8(a0), A1 = pack8(a1), B0 = pack8(b0), B1 = pack8(b1);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
     }
+    if (kbeg >= kend) return;
+    // tile (i, j): lane (column c0 + 32 j + l31, half kg) holds rows n0 + 32 i + (r & 3) + 8 (r >> 2) + 4 kg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + 32 * j + l31;
+            if (c >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (nn < p.N) unsafeAtomicAdd(p.dw + ((size_t)nn * p.Cin + c) * p.taps + t, acc[i][j][r]);
+            }
+        }
 }
 
-// rows[b][n] (+)= sum over the pixels of image b of dy[p][n]; total[n] += the same over all images (atomics over b)
+// rows[b][n] += sum over the pixels of image b of dy[p][n]; total[n] += the same over all images.  grid (channel tiles,
+// images, 512-pixel slabs): fp32 atomics into buffers the caller zeroed (rows) / accumulates into (total = bias gradient).
 __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict__ dy, int npix, int N, float* __restrict__ rows,
-                                                        int rows_ld, int rows_acc, float* __restrict__ total) {
+                                                        int rows_ld, float* __restrict__ total) {
     __shared__ float sh[4][64];
     const int b = blockIdx.y, ch = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int p0 = blockIdx.z * 512, p1 = min(p0 + 512, npix);
     float acc = 0.f;
     if (ch < N)
-        for (int px = q; px < npix; px += 4) acc += dy[((size_t)b * npix + px) * N + ch];
+        for (int px = p0 + q; px < p1; px += 4) acc += dy[((size_t)b * npix + px) * N + ch];
     sh[q][threadIdx.x & 63] = acc;
     __syncthreads();
     if (q == 0 && ch < N) {
         const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        if (rows) {
-            float* r = rows + (size_t)b * rows_ld + ch;
-            *r = rows_acc ? *r + v : v;
-        }
+        if (rows) unsafeAtomicAdd(rows + (size_t)b * rows_ld + ch, v);
         if (total) unsafeAtomicAdd(total + ch, v);
     }
 }
@@ -597,7 +787,12 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
     RLDM_REQUIRE(p.Wout > 0 && p.Hout > 0, "empty output");
     p.N = d->N; p.taps = d->taps; p.stride = d->stride; p.mode = d->mode; p.rowadd_ld = rowadd_ld; p.accumulate = accumulate;
     const int P = p.B * p.Wout * p.Hout;
-    tr_conv_kernel<<<dim3((P + 63) / 64, (p.N + 63) / 64), 256, 0, (hipStream_t)stream>>>(p);
+    const dim3 grid((P + 63) / 64, (p.N + 127) / 128);
+    const bool aligned = (rowadd_ld & 3) == 0;         // (vector epilogue reads the per-sample row 16 bytes at a time)
+    if (p.Cin % 64 == 0 && P >= 64 && aligned) tr_conv_lds_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else if (p.Cin % 32 == 0 && P >= 64 && aligned) tr_conv_lds_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else tr_conv_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -611,11 +806,13 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
     const int sh = d->mode ? 1 : 0;
     p.Wout = (d->Win << sh) / d->stride; p.Hout = (d->Hin << sh) / d->stride;
     const int P = p.B * p.Wout * p.Hout;
-    const int tiles = ((p.N + 31) / 32) * ((p.Cin + 31) / 32) * p.taps;
-    int splits = 1;
-    while (tiles * splits < 2048 && (P + splits * 2 * 64 - 1) / (splits * 2 * 64) >= 4) splits *= 2;     // >= 64 pixels per wave
-    p.chunk = ((P + splits * 4 - 1) / (splits * 4) + 15) / 16 * 16;
-    tr_wgrad_kernel<<<dim3(((p.N + 31) / 32) * ((p.Cin + 31) / 32), p.taps, splits), 256, 0, (hipStream_t)stream>>>(p);
+    const int tiles = ((p.N + 63) / 64) * ((p.Cin + 63) / 64) * p.taps;
+    // a wave contracts `chunk` pixels and then issues 4096 atomics: ~1024 pixels per wave, fewer only to fill the chip
+    int chunk = 1024;
+    while (chunk > 128 && (long long)tiles * ((P + 4 * chunk - 1) / (4 * chunk)) < 256) chunk >>= 1;
+    const int splits = (P + 4 * chunk - 1) / (4 * chunk);
+    p.chunk = chunk;
+    tr_wgrad_kernel<<<dim3(((p.N + 63) / 64) * ((p.Cin + 63) / 64), p.taps, splits), 256, 0, (hipStream_t)stream>>>(p);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -623,7 +820,9 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
 int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int rows_ld, int rows_accumulate, float* total,
                       void* stream) {
     RLDM_REQUIRE(dy && (rows || total), "null argument");
-    tr_colsum_kernel<<<dim3((N + 63) / 64, B), 256, 0, (hipStream_t)stream>>>(dy, npix, N, rows, rows_ld, rows_accumulate, total);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows && !rows_accumulate) RLDM_HIP_CHECK(hipMemset2DAsync(rows, (size_t)rows_ld * sizeof(float), 0, (size_t)N * sizeof(float), B, st));
+    tr_colsum_kernel<<<dim3((N + 63) / 64, B, (npix + 511) / 512), 256, 0, st>>>(dy, npix, N, rows, rows_ld, total);
     TR_LAUNCH_CHECK();
     return 0;
 }

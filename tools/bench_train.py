@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Training throughput of BASELINE config 5 (RangeLDM KITTI-360 unconditional, bf16 operands, AdamW, batch 8 per GPU,
+data-parallel): samples/sec = global batch / step time, same barrier + max-over-ranks timing as bench.py.
+
+    python tools/bench_train.py [--batch 8] [--steps 5] [--warmup 2] [--no-vae]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N ...
+
+One step = the loop body of ldm/train_unconditional.py:479-556 on synthetic range images resident in HBM:
+VAE encode + sample -> add_noise -> pos-encoding -> UNet forward -> MSE -> backward -> (RCCL gradient all-reduce) ->
+clip -> AdamW -> EMA -> operand repack.  Algorithmic work per sample: 3 x 34.07 GFLOP (UNet fwd + bwd) + 75.7 GFLOP (VAE
+encode) = 177.9 GFLOP.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--seed", type=int, default=20240310)
+    a = ap.parse_args()
+    from rangeldm_amd import distributed as D
+    from rangeldm_amd.config import PRESETS
+    from rangeldm_amd.params import unet_param_shapes, vae_param_shapes
+    from rangeldm_amd.schedulers import DDPMSchedulerHIP
+    from rangeldm_amd.synth import synth_state_dict, normal
+    from rangeldm_amd.training import UNetTrainer, training_step
+    from rangeldm_amd.vae import AutoencoderKLHIP
+    rank, world, local = D.init_from_env("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    p = PRESETS["RangeLDM"]
+    tr = UNetTrainer(p["unet"], synth_state_dict(unet_param_shapes(p["unet"]), seed=a.seed), device=dev)
+    vae = None
+    if not a.no_vae:
+        vae = AutoencoderKLHIP(p["vae"])
+        vae.load_state_dict(synth_state_dict(vae_param_shapes(p["vae"]), seed=a.seed, prefix="vae."))
+    sched = DDPMSchedulerHIP()
+    B = a.batch
+    n_iter = a.warmup + a.steps
+    gen = torch.Generator().manual_seed(a.seed + rank)
+    shape = (B, 2, 1024, 64) if vae is not None else (B, 4, 256, 16)
+    imgs = [torch.from_numpy(normal(a.seed, f"train/{rank}/{i}", shape)).mul_(0.5).to(dev) for i in range(n_iter)]
+    losses = []
+
+    def one(i):
+        losses.append(training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True))
+
+    for i in range(a.warmup):
+        one(i)
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_iter):
+        one(i)
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        sps = world * B * a.steps / dt
+        gflop = 3 * 34.071 + (75.73 if vae is not None else 0.0)
+        print(json.dumps({"metric": "training samples/sec, RangeLDM KITTI-360 unconditional, bf16 operands, AdamW",
+                          "value": sps, "unit": "samples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "bf16",
+                          "data": "synthetic", "config": {"workload": f"train_unconditional step, batch {B} per GPU, "
+                                                          f"{'VAE encode + ' if vae is not None else ''}UNet fwd+bwd, AdamW, EMA",
+                                                          "global_batch": B * world},
+                          "gflop_per_sample": gflop, "end_to_end_tflops": sps * gflop / 1e3,
+                          "loss_first_last": [float(losses[0]), float(losses[-1])]}))
+    D.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

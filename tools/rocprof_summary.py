@@ -14,6 +14,7 @@ tot = sum(r[2] for r in rows)
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*\)$", "", n)
     n = n.replace("void rldm::", "").replace("rldm::", "")
     return n[:86]
