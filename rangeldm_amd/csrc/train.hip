@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -136,19 +137,25 @@ __global__ __launch_bounds__(256) void tr_conv_kernel(const TrConv p) {
 }
 
 // LDS-staged variant for Cin % CK == 0 (CK = 32 | 64 channels per stage): the workgroup (64 pixels x 128 channels) stages the
-// pixel tile [64][CK] (fp32 -> bf16 on the way) and the weight tile [128][CK] with coalesced 32- / 64-byte pieces per thread,
-// next stage's global loads are in flight while the current one is multiplied out of LDS (row pitch CK * 2 + 16 bytes: an
-// odd number of 16-byte slots, conflict-free ds_read_b128).
-template <int CK>
+// pixel tile [64][CK] (fp32 -> bf16 on the way) and the weight tile [128][CK] with coalesced pieces per thread.  A stage
+// costs one memory latency (~1.5 us measured: activations of a level live in the Infinity Cache, not in L2) against 0.1 us
+// of MFMAs, so the global loads of the next D stages are kept in flight in registers (static ring, loop unrolled by D).
+// Row pitch CK * 2 + 16 bytes: an odd number of 16-byte slots, conflict-free ds_read_b128.
+template <int CK, int D>
 __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
+    static_assert(D == 1, "one stage of global loads in flight (deeper rings measured no faster: the stage is barrier-bound)");
     constexpr int PITCH = CK + 8;                   // bf16 elements
     constexpr int XV = CK / 32;                     // float4 pairs per thread for x (4 threads per pixel row, CK / 4 channels each)
     constexpr int WV = CK / 16;                     // uint4 per thread for w (2 threads per weight row)
     __shared__ __attribute__((aligned(16))) bf16_t sX[64 * PITCH];
     __shared__ __attribute__((aligned(16))) bf16_t sW[128 * PITCH];
+    // (native vector types: arrays of HIP's uint4 / float4 structs are not split into registers and went through scratch;
+    //  no lambda may capture the by-value argument `p` by reference either: that copies the struct to scratch)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int Cin = p.Cin, Cin_pad = p.Cin_pad, taps = p.taps, Wout = p.Wout, Hout = p.Hout, N = p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
-    const int P = p.B * p.Wout * p.Hout;
+    const int P = p.B * Wout * Hout;
     const int px0 = blockIdx.x * 64, n0 = blockIdx.y * 128;
     // staging roles
     const int spx = tid >> 2, spart = tid & 3;      // x: pixel row of the tile, quarter of the CK channels
@@ -156,38 +163,55 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     const int gpx = px0 + spx;
     const bool gpx_ok = gpx < P;
     const int pc = gpx_ok ? gpx : 0;
-    const int sho = pc % p.Hout, st1 = pc / p.Hout, swo = st1 % p.Wout, sb = st1 / p.Wout;
+    const int sho = pc % Hout, st1 = pc / Hout, swo = st1 % Wout, sb = st1 / Wout;
     const int wrow = n0 + swr;
-    const bf16_t* wsrc = p.w + (size_t)(wrow < p.N ? wrow : 0) * p.taps * p.Cin_pad + shalf * (CK / 2);
-    const int nck = p.Cin / CK, niter = p.taps * nck;
-    float4 xr[XV][2];
-    uint4 wr[WV];
-    auto fetch = [&](int it) {
-        const int t = it / nck, c0 = (it % nck) * CK;
-        const int dw = p.taps == 9 ? t / 3 - 1 : 0, dh = p.taps == 9 ? t % 3 - 1 : 0;
+    const bf16_t* wptr = p.w + (size_t)(wrow < N ? wrow : 0) * taps * Cin_pad + shalf * (CK / 2);     // walks [tap][chunk]
+    const float* const xbase = p.x + spart * (CK / 4);
+    const int nck = Cin / CK, niter = taps * nck;
+    const int wskip = Cin_pad - Cin;                // weight rows are padded to 16 channels per tap
+    // stage walker: (tap, chunk) advance without divisions; the tap's source pixel is looked up when the tap changes
+    int tap = 0, cc = 0;
+    const float* xs = xbase;
+    float live = 0.f;
+    auto new_tap = [&]() __attribute__((always_inline)) {
+        const int dw = taps == 9 ? tap / 3 - 1 : 0, dh = taps == 9 ? tap % 3 - 1 : 0;
         const int sp = gpx_ok ? src_pixel(sb, swo, sho, dw, dh, p.stride, p.mode, p.Win, p.Hin) : -1;
-        const float* xs = p.x + (size_t)(sp < 0 ? 0 : sp) * p.Cin + c0 + spart * (CK / 4);
-        const float live = sp < 0 ? 0.f : 1.f;
-#pragma unroll
-        for (int q = 0; q < XV; ++q) {
-            float4 a = reinterpret_cast<const float4*>(xs)[2 * q], b = reinterpret_cast<const float4*>(xs)[2 * q + 1];
-            a.x *= live; a.y *= live; a.z *= live; a.w *= live; b.x *= live; b.y *= live; b.z *= live; b.w *= live;
-            xr[q][0] = a; xr[q][1] = b;
-        }
-        const bf16_t* ws = wsrc + (size_t)t * p.Cin_pad + c0;
-#pragma unroll
-        for (int q = 0; q < WV; ++q) wr[q] = reinterpret_cast<const uint4*>(ws)[q];
+        live = sp < 0 ? 0.f : 1.f;
+        xs = xbase + (size_t)(sp < 0 ? 0 : sp) * Cin;
     };
-    auto stash = [&]() {
+    new_tap();
+    f32x4 xr[XV][2];
+    u32x4 wr[WV];
+    float lv = 0.f;
+    auto fetch = [&]() __attribute__((always_inline)) {
+        lv = live;
 #pragma unroll
         for (int q = 0; q < XV; ++q) {
-            uint4 u;
-            u.x = rldm::pack_bf16x2(xr[q][0].x, xr[q][0].y); u.y = rldm::pack_bf16x2(xr[q][0].z, xr[q][0].w);
-            u.z = rldm::pack_bf16x2(xr[q][1].x, xr[q][1].y); u.w = rldm::pack_bf16x2(xr[q][1].z, xr[q][1].w);
-            *reinterpret_cast<uint4*>(sX + spx * PITCH + spart * (CK / 4) + 8 * q) = u;
+            xr[q][0] = reinterpret_cast<const f32x4*>(xs)[2 * q];
+            xr[q][1] = reinterpret_cast<const f32x4*>(xs)[2 * q + 1];
         }
 #pragma unroll
-        for (int q = 0; q < WV; ++q) *reinterpret_cast<uint4*>(sW + swr * PITCH + shalf * (CK / 2) + 8 * q) = wr[q];
+        for (int q = 0; q < WV; ++q) wr[q] = reinterpret_cast<const u32x4*>(wptr)[q];
+        xs += CK;
+        wptr += CK;
+        if (++cc == nck) {
+            cc = 0;
+            ++tap;
+            wptr += wskip;
+            new_tap();
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < XV; ++q) {
+            const f32x4 a = xr[q][0], b = xr[q][1];
+            u32x4 u;
+            u.x = rldm::pack_bf16x2(a.x * lv, a.y * lv); u.y = rldm::pack_bf16x2(a.z * lv, a.w * lv);
+            u.z = rldm::pack_bf16x2(b.x * lv, b.y * lv); u.w = rldm::pack_bf16x2(b.z * lv, b.w * lv);
+            *reinterpret_cast<u32x4*>(sX + spx * PITCH + spart * (CK / 4) + 8 * q) = u;
+        }
+#pragma unroll
+        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / 2) + 8 * q) = wr[q];
     };
     f32x16 acc0, acc1;
 #pragma unroll
@@ -195,12 +219,12 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     const bf16_t* bx = sX + ((wave & 1) * 32 + l31) * PITCH + 8 * kg;
     const bf16_t* aw0 = sW + ((wave >> 1) * 64 + l31) * PITCH + 8 * kg;
     const bf16_t* aw1 = aw0 + 32 * PITCH;
-    fetch(0);
+    fetch();
     for (int it = 0; it < niter; ++it) {
         __syncthreads();                            // everyone is done reading the previous stage
         stash();
         __syncthreads();
-        if (it + 1 < niter) fetch(it + 1);          // in flight during the MFMAs below
+        if (it + 1 < niter) fetch();                // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < CK / 16; ++ks) {
             const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
 
 // ---- weight gradient --------------------------------------------------------------------------------------------------
 struct TrWgrad {
-    const float* dy; const float* x; float* dw;
+    const float* dy; const float* x; float* dw;   // dw: partial sums [taps][slices][N][Cin], slices = grid.z * 4 waves
     int B, Win, Hin, Cin, Wout, Hout, N, taps, stride, mode, chunk;      // chunk: pixels per wave (multiple of 16)
 };
 
@@ -338,8 +362,10 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const TrWgrad p) {
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
     }
-    if (kbeg >= kend) return;
+    // every wave stores its partial tile (coalesced along c); slices that had no pixels store zeros.
     // tile (i, j): lane (column c0 + 32 j + l31, half kg) holds rows n0 + 32 i + (r & 3) + 8 (r >> 2) + 4 kg
+    const int slices = gridDim.z * 4, slice = blockIdx.z * 4 + wave;
+    float* part = p.dw + ((size_t)t * slices + slice) * p.N * p.Cin;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -349,27 +375,61 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const TrWgrad p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nn = n0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (nn < p.N) unsafeAtomicAdd(p.dw + ((size_t)nn * p.Cin + c) * p.taps + t, acc[i][j][r]);
+                if (nn < p.N) part[(size_t)nn * p.Cin + c] = acc[i][j][r];
             }
         }
 }
 
-// rows[b][n] += sum over the pixels of image b of dy[p][n]; total[n] += the same over all images.  grid (channel tiles,
-// images, 512-pixel slabs): fp32 atomics into buffers the caller zeroed (rows) / accumulates into (total = bias gradient).
+// dw[n][c][t] += sum over slices of part[t][slice][n][c]   (one thread per (t, n, c); reads coalesced along c)
+__global__ __launch_bounds__(256) void tr_wgrad_reduce_kernel(const float* __restrict__ part, int slices, int N, int Cin, int taps,
+                                                              float* __restrict__ dw) {
+    const size_t nc = (size_t)N * Cin;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc * taps) return;
+    const int t = (int)(i / nc);
+    const size_t e = i % nc;
+    const float* src = part + (size_t)t * slices * nc + e;
+    float acc = 0.f;
+    for (int s = 0; s < slices; ++s) acc += src[(size_t)s * nc];
+    dw[e * taps + t] += acc;
+}
+
+// rows[b][n] += sum over the pixels of image b of dy[p][n]; total[n] += the same over all images.  grid (64-channel tiles,
+// images, 256-pixel slabs), 256 threads = 16 pixel lanes x 16 channel quads (16-byte loads when N % 4 == 0): fp32 atomics
+// into buffers the caller zeroed (rows) / accumulates into (total = bias gradient).
 __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict__ dy, int npix, int N, float* __restrict__ rows,
                                                         int rows_ld, float* __restrict__ total) {
-    __shared__ float sh[4][64];
-    const int b = blockIdx.y, ch = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int p0 = blockIdx.z * 512, p1 = min(p0 + 512, npix);
-    float acc = 0.f;
-    if (ch < N)
-        for (int px = p0 + q; px < p1; px += 4) acc += dy[((size_t)b * npix + px) * N + ch];
-    sh[q][threadIdx.x & 63] = acc;
+    __shared__ float sh[16][68];
+    const int b = blockIdx.y, cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 64 + cq * 4;
+    const int p0 = blockIdx.z * 256, p1 = min(p0 + 256, npix);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* base = dy + (size_t)b * npix * N + ch;
+    if ((N & 3) == 0 && ch + 3 < N) {
+        for (int px = p0 + pl; px < p1; px += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)px * N);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    } else {
+        for (int px = p0 + pl; px < p1; px += 16) {
+            const float* r = base + (size_t)px * N;
+            if (ch < N) a0 += r[0];
+            if (ch + 1 < N) a1 += r[1];
+            if (ch + 2 < N) a2 += r[2];
+            if (ch + 3 < N) a3 += r[3];
+        }
+    }
+    sh[pl][cq * 4] = a0; sh[pl][cq * 4 + 1] = a1; sh[pl][cq * 4 + 2] = a2; sh[pl][cq * 4 + 3] = a3;
     __syncthreads();
-    if (q == 0 && ch < N) {
-        const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        if (rows) unsafeAtomicAdd(rows + (size_t)b * rows_ld + ch, v);
-        if (total) unsafeAtomicAdd(total + ch, v);
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += sh[r][threadIdx.x];
+            if (rows) unsafeAtomicAdd(rows + (size_t)b * rows_ld + c, v);
+            if (total) unsafeAtomicAdd(total + c, v);
+        }
     }
 }
 
@@ -488,36 +548,63 @@ __global__ __launch_bounds__(256) void tr_gn_bwd_apply_kernel(const float* __res
 
 // ---- attention, head_dim 8 -----------------------------------------------------------------------------------------------
 // q, k, v, o: [B][L][C] fp32, head h = channels 8h .. 8h + 8.  grid (ceil(L / 128), heads, B), 128 threads = 128 queries.
+// The other side (keys / values, or queries / dO) passes through LDS in tiles of ATT_TK rows (16-18 KB: ten workgroups per
+// CU instead of two with the whole head resident), every thread reads the same row at a time (LDS broadcast).
+constexpr int ATT_TK = 256;
+
 __global__ __launch_bounds__(128) void tr_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, int L, int C, float scale,
                                                           float* __restrict__ o, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sK = sm;
-    float* sV = sm + (size_t)L * 8;
+    __shared__ __attribute__((aligned(16))) float sK[ATT_TK * 8];
+    __shared__ __attribute__((aligned(16))) float sV[ATT_TK * 8];
     const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
     const size_t base = (size_t)b * L * C + h * 8;
-    for (int e = threadIdx.x; e < L * 8; e += 128) {
-        sK[e] = k[base + (size_t)(e >> 3) * C + (e & 7)];
-        sV[e] = v[base + (size_t)(e >> 3) * C + (e & 7)];
-    }
-    __syncthreads();
     const int i = blockIdx.x * 128 + threadIdx.x;
-    if (i >= L) return;
+    const bool live = i < L;
     float qi[8], acc[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) { qi[d] = q[base + (size_t)i * C + d] * scale; acc[d] = 0.f; }
+    for (int d = 0; d < 8; ++d) { qi[d] = live ? q[base + (size_t)i * C + d] * scale : 0.f; acc[d] = 0.f; }
     float m = -INFINITY, l = 0.f;
-    for (int j = 0; j < L; ++j) {
-        float s = 0.f;
+    for (int j0 = 0; j0 < L; j0 += ATT_TK) {
+        const int nt = min(ATT_TK, L - j0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nt * 8; e += 128) {
+            sK[e] = k[base + (size_t)(j0 + (e >> 3)) * C + (e & 7)];
+            sV[e] = v[base + (size_t)(j0 + (e >> 3)) * C + (e & 7)];
+        }
+        __syncthreads();
+        // groups of 8 keys: one running-maximum update (one rescale of the accumulator) per group
+        for (int jj = 0; jj < nt; jj += 8) {
+            float sc[8];
+            float gm = m;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) s += qi[d] * sK[j * 8 + d];
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn), pj = __expf(s - mn);
-        l = l * corr + pj;
+            for (int u = 0; u < 8; ++u) {
+                float t = -INFINITY;
+                if (jj + u < nt) {
+                    t = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) acc[d] = acc[d] * corr + pj * sV[j * 8 + d];
-        m = mn;
+                    for (int d = 0; d < 8; ++d) t += qi[d] * sK[(jj + u) * 8 + d];
+                }
+                sc[u] = t;
+                gm = fmaxf(gm, t);
+            }
+            const float corr = __expf(m - gm);
+            l *= corr;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc[d] *= corr;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (jj + u < nt) {
+                    const float pj = __expf(sc[u] - gm);
+                    l += pj;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) acc[d] += pj * sV[(jj + u) * 8 + d];
+                }
+            }
+            m = gm;
+        }
     }
+    if (!live) return;
     const float inv = 1.f / l;
 #pragma unroll
     for (int d = 0; d < 8; ++d) o[base + (size_t)i * C + d] = acc[d] * inv;
@@ -529,81 +616,90 @@ __global__ __launch_bounds__(128) void tr_attn_bwd_dq_kernel(const float* __rest
                                                              const float* __restrict__ v, const float* __restrict__ o,
                                                              const float* __restrict__ dO, const float* __restrict__ lse, int L, int C,
                                                              float scale, float* __restrict__ dq, float* __restrict__ delta) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sK = sm;
-    float* sV = sm + (size_t)L * 8;
+    __shared__ __attribute__((aligned(16))) float sK[ATT_TK * 8];
+    __shared__ __attribute__((aligned(16))) float sV[ATT_TK * 8];
     const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
     const size_t base = (size_t)b * L * C + h * 8;
-    for (int e = threadIdx.x; e < L * 8; e += 128) {
-        sK[e] = k[base + (size_t)(e >> 3) * C + (e & 7)];
-        sV[e] = v[base + (size_t)(e >> 3) * C + (e & 7)];
-    }
-    __syncthreads();
     const int i = blockIdx.x * 128 + threadIdx.x;
-    if (i >= L) return;
+    const bool live = i < L;
     float qi[8], doi[8], acc[8];
     float D = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-        qi[d] = q[base + (size_t)i * C + d] * scale;
-        doi[d] = dO[base + (size_t)i * C + d];
-        D += doi[d] * o[base + (size_t)i * C + d];
+        qi[d] = live ? q[base + (size_t)i * C + d] * scale : 0.f;
+        doi[d] = live ? dO[base + (size_t)i * C + d] : 0.f;
+        D += live ? doi[d] * o[base + (size_t)i * C + d] : 0.f;
         acc[d] = 0.f;
     }
-    const float li = lse[((size_t)b * heads + h) * L + i];
-    for (int j = 0; j < L; ++j) {
-        float s = 0.f, dp = 0.f;
+    const float li = live ? lse[((size_t)b * heads + h) * L + i] : 0.f;
+    for (int j0 = 0; j0 < L; j0 += ATT_TK) {
+        const int nt = min(ATT_TK, L - j0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nt * 8; e += 128) {
+            sK[e] = k[base + (size_t)(j0 + (e >> 3)) * C + (e & 7)];
+            sV[e] = v[base + (size_t)(j0 + (e >> 3)) * C + (e & 7)];
+        }
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { s += qi[d] * sK[j * 8 + d]; dp += doi[d] * sV[j * 8 + d]; }
-        const float ds = __expf(s - li) * (dp - D);
+            for (int d = 0; d < 8; ++d) { s += qi[d] * sK[j * 8 + d]; dp += doi[d] * sV[j * 8 + d]; }
+            const float ds = __expf(s - li) * (dp - D);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) acc[d] += ds * sK[j * 8 + d];
+            for (int d = 0; d < 8; ++d) acc[d] += ds * sK[j * 8 + d];
+        }
     }
+    if (!live) return;
 #pragma unroll
     for (int d = 0; d < 8; ++d) dq[base + (size_t)i * C + d] = acc[d] * scale;
     delta[((size_t)b * heads + h) * L + i] = D;
 }
 
-// dk, dv: one thread per key against all queries (Q * scale, dO, lse, delta staged in LDS)
+// dk, dv: one thread per key against all queries (Q * scale, dO, lse, delta pass through LDS in tiles)
 __global__ __launch_bounds__(128) void tr_attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, const float* __restrict__ dO,
                                                               const float* __restrict__ lse, const float* __restrict__ delta, int L,
                                                               int C, float scale, float* __restrict__ dk, float* __restrict__ dv) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sQ = sm;
-    float* sDO = sm + (size_t)L * 8;
-    float* sL = sDO + (size_t)L * 8;
-    float* sD = sL + L;
+    __shared__ __attribute__((aligned(16))) float sQ[ATT_TK * 8];
+    __shared__ __attribute__((aligned(16))) float sDO[ATT_TK * 8];
+    __shared__ float sL[ATT_TK];
+    __shared__ float sD[ATT_TK];
     const int h = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
     const size_t base = (size_t)b * L * C + h * 8;
-    for (int e = threadIdx.x; e < L * 8; e += 128) {
-        sQ[e] = q[base + (size_t)(e >> 3) * C + (e & 7)] * scale;
-        sDO[e] = dO[base + (size_t)(e >> 3) * C + (e & 7)];
-    }
-    for (int e = threadIdx.x; e < L; e += 128) {
-        sL[e] = lse[((size_t)b * heads + h) * L + e];
-        sD[e] = delta[((size_t)b * heads + h) * L + e];
-    }
-    __syncthreads();
+    const size_t rbase = ((size_t)b * heads + h) * L;
     const int j = blockIdx.x * 128 + threadIdx.x;
-    if (j >= L) return;
+    const bool live = j < L;
     float kj[8], vj[8], ak[8], av[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-        kj[d] = k[base + (size_t)j * C + d];
-        vj[d] = v[base + (size_t)j * C + d];
+        kj[d] = live ? k[base + (size_t)j * C + d] : 0.f;
+        vj[d] = live ? v[base + (size_t)j * C + d] : 0.f;
         ak[d] = 0.f;
         av[d] = 0.f;
     }
-    for (int i = 0; i < L; ++i) {
-        float s = 0.f, dp = 0.f;
+    for (int i0 = 0; i0 < L; i0 += ATT_TK) {
+        const int nt = min(ATT_TK, L - i0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nt * 8; e += 128) {
+            sQ[e] = q[base + (size_t)(i0 + (e >> 3)) * C + (e & 7)] * scale;
+            sDO[e] = dO[base + (size_t)(i0 + (e >> 3)) * C + (e & 7)];
+        }
+        for (int e = threadIdx.x; e < nt; e += 128) {
+            sL[e] = lse[rbase + i0 + e];
+            sD[e] = delta[rbase + i0 + e];
+        }
+        __syncthreads();
+        for (int i = 0; i < nt; ++i) {
+            float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { s += sQ[i * 8 + d] * kj[d]; dp += sDO[i * 8 + d] * vj[d]; }
-        const float pij = __expf(s - sL[i]);
-        const float ds = pij * (dp - sD[i]);
+            for (int d = 0; d < 8; ++d) { s += sQ[i * 8 + d] * kj[d]; dp += sDO[i * 8 + d] * vj[d]; }
+            const float pij = __expf(s - sL[i]);
+            const float ds = pij * (dp - sD[i]);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { av[d] += pij * sDO[i * 8 + d]; ak[d] += ds * sQ[i * 8 + d]; }
+            for (int d = 0; d < 8; ++d) { av[d] += pij * sDO[i * 8 + d]; ak[d] += ds * sQ[i * 8 + d]; }
+        }
     }
+    if (!live) return;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         dk[base + (size_t)j * C + d] = ak[d];          // sQ already carries the scale
@@ -789,10 +885,16 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
     const int P = p.B * p.Wout * p.Hout;
     const dim3 grid((P + 63) / 64, (p.N + 127) / 128);
     const bool aligned = (rowadd_ld & 3) == 0;         // (vector epilogue reads the per-sample row 16 bytes at a time)
-    if (p.Cin % 64 == 0 && P >= 64 && aligned) tr_conv_lds_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else if (p.Cin % 32 == 0 && P >= 64 && aligned) tr_conv_lds_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else tr_conv_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    const bool lds = P >= 64 && aligned;               // Linear layers on a handful of rows: the direct kernel
+    static const int depth = getenv("RLDM_TR_DEPTH") ? atoi(getenv("RLDM_TR_DEPTH")) : 1;
+    hipStream_t st = (hipStream_t)stream;
+    (void)depth;
+    if (lds && p.Cin % 64 == 0) {
+        tr_conv_lds_kernel<64, 1><<<grid, 256, 0, st>>>(p);
+    } else if (lds && p.Cin % 32 == 0) {
+        tr_conv_lds_kernel<32, 1><<<grid, 256, 0, st>>>(p);
+    } else if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, st>>>(p);
+    else tr_conv_kernel<false><<<grid, 256, 0, st>>>(p);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -807,12 +909,27 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
     p.Wout = (d->Win << sh) / d->stride; p.Hout = (d->Hin << sh) / d->stride;
     const int P = p.B * p.Wout * p.Hout;
     const int tiles = ((p.N + 63) / 64) * ((p.Cin + 63) / 64) * p.taps;
-    // a wave contracts `chunk` pixels and then issues 4096 atomics: ~1024 pixels per wave, fewer only to fill the chip
-    int chunk = 1024;
+    // a wave contracts `chunk` pixels into its own partial tile; ~1024 pixels per wave, fewer only to fill the chip
+    int chunk = getenv("RLDM_TR_WG_CHUNK") ? atoi(getenv("RLDM_TR_WG_CHUNK")) : 1024;
     while (chunk > 128 && (long long)tiles * ((P + 4 * chunk - 1) / (4 * chunk)) < 256) chunk >>= 1;
     const int splits = (P + 4 * chunk - 1) / (4 * chunk);
     p.chunk = chunk;
-    tr_wgrad_kernel<<<dim3(((p.N + 63) / 64) * ((p.Cin + 63) / 64), p.taps, splits), 256, 0, (hipStream_t)stream>>>(p);
+    const size_t need = (size_t)p.taps * splits * 4 * p.N * p.Cin * sizeof(float);
+    static float* scratch = nullptr;                   // (one caller thread; launches are stream ordered)
+    static size_t scratch_cap = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (need > scratch_cap) {
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (scratch) RLDM_HIP_CHECK(hipFree(scratch));
+        scratch = nullptr;
+        scratch_cap = 0;
+        RLDM_HIP_CHECK(hipMalloc(&scratch, need));
+        scratch_cap = need;
+    }
+    p.dw = scratch;
+    tr_wgrad_kernel<<<dim3(((p.N + 63) / 64) * ((p.Cin + 63) / 64), p.taps, splits), 256, 0, st>>>(p);
+    TR_LAUNCH_CHECK();
+    tr_wgrad_reduce_kernel<<<nblk((size_t)p.N * p.Cin * p.taps), 256, 0, st>>>(scratch, splits * 4, p.N, p.Cin, p.taps, dw);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -822,7 +939,7 @@ int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int 
     RLDM_REQUIRE(dy && (rows || total), "null argument");
     hipStream_t st = (hipStream_t)stream;
     if (rows && !rows_accumulate) RLDM_HIP_CHECK(hipMemset2DAsync(rows, (size_t)rows_ld * sizeof(float), 0, (size_t)N * sizeof(float), B, st));
-    tr_colsum_kernel<<<dim3((N + 63) / 64, B, (npix + 511) / 512), 256, 0, st>>>(dy, npix, N, rows, rows_ld, total);
+    tr_colsum_kernel<<<dim3((N + 63) / 64, B, (npix + 255) / 256), 256, 0, st>>>(dy, npix, N, rows, rows_ld, total);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -855,19 +972,11 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
     return 0;
 }
 
-static int attn_lds(const void* fn, size_t bytes) {
-    RLDM_REQUIRE(bytes <= 160 * 1024, "attention: sequence too long for the LDS-resident head (L <= 2048)");
-    RLDM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
-}
-
 int rldm_train_attention_forward(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse,
                                  void* stream) {
     RLDM_REQUIRE(q && k && v && o && lse, "null argument");
     RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
-    const size_t lds = (size_t)L * 16 * sizeof(float);
-    if (attn_lds(reinterpret_cast<const void*>(tr_attn_fwd_kernel), lds)) return 1;
-    tr_attn_fwd_kernel<<<dim3((L + 127) / 128, C / 8, B), 128, lds, (hipStream_t)stream>>>(q, k, v, L, C, 0.35355339059327373f, o, lse);
+    tr_attn_fwd_kernel<<<dim3((L + 127) / 128, C / 8, B), 128, 0, (hipStream_t)stream>>>(q, k, v, L, C, 0.35355339059327373f, o, lse);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -878,12 +987,9 @@ int rldm_train_attention_backward(const float* q, const float* k, const float* v
     RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
     hipStream_t st = (hipStream_t)stream;
     const float scale = 0.35355339059327373f;
-    const size_t lds1 = (size_t)L * 16 * sizeof(float), lds2 = (size_t)L * 18 * sizeof(float);
-    if (attn_lds(reinterpret_cast<const void*>(tr_attn_bwd_dq_kernel), lds1)) return 1;
-    if (attn_lds(reinterpret_cast<const void*>(tr_attn_bwd_dkv_kernel), lds2)) return 1;
     const dim3 grid((L + 127) / 128, C / 8, B);
-    tr_attn_bwd_dq_kernel<<<grid, 128, lds1, st>>>(q, k, v, o, dO, lse, L, C, scale, dq, delta);
-    tr_attn_bwd_dkv_kernel<<<grid, 128, lds2, st>>>(q, k, v, dO, lse, delta, L, C, scale, dk, dv);
+    tr_attn_bwd_dq_kernel<<<grid, 128, 0, st>>>(q, k, v, o, dO, lse, L, C, scale, dq, delta);
+    tr_attn_bwd_dkv_kernel<<<grid, 128, 0, st>>>(q, k, v, dO, lse, delta, L, C, scale, dk, dv);
     TR_LAUNCH_CHECK();
     return 0;
 }
