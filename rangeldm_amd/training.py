@@ -380,10 +380,12 @@ class UNetTrainer:
 
 
 def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, pos_encoding=True, snr_gamma=None,
-                  noise=None, timesteps=None):
+                  noise=None, timesteps=None, condition=None):
     """One iteration of the reference's loop body (ldm/train_unconditional.py:479-556) with `with_vae: True`:
     latents = vae.encode(x).latent_dist.sample() * scaling_factor; eps ~ N(0, 1); t ~ U{0..T-1}; add_noise; pos-encoding
-    channel; epsilon-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA."""
+    channel; epsilon-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA.
+    condition (B, Cc, W, H): the conditional twin (ldm/train_conditional.py:418-447) -- the encoded low-resolution image
+    (`condition_encoder(batch["down"])`) or `cat([masked latents, mask])`, concatenated to the noisy latents."""
     dev = trainer.device
     if vae is not None:
         latents = vae.encode(clean_images.to(dev)).latent_dist.sample(generator=generator, scale=vae.config.scaling_factor)
@@ -395,6 +397,8 @@ def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, p
     if timesteps is None:
         timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (B,), generator=generator).long()
     noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+    if condition is not None:
+        noisy = torch.cat([noisy, condition.to(dev).float()], dim=1)        # (a copy: ldm/train_conditional.py:447)
     w = None
     if snr_gamma is not None:
         w = snr_weights(noise_scheduler.alphas_cumprod, timesteps, snr_gamma).to(dev)

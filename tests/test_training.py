@@ -183,3 +183,32 @@ def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
     from rangeldm_amd.unet import UNet2DModelHIP
     m = UNet2DModelHIP.from_pretrained(str(tmp_path), subfolder="unet_ema")
     assert torch.isfinite(m(x, 10).sample).all()
+
+
+@pytest.mark.gpu
+def test_training_step_loop_body_unconditional_and_conditional():
+    """`training_step` = the loop body of ldm/train_unconditional.py:479-556 (VAE encode + sample, add_noise, pos-encoding,
+    min-SNR weights) and its conditional twin (ldm/train_conditional.py:418-447, upsample: 4 + 8 folded-condition channels)."""
+    from rangeldm_amd.encoders import SparseRangeImageEncoder2
+    from rangeldm_amd.config import VAEConfig
+    from rangeldm_amd.params import vae_param_shapes
+    from rangeldm_amd.schedulers import DDPMSchedulerHIP
+    from rangeldm_amd.vae import AutoencoderKLHIP
+    vae = AutoencoderKLHIP(VAEConfig())
+    vae.load_state_dict(synth_state_dict(vae_param_shapes(VAEConfig()), prefix="vae."))
+    sched = DDPMSchedulerHIP()
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randn(2, 2, 128, 32, generator=g) * 0.5
+    cfg = UNetConfig(sample_size=(32, 8), in_channels=5, block_out_channels=(32, 32, 64, 64))
+    tr = TR.UNetTrainer(cfg, synth_state_dict(unet_param_shapes(cfg), prefix="tr."), lr_warmup_steps=0, lr=1e-3)
+    l0 = [float(TR.training_step(tr, vae, sched, imgs.cuda(), generator=torch.Generator().manual_seed(1), pos_encoding=True,
+                                 snr_gamma=5.0)) for _ in range(6)]
+    assert all(math.isfinite(v) for v in l0) and l0[-1] < l0[0]       # same noise / timesteps every call: it must fall
+    cfg_c = UNetConfig(sample_size=(32, 8), in_channels=12, block_out_channels=(32, 32, 64, 64))
+    trc = TR.UNetTrainer(cfg_c, synth_state_dict(unet_param_shapes(cfg_c), prefix="trc."), lr_warmup_steps=0, lr=1e-3)
+    down = torch.randn(2, 2, 128, 8, generator=g)
+    cond = SparseRangeImageEncoder2()(down)
+    assert tuple(cond.shape) == (2, 8, 32, 8)
+    l1 = [float(TR.training_step(trc, vae, sched, imgs.cuda(), generator=torch.Generator().manual_seed(1), pos_encoding=False,
+                                 condition=cond)) for _ in range(6)]
+    assert all(math.isfinite(v) for v in l1) and l1[-1] < l1[0]
