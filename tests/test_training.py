@@ -212,3 +212,42 @@ def test_training_step_loop_body_unconditional_and_conditional():
     l1 = [float(TR.training_step(trc, vae, sched, imgs.cuda(), generator=torch.Generator().manual_seed(1), pos_encoding=False,
                                  condition=cond)) for _ in range(6)]
     assert all(math.isfinite(v) for v in l1) and l1[-1] < l1[0]
+
+
+@pytest.mark.gpu
+def test_full_config_gradient_is_the_directional_derivative():
+    """BASELINE config-5 shapes (RangeLDM UNet, 256 x 16 latents, batch reduced to 2): a size-independent property instead of
+    the CPU oracle -- along the gradient direction the loss must change at the rate |g|:
+    (L(w + e g/|g|) - L(w - e g/|g|)) / (2 e) = |g| up to O(e^2) and the bf16 operand rounding of the forward passes."""
+    from rangeldm_amd import train_ops as T
+    cfg = UNetConfig()
+    sd = synth_state_dict(unet_param_shapes(cfg))
+    tr = TR.UNetTrainer(cfg, sd, use_ema=False)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 4, 256, 16, generator=g).cuda()
+    target = torch.randn(2, 4, 256, 16, generator=g).cuda()
+    t = torch.tensor([333, 871]).cuda()
+
+    def loss_at():
+        tr.repack()
+        return float(T.mse(tr.forward(x, t, pos_encoding=True), target)[0])
+    loss0, dpred = T.mse(tr.forward(x, t, pos_encoding=True), target)
+    tr.backward(dpred)
+    grad = tr.grads.clone()
+    assert torch.isfinite(grad).all() and float(loss0) > 0
+    gn = float(grad.double().norm())
+    assert gn > 0
+    eps = 0.02
+    w0 = tr.params.clone()
+    tr.params.copy_(w0 + eps * grad / gn)
+    lp = loss_at()
+    tr.params.copy_(w0 - eps * grad / gn)
+    lm = loss_at()
+    tr.params.copy_(w0)
+    slope = (lp - lm) / (2 * eps)
+    assert abs(slope / gn - 1) < 0.1, (slope, gn, float(loss0), lp, lm)
+    # every parameter received a gradient (no dead branch in the tape), including both ends of the network
+    for n in ("conv_in.weight", "time_embedding.linear_1.weight", "mid_block.attentions.0.to_q.weight",
+              "up_blocks.3.resnets.2.conv_shortcut.weight", "conv_out.bias", "down_blocks.1.downsamplers.0.conv.weight",
+              "up_blocks.0.upsamplers.0.conv.weight"):
+        assert float(tr.g[n].abs().max()) > 0, n
