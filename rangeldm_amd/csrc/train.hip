@@ -141,14 +141,15 @@ __global__ __launch_bounds__(256) void tr_conv_kernel(const TrConv p) {
 // costs one memory latency (~1.5 us measured: activations of a level live in the Infinity Cache, not in L2) against 0.1 us
 // of MFMAs, so the global loads of the next D stages are kept in flight in registers (static ring, loop unrolled by D).
 // Row pitch CK * 2 + 16 bytes: an odd number of 16-byte slots, conflict-free ds_read_b128.
-template <int CK, int D>
+template <int CK, int BN>
 __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
-    static_assert(D == 1, "one stage of global loads in flight (deeper rings measured no faster: the stage is barrier-bound)");
+    static_assert(BN == 64 || BN == 128, "channel tile");
+    constexpr int TPR = 256 / BN, NR = BN / 64;     // threads per weight row of a stage; 32-channel MFMA rows per wave
     constexpr int PITCH = CK + 8;                   // bf16 elements
     constexpr int XV = CK / 32;                     // float4 pairs per thread for x (4 threads per pixel row, CK / 4 channels each)
-    constexpr int WV = CK / 16;                     // uint4 per thread for w (2 threads per weight row)
+    constexpr int WV = CK / (8 * TPR);              // uint4 per thread for w
     __shared__ __attribute__((aligned(16))) bf16_t sX[64 * PITCH];
-    __shared__ __attribute__((aligned(16))) bf16_t sW[128 * PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t sW[BN * PITCH];
     // (native vector types: arrays of HIP's uint4 / float4 structs are not split into registers and went through scratch;
     //  no lambda may capture the by-value argument `p` by reference either: that copies the struct to scratch)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -156,16 +157,16 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     const int P = p.B * Wout * Hout;
-    const int px0 = blockIdx.x * 64, n0 = blockIdx.y * 128;
+    const int px0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
     // staging roles
     const int spx = tid >> 2, spart = tid & 3;      // x: pixel row of the tile, quarter of the CK channels
-    const int swr = tid >> 1, shalf = tid & 1;      // w: weight row of the tile, half of the CK channels
+    const int swr = tid / TPR, shalf = tid % TPR;   // w: weight row of the tile, 1 / TPR of the CK channels
     const int gpx = px0 + spx;
     const bool gpx_ok = gpx < P;
     const int pc = gpx_ok ? gpx : 0;
     const int sho = pc % Hout, st1 = pc / Hout, swo = st1 % Wout, sb = st1 / Wout;
     const int wrow = n0 + swr;
-    const bf16_t* wptr = p.w + (size_t)(wrow < N ? wrow : 0) * taps * Cin_pad + shalf * (CK / 2);     // walks [tap][chunk]
+    const bf16_t* wptr = p.w + (size_t)(wrow < N ? wrow : 0) * taps * Cin_pad + shalf * (CK / TPR);     // walks [tap][chunk]
     const float* const xbase = p.x + spart * (CK / 4);
     const int nck = Cin / CK, niter = taps * nck;
     const int wskip = Cin_pad - Cin;                // weight rows are padded to 16 channels per tap
@@ -211,14 +212,14 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
             *reinterpret_cast<u32x4*>(sX + spx * PITCH + spart * (CK / 4) + 8 * q) = u;
         }
 #pragma unroll
-        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / 2) + 8 * q) = wr[q];
+        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / TPR) + 8 * q) = wr[q];
     };
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const bf16_t* bx = sX + ((wave & 1) * 32 + l31) * PITCH + 8 * kg;
-    const bf16_t* aw0 = sW + ((wave >> 1) * 64 + l31) * PITCH + 8 * kg;
-    const bf16_t* aw1 = aw0 + 32 * PITCH;
+    const bf16_t* aw0 = sW + ((wave >> 1) * (BN / 2) + l31) * PITCH + 8 * kg;
+    const bf16_t* aw1 = aw0 + (NR == 2 ? 32 : 0) * PITCH;
     fetch();
     for (int it = 0; it < niter; ++it) {
         __syncthreads();                            // everyone is done reading the previous stage
@@ -229,19 +230,21 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
         for (int ks = 0; ks < CK / 16; ++ks) {
             const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aw0 + 16 * ks);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+            if (NR == 2) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+            }
         }
     }
     const int px = px0 + (wave & 1) * 32 + l31;
     if (px >= P) return;
     const int b = px / (p.Wout * p.Hout);
-    const int nb = n0 + (wave >> 1) * 64;
+    const int nb = n0 + (wave >> 1) * (BN / 2);
     float* yrow = p.y + (size_t)px * p.N;
     const float* rrow = p.res ? p.res + (size_t)px * p.N : nullptr;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NR; ++h)
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
             const int ch = nb + 32 * h + 8 * (r >> 2) + 4 * kg;       // 4 consecutive channels per register quad
@@ -883,16 +886,24 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
     RLDM_REQUIRE(p.Wout > 0 && p.Hout > 0, "empty output");
     p.N = d->N; p.taps = d->taps; p.stride = d->stride; p.mode = d->mode; p.rowadd_ld = rowadd_ld; p.accumulate = accumulate;
     const int P = p.B * p.Wout * p.Hout;
-    const dim3 grid((P + 63) / 64, (p.N + 127) / 128);
+    dim3 grid((P + 63) / 64, (p.N + 127) / 128);
     const bool aligned = (rowadd_ld & 3) == 0;         // (vector epilogue reads the per-sample row 16 bytes at a time)
     const bool lds = P >= 64 && aligned;               // Linear layers on a handful of rows: the direct kernel
-    static const int depth = getenv("RLDM_TR_DEPTH") ? atoi(getenv("RLDM_TR_DEPTH")) : 1;
     hipStream_t st = (hipStream_t)stream;
-    (void)depth;
-    if (lds && p.Cin % 64 == 0) {
-        tr_conv_lds_kernel<64, 1><<<grid, 256, 0, st>>>(p);
-    } else if (lds && p.Cin % 32 == 0) {
-        tr_conv_lds_kernel<32, 1><<<grid, 256, 0, st>>>(p);
+    if (lds && p.Cin % 32 == 0) {
+        // 128-channel tiles stage the pixel operand half as often; 64-channel tiles double the workgroups in flight, which
+        // is what hides a stage's load latency when the launch has fewer than ~2 workgroups per CU (3x3 levels 1-3: 10-20 %
+        // faster; the 512-workgroup level 0 and the two-stage 1x1 convs are faster with the wide tile)
+        static const int bn_env = getenv("RLDM_TR_BN") ? atoi(getenv("RLDM_TR_BN")) : 0;
+        const bool narrow = bn_env ? bn_env == 64 : (p.taps == 9 && (long long)grid.x * grid.y < 512);   // (measured per level)
+        if (narrow) grid.y = (p.N + 63) / 64;
+        if (p.Cin % 64 == 0) {
+            if (narrow) tr_conv_lds_kernel<64, 64><<<grid, 256, 0, st>>>(p);
+            else tr_conv_lds_kernel<64, 128><<<grid, 256, 0, st>>>(p);
+        } else {
+            if (narrow) tr_conv_lds_kernel<32, 64><<<grid, 256, 0, st>>>(p);
+            else tr_conv_lds_kernel<32, 128><<<grid, 256, 0, st>>>(p);
+        }
     } else if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, st>>>(p);
     else tr_conv_kernel<false><<<grid, 256, 0, st>>>(p);
     TR_LAUNCH_CHECK();
