@@ -255,6 +255,16 @@ int rldm_train_adamw(float* params, const float* grads, float* exp_avg, float* e
 /* master fp32 [N][Cin][taps] -> bf16 [N][taps][ceil16(Cin)] (forward) and bf16 [Cin][taps][ceil16(N)] (flipped / transposed:
  * data gradient; may be NULL). */
 int rldm_train_pack_weights(const float* w, int N, int Cin, int taps, void* w_forward, void* w_transposed, void* stream);
+/* the same for every layer of the model in one launch: descs = DEVICE array sorted by `first` (cumulative count of
+ * max(forward, transposed) copy elements), params = the flat fp32 parameter buffer. */
+typedef struct rldm_pack_desc {
+    int64_t first;          /* cumulative element index of this layer in the launch                               */
+    int64_t param_offset;   /* offset of the layer's [N][Cin][taps] weight in the flat parameter buffer (elements) */
+    void* w_forward;        /* bf16 [N][taps][ceil16(Cin)]                                                         */
+    void* w_transposed;     /* bf16 [Cin][taps][ceil16(N)] or NULL                                                 */
+    int32_t N, Cin, taps, pad_;
+} rldm_pack_desc;
+int rldm_train_pack_weights_all(const float* params, const rldm_pack_desc* descs, int num_layers, int64_t total, void* stream);
 
 /* ---- introspection used by bench.py / tests ----------------------------------------------------------------- */
 /* algorithmic FLOPs (2*MACs of conv/linear/QK^T/PV) of one UNet forward / VAE decode / encode for batch B */

@@ -46,6 +46,11 @@ class TrainConvDescC(C.Structure):
                 ("taps", C.c_int32), ("stride", C.c_int32), ("mode", C.c_int32)]
 
 
+class PackDescC(C.Structure):
+    _fields_ = [("first", C.c_int64), ("param_offset", C.c_int64), ("w_forward", C.c_void_p), ("w_transposed", C.c_void_p),
+                ("N", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("pad_", C.c_int32)]
+
+
 class AdamWConfigC(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("ema_decay", C.c_float), ("step", C.c_int32)]
@@ -104,6 +109,7 @@ PROTOTYPES = {
     "rldm_train_sqnorm": (C.c_int, [_P, C.c_int64, _P, _P]),
     "rldm_train_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(AdamWConfigC), _P]),
     "rldm_train_pack_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "rldm_train_pack_weights_all": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
     "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),

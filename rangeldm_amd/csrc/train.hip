@@ -469,6 +469,49 @@ __global__ __launch_bounds__(256) void tr_gn_stats_kernel(const float* __restric
     }
 }
 
+// Large tensors: the one-block-per-(image, group) kernels above read 16-byte pieces 2 KB apart.  These variants give a
+// block a slab of 64 pixels x all channels (fully coalesced float4 rows); a thread's channel quad is the same in every
+// iteration when C divides 1024, so it accumulates in registers and ends with one LDS atomic per group it touched.
+// acc [B][groups][2] doubles (zeroed by the caller): (sum, sum of squares).
+__global__ __launch_bounds__(256) void tr_gn_stats_slab_kernel(const float* __restrict__ x, int npix, int C, int groups,
+                                                               double* __restrict__ acc) {
+    __shared__ double sS[64], sSS[64];
+    const int b = blockIdx.y, cpg = C / groups;
+    const int p0 = blockIdx.x * 64, p1 = min(p0 + 64, npix);
+    if (threadIdx.x < groups) { sS[threadIdx.x] = 0.0; sSS[threadIdx.x] = 0.0; }
+    __syncthreads();
+    const float4* base = reinterpret_cast<const float4*>(x + ((size_t)b * npix + p0) * C);
+    const int n4 = (p1 - p0) * C / 4;
+    const int c0 = (threadIdx.x * 4) % C;                  // fixed channel quad (C divides 1024)
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = base[i];
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (c0 + e) / cpg;
+        atomicAdd(&sS[g], (double)s[e]);
+        atomicAdd(&sSS[g], (double)ss[e]);
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        unsafeAtomicAdd(acc + ((size_t)b * groups + threadIdx.x) * 2, sS[threadIdx.x]);
+        unsafeAtomicAdd(acc + ((size_t)b * groups + threadIdx.x) * 2 + 1, sSS[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void tr_gn_stats_finish_kernel(const double* __restrict__ acc, int n, double count, float eps,
+                                                                 float2* __restrict__ stats) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double mean = acc[2 * i] / count;
+    double var = acc[2 * i + 1] / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
 __device__ inline float sigmoid_f(float z) { return 1.f / (1.f + __expf(-z)); }
 
 __global__ __launch_bounds__(256) void tr_gn_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
@@ -525,6 +568,73 @@ __global__ __launch_bounds__(256) void tr_gn_bwd_reduce_kernel(const float* __re
         unsafeAtomicAdd(dbeta + g * cpg + threadIdx.x, tb);
     }
     if (threadIdx.x == 0) sums[b * groups + g] = make_float2((float)s1, (float)s2);
+}
+
+// slab variant of the reduction (see tr_gn_stats_slab_kernel): acc [B][groups][2] doubles = (sum dz gamma, sum dz gamma xhat);
+// dgamma / dbeta by one global atomic per channel and block
+__global__ __launch_bounds__(256) void tr_gn_bwd_reduce_slab_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int npix, int C, int groups,
+                                                                    int silu, double* __restrict__ acc, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta) {
+    __shared__ double s1[64], s2[64];
+    __shared__ float sg[1024], sb[1024];
+    const int b = blockIdx.y, cpg = C / groups;
+    const int p0 = blockIdx.x * 64, p1 = min(p0 + 64, npix);
+    if (threadIdx.x < groups) { s1[threadIdx.x] = 0.0; s2[threadIdx.x] = 0.0; }
+    for (int c = threadIdx.x; c < C; c += 256) { sg[c] = 0.f; sb[c] = 0.f; }
+    __syncthreads();
+    const size_t off = ((size_t)b * npix + p0) * C;
+    const float4* bx = reinterpret_cast<const float4*>(x + off);
+    const float4* bd = reinterpret_cast<const float4*>(dy + off);
+    const int n4 = (p1 - p0) * C / 4;
+    const int c0 = (threadIdx.x * 4) % C;
+    float ga[4], be[4], mean[4], rstd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float2 st = stats[b * groups + (c0 + e) / cpg];
+        ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; mean[e] = st.x; rstd[e] = st.y;
+    }
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 xv = bx[i], dv = bd[i];
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xe[e] - mean[e]) * rstd[e];
+            float dz = de[e];
+            if (silu) {
+                const float z = xh * ga[e] + be[e], sgm = sigmoid_f(z);
+                dz *= sgm * (1.f + z * (1.f - sgm));
+            }
+            a1[e] += dz * ga[e];
+            a2[e] += dz * ga[e] * xh;
+            dg[e] += dz * xh;
+            db[e] += dz;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (c0 + e) / cpg;
+        atomicAdd(&s1[g], (double)a1[e]);
+        atomicAdd(&s2[g], (double)a2[e]);
+        atomicAdd(&sg[c0 + e], dg[e]);
+        atomicAdd(&sb[c0 + e], db[e]);
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        unsafeAtomicAdd(acc + ((size_t)b * groups + threadIdx.x) * 2, s1[threadIdx.x]);
+        unsafeAtomicAdd(acc + ((size_t)b * groups + threadIdx.x) * 2 + 1, s2[threadIdx.x]);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        unsafeAtomicAdd(dgamma + c, sg[c]);
+        unsafeAtomicAdd(dbeta + c, sb[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void tr_gn_sums_finish_kernel(const double* __restrict__ acc, int n, float2* __restrict__ sums) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) sums[i] = make_float2((float)acc[2 * i], (float)acc[2 * i + 1]);
 }
 
 __global__ __launch_bounds__(256) void tr_gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -865,6 +975,35 @@ __global__ __launch_bounds__(256) void tr_pack_weights_kernel(const float* __res
     }
 }
 
+// every conv / linear weight of the model in ONE launch: thread i finds its layer by bisection over the cumulative element
+// counts (elements of a layer = max(forward copy, transposed copy))
+__global__ __launch_bounds__(256) void tr_pack_all_kernel(const float* __restrict__ params, const rldm_pack_desc* __restrict__ d,
+                                                          int nlayers, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    const rldm_pack_desc L = d[lo];
+    const long long e = i - L.first;
+    const float* w = params + L.param_offset;
+    const int Cin_pad = (L.Cin + 15) / 16 * 16, N_pad = (L.N + 15) / 16 * 16;
+    const long long nf = (long long)L.N * L.taps * Cin_pad, nt = (long long)L.Cin * L.taps * N_pad;
+    if (e < nf) {
+        const int c = (int)(e % Cin_pad);
+        const int t = (int)((e / Cin_pad) % L.taps), n = (int)(e / ((long long)Cin_pad * L.taps));
+        static_cast<bf16_t*>(L.w_forward)[e] = c < L.Cin ? rldm::f32_to_bf16(w[((size_t)n * L.Cin + c) * L.taps + t]) : (bf16_t)0;
+    }
+    if (L.w_transposed && e < nt) {
+        const int n = (int)(e % N_pad);
+        const int t = (int)((e / N_pad) % L.taps), c = (int)(e / ((long long)N_pad * L.taps));
+        static_cast<bf16_t*>(L.w_transposed)[e] =
+            n < L.N ? rldm::f32_to_bf16(w[((size_t)n * L.Cin + c) * L.taps + (L.taps - 1 - t)]) : (bf16_t)0;
+    }
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -960,7 +1099,17 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
     RLDM_REQUIRE(x && gamma && beta && stats && y, "null argument");
     RLDM_REQUIRE(C % groups == 0, "channels must be a multiple of the group count");
     hipStream_t st = (hipStream_t)stream;
-    tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
+    const bool slab = 1024 % C == 0 && C >= 4 && groups <= 64 && (size_t)npix * C >= (1u << 18);     // large tensors, see the kernel
+    if (slab) {
+        double* acc = nullptr;
+        RLDM_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&acc), (size_t)B * groups * 2 * sizeof(double), st));
+        RLDM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), st));
+        tr_gn_stats_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, npix, C, groups, acc);
+        tr_gn_stats_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, (double)npix * (C / groups), eps,
+                                                                           reinterpret_cast<float2*>(stats));
+        RLDM_HIP_CHECK(hipFreeAsync(acc, st));
+    } else
+        tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
     const size_t total = (size_t)B * npix * C;
     tr_gn_fwd_kernel<<<nblk(total), 256, 0, st>>>(x, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C, groups, silu, total, y);
     TR_LAUNCH_CHECK();
@@ -973,8 +1122,18 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
     RLDM_REQUIRE(x && dy && stats && gamma && beta && scratch && dx && dgamma && dbeta, "null argument");
     RLDM_REQUIRE(C % groups == 0 && C / groups <= 256, "channels per group must be <= 256");
     hipStream_t st = (hipStream_t)stream;
-    tr_gn_bwd_reduce_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
-                                                             groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
+    const bool slab = 1024 % C == 0 && C >= 4 && C <= 1024 && groups <= 64 && (size_t)npix * C >= (1u << 18);
+    if (slab) {
+        double* acc = nullptr;
+        RLDM_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&acc), (size_t)B * groups * 2 * sizeof(double), st));
+        RLDM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), st));
+        tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
+                                                                               beta, npix, C, groups, silu, acc, dgamma, dbeta);
+        tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
+        RLDM_HIP_CHECK(hipFreeAsync(acc, st));
+    } else
+        tr_gn_bwd_reduce_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
+                                                                 groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
     const size_t total = (size_t)B * npix * C;
     tr_gn_bwd_apply_kernel<<<nblk(total), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats),
                                                         reinterpret_cast<const float2*>(scratch), gamma, beta, npix, C, groups, silu,
@@ -1099,6 +1258,13 @@ int rldm_train_pack_weights(const float* w, int N, int Cin, int taps, void* w_fo
     const size_t n = std::max((size_t)N * taps * Cin_pad, w_transposed ? (size_t)Cin * taps * N_pad : (size_t)0);
     tr_pack_weights_kernel<<<nblk(n), 256, 0, (hipStream_t)stream>>>(w, N, Cin, taps, Cin_pad, N_pad, static_cast<bf16_t*>(w_forward),
                                                                     static_cast<bf16_t*>(w_transposed));
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_pack_weights_all(const float* params, const rldm_pack_desc* descs, int num_layers, int64_t total, void* stream) {
+    RLDM_REQUIRE(params && descs && num_layers > 0 && total > 0, "null argument");
+    tr_pack_all_kernel<<<nblk((size_t)total), 256, 0, (hipStream_t)stream>>>(params, descs, num_layers, (long long)total);
     TR_LAUNCH_CHECK();
     return 0;
 }

@@ -111,14 +111,26 @@ class UNetTrainer:
         return flat[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(self.shapes[n])
 
     def repack(self):
+        """Refresh the bf16 operand copies of every conv / linear weight from the fp32 masters: one launch."""
         import ctypes as C
-        L = _lib.lib()
-        for n, wf in self.wf.items():
-            N, Cin = self.shapes[n][:2]
-            wt = self.wt[n]
-            _lib.check(L.rldm_train_pack_weights(C.c_void_p(self.p[n].data_ptr()), N, Cin, wf.shape[1], C.c_void_p(wf.data_ptr()),
-                                                 C.c_void_p(wt.data_ptr()) if wt is not None else None,
-                                                 _lib.stream_ptr(self.device)), "rldm_train_pack_weights")
+        if getattr(self, "_pack_table", None) is None:
+            descs = (_lib.PackDescC * len(self.wf))()
+            first = 0
+            for i, (n, wf) in enumerate(self.wf.items()):
+                N, Cin = self.shapes[n][:2]
+                wt = self.wt[n]
+                d = descs[i]
+                d.first, d.param_offset = first, self.offsets[n]
+                d.w_forward = wf.data_ptr()
+                d.w_transposed = wt.data_ptr() if wt is not None else None
+                d.N, d.Cin, d.taps = N, Cin, wf.shape[1]
+                first += max(wf.numel(), wt.numel() if wt is not None else 0)
+            raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+            self._pack_table, self._pack_total = raw, first
+        _lib.check(_lib.lib().rldm_train_pack_weights_all(C.c_void_p(self.params.data_ptr()),
+                                                          C.c_void_p(self._pack_table.data_ptr()), len(self.wf),
+                                                          self._pack_total, _lib.stream_ptr(self.device)),
+                   "rldm_train_pack_weights_all")
 
     def state_dict(self, ema=False):
         flat = (self.ema if ema else self.params).cpu()

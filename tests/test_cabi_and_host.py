@@ -37,6 +37,9 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.UNetConfigC) == 4 * (6 + 3 * 8 + 4)
     assert ctypes.sizeof(_lib.VAEConfigC) == 4 * (4 + 8 + 6)
     assert ctypes.sizeof(_lib.ConvDescC) == 4 * 13
+    assert ctypes.sizeof(_lib.TrainConvDescC) == 4 * 8 and ctypes.sizeof(_lib.AdamWConfigC) == 4 * 8
+    assert ctypes.sizeof(_lib.PackDescC) == 48 and _lib.PackDescC.N.offset == 32
+    assert ctypes.sizeof(_lib.LidarConfigC) == 4 * (7 + 3 + 6 + 1)
     assert _lib.SamplerConfigC.coef.offset == 24 and _lib.SamplerConfigC.timesteps.offset == 32
 
 
