@@ -252,6 +252,18 @@ typedef struct rldm_adamw_config {
 } rldm_adamw_config;
 int rldm_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
                      int64_t n, const rldm_adamw_config* c, void* stream);
+/* The same step with its per-step scalars read from device memory -- dyn[4] = (lr, 1 - beta1^step, 1 - beta2^step, ema decay),
+ * written by rldm_train_hyper_step -- so a captured step graph can be replayed; zero_grads != 0 also clears `grads`
+ * (optimizer.zero_grad(), ldm/train_unconditional.py:551). c->lr / c->step / c->ema_decay are ignored. */
+int rldm_train_adamw_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
+                         int64_t n, const rldm_adamw_config* c, const float* dyn, int zero_grads, void* stream);
+typedef struct rldm_hyper_config {
+    float lr, beta1, beta2;                     /* base learning rate, AdamW betas                                  */
+    float ema_max_decay, ema_inv_gamma, ema_power; /* EMAModel(use_ema_warmup=True) (:320-329)                      */
+    int64_t lr_warmup_steps, total_steps;       /* get_scheduler("cosine", ...) (:394-399)                          */
+} rldm_hyper_config;
+/* step = ++*step_counter (device int64); dyn[4] <- the scalars of optimizer step `step` (lr of step - 1 scheduler steps). */
+int rldm_train_hyper_step(int64_t* step_counter, const rldm_hyper_config* c, float* dyn, void* stream);
 /* master fp32 [N][Cin][taps] -> bf16 [N][taps][ceil16(Cin)] (forward) and bf16 [Cin][taps][ceil16(N)] (flipped / transposed:
  * data gradient; may be NULL). */
 int rldm_train_pack_weights(const float* w, int N, int Cin, int taps, void* w_forward, void* w_transposed, void* stream);

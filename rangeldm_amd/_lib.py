@@ -51,6 +51,11 @@ class PackDescC(C.Structure):
                 ("N", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("pad_", C.c_int32)]
 
 
+class HyperConfigC(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("ema_max_decay", C.c_float),
+                ("ema_inv_gamma", C.c_float), ("ema_power", C.c_float), ("lr_warmup_steps", C.c_int64), ("total_steps", C.c_int64)]
+
+
 class AdamWConfigC(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("ema_decay", C.c_float), ("step", C.c_int32)]
@@ -108,6 +113,8 @@ PROTOTYPES = {
     "rldm_train_mse": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_sqnorm": (C.c_int, [_P, C.c_int64, _P, _P]),
     "rldm_train_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(AdamWConfigC), _P]),
+    "rldm_train_adamw_dyn": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(AdamWConfigC), _P, C.c_int, _P]),
+    "rldm_train_hyper_step": (C.c_int, [_P, C.POINTER(HyperConfigC), _P, _P]),
     "rldm_train_pack_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_pack_weights_all": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),

@@ -26,7 +26,20 @@
 #include <cmath>
 #include <cstdlib>
 
+namespace rldm {
+// train_attn.hip: the same three passes on the matrix cores (bf16 operands, fp32 statistics / accumulation)
+int tr_attention_forward_mfma(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse, hipStream_t st);
+int tr_attention_backward_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
+                               int B, int L, int C, float* delta, float* dq, float* dk, float* dv, hipStream_t st);
+}  // namespace rldm
+
 namespace {
+
+// RLDM_TR_ATTN=scalar: the fp32 one-thread-per-query kernels of this file (A/B runs)
+inline bool attention_scalar() {
+    static const bool v = getenv("RLDM_TR_ATTN") && std::string(getenv("RLDM_TR_ATTN")) == "scalar";
+    return v;
+}
 
 // source pixel of output pixel (b, wo, ho) under tap (dw, dh): index into the input's pixel array, or -1 for a zero.
 // mode 0: plain; 1: nearest x2 (virtual input is twice as large); 2: zero insertion (virtual odd coordinates are zeros)
@@ -934,8 +947,10 @@ __global__ __launch_bounds__(256) void tr_sqnorm_kernel(const float* __restrict_
 
 // torch.optim.AdamW step on flat buffers with the clip_grad_norm_ coefficient folded in, then diffusers EMAModel.step
 struct TrAdam {
-    float* p; const float* g; float* m; float* v; float* ema; const double* sqnorm;
+    float* p; float* g; float* m; float* v; float* ema; const double* sqnorm;
     size_t n; float lr, b1, b2, eps, wd, bc1, bc2, max_norm, ema_decay;
+    const float* dyn;          // device [4] = (lr, bias correction 1, bias correction 2, ema decay) or null: the fields above
+    int zero_grads;            // also clear the gradient buffer (saves a separate fill pass)
 };
 __global__ __launch_bounds__(256) void tr_adamw_kernel(const TrAdam a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -945,16 +960,48 @@ __global__ __launch_bounds__(256) void tr_adamw_kernel(const TrAdam a) {
         const float tn = (float)sqrt(*a.sqnorm);
         coef = fminf(a.max_norm / (tn + 1e-6f), 1.f);
     }
+    const float lr = a.dyn ? a.dyn[0] : a.lr, bc1 = a.dyn ? a.dyn[1] : a.bc1, bc2 = a.dyn ? a.dyn[2] : a.bc2;
+    const float ema_decay = a.dyn ? a.dyn[3] : a.ema_decay;
     const float g = a.g[i] * coef;
-    float w = a.p[i] * (1.f - a.lr * a.wd);
+    if (a.zero_grads) a.g[i] = 0.f;
+    float w = a.p[i] * (1.f - lr * a.wd);
     const float m = a.b1 * a.m[i] + (1.f - a.b1) * g;
     const float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
     a.m[i] = m;
     a.v[i] = v;
-    const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
-    w -= (a.lr / a.bc1) * (m / denom);
+    const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
+    w -= (lr / bc1) * (m / denom);
     a.p[i] = w;
-    if (a.ema) a.ema[i] -= (1.f - a.ema_decay) * (a.ema[i] - w);
+    if (a.ema) a.ema[i] -= (1.f - ema_decay) * (a.ema[i] - w);
+}
+
+// the per-step scalars of the optimizer from a DEVICE step counter, so that a captured step graph advances by itself:
+// step = ++*counter; lr = diffusers "cosine" schedule with warmup at (step - 1) scheduler steps; AdamW bias corrections;
+// EMAModel.get_decay(step) with use_ema_warmup (ldm/train_unconditional.py:320-329,394-399,546-556)
+__global__ void tr_hyper_kernel(long long* __restrict__ counter, const rldm_hyper_config c, float* __restrict__ dyn) {
+    if (threadIdx.x || blockIdx.x) return;
+    const long long step = *counter + 1;
+    *counter = step;
+    const long long k = step - 1;
+    double lr;
+    if (k < c.lr_warmup_steps) lr = (double)c.lr * (double)k / (double)(c.lr_warmup_steps > 1 ? c.lr_warmup_steps : 1);
+    else {
+        const long long span = c.total_steps - c.lr_warmup_steps;
+        const double progress = (double)(k - c.lr_warmup_steps) / (double)(span > 1 ? span : 1);
+        const double f = 0.5 * (1.0 + cos(3.14159265358979323846 * progress));
+        lr = (double)c.lr * (f > 0.0 ? f : 0.0);
+    }
+    dyn[0] = (float)lr;
+    dyn[1] = (float)(1.0 - pow((double)c.beta1, (double)step));
+    dyn[2] = (float)(1.0 - pow((double)c.beta2, (double)step));
+    double dec = 0.0;
+    const long long es = step - 1 > 0 ? step - 1 : 0;
+    if (es > 0) {
+        dec = 1.0 - pow(1.0 + (double)es / (double)c.ema_inv_gamma, -(double)c.ema_power);
+        dec = dec < (double)c.ema_max_decay ? dec : (double)c.ema_max_decay;
+        dec = dec > 0.0 ? dec : 0.0;
+    }
+    dyn[3] = (float)dec;
 }
 
 // master fp32 [N][Cin][taps] -> forward copy bf16 [N][taps][Cin_pad] and data-gradient copy bf16 [Cin][taps][N_pad]
@@ -1094,6 +1141,25 @@ int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int 
     return 0;
 }
 
+// fp64 accumulators of the slab GroupNorm kernels: one growing device buffer (one caller thread; launches are stream
+// ordered, so consecutive launches may share it).  Never reallocated while a stream capture is running: the first
+// (eager) step of a shape sizes it.
+static int gn_accumulators(size_t count, hipStream_t st, double** out) {
+    static double* buf = nullptr;
+    static size_t cap = 0;
+    if (count > cap) {
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (buf) RLDM_HIP_CHECK(hipFree(buf));
+        buf = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(count, 4096);
+        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&buf), want * sizeof(double)));
+        cap = want;
+    }
+    *out = buf;
+    return 0;
+}
+
 int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, float eps, const float* gamma, const float* beta,
                           int silu, float* stats, float* y, void* stream) {
     RLDM_REQUIRE(x && gamma && beta && stats && y, "null argument");
@@ -1102,12 +1168,11 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
     const bool slab = 1024 % C == 0 && C >= 4 && groups <= 64 && (size_t)npix * C >= (1u << 18);     // large tensors, see the kernel
     if (slab) {
         double* acc = nullptr;
-        RLDM_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&acc), (size_t)B * groups * 2 * sizeof(double), st));
+        if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
         RLDM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), st));
         tr_gn_stats_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, npix, C, groups, acc);
         tr_gn_stats_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, (double)npix * (C / groups), eps,
                                                                            reinterpret_cast<float2*>(stats));
-        RLDM_HIP_CHECK(hipFreeAsync(acc, st));
     } else
         tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
     const size_t total = (size_t)B * npix * C;
@@ -1125,12 +1190,11 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
     const bool slab = 1024 % C == 0 && C >= 4 && C <= 1024 && groups <= 64 && (size_t)npix * C >= (1u << 18);
     if (slab) {
         double* acc = nullptr;
-        RLDM_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&acc), (size_t)B * groups * 2 * sizeof(double), st));
+        if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
         RLDM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), st));
         tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
-        RLDM_HIP_CHECK(hipFreeAsync(acc, st));
     } else
         tr_gn_bwd_reduce_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
                                                                  groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
@@ -1146,6 +1210,7 @@ int rldm_train_attention_forward(const float* q, const float* k, const float* v,
                                  void* stream) {
     RLDM_REQUIRE(q && k && v && o && lse, "null argument");
     RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
+    if (!attention_scalar()) return rldm::tr_attention_forward_mfma(q, k, v, B, L, C, o, lse, (hipStream_t)stream);
     tr_attn_fwd_kernel<<<dim3((L + 127) / 128, C / 8, B), 128, 0, (hipStream_t)stream>>>(q, k, v, L, C, 0.35355339059327373f, o, lse);
     TR_LAUNCH_CHECK();
     return 0;
@@ -1156,6 +1221,7 @@ int rldm_train_attention_backward(const float* q, const float* k, const float* v
     RLDM_REQUIRE(q && k && v && o && dO && lse && delta && dq && dk && dv, "null argument");
     RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
     hipStream_t st = (hipStream_t)stream;
+    if (!attention_scalar()) return rldm::tr_attention_backward_mfma(q, k, v, o, dO, lse, B, L, C, delta, dq, dk, dv, st);
     const float scale = 0.35355339059327373f;
     const dim3 grid((L + 127) / 128, C / 8, B);
     tr_attn_bwd_dq_kernel<<<grid, 128, 0, st>>>(q, k, v, o, dO, lse, L, C, scale, dq, delta);
@@ -1237,15 +1303,38 @@ int rldm_train_sqnorm(const float* g, int64_t n, double* out, void* stream) {
     return 0;
 }
 
+int rldm_train_hyper_step(int64_t* step_counter, const rldm_hyper_config* c, float* dyn, void* stream) {
+    RLDM_REQUIRE(step_counter && c && dyn, "null argument");
+    tr_hyper_kernel<<<1, 64, 0, (hipStream_t)stream>>>(reinterpret_cast<long long*>(step_counter), *c, dyn);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+static int adamw_launch(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
+                        int64_t n, const rldm_adamw_config* c, const float* dyn, int zero_grads, void* stream);
+
 int rldm_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
                      int64_t n, const rldm_adamw_config* c, void* stream) {
+    RLDM_REQUIRE(c && c->step >= 1, "step counts from 1 (torch.optim.AdamW)");
+    return adamw_launch(params, const_cast<float*>(grads), exp_avg, exp_avg_sq, ema, sqnorm, n, c, nullptr, 0, stream);
+}
+
+int rldm_train_adamw_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
+                         int64_t n, const rldm_adamw_config* c, const float* dyn, int zero_grads, void* stream) {
+    RLDM_REQUIRE(dyn, "null argument");
+    return adamw_launch(params, grads, exp_avg, exp_avg_sq, ema, sqnorm, n, c, dyn, zero_grads, stream);
+}
+
+static int adamw_launch(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema, const double* sqnorm,
+                        int64_t n, const rldm_adamw_config* c, const float* dyn, int zero_grads, void* stream) {
     RLDM_REQUIRE(params && grads && exp_avg && exp_avg_sq && c && n >= 0, "null argument");
-    RLDM_REQUIRE(c->step >= 1, "step counts from 1 (torch.optim.AdamW)");
     TrAdam a;
+    a.dyn = dyn; a.zero_grads = zero_grads;
     a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.ema = ema; a.sqnorm = sqnorm; a.n = (size_t)n;
     a.lr = c->lr; a.b1 = c->beta1; a.b2 = c->beta2; a.eps = c->eps; a.wd = c->weight_decay;
-    a.bc1 = (float)(1.0 - pow((double)c->beta1, (double)c->step));
-    a.bc2 = (float)(1.0 - pow((double)c->beta2, (double)c->step));
+    const int step = c->step >= 1 ? c->step : 1;
+    a.bc1 = (float)(1.0 - pow((double)c->beta1, (double)step));
+    a.bc2 = (float)(1.0 - pow((double)c->beta2, (double)step));
     a.max_norm = c->max_grad_norm; a.ema_decay = c->ema_decay;
     if (n) tr_adamw_kernel<<<nblk((size_t)n), 256, 0, (hipStream_t)stream>>>(a);
     TR_LAUNCH_CHECK();

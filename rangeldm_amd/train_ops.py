@@ -192,3 +192,23 @@ def adamw(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=
     c.max_grad_norm, c.ema_decay, c.step = float(max_grad_norm), float(ema_decay), int(step)
     _chk(_lib.lib().rldm_train_adamw(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(ema), _p(sqnorm_dev),
                                      params.numel(), C.byref(c), _s(params)), "rldm_train_adamw")
+
+
+def hyper_step(step_counter, dyn, lr, betas, ema_max_decay, ema_inv_gamma, ema_power, lr_warmup_steps, total_steps):
+    """step = ++step_counter (device int64); dyn (4,) <- (lr, 1 - b1^step, 1 - b2^step, ema decay) of that optimizer step."""
+    c = _lib.HyperConfigC()
+    c.lr, c.beta1, c.beta2 = float(lr), float(betas[0]), float(betas[1])
+    c.ema_max_decay, c.ema_inv_gamma, c.ema_power = float(ema_max_decay), float(ema_inv_gamma), float(ema_power)
+    c.lr_warmup_steps, c.total_steps = int(lr_warmup_steps), int(total_steps)
+    _chk(_lib.lib().rldm_train_hyper_step(_p(step_counter), C.byref(c), _p(dyn), _s(dyn)), "rldm_train_hyper_step")
+
+
+def adamw_dyn(params, grads, exp_avg, exp_avg_sq, dyn, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, ema=None,
+              sqnorm_dev=None, max_grad_norm=0.0, zero_grads=True):
+    """AdamW (+ clip + EMA) with lr / bias corrections / EMA decay read from the device vector `dyn` (see hyper_step)."""
+    c = _lib.AdamWConfigC()
+    c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = 0.0, float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+    c.max_grad_norm, c.ema_decay, c.step = float(max_grad_norm), 0.0, 1
+    _chk(_lib.lib().rldm_train_adamw_dyn(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(ema), _p(sqnorm_dev),
+                                         params.numel(), C.byref(c), _p(dyn), 1 if zero_grads else 0, _s(params)),
+         "rldm_train_adamw_dyn")

@@ -105,6 +105,11 @@ class UNetTrainer:
         self._tape, self._grad, self._keep = [], {}, []
         self._pending, self._ready = [], None
         self.last_grad_norm = None
+        # captured step graphs (train_step_graphed): device-side step counter + per-step optimizer scalars
+        self._graphs, self._on_bucket = {}, None
+        self._step_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._step_dev_mirror = 0
+        self._dyn = torch.zeros(4, dtype=torch.float32, device=self.device)
 
     # ---- parameters -------------------------------------------------------------------------------------------
     def _view(self, flat, n):
@@ -171,8 +176,14 @@ class UNetTrainer:
                 if lo <= i < hi:
                     self._ready[b] -= 1
                     if self._ready[b] == 0:
-                        seg = self.grads[off:off + cnt]
-                        self._pending.append(torch.distributed.all_reduce(seg, op=self._reduce_op, async_op=True))
+                        if self._on_bucket is not None:          # stream capture: cut the graph here, reduce at replay
+                            self._on_bucket(b)
+                        else:
+                            self._reduce_bucket(b)
+
+    def _reduce_bucket(self, b):
+        _, _, off, cnt = self.buckets[b]
+        self._pending.append(torch.distributed.all_reduce(self.grads[off:off + cnt], op=self._reduce_op, async_op=True))
 
     # ---- ops --------------------------------------------------------------------------------------------------
     def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True):
@@ -341,7 +352,7 @@ class UNetTrainer:
         self._out = self._conv(h, "conv_out")
         return self._out
 
-    def backward(self, dpred, reduce=None):
+    def backward(self, dpred, reduce=None, launch_collectives=True):
         """Replays the tape in reverse.  reduce: None = single process; True = bucketed RCCL all-reduce (average) of the flat
         gradient buffer, overlapped with the rest of backward."""
         if reduce is None:
@@ -358,19 +369,33 @@ class UNetTrainer:
         for fn in reversed(self._tape):
             fn()
         self._tape, self._grad = [], {}
-        for w in self._pending:
-            w.wait()
+        if launch_collectives:
+            for w in self._pending:
+                w.wait()
         self._ready = None
         return torch.distributed.get_world_size() if (reduce and not avg) else 1
 
-    def optimizer_step(self, grad_world=1):
+    def optimizer_step(self, grad_world=1, device_scalars=False):
         """clip_grad_norm_(1.0) + AdamW + cosine/warmup lr + EMA (ldm/train_unconditional.py:546-556), then refresh the
-        bf16 operand copies and zero the gradients."""
+        bf16 operand copies and zero the gradients.  device_scalars: the step number lives in device memory and the
+        learning rate / bias corrections / EMA decay are computed there (what a captured step graph replays)."""
         hp = self.hp
+        if device_scalars and self._step_dev_mirror != self.global_step:
+            self._step_dev.fill_(self.global_step)
+            self._step_dev_mirror = self.global_step
         self.global_step += 1
         if grad_world > 1:                              # a summing backend (gloo): finish the average
             self.grads.mul_(1.0 / grad_world)
         sq = T.sqnorm(self.grads)
+        if device_scalars:
+            self._step_dev_mirror += 1
+            T.hyper_step(self._step_dev, self._dyn, hp["lr"], hp["betas"], hp["ema_max_decay"], hp["ema_inv_gamma"],
+                         hp["ema_power"], hp["lr_warmup_steps"], hp["total_steps"])
+            T.adamw_dyn(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self._dyn, hp["betas"], hp["eps"],
+                        hp["weight_decay"], ema=self.ema, sqnorm_dev=sq, max_grad_norm=hp["max_grad_norm"], zero_grads=True)
+            self.last_grad_norm = sq
+            self.repack()
+            return None
         lr = cosine_lr(self.global_step - 1, hp["lr"], hp["lr_warmup_steps"], hp["total_steps"])
         # (lr_scheduler.step() runs AFTER optimizer.step(): step k uses the rate of k - 1 scheduler steps)
         dec = ema_decay(self.global_step, hp["ema_max_decay"], hp["ema_inv_gamma"], hp["ema_power"])
@@ -390,14 +415,103 @@ class UNetTrainer:
         self.optimizer_step(world)
         return loss
 
+    # ---- captured step graphs ---------------------------------------------------------------------------------
+    def train_step_graphed(self, noisy_nchw, timesteps, target_nchw, loss_weights=None, pos_encoding=False, reduce=None):
+        """`train_step` replayed from HIP graphs: the ~1 300 launches of a step cost more host time to enqueue than the GPU
+        needs to run them.  The first call of a shape runs eagerly (it sizes the library's scratch buffers), the second
+        captures, later ones copy their inputs into the graph's static buffers and replay.  With more than one rank the
+        step is cut into one graph per gradient bucket: after each, the bucket's RCCL all-reduce is launched eagerly on
+        the communication stream and overlaps the next segment of backward; the optimizer segment waits for all of them.
+        Returns the loss (0-d float64 device tensor, a copy)."""
+        dist = torch.distributed
+        if reduce is None:
+            reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        key = (tuple(noisy_nchw.shape), tuple(target_nchw.shape), loss_weights is not None, bool(pos_encoding), bool(reduce))
+        st = self._graphs.get(key)
+        if st is None:
+            self._graphs[key] = "warm"
+            return self.train_step(noisy_nchw, timesteps, target_nchw, loss_weights, pos_encoding)
+        if st == "warm":
+            st = self._graphs[key] = self._capture_step(noisy_nchw, timesteps, target_nchw, loss_weights, pos_encoding, reduce)
+        st["noisy"].copy_(noisy_nchw, non_blocking=True)
+        st["t"].copy_(timesteps.reshape(-1), non_blocking=True)
+        st["target"].copy_(target_nchw, non_blocking=True)
+        if loss_weights is not None:
+            st["w"].copy_(loss_weights, non_blocking=True)
+        if self._step_dev_mirror != self.global_step:
+            self._step_dev.fill_(self.global_step)
+            self._step_dev_mirror = self.global_step
+        pending = []
+        for graph, action in st["segments"]:
+            graph.replay()
+            if action == "wait":
+                for w in pending:
+                    w.wait()
+            elif action is not None:
+                _, _, off, cnt = self.buckets[action]
+                pending.append(torch.distributed.all_reduce(self.grads[off:off + cnt], op=st["reduce_op"], async_op=True))
+        self.global_step += 1
+        self._step_dev_mirror += 1
+        self.last_grad_norm = st["sqnorm"]
+        return st["loss"].clone()
+
+    def _capture_step(self, noisy, timesteps, target, loss_weights, pos_encoding, reduce):
+        st = {"noisy": noisy.detach().float().clone(), "t": timesteps.to(self.device, torch.int64).reshape(-1).clone(),
+              "target": target.detach().float().clone(), "w": None if loss_weights is None else loss_weights.detach().float().clone(),
+              "segments": [], "reduce_op": None}
+        pool = torch.cuda.graph_pool_handle()
+        tick = torch.zeros(1, device=self.device)
+        if self._step_dev_mirror != self.global_step:
+            self._step_dev.fill_(self.global_step)
+            self._step_dev_mirror = self.global_step
+        step0, mirror0 = self.global_step, self._step_dev_mirror
+        cap = torch.cuda.Stream(self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        cur = [None]
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=pool)
+            tick.zero_()                                  # (a segment is never empty)
+
+        def cut(action):
+            cur[0].capture_end()
+            st["segments"].append((cur[0], action))
+
+        def on_bucket(b):
+            cut(b)
+            begin()
+
+        with torch.cuda.stream(cap):
+            begin()
+            try:
+                self._on_bucket = on_bucket if reduce else None
+                pred = self.forward(st["noisy"], st["t"], pos_encoding)
+                loss, dpred = T.mse(pred, st["target"], st["w"])
+                world = self.backward(dpred, reduce=reduce, launch_collectives=False)
+                if reduce:
+                    on_bucket("wait")
+                self.optimizer_step(world, device_scalars=True)
+                cut(None)
+            finally:
+                self._on_bucket = None
+        torch.cuda.current_stream(self.device).wait_stream(cap)
+        # capture launched nothing: the step counters still describe the state before this step
+        self.global_step, self._step_dev_mirror = step0, mirror0
+        st["loss"], st["sqnorm"], st["tick"], st["pool"] = loss, self.last_grad_norm, tick, pool
+        if reduce:
+            st["reduce_op"] = self._reduce_op
+        return st
+
 
 def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, pos_encoding=True, snr_gamma=None,
-                  noise=None, timesteps=None, condition=None):
+                  noise=None, timesteps=None, condition=None, graphed=False):
     """One iteration of the reference's loop body (ldm/train_unconditional.py:479-556) with `with_vae: True`:
     latents = vae.encode(x).latent_dist.sample() * scaling_factor; eps ~ N(0, 1); t ~ U{0..T-1}; add_noise; pos-encoding
     channel; epsilon-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA.
     condition (B, Cc, W, H): the conditional twin (ldm/train_conditional.py:418-447) -- the encoded low-resolution image
-    (`condition_encoder(batch["down"])`) or `cat([masked latents, mask])`, concatenated to the noisy latents."""
+    (`condition_encoder(batch["down"])`) or `cat([masked latents, mask])`, concatenated to the noisy latents.
+    graphed: replay the UNet forward / backward / optimizer from captured HIP graphs (UNetTrainer.train_step_graphed)."""
     dev = trainer.device
     if vae is not None:
         latents = vae.encode(clean_images.to(dev)).latent_dist.sample(generator=generator, scale=vae.config.scaling_factor)
@@ -414,4 +528,5 @@ def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, p
     w = None
     if snr_gamma is not None:
         w = snr_weights(noise_scheduler.alphas_cumprod, timesteps, snr_gamma).to(dev)
-    return trainer.train_step(noisy, timesteps.to(dev), noise, w, pos_encoding)
+    step = trainer.train_step_graphed if graphed else trainer.train_step
+    return step(noisy, timesteps.to(dev), noise, w, pos_encoding)

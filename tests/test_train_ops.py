@@ -2,10 +2,12 @@
 the oracle's leaf ops (oracle/ops.py: circular-W / zero-H conv, GroupNorm + SiLU, head_dim-8 attention).
 
 Tolerances: GEMM operands are rounded to bf16 (8 mantissa bits) with fp32 accumulation, so conv / linear results and
-gradients carry ~4e-3 relative L2 error against pure fp32; everything else (GroupNorm, attention, elementwise, AdamW) is
-fp32 end to end: 1e-5 relative.
+gradients carry ~4e-3 relative L2 error against pure fp32 (attention: see its test); everything else (GroupNorm,
+elementwise, AdamW) is fp32 end to end: 1e-5 relative.
 """
 import numpy as np
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -101,20 +103,34 @@ def test_group_norm_forward_backward(B, C, W, H, silu):
     assert rel(nchw(dx2), 2 * x.grad) < 1e-4
 
 
-@pytest.mark.parametrize("B,L,C", [(2, 64, 32), (1, 200, 16), (2, 1024, 16)])
+@pytest.mark.parametrize("B,L,C", [(2, 64, 32), (1, 200, 16), (2, 1024, 16), (3, 16, 64), (2, 4, 8), (1, 256, 256)])
 def test_attention_forward_backward(B, L, C):
+    """MFMA attention (train_attn.hip): q, k, v, dO and the probabilities enter the matrix cores as bf16 (the reference's
+    `mixed_precision: bf16`), statistics / accumulation fp32.  Gates: 5e-3 (output) / 8e-3 (gradients: dS is rounded too) relative L2 against fp32 SDPA on bf16-rounded
+    inputs (what remains is the rounding of q * scale and of the probabilities), 1.5e-2 against SDPA on the fp32 inputs;
+    log-sum-exp 8e-2 absolute (scores reach +-10 here and bf16(q * scale) carries 2^-9 of that)."""
     from rangeldm_amd import train_ops as T
-    q, k, v = (rnd(B, L, C, seed=s).requires_grad_() for s in (1, 2, 3))
-    nh = C // 8
-    qh, kh, vh = (z.view(B, L, nh, 8).transpose(1, 2) for z in (q, k, v))
-    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
     dO = rnd(B, L, C, seed=4)
-    ref.backward(dO)
-    qd, kd, vd = q.detach().cuda(), k.detach().cuda(), v.detach().cuda()
+    nh = C // 8
+    refs = []
+    for rounded in (True, False):
+        q, k, v = (rnd(B, L, C, seed=s) * 1.5 for s in (1, 2, 3))
+        if rounded:
+            q, k, v = (z.bfloat16().float() for z in (q, k, v))
+        q, k, v = (z.requires_grad_() for z in (q, k, v))
+        qh, kh, vh = (z.view(B, L, nh, 8).transpose(1, 2) for z in (q, k, v))
+        ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
+        ref.backward(dO.bfloat16().float() if rounded else dO)
+        lse_ref = torch.logsumexp(qh.detach() @ kh.detach().transpose(-1, -2) / math.sqrt(8), -1)
+        refs.append((ref.detach(), q.grad, k.grad, v.grad, lse_ref))
+    qd, kd, vd = (rnd(B, L, C, seed=s).cuda() * 1.5 for s in (1, 2, 3))
     o, lse = T.attention_forward(qd, kd, vd)
-    assert rel(o, ref.detach()) < TOL_F32
     dq, dk, dv = T.attention_backward(qd, kd, vd, o, dO.cuda(), lse)
-    assert rel(dq, q.grad) < 1e-4 and rel(dk, k.grad) < 1e-4 and rel(dv, v.grad) < 1e-4
+    for (ref, gq, gk, gv, lse_ref), tol in zip(refs, (5e-3, 1.5e-2)):
+        assert rel(o, ref) < tol, (tol, rel(o, ref))
+        assert float((lse.cpu() - lse_ref).abs().max()) < 8e-2
+        gt = max(tol, 8e-3)
+        assert rel(dq, gq) < gt and rel(dk, gk) < gt and rel(dv, gv) < gt, (gt, rel(dq, gq), rel(dk, gk), rel(dv, gv))
 
 
 def test_elementwise_and_loss():

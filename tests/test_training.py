@@ -104,8 +104,11 @@ def test_unet_gradients_match_autograd(kw, B, weights):
     def err(n):
         # relative L2 with a floor: some gradients are analytically ZERO (a key bias shifts every score of a query equally
         # and softmax does not see it), so their reference norm is rounding noise
+        # (the key bias's zero comes from sum_j dS_ij = 0, which bf16-rounded dS -- the matrix-core attention backward --
+        # only honours to 2^-9 per term: its floor is three times higher)
         d = float((tr.g[n].double().cpu() - gref[n].double()).norm())
-        return d / (float(gref[n].double().norm()) + 2e-2 * rms * gref[n].numel() ** 0.5)
+        floor = 6e-2 if n.endswith("to_k.bias") else 2e-2
+        return d / (float(gref[n].double().norm()) + floor * rms * gref[n].numel() ** 0.5)
     ranked = sorted(((err(n), n) for n in tr.names), reverse=True)
     assert ranked[0][0] < 4e-2, ranked[:6]
     assert rel(tr.grads, flat_ref) < 1.5e-2
@@ -183,6 +186,80 @@ def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
     from rangeldm_amd.unet import UNet2DModelHIP
     m = UNet2DModelHIP.from_pretrained(str(tmp_path), subfolder="unet_ema")
     assert torch.isfinite(m(x, 10).sample).all()
+
+
+def _adam_close(a, b, lr, what):
+    """parameters of two runs agree: a sign flip of a near-zero gradient moves an Adam parameter by 2 lr, nothing else may"""
+    d = torch.cat([(a[k] - b[k]).reshape(-1) for k in a]).abs()
+    frac = float((d > 0.5 * lr).float().mean())
+    assert frac < 0.01, (what, frac)
+
+
+@pytest.mark.gpu
+def test_graphed_steps_equal_eager_steps():
+    """train_step_graphed (captured HIP graphs, step number / lr / bias corrections / EMA decay computed on the device) against
+    train_step (every launch from the host, scalars from the host) over six different batches, lr warm-up included."""
+    cfg = UNetConfig(**SMALL)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    lr = 1e-3
+    kw = dict(lr=lr, lr_warmup_steps=3, total_steps=40, use_ema=True)
+    a, b = TR.UNetTrainer(cfg, sd, **kw), TR.UNetTrainer(cfg, sd, **kw)
+    g = torch.Generator().manual_seed(11)
+    for step in range(1, 7):
+        x = torch.randn(2, 4, 32, 8, generator=g).cuda()
+        target = torch.randn(2, 4, 32, 8, generator=g).cuda()
+        t = torch.randint(0, 1000, (2,), generator=g).cuda()
+        w = torch.rand(2, generator=g).cuda()
+        la = a.train_step(x, t, target, w, pos_encoding=True)
+        lb = b.train_step_graphed(x, t, target, w, pos_encoding=True)
+        assert abs(float(la) - float(lb)) < (1e-6 if step <= 2 else 2e-3) * abs(float(la)), (step, float(la), float(lb))
+        assert a.global_step == b.global_step == step
+        if step >= 2:                                     # (step 1 of the graphed trainer is the eager sizing step)
+            dyn = b._dyn.cpu()
+            assert abs(float(dyn[0]) - TR.cosine_lr(step - 1, lr, 3, 40)) < 1e-9
+            assert abs(float(dyn[1]) - (1 - 0.95 ** step)) < 1e-6 and abs(float(dyn[2]) - (1 - 0.999 ** step)) < 1e-7
+            assert abs(float(dyn[3]) - TR.ema_decay(step)) < 1e-6
+            assert int(b._step_dev) == step
+    assert len(b._graphs) == 1 and len(next(iter(b._graphs.values()))["segments"]) == 1
+    _adam_close(a.state_dict(), b.state_dict(), lr, "parameters")
+    _adam_close(a.state_dict(ema=True), b.state_dict(ema=True), lr, "ema")
+    assert abs(float(a.last_grad_norm) - float(b.last_grad_norm)) < 1e-3 * float(a.last_grad_norm)
+    # mixing the two kinds of step keeps the device step counter in line
+    x = torch.randn(2, 4, 32, 8, generator=g).cuda()
+    a.train_step(x, t, target, w, pos_encoding=True)
+    b.train_step(x, t, target, w, pos_encoding=True)
+    a.train_step(x, t, target, w, pos_encoding=True)
+    b.train_step_graphed(x, t, target, w, pos_encoding=True)
+    assert int(b._step_dev) == b.global_step == 8
+    _adam_close(a.state_dict(), b.state_dict(), lr, "parameters after mixed steps")
+
+
+@pytest.mark.gpu
+def test_graphed_steps_cut_at_gradient_buckets_on_one_gpu():
+    """The multi-rank form of the captured step with world size 1: one graph per gradient bucket, the RCCL all-reduce of a
+    bucket launched between the replays, the optimizer segment after the waits -- same parameters as eager steps."""
+    cfg = UNetConfig(**SMALL)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    lr = 1e-3
+    kw = dict(lr=lr, lr_warmup_steps=0, total_steps=100, use_ema=True, bucket_mb=1)
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 5, 32, 8, generator=g).cuda(), torch.randint(0, 1000, (2,), generator=g).cuda(),
+                torch.randn(2, 4, 32, 8, generator=g).cuda()) for _ in range(4)]
+    a = TR.UNetTrainer(cfg, sd, **kw)
+    for x, t, target in batches:
+        a.train_step(x, t, target)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1")
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        b = TR.UNetTrainer(cfg, sd, **kw)
+        for x, t, target in batches:
+            b.train_step_graphed(x, t, target, reduce=True)
+        torch.cuda.synchronize()
+        segs = next(iter(b._graphs.values()))["segments"]
+        assert [act for _, act in segs] == list(range(len(b.buckets) - 1, -1, -1)) + ["wait", None]
+    finally:
+        torch.distributed.destroy_process_group()
+    _adam_close(a.state_dict(), b.state_dict(), lr, "parameters")
 
 
 @pytest.mark.gpu

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured step graphs")
     ap.add_argument("--seed", type=int, default=20240310)
     a = ap.parse_args()
     from rangeldm_amd import distributed as D
@@ -49,6 +50,8 @@ def main():
         vae.load_state_dict(synth_state_dict(vae_param_shapes(p["vae"]), seed=a.seed, prefix="vae."))
     sched = DDPMSchedulerHIP()
     B = a.batch
+    if not a.eager:
+        a.warmup = max(a.warmup, 2)                    # (step 1 runs eagerly and sizes the scratch buffers, step 2 captures)
     n_iter = a.warmup + a.steps
     gen = torch.Generator().manual_seed(a.seed + rank)
     shape = (B, 2, 1024, 64) if vae is not None else (B, 4, 256, 16)
@@ -56,7 +59,7 @@ def main():
     losses = []
 
     def one(i):
-        losses.append(training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True))
+        losses.append(training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True, graphed=not a.eager))
 
     for i in range(a.warmup):
         one(i)
@@ -74,6 +77,7 @@ def main():
                           "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "bf16",
                           "data": "synthetic", "config": {"workload": f"train_unconditional step, batch {B} per GPU, "
                                                           f"{'VAE encode + ' if vae is not None else ''}UNet fwd+bwd, AdamW, EMA",
+                                                          "launch": "eager" if a.eager else "captured HIP graphs",
                                                           "global_batch": B * world},
                           "gflop_per_sample": gflop, "end_to_end_tflops": sps * gflop / 1e3,
                           "loss_first_last": [float(losses[0]), float(losses[-1])]}))
