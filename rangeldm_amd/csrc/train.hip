@@ -396,6 +396,119 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const TrWgrad p) {
         }
 }
 
+// Weight gradient, all taps in one workgroup (stride 1; every 3x3 / 1x1 conv of the UNet body).  The kernel above gives a
+// workgroup ONE tap, so dy and x are read from L2 / HBM nine times per tile pair (604 MB for a 33 MB level-0 problem: it ran at
+// the memory system's speed, 85 TFLOP/s).  Here a workgroup owns a 64 x 64 (n, c) tile for ALL taps over a range of pixel
+// chunks.  A chunk = WC azimuth columns x all H beams of one image, staged once, transposed, as bf16:
+//   sA[n][k]            k = h * WC + wl  (beam-major inside the chunk, so 8 consecutive k = 8 azimuth neighbours of a beam)
+//   sB[d][c][(h + 1) * WC + wl] = x[w0 + wl + d - 1][h]   three copies pre-shifted by the azimuth tap (circular halo), beam
+//                       rows -1 and H are zeros written once: the beam tap is a shift by WC elements = 16-byte aligned
+// so every MFMA fragment of every tap is one aligned 16-byte LDS read: a wave does 9 MFMAs (one per tap, 32 x 32 x 16, its
+// own quarter of the tile) per 10 fragment reads.  Staging lanes = 4 channel quads x 16 pixel pairs: 64-byte global segments
+// and conflict-free 4-byte transposed LDS stores (pitch = odd number of 16-byte slots).  mode 1 (nearest x2 in front of the
+// conv) is an index map at staging.  part: [taps][grid.y][N][Cin] partial sums (summed by tr_wgrad_reduce_kernel).
+struct TrWgrad2 {
+    const float* dy; const float* x; float* part;
+    int B, W, H, Win, Hin, Cin, N, mode, lwc, cpw, nchunks, pitchA, pitchB;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    constexpr int NC = TAPS == 9 ? 3 : 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int WC = 1 << p.lwc, H = p.H, W = p.W, N = p.N, Cin = p.Cin;
+    const int KP = WC * H;
+    const int pitchA = p.pitchA, pitchB = p.pitchB;
+    bf16_t* sA = reinterpret_cast<bf16_t*>(wg_smem);                 // [64][pitchA]
+    bf16_t* sB = sA + 64 * pitchA;                                   // [NC][64][pitchB]
+    const int ct = Cin >> 6;
+    const int n0 = (blockIdx.x / ct) * 64, c0 = (blockIdx.x % ct) * 64;
+    const int z = blockIdx.y;
+    const int wi = wave >> 1, wj = wave & 1;                         // this wave's 32 x 32 quarter of the tile
+    if (TAPS == 9) {                                                 // zero beam rows -1 and H of the three copies
+        for (int e = tid; e < NC * 64 * 2 * WC; e += 256) {
+            const int wl = e & (WC - 1), r = (e >> p.lwc) & 1, rc = e >> (p.lwc + 1);
+            sB[rc * pitchB + (r ? (H + 1) * WC : 0) + wl] = (bf16_t)0;
+        }
+    }
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int cq = 4 * wave + (lane & 3), ppl = lane >> 2;           // staging role
+    const int nwc = W >> p.lwc;
+    const int sh = p.mode ? 1 : 0;
+    const int chunk_end = min((z + 1) * p.cpw, p.nchunks);
+    for (int chunk = z * p.cpw; chunk < chunk_end; ++chunk) {
+        const int b = chunk / nwc, w0 = (chunk - b * nwc) << p.lwc;
+        __syncthreads();                                             // the previous chunk's fragments have been read
+        for (int pp = ppl; 2 * pp < KP; pp += 16) {
+            const int k = 2 * pp, h = k >> p.lwc, wl = k & (WC - 1);
+            {
+                const float* src = p.dy + ((size_t)(b * W + w0 + wl) * H + h) * N + n0 + 4 * cq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)H * N);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(sA + (4 * cq) * pitchA + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e * (pitchA >> 1)] = rldm::pack_bf16x2(v0[e], v1[e]);
+            }
+            const int hs = h >> sh;
+            if (TAPS == 9) {
+                int wm = w0 + wl - 1, w2 = w0 + wl + 2;
+                wm = wm < 0 ? wm + W : wm;
+                w2 = w2 >= W ? w2 - W : w2;
+                const float* xb = p.x + c0 + 4 * cq;
+                const f32x4 xm = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + (wm >> sh)) * p.Hin + hs) * Cin);
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl) >> sh)) * p.Hin + hs) * Cin);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl + 1) >> sh)) * p.Hin + hs) * Cin);
+                const f32x4 x2 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + (w2 >> sh)) * p.Hin + hs) * Cin);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(sB + (4 * cq) * pitchB + (h + 1) * WC + wl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dst[e * (pitchB >> 1)] = rldm::pack_bf16x2(xm[e], x0[e]);
+                    dst[(64 + e) * (pitchB >> 1)] = rldm::pack_bf16x2(x0[e], x1[e]);
+                    dst[(128 + e) * (pitchB >> 1)] = rldm::pack_bf16x2(x1[e], x2[e]);
+                }
+            } else {
+                const float* xb = p.x + c0 + 4 * cq;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl) >> sh)) * p.Hin + hs) * Cin);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl + 1) >> sh)) * p.Hin + hs) * Cin);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(sB + (4 * cq) * pitchB + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e * (pitchB >> 1)] = rldm::pack_bf16x2(x0[e], x1[e]);
+            }
+        }
+        __syncthreads();
+        const bf16_t* fa = sA + (32 * wi + l31) * pitchA + 8 * kg;
+        const bf16_t* fb = sB + (32 * wj + l31) * pitchB + 8 * kg;
+#pragma unroll 2
+        for (int k = 0; k < KP; k += 16) {
+            const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + k));
+            if (TAPS == 9) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const bf16x8 Bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + (t / 3) * 64 * pitchB + k + (t % 3) * WC));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[t], 0, 0, 0);
+                }
+            } else {
+                const bf16x8 Bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + k));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[0], 0, 0, 0);
+            }
+        }
+    }
+    // lane (column c = c0 + 32 wj + l31, half kg), register r <-> row n0 + 32 wi + (r & 3) + 8 (r >> 2) + 4 kg
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        float* part = p.part + (((size_t)t * gridDim.y + z) * N + n0 + 32 * wi + 4 * kg) * Cin + c0 + 32 * wj + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[t][r];
+    }
+}
+
 // dw[n][c][t] += sum over slices of part[t][slice][n][c]   (one thread per (t, n, c); reads coalesced along c)
 __global__ __launch_bounds__(256) void tr_wgrad_reduce_kernel(const float* __restrict__ part, int slices, int N, int Cin, int taps,
                                                               float* __restrict__ dw) {
@@ -1109,9 +1222,35 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
     // a wave contracts `chunk` pixels into its own partial tile; ~1024 pixels per wave, fewer only to fill the chip
     int chunk = getenv("RLDM_TR_WG_CHUNK") ? atoi(getenv("RLDM_TR_WG_CHUNK")) : 1024;
     while (chunk > 128 && (long long)tiles * ((P + 4 * chunk - 1) / (4 * chunk)) < 256) chunk >>= 1;
-    const int splits = (P + 4 * chunk - 1) / (4 * chunk);
+    int splits = (P + 4 * chunk - 1) / (4 * chunk);
     p.chunk = chunk;
-    const size_t need = (size_t)p.taps * splits * 4 * p.N * p.Cin * sizeof(float);
+    size_t need = (size_t)p.taps * splits * 4 * p.N * p.Cin * sizeof(float);
+    // all-taps kernel (see tr_wgrad2_kernel): stride 1, 64-multiples of channels, H a power of two <= 16, chunk of WC columns
+    static const bool v1_env = getenv("RLDM_TR_WG_V1") != nullptr;                // A/B: the one-tap-per-workgroup kernel
+    TrWgrad2 w2{};
+    bool v2 = !v1_env && d->stride == 1 && d->mode <= 1 && p.N % 64 == 0 && p.Cin % 64 == 0 && p.Hout >= 2 && p.Hout <= 16 &&
+              (p.Hout & (p.Hout - 1)) == 0;
+    if (v2) {
+        const int H = p.Hout, W = p.Wout;
+        int lwc = -1;
+        for (int l = 6; l >= 3; --l)
+            if ((H << l) <= 128 && ((H + 2) << l) <= 160 && W % (1 << l) == 0) { lwc = l; break; }
+        if (lwc < 0) v2 = false;
+        else {
+            w2.B = p.B; w2.W = W; w2.H = H; w2.Win = p.Win; w2.Hin = p.Hin; w2.Cin = p.Cin; w2.N = p.N; w2.mode = d->mode; w2.lwc = lwc;
+            const int WC = 1 << lwc;
+            w2.nchunks = p.B * (W / WC);
+            const int tiles2 = (p.N / 64) * (p.Cin / 64);
+            static const int wg_env = getenv("RLDM_TR_WG_BLOCKS") ? atoi(getenv("RLDM_TR_WG_BLOCKS")) : 256;
+            int Z = std::max(1, std::min(w2.nchunks, (wg_env + tiles2 - 1) / tiles2));
+            w2.cpw = (w2.nchunks + Z - 1) / Z;
+            Z = (w2.nchunks + w2.cpw - 1) / w2.cpw;
+            w2.pitchA = WC * H + 8;
+            w2.pitchB = (p.taps == 9 ? (H + 2) : H) * WC + 8;
+            splits = Z;
+            need = (size_t)p.taps * Z * p.N * p.Cin * sizeof(float);
+        }
+    }
     static float* scratch = nullptr;                   // (one caller thread; launches are stream ordered)
     static size_t scratch_cap = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1124,6 +1263,23 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
         scratch_cap = need;
     }
     p.dw = scratch;
+    if (v2) {
+        w2.dy = dy; w2.x = x; w2.part = scratch;
+        const size_t smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
+        static bool attr = false;
+        if (!attr) {
+            RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        const dim3 grid((p.N / 64) * (p.Cin / 64), splits);
+        if (p.taps == 9) tr_wgrad2_kernel<9><<<grid, 256, smem, st>>>(w2);
+        else tr_wgrad2_kernel<1><<<grid, 256, smem, st>>>(w2);
+        TR_LAUNCH_CHECK();
+        tr_wgrad_reduce_kernel<<<nblk((size_t)p.N * p.Cin * p.taps), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
+        TR_LAUNCH_CHECK();
+        return 0;
+    }
     tr_wgrad_kernel<<<dim3(((p.N + 63) / 64) * ((p.Cin + 63) / 64), p.taps, splits), 256, 0, st>>>(p);
     TR_LAUNCH_CHECK();
     tr_wgrad_reduce_kernel<<<nblk((size_t)p.N * p.Cin * p.taps), 256, 0, st>>>(scratch, splits * 4, p.N, p.Cin, p.taps, dw);

@@ -40,6 +40,10 @@ def rnd(*shape, seed=0):
     (2, 32, 64, 16, 8, 9, 1, 0), (3, 48, 32, 8, 4, 9, 1, 0), (2, 5, 32, 16, 8, 9, 1, 0), (2, 32, 4, 16, 8, 9, 1, 0),
     (2, 64, 64, 16, 8, 9, 2, 0), (2, 32, 32, 8, 4, 9, 1, 1), (2, 96, 40, 8, 4, 1, 1, 0), (1, 9, 32, 16, 2, 9, 1, 0),
     (5, 128, 512, 1, 1, 1, 1, 0),                       # a Linear on 5 rows
+    # the all-taps weight-gradient kernel (64-multiples of channels, stride 1): every chunk geometry (H = 16 / 8 / 4 / 2),
+    # several chunks per workgroup, the nearest-x2 index map, 1x1
+    (2, 64, 64, 16, 8, 9, 1, 0), (1, 128, 64, 32, 16, 9, 1, 0), (3, 64, 128, 32, 4, 9, 1, 0), (2, 192, 64, 64, 2, 9, 1, 0),
+    (2, 64, 64, 8, 4, 9, 1, 1), (2, 128, 64, 16, 8, 1, 1, 0), (9, 64, 64, 64, 16, 9, 1, 0), (2, 64, 64, 24, 8, 9, 1, 0),
 ])
 def test_conv_forward_dgrad_wgrad(B, Cin, N, W, H, taps, stride, mode):
     from rangeldm_amd import train_ops as T

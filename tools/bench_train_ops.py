@@ -24,9 +24,12 @@ def timed(fn, iters=20):
 
 
 B = 8
-for name, W, H, Cin, N, taps in (("L0 128->128", 256, 16, 128, 128, 9), ("L1 256->256", 128, 8, 256, 256, 9),
-                                 ("L1 up 512->256", 128, 8, 512, 256, 9), ("L2 256->256", 64, 4, 256, 256, 9),
-                                 ("L3 256->256", 32, 2, 256, 256, 9), ("L1 1x1 256->256", 128, 8, 256, 256, 1)):
+for name, W, H, Cin, N, taps in (("L0 128->128", 256, 16, 128, 128, 9), ("L0 up 256->128", 256, 16, 256, 128, 9),
+                                 ("L1 128->128", 128, 8, 128, 128, 9), ("L1 up 256->128", 128, 8, 256, 128, 9),
+                                 ("L1 upsample 256->256", 128, 8, 256, 256, 9),
+                                 ("L2 256->256", 64, 4, 256, 256, 9), ("L2 up 512->256", 64, 4, 512, 256, 9),
+                                 ("L3 256->256", 32, 2, 256, 256, 9), ("L3 up 512->256", 32, 2, 512, 256, 9),
+                                 ("L0 1x1 256->128", 256, 16, 256, 128, 1), ("L2 1x1 256->256", 64, 4, 256, 256, 1)):
     x = torch.randn(B, W, H, Cin, device="cuda")
     w = torch.randn(N, Cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, device="cuda") * 0.02
     wf, wt = T.pack_weights(w, taps)
