@@ -225,11 +225,23 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
 int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, int B, int npix, int C, int groups,
                            const float* gamma, const float* beta, int silu, float* scratch /*[B][groups][2]*/, float* dx,
                            int accumulate, float* dgamma, float* dbeta, void* stream);
+/* Linear layers on B <= 16 rows (TimestepEmbedding MLP, ResnetBlock2D.time_emb_proj): y[b][n] (+)= sum_k x[b][k]
+ * W[n][k] + bias[n] with W the packed bf16 copy [N][ceil16(K)] (forward copy; the transposed copy gives the data gradient);
+ * x / y rows may be slices of wider matrices (ldx / ldy in floats).  _wgrad: dw [N][K] fp32 += dy^T x, dbias[n] += sum_b dy. */
+int rldm_train_linear_rows(const float* x, int ldx, const void* w_packed, int K, const float* bias, float* y, int ldy, int B, int N,
+                           int accumulate, void* stream);
+int rldm_train_linear_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, int B, int N, int K, float* dw, float* dbias,
+                                 void* stream);
 /* softmax(q k^T / sqrt(8)) v per head of 8 channels; q, k, v, o [B][L][C]; lse / delta [B][C/8][L]. */
 int rldm_train_attention_forward(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse,
                                  void* stream);
 int rldm_train_attention_backward(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
                                   int B, int L, int C, float* delta, float* dq, float* dk, float* dv, void* stream);
+/* The same with q, k, v the three thirds of ONE projection output qkv [B][L][3C] (to_q / to_k / to_v fused into one 1x1 conv
+ * with 3C outputs) and dq, dk, dv the thirds of dqkv [B][L][3C]; o, dO [B][L][C]. */
+int rldm_train_attention_qkv_forward(const float* qkv, int B, int L, int C, float* o, float* lse, void* stream);
+int rldm_train_attention_qkv_backward(const float* qkv, const float* o, const float* dO, const float* lse, int B, int L, int C,
+                                      float* delta, float* dqkv, void* stream);
 int rldm_train_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 int rldm_train_copy_channels(const float* src, int src_ld, int src_off, float* dst, int dst_ld, int dst_off, int ncopy,
                              int64_t npix, int accumulate, void* stream);

@@ -101,8 +101,12 @@ PROTOTYPES = {
     "rldm_train_gn_forward": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P]),
     "rldm_train_gn_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int,
                                          _P, _P, _P]),
+    "rldm_train_linear_rows": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "rldm_train_linear_rows_wgrad": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_attention_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_attention_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "rldm_train_attention_qkv_forward": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "rldm_train_attention_qkv_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "rldm_train_copy_channels": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
     "rldm_train_sum2x2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -28,9 +28,10 @@
 
 namespace rldm {
 // train_attn.hip: the same three passes on the matrix cores (bf16 operands, fp32 statistics / accumulation)
-int tr_attention_forward_mfma(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse, hipStream_t st);
-int tr_attention_backward_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
-                               int B, int L, int C, float* delta, float* dq, float* dk, float* dv, hipStream_t st);
+int tr_attention_forward_mfma(const float* q, const float* k, const float* v, int ld, int B, int L, int C, float* o, float* lse,
+                              hipStream_t st);
+int tr_attention_backward_mfma(const float* q, const float* k, const float* v, int ld, const float* o, const float* dO,
+                               const float* lse, int B, int L, int C, float* delta, float* dq, float* dk, float* dv, hipStream_t st);
 }  // namespace rldm
 
 namespace {
@@ -1164,6 +1165,69 @@ __global__ __launch_bounds__(256) void tr_pack_all_kernel(const float* __restric
     }
 }
 
+// ---- Linear layers on a handful of rows (time embedding MLP, the resnets' time_emb_proj: B <= 16 rows) -------------------------
+// The MFMA conv kernel gives such a layer 4 workgroups that walk K serially (19 us for K = 512).  Here one wave owns one output
+// feature: lanes stride over K in 16-byte pieces of the bf16 weight row, fp32 FMAs against the rows of x, butterfly at the end.
+constexpr int LIN_MAXB = 16;
+__global__ __launch_bounds__(256) void tr_linear_rows_kernel(const float* __restrict__ x, int ldx, const bf16_t* __restrict__ w, int Kp,
+                                                             int K, const float* __restrict__ bias, float* __restrict__ y, int ldy,
+                                                             int B, int N, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[LIN_MAXB];
+#pragma unroll
+    for (int b = 0; b < LIN_MAXB; ++b) acc[b] = 0.f;
+    const bf16_t* wr = w + (size_t)n * Kp;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(wr + k0);
+        const float wf[8] = {rldm::bf16lo(wv.x), rldm::bf16hi(wv.x), rldm::bf16lo(wv.y), rldm::bf16hi(wv.y),
+                             rldm::bf16lo(wv.z), rldm::bf16hi(wv.z), rldm::bf16lo(wv.w), rldm::bf16hi(wv.w)};
+#pragma unroll
+        for (int b = 0; b < LIN_MAXB; ++b) {
+            if (b < B) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (size_t)b * ldx + k0);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (size_t)b * ldx + k0 + 4);
+                acc[b] += a0[0] * wf[0] + a0[1] * wf[1] + a0[2] * wf[2] + a0[3] * wf[3] + a1[0] * wf[4] + a1[1] * wf[5] + a1[2] * wf[6] +
+                          a1[3] * wf[7];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < LIN_MAXB; ++b) {
+        if (b < B) {
+            float v = acc[b];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            if (lane == 0) {
+                float* dst = y + (size_t)b * ldy + n;
+                v += bias ? bias[n] : 0.f;
+                *dst = accumulate ? *dst + v : v;
+            }
+        }
+    }
+}
+
+// dw[n][k] += sum_b dy[b][n] x[b][k] (fp32 master gradient, row-major [N][K]); dbias[n] += sum_b dy[b][n]
+__global__ __launch_bounds__(256) void tr_linear_rows_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                                   int ldx, int B, int N, int K, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int kq = K >> 2;
+    if (i >= (size_t)N * kq) return;
+    const int n = (int)(i / kq), k = (int)(i % kq) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(dw + (size_t)n * K + k);
+    float sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g = dy[(size_t)b * ldy + n];
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * ldx + k);
+        acc += g * xv;
+        sb += g;
+    }
+    *reinterpret_cast<f32x4*>(dw + (size_t)n * K + k) = acc;
+    if (k == 0 && dbias) dbias[n] += sb;
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -1287,6 +1351,26 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
     return 0;
 }
 
+int rldm_train_linear_rows(const float* x, int ldx, const void* w_packed, int K, const float* bias, float* y, int ldy, int B, int N,
+                           int accumulate, void* stream) {
+    RLDM_REQUIRE(x && w_packed && y, "null argument");
+    RLDM_REQUIRE(B >= 1 && B <= LIN_MAXB && K % 8 == 0 && ldx % 4 == 0, "rows <= 16, K a multiple of 8");
+    const int Kp = (K + 15) / 16 * 16;
+    tr_linear_rows_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ldx, static_cast<const bf16_t*>(w_packed), Kp, K, bias, y, ldy, B,
+                                                                       N, accumulate);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_linear_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, int B, int N, int K, float* dw, float* dbias,
+                                 void* stream) {
+    RLDM_REQUIRE(dy && x && dw, "null argument");
+    RLDM_REQUIRE(B >= 1 && K % 4 == 0 && ldx % 4 == 0, "K a multiple of 4");
+    tr_linear_rows_wgrad_kernel<<<nblk((size_t)N * (K / 4)), 256, 0, (hipStream_t)stream>>>(dy, ldy, x, ldx, B, N, K, dw, dbias);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
 int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int rows_ld, int rows_accumulate, float* total,
                       void* stream) {
     RLDM_REQUIRE(dy && (rows || total), "null argument");
@@ -1366,10 +1450,24 @@ int rldm_train_attention_forward(const float* q, const float* k, const float* v,
                                  void* stream) {
     RLDM_REQUIRE(q && k && v && o && lse, "null argument");
     RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
-    if (!attention_scalar()) return rldm::tr_attention_forward_mfma(q, k, v, B, L, C, o, lse, (hipStream_t)stream);
+    if (!attention_scalar()) return rldm::tr_attention_forward_mfma(q, k, v, C, B, L, C, o, lse, (hipStream_t)stream);
     tr_attn_fwd_kernel<<<dim3((L + 127) / 128, C / 8, B), 128, 0, (hipStream_t)stream>>>(q, k, v, L, C, 0.35355339059327373f, o, lse);
     TR_LAUNCH_CHECK();
     return 0;
+}
+
+int rldm_train_attention_qkv_forward(const float* qkv, int B, int L, int C, float* o, float* lse, void* stream) {
+    RLDM_REQUIRE(qkv && o && lse, "null argument");
+    RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
+    return rldm::tr_attention_forward_mfma(qkv, qkv + C, qkv + 2 * C, 3 * C, B, L, C, o, lse, (hipStream_t)stream);
+}
+
+int rldm_train_attention_qkv_backward(const float* qkv, const float* o, const float* dO, const float* lse, int B, int L, int C,
+                                      float* delta, float* dqkv, void* stream) {
+    RLDM_REQUIRE(qkv && o && dO && lse && delta && dqkv, "null argument");
+    RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
+    return rldm::tr_attention_backward_mfma(qkv, qkv + C, qkv + 2 * C, 3 * C, o, dO, lse, B, L, C, delta, dqkv, dqkv + C, dqkv + 2 * C,
+                                            (hipStream_t)stream);
 }
 
 int rldm_train_attention_backward(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
@@ -1377,7 +1475,7 @@ int rldm_train_attention_backward(const float* q, const float* k, const float* v
     RLDM_REQUIRE(q && k && v && o && dO && lse && delta && dq && dk && dv, "null argument");
     RLDM_REQUIRE(C % 8 == 0, "head_dim is 8");
     hipStream_t st = (hipStream_t)stream;
-    if (!attention_scalar()) return rldm::tr_attention_backward_mfma(q, k, v, o, dO, lse, B, L, C, delta, dq, dk, dv, st);
+    if (!attention_scalar()) return rldm::tr_attention_backward_mfma(q, k, v, C, o, dO, lse, B, L, C, delta, dq, dk, dv, st);
     const float scale = 0.35355339059327373f;
     const dim3 grid((L + 127) / 128, C / 8, B);
     tr_attn_bwd_dq_kernel<<<grid, 128, 0, st>>>(q, k, v, o, dO, lse, L, C, scale, dq, delta);

@@ -59,6 +59,7 @@ struct AttnArgs {
     const float* q; const float* k; const float* v; const float* o; const float* dO; const float* lse;
     float* out; float* lse_out; float* delta; float* dq; float* dk; float* dv;
     int L, Lp, C, waves;
+    int ld;             // row stride (floats) of q / k / v and dq / dk / dv: C, or 3C when they are thirds of one [B][L][3C] tensor
 };
 
 // ---- forward -------------------------------------------------------------------------------------------------------
@@ -74,13 +75,15 @@ __global__ __launch_bounds__(512) void tr_attn_fwd_mfma_kernel(const AttnArgs p)
     const int vst = Lp + 8;
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);         // [Lp][8]
     bf16_t* sVt = sK + (size_t)Lp * 8;                    // [10][vst]: V^T, ones, zeros
-    const size_t base = (size_t)b * L * C + h * 8;
+    const int ld = p.ld;
+    const size_t base = (size_t)b * L * C + h * 8;        // o
+    const size_t qbase = (size_t)b * L * ld + h * 8;      // q, k, v
 
     for (int key = tid; key < Lp; key += NT) {
         uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
         if (key < L) {
-            const float4* kp = reinterpret_cast<const float4*>(p.k + base + (size_t)key * C);
-            const float4* vp = reinterpret_cast<const float4*>(p.v + base + (size_t)key * C);
+            const float4* kp = reinterpret_cast<const float4*>(p.k + qbase + (size_t)key * ld);
+            const float4* vp = reinterpret_cast<const float4*>(p.v + qbase + (size_t)key * ld);
             kv = pack8(kp[0], kp[1], 1.f);
             vv = pack8(vp[0], vp[1], 1.f);
         }
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512) void tr_attn_fwd_mfma_kernel(const AttnArgs p)
     const int qrow = min(q0 + l31, L - 1);
     s16x4 qf;
     {
-        const float4 qv = *reinterpret_cast<const float4*>(p.q + base + (size_t)qrow * C + 4 * hh);
+        const float4 qv = *reinterpret_cast<const float4*>(p.q + qbase + (size_t)qrow * ld + 4 * hh);
         const uint2 u = make_uint2(pack_bf16x2(qv.x * (kScale * kLog2e), qv.y * (kScale * kLog2e)),
                                    pack_bf16x2(qv.z * (kScale * kLog2e), qv.w * (kScale * kLog2e)));
         qf = __builtin_bit_cast(s16x4, u);
@@ -179,13 +182,15 @@ __global__ __launch_bounds__(512) void tr_attn_dq_mfma_kernel(const AttnArgs p) 
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem);         // [Lp][8]
     bf16_t* sV = sK + (size_t)Lp * 8;                     // [Lp][8]
     bf16_t* sKt = sV + (size_t)Lp * 8;                    // [9][vst]: K^T, zeros
-    const size_t base = (size_t)b * L * C + h * 8;
+    const int ld = p.ld;
+    const size_t base = (size_t)b * L * C + h * 8;        // o, dO
+    const size_t qbase = (size_t)b * L * ld + h * 8;      // q, k, v, dq
 
     for (int key = tid; key < Lp; key += NT) {
         uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
         if (key < L) {
-            const float4* kp = reinterpret_cast<const float4*>(p.k + base + (size_t)key * C);
-            const float4* vp = reinterpret_cast<const float4*>(p.v + base + (size_t)key * C);
+            const float4* kp = reinterpret_cast<const float4*>(p.k + qbase + (size_t)key * ld);
+            const float4* vp = reinterpret_cast<const float4*>(p.v + qbase + (size_t)key * ld);
             kv = pack8(kp[0], kp[1], 1.f);
             vv = pack8(vp[0], vp[1], 1.f);
         }
@@ -199,13 +204,14 @@ __global__ __launch_bounds__(512) void tr_attn_dq_mfma_kernel(const AttnArgs p) 
     const int q0 = (qb * p.waves + wave) * 32;
     if (q0 >= L) return;
     const int qrow = min(q0 + l31, L - 1);
-    const size_t qoff = base + (size_t)qrow * C + 4 * hh;
+    const size_t ooff = base + (size_t)qrow * C + 4 * hh;
+    const size_t qoff = qbase + (size_t)qrow * ld + 4 * hh;
     s16x4 qf, dof;
     float delta;
     {
         const float4 qv = *reinterpret_cast<const float4*>(p.q + qoff);
-        const float4 dv = *reinterpret_cast<const float4*>(p.dO + qoff);
-        const float4 ov = *reinterpret_cast<const float4*>(p.o + qoff);
+        const float4 dv = *reinterpret_cast<const float4*>(p.dO + ooff);
+        const float4 ov = *reinterpret_cast<const float4*>(p.o + ooff);
         const float c = kScale * kLog2e;
         qf = __builtin_bit_cast(s16x4, make_uint2(pack_bf16x2(qv.x * c, qv.y * c), pack_bf16x2(qv.z * c, qv.w * c)));
         dof = __builtin_bit_cast(s16x4, make_uint2(pack_bf16x2(dv.x, dv.y), pack_bf16x2(dv.z, dv.w)));
@@ -263,14 +269,16 @@ __global__ __launch_bounds__(512) void tr_attn_dkv_mfma_kernel(const AttnArgs p)
     bf16_t* sD = sQ + (size_t)Lp * 16;                    // [Lp][16]: dO | delta pieces | 0
     bf16_t* sQt = sD + (size_t)Lp * 16;                   // [9][vst]: Q^T, zeros
     bf16_t* sDt = sQt + 9 * vst;                          // [9][vst]: dO^T, zeros
-    const size_t base = (size_t)b * L * C + h * 8;
+    const int ld = p.ld;
+    const size_t base = (size_t)b * L * C + h * 8;        // dO
+    const size_t qbase = (size_t)b * L * ld + h * 8;      // q, k, v, dk, dv
     const size_t sbase = ((size_t)b * heads + h) * L;
 
     for (int i = tid; i < Lp; i += NT) {
         uint4 qv = make_uint4(0u, 0u, 0u, 0u), dv = qv;
         bf16_t e0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (i < L) {
-            const float4* qp = reinterpret_cast<const float4*>(p.q + base + (size_t)i * C);
+            const float4* qp = reinterpret_cast<const float4*>(p.q + qbase + (size_t)i * ld);
             const float4* dp = reinterpret_cast<const float4*>(p.dO + base + (size_t)i * C);
             qv = pack8(qp[0], qp[1], kScale * kLog2e);
             dv = pack8(dp[0], dp[1], 1.f);
@@ -298,8 +306,8 @@ __global__ __launch_bounds__(512) void tr_attn_dkv_mfma_kernel(const AttnArgs p)
     // B operands: half 0 = the key's k / v, half 1 = (-1, -1, -1, 0 ...) against the lse / delta pieces
     uint4 kB = make_uint4(0xbf80bf80u, 0x0000bf80u, 0u, 0u), vB = kB;
     if (hh == 0) {
-        const float4* kp = reinterpret_cast<const float4*>(p.k + base + (size_t)krow * C);
-        const float4* vp = reinterpret_cast<const float4*>(p.v + base + (size_t)krow * C);
+        const float4* kp = reinterpret_cast<const float4*>(p.k + qbase + (size_t)krow * ld);
+        const float4* vp = reinterpret_cast<const float4*>(p.v + qbase + (size_t)krow * ld);
         kB = pack8(kp[0], kp[1], 1.f);
         vB = pack8(vp[0], vp[1], 1.f);
     }
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(512) void tr_attn_dkv_mfma_kernel(const AttnArgs p)
                                                        __builtin_bit_cast(bf16x8, make_uint4(ps[4], ps[5], ps[6], ps[7])), accK, 0, 0, 0);
     }
     if (key0 + l31 < L) {
-        const size_t off = base + (size_t)(key0 + l31) * C + 4 * hh;
+        const size_t off = qbase + (size_t)(key0 + l31) * ld + 4 * hh;
         *reinterpret_cast<float4*>(p.dk + off) = make_float4(accK[0] * kLn2, accK[1] * kLn2, accK[2] * kLn2, accK[3] * kLn2);
         *reinterpret_cast<float4*>(p.dv + off) = make_float4(accV[0], accV[1], accV[2], accV[3]);
     }
@@ -345,10 +353,10 @@ int pick_waves(int Lp) { return std::min(8, Lp >> 5); }
 
 }  // namespace
 
-int tr_attention_forward_mfma(const float* q, const float* k, const float* v, int B, int L, int C, float* o, float* lse,
+int tr_attention_forward_mfma(const float* q, const float* k, const float* v, int ld, int B, int L, int C, float* o, float* lse,
                               hipStream_t st) {
     AttnArgs a{};
-    a.q = q; a.k = k; a.v = v; a.out = o; a.lse_out = lse; a.L = L; a.C = C;
+    a.q = q; a.k = k; a.v = v; a.out = o; a.lse_out = lse; a.L = L; a.C = C; a.ld = ld;
     a.Lp = (L + 31) / 32 * 32;
     a.waves = pick_waves(a.Lp);
     const int qblocks = ((a.Lp >> 5) + a.waves - 1) / a.waves;
@@ -365,9 +373,10 @@ int tr_attention_forward_mfma(const float* q, const float* k, const float* v, in
     return 0;
 }
 
-int tr_attention_backward_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
-                               int B, int L, int C, float* delta, float* dq, float* dk, float* dv, hipStream_t st) {
+int tr_attention_backward_mfma(const float* q, const float* k, const float* v, int ld, const float* o, const float* dO,
+                               const float* lse, int B, int L, int C, float* delta, float* dq, float* dk, float* dv, hipStream_t st) {
     AttnArgs a{};
+    a.ld = ld;
     a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.L = L; a.C = C;
     a.Lp = (L + 31) / 32 * 32;
     a.waves = pick_waves(a.Lp);

@@ -54,7 +54,7 @@ def conv(x, w_packed, N, taps, stride=1, mode=0, bias=None, rowadd=None, res=Non
     Wo, Ho = out_size(x.shape[1], x.shape[2], stride, mode)
     y = out if out is not None else empty((x.shape[0], Wo, Ho, N), x)
     _chk(_lib.lib().rldm_train_conv(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(rowadd),
-                                    0 if rowadd is None else rowadd.shape[1], _p(res), _p(y), 1 if accumulate else 0, _s(x)),
+                                    0 if rowadd is None else rowadd.stride(0), _p(res), _p(y), 1 if accumulate else 0, _s(x)),
          "rldm_train_conv")
     return y
 
@@ -67,7 +67,7 @@ def wgrad(dy, x, dw, taps, stride=1, mode=0):
 
 def colsum(dy, rows=None, total=None, rows_accumulate=False):
     B, W, H, N = dy.shape
-    _chk(_lib.lib().rldm_train_colsum(_p(dy), B, W * H, N, _p(rows), 0 if rows is None else rows.shape[1],
+    _chk(_lib.lib().rldm_train_colsum(_p(dy), B, W * H, N, _p(rows), 0 if rows is None else rows.stride(0),
                                       1 if rows_accumulate else 0, _p(total), _s(dy)), "rldm_train_colsum")
 
 
@@ -107,6 +107,42 @@ def attention_backward(q, k, v, o, dO, lse):
     _chk(_lib.lib().rldm_train_attention_backward(_p(q), _p(k), _p(v), _p(o), _p(dO), _p(lse), B, L, Cc, _p(delta), _p(dq),
                                                   _p(dk), _p(dv), _s(q)), "rldm_train_attention_backward")
     return dq, dk, dv
+
+
+def linear_rows(x, w_packed, N, bias=None, out=None, accumulate=False):
+    """x (B <= 16, K) fp32 rows (may be a column slice of a wider matrix) -> (B, N) = x W^T + bias; W bf16 [N][ceil16 K]."""
+    B, K = x.shape
+    y = out if out is not None else empty((B, N), x)
+    _chk(_lib.lib().rldm_train_linear_rows(_p(x), x.stride(0), _p(w_packed), K, _p(bias), _p(y), y.stride(0), B, N,
+                                           1 if accumulate else 0, _s(x)), "rldm_train_linear_rows")
+    return y
+
+
+def linear_rows_wgrad(dy, x, dw, dbias=None):
+    """dw (N, K) += dy^T x; dbias (N,) += dy.sum(0)"""
+    B, N = dy.shape
+    _chk(_lib.lib().rldm_train_linear_rows_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), B, N, x.shape[1], _p(dw), _p(dbias),
+                                                 _s(x)), "rldm_train_linear_rows_wgrad")
+
+
+def attention_qkv_forward(qkv):
+    """qkv (B, L, 3C) = [q | k | v] -> o (B, L, C), lse (B, C/8, L)"""
+    B, L, C3 = qkv.shape
+    Cc = C3 // 3
+    o = empty((B, L, Cc), qkv)
+    lse = empty((B, Cc // 8, L), qkv)
+    _chk(_lib.lib().rldm_train_attention_qkv_forward(_p(qkv), B, L, Cc, _p(o), _p(lse), _s(qkv)), "rldm_train_attention_qkv_forward")
+    return o, lse
+
+
+def attention_qkv_backward(qkv, o, dO, lse):
+    """-> dqkv (B, L, 3C) = [dq | dk | dv]"""
+    B, L, C3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    _chk(_lib.lib().rldm_train_attention_qkv_backward(_p(qkv), _p(o), _p(dO), _p(lse), B, L, C3 // 3, _p(delta), _p(dqkv), _s(qkv)),
+         "rldm_train_attention_qkv_backward")
+    return dqkv
 
 
 def add(a, b, out=None):

@@ -36,6 +36,39 @@ def plan_buckets(sizes, target_elems):
     return out
 
 
+def plan_parameter_order(names, shapes):
+    """Order of the parameters inside the flat buffers (state-dict views do not care) and the fused layer groups it makes
+    possible: every ResnetBlock2D.time_emb_proj reads the same silu(temb), so their weights laid end to end are ONE
+    Linear(512 -> sum of channels) (one launch instead of 22 forward, 22 backward); to_q / to_k / to_v of an Attention read
+    the same normalised input: one 1x1 conv with 3C outputs.  Returns (names, {key: {"weights": [...], "biases": [...]}});
+    a group's weights are consecutive in `names`, so are its biases."""
+    fused = OrderedDict()
+    tw = [n for n in names if n.endswith(".time_emb_proj.weight")]
+    if len(tw) > 1 and len({shapes[n][1] for n in tw}) == 1:
+        fused["time_emb_proj_all"] = {"weights": tw, "biases": [n[:-len("weight")] + "bias" for n in tw]}
+    for n in names:
+        if n.endswith(".to_q.weight"):
+            pre = n[:-len("to_q.weight")]
+            trio = [pre + f"to_{c}.weight" for c in "qkv"]
+            if all(t in shapes and shapes[t] == shapes[n] for t in trio):
+                fused[pre + "to_qkv"] = {"weights": trio, "biases": [pre + f"to_{c}.bias" for c in "qkv"]}
+    members = {m for grp in fused.values() for m in grp["weights"] + grp["biases"]}
+    out = []
+    temb_done = "time_emb_proj_all" not in fused
+    for n in names:
+        if not temb_done and n.startswith(("down_blocks", "mid_block", "up_blocks")):
+            out += fused["time_emb_proj_all"]["weights"] + fused["time_emb_proj_all"]["biases"]
+            temb_done = True
+        if n in members:
+            if n.endswith(".to_q.weight"):
+                grp = fused[n[:-len("to_q.weight")] + "to_qkv"]
+                out += grp["weights"] + grp["biases"]
+            continue
+        out.append(n)
+    assert sorted(out) == sorted(names)
+    return out, fused
+
+
 def cosine_lr(step, base_lr, warmup, total):
     """diffusers get_scheduler("cosine", num_warmup_steps, num_training_steps) (ldm/train_unconditional.py:394-399)."""
     if step < warmup:
@@ -67,7 +100,7 @@ class UNetTrainer:
         _lib.require_gpu()
         self.device = torch.device(device)
         self.shapes = unet_param_shapes(self.cfg)
-        self.names = list(self.shapes)
+        self.names, self.fused = plan_parameter_order(list(self.shapes), self.shapes)
         sizes = [int(np.prod(self.shapes[n])) for n in self.names]
         self.offsets = dict(zip(self.names, np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()))
         self.sizes = dict(zip(self.names, sizes))
@@ -87,15 +120,27 @@ class UNetTrainer:
             self.ema.copy_(self.params)
         self.p = {n: self._view(self.params, n) for n in self.names}
         self.g = {n: self._view(self.grads, n) for n in self.names}
-        # bf16 operand copies of every conv / linear weight: forward [N][taps][Cin], data gradient [Cin][taps][N]
-        self.wf, self.wt = {}, {}
+        # bf16 operand copies of every conv / linear weight: forward [N][taps][Cin], data gradient [Cin][taps][N].
+        # layers: key -> (N, Cin, taps, offset of the fp32 weight in the flat buffer).  A fused group (all time_emb_proj
+        # layers; to_q / to_k / to_v of an attention block) is ONE layer over its members' contiguous parameters.
+        self.layers, self.wf, self.wt = OrderedDict(), {}, {}
+        members = {m for grp in self.fused.values() for m in grp["weights"] + grp["biases"]}
         for n in self.names:
-            if n.endswith(".weight") and len(self.shapes[n]) >= 2:
+            if n.endswith(".weight") and len(self.shapes[n]) >= 2 and n not in members:
                 N, Cin = self.shapes[n][:2]
                 taps = 9 if len(self.shapes[n]) == 4 and self.shapes[n][2] == 3 else 1
-                self.wf[n] = torch.empty((N, taps, (Cin + 15) // 16 * 16), dtype=torch.bfloat16, device=self.device)
-                need_t = n not in ("conv_in.weight", "time_embedding.linear_1.weight")
-                self.wt[n] = torch.empty((Cin, taps, (N + 15) // 16 * 16), dtype=torch.bfloat16, device=self.device) if need_t else None
+                self.layers[n] = (N, Cin, taps, self.offsets[n], n not in ("conv_in.weight", "time_embedding.linear_1.weight"))
+        for key, grp in self.fused.items():
+            N = sum(self.shapes[m][0] for m in grp["weights"])
+            Cin = self.shapes[grp["weights"][0]][1]
+            ow, ob = self.offsets[grp["weights"][0]], self.offsets[grp["biases"][0]]
+            self.layers[key + ".weight"] = (N, Cin, 1, ow, True)
+            self.p[key + ".bias"] = self.params[ob:ob + N]
+            self.g[key + ".bias"] = self.grads[ob:ob + N]
+            self.g[key + ".weight"] = self.grads[ow:ow + N * Cin].view(N, Cin)
+        for n, (N, Cin, taps, _, need_t) in self.layers.items():
+            self.wf[n] = torch.empty((N, taps, (Cin + 15) // 16 * 16), dtype=torch.bfloat16, device=self.device)
+            self.wt[n] = torch.empty((Cin, taps, (N + 15) // 16 * 16), dtype=torch.bfloat16, device=self.device) if need_t else None
         self.repack()
         self.hp = dict(lr=lr, betas=betas, weight_decay=weight_decay, eps=eps, max_grad_norm=max_grad_norm,
                        ema_max_decay=ema_max_decay, ema_inv_gamma=ema_inv_gamma, ema_power=ema_power,
@@ -103,6 +148,7 @@ class UNetTrainer:
         self.global_step = 0
         self.buckets = plan_buckets([self.sizes[n] for n in self.names], bucket_mb * (1 << 20) // 4)
         self._tape, self._grad, self._keep = [], {}, []
+        self._rows, self._row_parent = {}, {}
         self._pending, self._ready = [], None
         self.last_grad_norm = None
         # captured step graphs (train_step_graphed): device-side step counter + per-step optimizer scalars
@@ -122,10 +168,10 @@ class UNetTrainer:
             descs = (_lib.PackDescC * len(self.wf))()
             first = 0
             for i, (n, wf) in enumerate(self.wf.items()):
-                N, Cin = self.shapes[n][:2]
+                N, Cin, _, offset, _ = self.layers[n]
                 wt = self.wt[n]
                 d = descs[i]
-                d.first, d.param_offset = first, self.offsets[n]
+                d.first, d.param_offset = first, offset
                 d.w_forward = wf.data_ptr()
                 d.w_transposed = wt.data_ptr() if wt is not None else None
                 d.N, d.Cin, d.taps = N, Cin, wf.shape[1]
@@ -186,10 +232,10 @@ class UNetTrainer:
         self._pending.append(torch.distributed.all_reduce(self.grads[off:off + cnt], op=self._reduce_op, async_op=True))
 
     # ---- ops --------------------------------------------------------------------------------------------------
-    def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True):
+    def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True, done=None):
         w = name + ".weight"
-        N = self.shapes[w][0]
-        taps = self.wf[w].shape[1]
+        N, _, taps = self.layers[w][:3]
+        done = done or (w, name + ".bias")
         y = T.conv(x, self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], rowadd=rowadd, res=res)
 
         def bwd():
@@ -197,10 +243,17 @@ class UNetTrainer:
             T.wgrad(dy, x, self.g[w], taps, stride, mode)
             drow = None
             if rowadd is not None:
-                drow = T.empty(rowadd.shape, rowadd)
+                parent = self._row_parent.get(id(rowadd))
+                if parent is None:
+                    drow = T.empty(rowadd.shape, rowadd)
+                else:                                   # a slice of the fused time_emb_proj output: write its slice of the gradient
+                    rows, off = parent
+                    if id(rows) not in self._grad:
+                        self._grad[id(rows)] = (T.empty(rows.shape, rows), True)
+                    drow = self._grad[id(rows)][0][:, off:off + rowadd.shape[1]]
             T.colsum(dy, rows=drow, total=self.g[name + ".bias"])
-            self._done(w, name + ".bias")
-            if rowadd is not None:
+            self._done(*done)
+            if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)
             if res is not None:
                 self._acc(res, dy, False)
@@ -217,16 +270,29 @@ class UNetTrainer:
         self._tape.append(bwd)
         return y
 
-    def _linear(self, x2d, name, need_dx=True):
-        """x2d (B, K) -> (B, N): a 1x1 conv over B one-pixel images"""
-        B, K = x2d.shape
-        x4 = x2d.view(B, 1, 1, K)
-        y4 = self._conv_view(x4, x2d, name, need_dx)
-        return y4
-
-    def _conv_view(self, x4, x2d, name, need_dx):
+    def _linear(self, x2d, name, need_dx=True, done=None):
+        """x2d (B <= 16, K) -> (B, N): the row-wise kernels (one wave per output feature); more rows: a 1x1 conv over B
+        one-pixel images"""
         w = name + ".weight"
-        N = self.shapes[w][0]
+        N = self.layers[w][0]
+        done = done or (w, name + ".bias")
+        B, K = x2d.shape
+        if B > 16 or K % 8:
+            return self._conv_view(x2d.view(B, 1, 1, K), x2d, name, need_dx, done)
+        y = T.linear_rows(x2d, self.wf[w], N, bias=self.p[name + ".bias"])
+
+        def bwd():
+            dy = self._pop(y)
+            T.linear_rows_wgrad(dy, x2d, self.g[w], self.g[name + ".bias"])
+            self._done(*done)
+            if need_dx:
+                self._acc(x2d, T.linear_rows(dy, self.wt[w], K), True)
+        self._tape.append(bwd)
+        return y
+
+    def _conv_view(self, x4, x2d, name, need_dx, done):
+        w = name + ".weight"
+        N = self.layers[w][0]
         y4 = T.conv(x4, self.wf[w], N, 1, bias=self.p[name + ".bias"])
         y2 = y4.view(x2d.shape[0], N)
 
@@ -235,7 +301,7 @@ class UNetTrainer:
             dy4 = dy.view(dy.shape[0], 1, 1, N)
             T.wgrad(dy4, x4, self.g[w], 1)
             T.colsum(dy4, total=self.g[name + ".bias"])
-            self._done(w, name + ".bias")
+            self._done(*done)
             if need_dx:
                 dx = T.conv(dy4, self.wt[w], x2d.shape[1], 1)
                 self._acc(x2d, dx.view(x2d.shape), True)
@@ -280,7 +346,7 @@ class UNetTrainer:
 
     def _resnet(self, x, p, temb_act):
         h = self._gn(x, p + ".norm1", True)
-        row = self._linear(temb_act, p + ".time_emb_proj")
+        row = self._rows[p + ".time_emb_proj"] if self._rows else self._linear(temb_act, p + ".time_emb_proj")
         h = self._conv(h, p + ".conv1", rowadd=row)
         h = self._gn(h, p + ".norm2", True)
         sc = self._conv(x, p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in self.shapes else x
@@ -289,6 +355,18 @@ class UNetTrainer:
     def _attention(self, x, p):
         B, W, H, Cc = x.shape
         y = self._gn(x, p + ".group_norm", False)
+        if (p + ".to_qkv") in self.fused:
+            grp = self.fused[p + ".to_qkv"]
+            qkv = self._conv(y, p + ".to_qkv", done=grp["weights"] + grp["biases"])         # (B, W, H, 3C) = [q | k | v]
+            qkv3 = qkv.view(B, W * H, 3 * Cc)
+            o3, lse = T.attention_qkv_forward(qkv3)
+            o = o3.view(B, W, H, Cc)
+
+            def bwd():
+                dO = self._pop(o)
+                self._acc(qkv, T.attention_qkv_backward(qkv3, o3, dO.view(B, W * H, Cc), lse).view(qkv.shape), True)
+            self._tape.append(bwd)
+            return self._conv(o, p + ".to_out.0", res=x)
         q = self._conv(y, p + ".to_q")
         k = self._conv(y, p + ".to_k")
         v = self._conv(y, p + ".to_v")
@@ -323,6 +401,16 @@ class UNetTrainer:
         e = self._linear(e, "time_embedding.linear_1", need_dx=False)
         temb = self._linear(self._silu(e), "time_embedding.linear_2")
         temb_act = self._silu(temb)
+        self._rows, self._row_parent = {}, {}
+        if "time_emb_proj_all" in self.fused:           # every resnet's time_emb_proj in one launch; the resnets add column slices
+            grp = self.fused["time_emb_proj_all"]
+            rows = self._linear(temb_act, "time_emb_proj_all", done=grp["weights"] + grp["biases"])
+            off = 0
+            for wn in grp["weights"]:
+                view = rows[:, off:off + self.shapes[wn][0]]
+                self._rows[wn[:-len(".weight")]] = view
+                self._row_parent[id(view)] = (rows, off)
+                off += self.shapes[wn][0]
         h = self._conv(x, "conv_in", need_dx=False)
         skips = [h]
         nl = len(cfg.block_out_channels)

@@ -137,6 +137,29 @@ def test_attention_forward_backward(B, L, C):
         assert rel(dq, gq) < gt and rel(dk, gk) < gt and rel(dv, gv) < gt, (gt, rel(dq, gq), rel(dk, gk), rel(dv, gv))
 
 
+@pytest.mark.parametrize("B,K,N", [(8, 512, 4352), (2, 128, 96), (16, 4352, 512), (3, 40, 24)])
+def test_linear_rows_forward_backward(B, K, N):
+    """Row-wise Linear kernels (TimestepEmbedding MLP, the fused time_emb_proj of all resnets): weights bf16, rows fp32."""
+    from rangeldm_amd import train_ops as T
+    x = rnd(B, K, seed=1).requires_grad_()
+    w = (rnd(N, K, seed=2) / K ** 0.5).requires_grad_()
+    bias = rnd(N, seed=3).requires_grad_()
+    ref = F.linear(x, w, bias)
+    dy = rnd(B, N, seed=4)
+    ref.backward(dy)
+    wf, wt = T.pack_weights(w.detach().cuda(), 1)
+    wide = torch.zeros(B, K + 8).cuda()                 # rows as a column slice of a wider matrix
+    wide[:, 4:4 + K] = x.detach().cuda()
+    y = T.linear_rows(wide[:, 4:4 + K], wf, N, bias=bias.detach().cuda())
+    assert rel(y, ref.detach()) < TOL_MM
+    dyd = dy.cuda()
+    assert rel(T.linear_rows(dyd, wt, K), x.grad) < TOL_MM
+    dw, db = torch.zeros(N, K).cuda(), torch.zeros(N).cuda()
+    for _ in range(2):                                  # accumulates
+        T.linear_rows_wgrad(dyd, wide[:, 4:4 + K], dw, db)
+    assert rel(dw, 2 * w.grad) < 1e-5 and rel(db, 2 * bias.grad) < 1e-5
+
+
 def test_elementwise_and_loss():
     from rangeldm_amd import train_ops as T
     a, b = rnd(2, 8, 4, 6, seed=1).cuda(), rnd(2, 8, 4, 6, seed=2).cuda()
