@@ -162,8 +162,11 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     constexpr int PITCH = CK + 8;                   // bf16 elements
     constexpr int XV = CK / 32;                     // float4 pairs per thread for x (4 threads per pixel row, CK / 4 channels each)
     constexpr int WV = CK / (8 * TPR);              // uint4 per thread for w
-    __shared__ __attribute__((aligned(16))) bf16_t sX[64 * PITCH];
-    __shared__ __attribute__((aligned(16))) bf16_t sW[BN * PITCH];
+    // one buffer: the two stage tiles during the K loop, the fp32 output tile [64][BN + 1] of the split-K epilogue afterwards
+    constexpr int STAGE_BYTES = (64 + BN) * PITCH * 2, TILE_BYTES = 64 * (BN + 1) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char raw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
+    bf16_t* const sX = reinterpret_cast<bf16_t*>(raw);
+    bf16_t* const sW = sX + 64 * PITCH;
     // (native vector types: arrays of HIP's uint4 / float4 structs are not split into registers and went through scratch;
     //  no lambda may capture the by-value argument `p` by reference either: that copies the struct to scratch)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -194,7 +197,15 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
         live = sp < 0 ? 0.f : 1.f;
         xs = xbase + (size_t)(sp < 0 ? 0 : sp) * Cin;
     };
+    // split K: workgroup z of gridDim.z contracts stages [it0, it1) and adds its partial tile to y atomically (y zeroed by the
+    // launcher; z == 0 carries bias / row / residual).  The low-resolution levels have 32 - 128 output tiles for 36 - 72
+    // serial stages of ~0.7 us each: latency, not work, was their whole cost.
+    const int it0 = (int)((long long)niter * blockIdx.z / gridDim.z), it1 = (int)((long long)niter * (blockIdx.z + 1) / gridDim.z);
+    tap = it0 / nck;
+    cc = it0 - tap * nck;
+    wptr += (size_t)tap * Cin_pad + cc * CK;
     new_tap();
+    xs += cc * CK;
     f32x4 xr[XV][2];
     u32x4 wr[WV];
     float lv = 0.f;
@@ -235,11 +246,11 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     const bf16_t* aw0 = sW + ((wave >> 1) * (BN / 2) + l31) * PITCH + 8 * kg;
     const bf16_t* aw1 = aw0 + (NR == 2 ? 32 : 0) * PITCH;
     fetch();
-    for (int it = 0; it < niter; ++it) {
+    for (int it = it0; it < it1; ++it) {
         __syncthreads();                            // everyone is done reading the previous stage
         stash();
         __syncthreads();
-        if (it + 1 < niter) fetch();                // in flight during the MFMAs below
+        if (it + 1 < it1) fetch();                  // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < CK / 16; ++ks) {
             const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
@@ -250,6 +261,35 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
             }
         }
+    }
+    if (gridDim.z > 1) {
+        // through LDS so that the atomics run along the channels (one cache line per 32 lanes; lane = pixel would touch 64 lines
+        // per instruction: measured 4x slower than not splitting at all)
+        float* tile = reinterpret_cast<float*>(raw);
+        __syncthreads();
+        {
+            float* trow = tile + ((wave & 1) * 32 + l31) * (BN + 1) + (wave >> 1) * (BN / 2);
+#pragma unroll
+            for (int h = 0; h < NR; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) trow[32 * h + 8 * (r >> 2) + 4 * kg + (r & 3)] = h ? acc1[r] : acc0[r];
+        }
+        __syncthreads();
+        const bool first = blockIdx.z == 0;
+        const int HW = p.Wout * p.Hout;
+        for (int e = tid; e < 64 * BN; e += 256) {
+            const int pl = e / BN, cl = e % BN;
+            const int gp = px0 + pl, ch = n0 + cl;
+            if (gp >= P || ch >= p.N) continue;
+            float u = tile[pl * (BN + 1) + cl];
+            if (first) {
+                if (p.bias) u += p.bias[ch];
+                if (p.rowadd) u += p.rowadd[(size_t)(gp / HW) * p.rowadd_ld + ch];
+                if (p.res) u += p.res[(size_t)gp * p.N + ch];
+            }
+            unsafeAtomicAdd(p.y + (size_t)gp * p.N + ch, u);
+        }
+        return;
     }
     const int px = px0 + (wave & 1) * 32 + l31;
     if (px >= P) return;
@@ -1260,6 +1300,17 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
         static const int bn_env = getenv("RLDM_TR_BN") ? atoi(getenv("RLDM_TR_BN")) : 0;
         const bool narrow = bn_env ? bn_env == 64 : (p.taps == 9 && (long long)grid.x * grid.y < 512);   // (measured per level)
         if (narrow) grid.y = (p.N + 63) / 64;
+        // split K when the launch cannot fill the chip (see the kernel): aim at >= 512 workgroups, >= 3 stages each
+        static const int ks_env = getenv("RLDM_TR_KSPLIT") ? atoi(getenv("RLDM_TR_KSPLIT")) : -1;
+        const int niter = p.taps * (p.Cin / (p.Cin % 64 == 0 ? 64 : 32));
+        const long long wgs = (long long)grid.x * grid.y;
+        int ksplit = wgs > 192 ? 1 : (int)std::min<long long>((512 + wgs - 1) / wgs, niter / 3);
+        if (ks_env >= 0) ksplit = ks_env;
+        ksplit = std::max(1, std::min(ksplit, niter));
+        if (ksplit > 1) {
+            if (!accumulate) RLDM_HIP_CHECK(hipMemsetAsync(y, 0, (size_t)P * p.N * sizeof(float), st));
+            grid.z = ksplit;
+        }
         if (p.Cin % 64 == 0) {
             if (narrow) tr_conv_lds_kernel<64, 64><<<grid, 256, 0, st>>>(p);
             else tr_conv_lds_kernel<64, 128><<<grid, 256, 0, st>>>(p);
