@@ -1205,6 +1205,20 @@ __global__ __launch_bounds__(256) void tr_pack_all_kernel(const float* __restric
     }
 }
 
+// zero fill as a kernel: inside a captured graph, hipMemsetAsync nodes over these (large, pool-allocated) outputs replayed
+// wrongly from the second replay on (garbage gradients; tools/determinism_probe.py), a kernel node does not
+__global__ __launch_bounds__(256) void tr_zero_kernel(float* __restrict__ y, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<float4*>(y + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else
+        for (size_t e = i; e < n; ++e) y[e] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void tr_zero2d_kernel(float* __restrict__ y, int ld, int N, int B) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)B * N) y[(i / N) * ld + i % N] = 0.f;
+}
+
 // ---- Linear layers on a handful of rows (time embedding MLP, the resnets' time_emb_proj: B <= 16 rows) -------------------------
 // The MFMA conv kernel gives such a layer 4 workgroups that walk K serially (19 us for K = 512).  Here one wave owns one output
 // feature: lanes stride over K in 16-byte pieces of the bf16 weight row, fp32 FMAs against the rows of x, butterfly at the end.
@@ -1308,7 +1322,7 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
         if (ks_env >= 0) ksplit = ks_env;
         ksplit = std::max(1, std::min(ksplit, niter));
         if (ksplit > 1) {
-            if (!accumulate) RLDM_HIP_CHECK(hipMemsetAsync(y, 0, (size_t)P * p.N * sizeof(float), st));
+            if (!accumulate) tr_zero_kernel<<<nblk((size_t)P * p.N / 4 + 1), 256, 0, st>>>(y, (size_t)P * p.N);   // (a kernel, not a memset node: see tr_zero_kernel)
             grid.z = ksplit;
         }
         if (p.Cin % 64 == 0) {
@@ -1426,7 +1440,7 @@ int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int 
                       void* stream) {
     RLDM_REQUIRE(dy && (rows || total), "null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (rows && !rows_accumulate) RLDM_HIP_CHECK(hipMemset2DAsync(rows, (size_t)rows_ld * sizeof(float), 0, (size_t)N * sizeof(float), B, st));
+    if (rows && !rows_accumulate) tr_zero2d_kernel<<<nblk((size_t)B * N), 256, 0, st>>>(rows, rows_ld, N, B);
     tr_colsum_kernel<<<dim3((N + 63) / 64, B, (npix + 255) / 256), 256, 0, st>>>(dy, npix, N, rows, rows_ld, total);
     TR_LAUNCH_CHECK();
     return 0;
@@ -1460,7 +1474,7 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
     if (slab) {
         double* acc = nullptr;
         if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
-        RLDM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), st));
+        tr_zero_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(reinterpret_cast<float*>(acc), (size_t)B * groups * 4);
         tr_gn_stats_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, npix, C, groups, acc);
         tr_gn_stats_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, (double)npix * (C / groups), eps,
                                                                            reinterpret_cast<float2*>(stats));
@@ -1482,7 +1496,7 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
     if (slab) {
         double* acc = nullptr;
         if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
-        RLDM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), st));
+        tr_zero_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(reinterpret_cast<float*>(acc), (size_t)B * groups * 4);
         tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
@@ -1593,7 +1607,7 @@ int rldm_train_mse(const float* pred, const float* target, const float* weight, 
                    double* loss, void* stream) {
     RLDM_REQUIRE(pred && target && dpred && loss, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    RLDM_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(double), st));
+    tr_zero_kernel<<<1, 256, 0, st>>>(reinterpret_cast<float*>(loss), 2);
     tr_mse_kernel<<<nblk((size_t)B * W * H * C), 256, 0, st>>>(pred, target, weight, B, C, W, H, dpred, loss);
     TR_LAUNCH_CHECK();
     return 0;
@@ -1602,7 +1616,7 @@ int rldm_train_mse(const float* pred, const float* target, const float* weight, 
 int rldm_train_sqnorm(const float* g, int64_t n, double* out, void* stream) {
     RLDM_REQUIRE(g && out && n >= 0, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    RLDM_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), st));
+    tr_zero_kernel<<<1, 256, 0, st>>>(reinterpret_cast<float*>(out), 2);
     if (n) tr_sqnorm_kernel<<<std::min<unsigned>(nblk((size_t)n), 2048u), 256, 0, st>>>(g, (size_t)n, out);
     TR_LAUNCH_CHECK();
     return 0;

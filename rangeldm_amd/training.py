@@ -210,7 +210,14 @@ class UNetTrainer:
 
     def _pop(self, t):
         g = self._grad.pop(id(t), None)
+        self._popped_owned = bool(g is not None and g[1])
         return None if g is None else g[0]
+
+    def _slot(self, t):
+        """The gradient buffer tensor t already has, if this tape owns it: kernels that can accumulate write into it directly
+        (no separate add launch)."""
+        g = self._grad.get(id(t))
+        return g[0] if g is not None and g[1] else None
 
     def _done(self, *names):
         """The gradients of these parameters are final: launch the all-reduce of every bucket that just completed."""
@@ -240,6 +247,7 @@ class UNetTrainer:
 
         def bwd():
             dy = self._pop(y)
+            dy_owned = self._popped_owned
             T.wgrad(dy, x, self.g[w], taps, stride, mode)
             drow = None
             if rowadd is not None:
@@ -256,17 +264,19 @@ class UNetTrainer:
             if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)
             if res is not None:
-                self._acc(res, dy, False)
+                self._acc(res, dy, dy_owned)            # (everything below that reads dy is enqueued before anyone adds to it)
             if need_dx:
                 wt = self.wt[w]
                 Cin = x.shape[3]
+                cur = self._slot(x) if mode != 1 else None
                 if stride == 2:
-                    dx = T.conv(dy, wt, Cin, taps, 1, 2)
+                    dx = T.conv(dy, wt, Cin, taps, 1, 2, out=cur, accumulate=cur is not None)
                 elif mode == 1:
                     dx = T.sum2x2(T.conv(dy, wt, Cin, taps, 1, 0))
                 else:
-                    dx = T.conv(dy, wt, Cin, taps, 1, 0)
-                self._acc(x, dx, True)
+                    dx = T.conv(dy, wt, Cin, taps, 1, 0, out=cur, accumulate=cur is not None)
+                if cur is None:
+                    self._acc(x, dx, True)
         self._tape.append(bwd)
         return y
 
@@ -315,9 +325,12 @@ class UNetTrainer:
 
         def bwd():
             dy = self._pop(y)
-            dx = T.gn_backward(x, dy, stats, gamma, beta, cfg.norm_num_groups, silu, self.g[name + ".weight"], self.g[name + ".bias"])
+            cur = self._slot(x)
+            dx = T.gn_backward(x, dy, stats, gamma, beta, cfg.norm_num_groups, silu, self.g[name + ".weight"], self.g[name + ".bias"],
+                               dx=cur, accumulate=cur is not None)
             self._done(name + ".weight", name + ".bias")
-            self._acc(x, dx, True)
+            if cur is None:
+                self._acc(x, dx, True)
         self._tape.append(bwd)
         return y
 

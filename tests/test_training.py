@@ -212,7 +212,7 @@ def test_graphed_steps_equal_eager_steps():
         w = torch.rand(2, generator=g).cuda()
         la = a.train_step(x, t, target, w, pos_encoding=True)
         lb = b.train_step_graphed(x, t, target, w, pos_encoding=True)
-        assert abs(float(la) - float(lb)) < (1e-6 if step <= 2 else 2e-3) * abs(float(la)), (step, float(la), float(lb))
+        assert abs(float(la) - float(lb)) < (1e-4 if step <= 2 else 2e-3) * abs(float(la)), (step, float(la), float(lb))
         assert a.global_step == b.global_step == step
         if step >= 2:                                     # (step 1 of the graphed trainer is the eager sizing step)
             dyn = b._dyn.cpu()
@@ -232,6 +232,29 @@ def test_graphed_steps_equal_eager_steps():
     b.train_step_graphed(x, t, target, w, pos_encoding=True)
     assert int(b._step_dev) == b.global_step == 8
     _adam_close(a.state_dict(), b.state_dict(), lr, "parameters after mixed steps")
+
+
+@pytest.mark.gpu
+def test_graphed_full_config_matches_eager():
+    """RangeLDM-size UNet, batch 4: five steps replayed from the captured graph against five eager steps (the large-tensor paths
+    -- slab GroupNorm, split-K convs, all-taps weight gradient -- only exist at this size; a memset node inside the graph once
+    replayed wrongly from the second replay on, which only this comparison sees)."""
+    cfg = UNetConfig()
+    sd = synth_state_dict(unet_param_shapes(cfg))
+    kw = dict(lr=1e-4, lr_warmup_steps=2, total_steps=100, use_ema=True)
+    a, b = TR.UNetTrainer(cfg, sd, **kw), TR.UNetTrainer(cfg, sd, **kw)
+    g = torch.Generator().manual_seed(5)
+    for step in range(1, 6):
+        x = torch.randn(4, 4, 256, 16, generator=g).cuda()
+        target = torch.randn(4, 4, 256, 16, generator=g).cuda()
+        t = torch.randint(0, 1000, (4,), generator=g).cuda()
+        la = float(a.train_step(x, t, target, pos_encoding=True))
+        lb = float(b.train_step_graphed(x, t, target, pos_encoding=True))
+        na, nb = float(a.last_grad_norm) ** 0.5, float(b.last_grad_norm) ** 0.5
+        assert math.isfinite(lb) and abs(la - lb) < 2e-3 * abs(la), (step, la, lb)
+        assert abs(na - nb) < 2e-2 * na, (step, na, nb)
+    d = (a.params - b.params).abs()
+    assert float((d > 0.5e-4).float().mean()) < 0.02
 
 
 @pytest.mark.gpu
