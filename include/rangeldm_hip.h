@@ -216,6 +216,10 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
                     int rowadd_ld, const float* res, float* y, int accumulate, void* stream);
 /* dw[N][Cin][taps] += sum over pixels of dy (x) x  (torch weight layout; dw must be zeroed by the caller). */
 int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, void* stream);
+/* The same plus the bias / per-image row gradients of rldm_train_colsum from the same pass over dy (rows / total may be NULL);
+ * inside the all-taps kernel the sums are taken from the staged bf16 tile. */
+int rldm_train_wgrad_bias(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, float* rows, int rows_ld,
+                          int rows_accumulate, float* total, void* stream);
 /* rows[b][n] (+)= sum over image b's pixels of dy[p][n] (time-embedding row gradient); total[n] += over all images (bias). */
 int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int rows_ld, int rows_accumulate, float* total,
                       void* stream);

@@ -451,6 +451,9 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const TrWgrad p) {
 struct TrWgrad2 {
     const float* dy; const float* x; float* part;
     int B, W, H, Win, Hin, Cin, N, mode, lwc, cpw, nchunks, pitchA, pitchB;
+    float* dw;                 // non-null: add the tile straight into the fp32 gradient [N][Cin][taps] (coalesced atomics), no partials
+    float* rows; int rows_ld;  // bias / time-embedding-row gradients from the staged dy tile (workgroups of channel tile 0):
+    float* total;              //   rows[b][n] += sum over image b's pixels, total[n] += sum over all pixels; either may be null
 };
 
 template <int TAPS>
@@ -484,6 +487,9 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
     const int nwc = W >> p.lwc;
     const int sh = p.mode ? 1 : 0;
     const int chunk_end = min((z + 1) * p.cpw, p.nchunks);
+    const bool do_sums = (p.rows || p.total) && c0 == 0;
+    int sum_b = -1;
+    float sum_img = 0.f, sum_all = 0.f;
     for (int chunk = z * p.cpw; chunk < chunk_end; ++chunk) {
         const int b = chunk / nwc, w0 = (chunk - b * nwc) << p.lwc;
         __syncthreads();                                             // the previous chunk's fragments have been read
@@ -524,6 +530,23 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
             }
         }
         __syncthreads();
+        if (do_sums) {                                               // thread (row n = tid >> 2, quarter of the chunk's pixels)
+            const bf16_t* r = sA + (tid >> 2) * pitchA + (tid & 3) * (KP >> 2);
+            float sacc = 0.f;
+            for (int k = 0; k < (KP >> 2); k += 2) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(r + k);
+                sacc += rldm::bf16lo(u) + rldm::bf16hi(u);
+            }
+            sacc += __shfl_xor(sacc, 1);
+            sacc += __shfl_xor(sacc, 2);
+            if (b != sum_b) {
+                if (sum_b >= 0 && p.rows && (tid & 3) == 0) unsafeAtomicAdd(p.rows + (size_t)sum_b * p.rows_ld + n0 + (tid >> 2), sum_img);
+                sum_b = b;
+                sum_img = 0.f;
+            }
+            sum_img += sacc;
+            sum_all += sacc;
+        }
         const bf16_t* fa = sA + (32 * wi + l31) * pitchA + 8 * kg;
         const bf16_t* fb = sB + (32 * wj + l31) * pitchB + 8 * kg;
 #pragma unroll 2
@@ -541,7 +564,32 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
             }
         }
     }
+    if (do_sums && (tid & 3) == 0) {
+        if (sum_b >= 0 && p.rows) unsafeAtomicAdd(p.rows + (size_t)sum_b * p.rows_ld + n0 + (tid >> 2), sum_img);
+        if (p.total) unsafeAtomicAdd(p.total + n0 + (tid >> 2), sum_all);
+    }
     // lane (column c = c0 + 32 wj + l31, half kg), register r <-> row n0 + 32 wi + (r & 3) + 8 (r >> 2) + 4 kg
+    if (p.dw) {
+        // the tile in the gradient's own layout ([n][c][tap]: 64 * TAPS contiguous floats per row) through LDS, 32 rows at a
+        // time, then atomics along a row: one cache line per 32 lanes
+        constexpr int TP = 64 * TAPS + 1;
+        float* tile = reinterpret_cast<float*>(wg_smem);
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (wi == half) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * kg) * TP + (32 * wj + l31) * TAPS + t] = acc[t][r];
+            }
+            __syncthreads();
+            for (int e = tid; e < 32 * 64 * TAPS; e += 256) {
+                const int row = e / (64 * TAPS), col = e - row * (64 * TAPS);
+                unsafeAtomicAdd(p.dw + ((size_t)(n0 + 32 * half + row) * Cin + c0) * TAPS + col, tile[row * TP + col]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
         float* part = p.part + (((size_t)t * gridDim.y + z) * N + n0 + 32 * wi + 4 * kg) * Cin + c0 + 32 * wj + l31;
@@ -1339,6 +1387,11 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
 }
 
 int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, void* stream) {
+    return rldm_train_wgrad_bias(d, dy, x, dw, nullptr, 0, 0, nullptr, stream);
+}
+
+int rldm_train_wgrad_bias(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, float* rows, int rows_ld,
+                          int rows_accumulate, float* total, void* stream) {
     RLDM_REQUIRE(d && dy && x && dw, "null argument");
     RLDM_REQUIRE((d->taps == 1 || d->taps == 9) && (d->stride == 1 || d->stride == 2) && d->mode >= 0 && d->mode <= 2, "bad conv desc");
     TrWgrad p;
@@ -1393,8 +1446,14 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
     }
     p.dw = scratch;
     if (v2) {
+        static const bool part_env = getenv("RLDM_TR_WG_PARTIALS") != nullptr;      // A/B: partial tiles + reduction launch
         w2.dy = dy; w2.x = x; w2.part = scratch;
-        const size_t smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
+        w2.dw = (part_env || p.taps == 9) ? nullptr : dw;      // (measured: 3x3 tiles are 9x larger, their 38 MB of atomics lose to the
+                                                                //  partial tiles + reduction launch by 10-30 %; 1x1 wins 25-35 %)
+        w2.rows = rows; w2.rows_ld = rows_ld; w2.total = total;
+        if (rows && !rows_accumulate) tr_zero2d_kernel<<<nblk((size_t)p.B * p.N), 256, 0, st>>>(rows, rows_ld, p.N, p.B);
+        size_t smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
+        if (w2.dw) smem = std::max(smem, (size_t)32 * (64 * p.taps + 1) * sizeof(float));
         static bool attr = false;
         if (!attr) {
             RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1405,9 +1464,13 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
         if (p.taps == 9) tr_wgrad2_kernel<9><<<grid, 256, smem, st>>>(w2);
         else tr_wgrad2_kernel<1><<<grid, 256, smem, st>>>(w2);
         TR_LAUNCH_CHECK();
-        tr_wgrad_reduce_kernel<<<nblk((size_t)p.N * p.Cin * p.taps), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
+        if (!w2.dw) tr_wgrad_reduce_kernel<<<nblk((size_t)p.N * p.Cin * p.taps), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
         TR_LAUNCH_CHECK();
         return 0;
+    }
+    if (rows || total) {                              // the one-tap kernel does not carry the column sums
+        const int rc = rldm_train_colsum(dy, p.B, p.Wout * p.Hout, p.N, rows, rows_ld, rows_accumulate, total, stream);
+        if (rc) return rc;
     }
     tr_wgrad_kernel<<<dim3(((p.N + 63) / 64) * ((p.Cin + 63) / 64), p.taps, splits), 256, 0, st>>>(p);
     TR_LAUNCH_CHECK();

@@ -65,6 +65,13 @@ def wgrad(dy, x, dw, taps, stride=1, mode=0):
     _chk(_lib.lib().rldm_train_wgrad(C.byref(d), _p(dy), _p(x), _p(dw), _s(x)), "rldm_train_wgrad")
 
 
+def wgrad_bias(dy, x, dw, taps, stride=1, mode=0, rows=None, total=None, rows_accumulate=False):
+    """wgrad + colsum in one call (one launch where the all-taps kernel applies)."""
+    d = conv_desc(x, dy.shape[3], taps, stride, mode)
+    _chk(_lib.lib().rldm_train_wgrad_bias(C.byref(d), _p(dy), _p(x), _p(dw), _p(rows), 0 if rows is None else rows.stride(0),
+                                          1 if rows_accumulate else 0, _p(total), _s(x)), "rldm_train_wgrad_bias")
+
+
 def colsum(dy, rows=None, total=None, rows_accumulate=False):
     B, W, H, N = dy.shape
     _chk(_lib.lib().rldm_train_colsum(_p(dy), B, W * H, N, _p(rows), 0 if rows is None else rows.stride(0),

@@ -248,7 +248,6 @@ class UNetTrainer:
         def bwd():
             dy = self._pop(y)
             dy_owned = self._popped_owned
-            T.wgrad(dy, x, self.g[w], taps, stride, mode)
             drow = None
             if rowadd is not None:
                 parent = self._row_parent.get(id(rowadd))
@@ -259,7 +258,7 @@ class UNetTrainer:
                     if id(rows) not in self._grad:
                         self._grad[id(rows)] = (T.empty(rows.shape, rows), True)
                     drow = self._grad[id(rows)][0][:, off:off + rowadd.shape[1]]
-            T.colsum(dy, rows=drow, total=self.g[name + ".bias"])
+            T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"])
             self._done(*done)
             if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)

@@ -78,6 +78,11 @@ def test_conv_forward_dgrad_wgrad(B, Cin, N, W, H, taps, stride, mode):
     assert rel(dw.cpu(), w.grad) < TOL_MM
     T.wgrad(dyd, xd, dw, taps, stride, mode)
     assert rel(dw.cpu(), 2 * w.grad) < TOL_MM
+    # the same with the bias / row sums from the same pass (taken from the staged bf16 tile where the all-taps kernel applies)
+    dw3, rows3, tot3 = torch.zeros_like(dw), torch.full((B, N + 4), 7.0).cuda(), torch.zeros(N).cuda()
+    T.wgrad_bias(dyd, xd, dw3, taps, stride, mode, rows=rows3[:, 4:], total=tot3)
+    assert rel(dw3.cpu(), w.grad) < TOL_MM and float((rows3[:, :4] - 7.0).abs().max()) == 0
+    assert rel(rows3[:, 4:].cpu(), dy.sum((2, 3))) < 3e-3 and rel(tot3.cpu(), dy.sum((0, 2, 3))) < 3e-3
     # bias / per-sample row gradients
     rows = torch.zeros(B, N).cuda()
     tot = torch.zeros(N).cuda()
