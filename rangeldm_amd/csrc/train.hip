@@ -741,6 +741,54 @@ __global__ __launch_bounds__(256) void tr_gn_fwd_kernel(const float* __restrict_
     y[i] = silu ? z * sigmoid_f(z) : z;
 }
 
+// four channels per thread (channels per group a multiple of 4, fewer than 2^31 elements): 16-byte accesses, 32-bit index math
+__global__ __launch_bounds__(256) void tr_gn_fwd_vec_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            unsigned per_image, unsigned C, unsigned cpg, int groups, int silu,
+                                                            unsigned total4, float* __restrict__ y) {
+    const unsigned i4 = blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const unsigned i = i4 * 4, c = i % C, b = i / per_image;
+    const float2 st = stats[b * groups + c / cpg];
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float z = (xv[e] - st.x) * st.y * ga[e] + be[e];
+        out[e] = silu ? z * sigmoid_f(z) : z;
+    }
+    *reinterpret_cast<f32x4*>(y + i) = out;
+}
+
+__global__ __launch_bounds__(256) void tr_gn_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float2* __restrict__ stats, const float2* __restrict__ sums,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  unsigned per_image, unsigned C, unsigned cpg, int groups, int silu,
+                                                                  int accumulate, float inv_n, unsigned total4, float* __restrict__ dx) {
+    const unsigned i4 = blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const unsigned i = i4 * 4, c = i % C, b = i / per_image;
+    const int sg_i = b * groups + c / cpg;
+    const float2 st = stats[sg_i], sm = sums[sg_i];
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i), dv = *reinterpret_cast<const f32x4*>(dy + i);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 out;
+    if (accumulate) out = *reinterpret_cast<const f32x4*>(dx + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - st.x) * st.y;
+        float dz = dv[e];
+        if (silu) {
+            const float z = xh * ga[e] + be[e], sg = sigmoid_f(z);
+            dz *= sg * (1.f + z * (1.f - sg));
+        }
+        const float v = st.y * (dz * ga[e] - sm.x * inv_n - xh * sm.y * inv_n);
+        out[e] = accumulate ? out[e] + v : v;
+    }
+    *reinterpret_cast<f32x4*>(dx + i) = out;
+}
+
 // grid (groups, B): sums[b][g] = (sum dz gamma, sum dz gamma xhat); dgamma[c] += sum dz xhat, dbeta[c] += sum dz
 // (dz = dy * act'(z)); the first T = 256 - 256 % cpg threads stride by T, so thread t always meets channel t % cpg
 __global__ __launch_bounds__(256) void tr_gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1544,7 +1592,12 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
     } else
         tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
     const size_t total = (size_t)B * npix * C;
-    tr_gn_fwd_kernel<<<nblk(total), 256, 0, st>>>(x, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C, groups, silu, total, y);
+    const int cpg = C / groups;
+    if (cpg % 4 == 0 && total < (1ull << 31))
+        tr_gn_fwd_vec_kernel<<<nblk(total / 4), 256, 0, st>>>(x, reinterpret_cast<const float2*>(stats), gamma, beta, (unsigned)npix * C, C,
+                                                            cpg, groups, silu, (unsigned)(total / 4), y);
+    else
+        tr_gn_fwd_kernel<<<nblk(total), 256, 0, st>>>(x, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C, groups, silu, total, y);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -1567,7 +1620,13 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
         tr_gn_bwd_reduce_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
                                                                  groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
     const size_t total = (size_t)B * npix * C;
-    tr_gn_bwd_apply_kernel<<<nblk(total), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats),
+    if ((C / groups) % 4 == 0 && total < (1ull << 31))
+        tr_gn_bwd_apply_vec_kernel<<<nblk(total / 4), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats),
+                                                                  reinterpret_cast<const float2*>(scratch), gamma, beta, (unsigned)npix * C,
+                                                                  C, C / groups, groups, silu, accumulate,
+                                                                  1.f / ((float)npix * (C / groups)), (unsigned)(total / 4), dx);
+    else
+        tr_gn_bwd_apply_kernel<<<nblk(total), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats),
                                                         reinterpret_cast<const float2*>(scratch), gamma, beta, npix, C, groups, silu,
                                                         accumulate, total, dx);
     TR_LAUNCH_CHECK();
