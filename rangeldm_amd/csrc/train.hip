@@ -1103,6 +1103,17 @@ __global__ __launch_bounds__(256) void tr_copy_channels_kernel(const float* __re
     *d = accumulate ? *d + v : v;
 }
 
+__global__ __launch_bounds__(256) void tr_copy_channels_vec_kernel(const float* __restrict__ src, unsigned src_ld, unsigned src_off,
+                                                                   float* __restrict__ dst, unsigned dst_ld, unsigned dst_off,
+                                                                   unsigned ncopy4, unsigned total4, int accumulate) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned px = i / ncopy4, c = (i % ncopy4) * 4;
+    f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)px * dst_ld + dst_off + c);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)px * src_ld + src_off + c);
+    *d = accumulate ? *d + v : v;
+}
+
 // nearest-x2 backward: dx[b][w][h][c] = sum of the 2 x 2 block of du[b][2w..][2h..][c]
 __global__ __launch_bounds__(256) void tr_sum2x2_kernel(const float* __restrict__ du, int B, int W, int H, int C,
                                                         float* __restrict__ dx) {
@@ -1682,7 +1693,11 @@ int rldm_train_copy_channels(const float* src, int src_ld, int src_off, float* d
                              int64_t npix, int accumulate, void* stream) {
     RLDM_REQUIRE(src && dst && ncopy > 0 && npix >= 0, "null argument");
     RLDM_REQUIRE(src_off + ncopy <= src_ld && dst_off + ncopy <= dst_ld, "channel slice out of range");
-    if (npix) tr_copy_channels_kernel<<<nblk((size_t)npix * ncopy), 256, 0, (hipStream_t)stream>>>(src, src_ld, src_off, dst, dst_ld,
+    if (npix && ((src_ld | src_off | dst_ld | dst_off | ncopy) & 3) == 0 && (size_t)npix * ncopy < (1ull << 32)) {
+        const unsigned total4 = (unsigned)((size_t)npix * ncopy / 4);
+        tr_copy_channels_vec_kernel<<<nblk(total4), 256, 0, (hipStream_t)stream>>>(src, src_ld, src_off, dst, dst_ld, dst_off, ncopy / 4,
+                                                                                 total4, accumulate);
+    } else if (npix) tr_copy_channels_kernel<<<nblk((size_t)npix * ncopy), 256, 0, (hipStream_t)stream>>>(src, src_ld, src_off, dst, dst_ld,
                                                                                                    dst_off, ncopy, (size_t)npix, accumulate);
     TR_LAUNCH_CHECK();
     return 0;
