@@ -717,12 +717,16 @@ __global__ __launch_bounds__(256) void tr_gn_stats_slab_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void tr_gn_stats_finish_kernel(const double* __restrict__ acc, int n, double count, float eps,
+// (the finish kernels leave the accumulators zeroed for the next launch: no separate fill)
+__global__ __launch_bounds__(256) void tr_gn_stats_finish_kernel(double* __restrict__ acc, int n, double count, float eps,
                                                                  float2* __restrict__ stats) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double mean = acc[2 * i] / count;
-    double var = acc[2 * i + 1] / count - mean * mean;
+    const double s0 = acc[2 * i], s1 = acc[2 * i + 1];
+    acc[2 * i] = 0.0;
+    acc[2 * i + 1] = 0.0;
+    const double mean = s0 / count;
+    double var = s1 / count - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
 }
@@ -895,9 +899,12 @@ __global__ __launch_bounds__(256) void tr_gn_bwd_reduce_slab_kernel(const float*
     }
 }
 
-__global__ __launch_bounds__(256) void tr_gn_sums_finish_kernel(const double* __restrict__ acc, int n, float2* __restrict__ sums) {
+__global__ __launch_bounds__(256) void tr_gn_sums_finish_kernel(double* __restrict__ acc, int n, float2* __restrict__ sums) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) sums[i] = make_float2((float)acc[2 * i], (float)acc[2 * i + 1]);
+    if (i >= n) return;
+    sums[i] = make_float2((float)acc[2 * i], (float)acc[2 * i + 1]);
+    acc[2 * i] = 0.0;
+    acc[2 * i + 1] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void tr_gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1581,6 +1588,7 @@ static int gn_accumulators(size_t count, hipStream_t st, double** out) {
         cap = 0;
         const size_t want = std::max<size_t>(count, 4096);
         RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&buf), want * sizeof(double)));
+        RLDM_HIP_CHECK(hipMemset(buf, 0, want * sizeof(double)));        // zero once; every user leaves it zeroed (finish kernels)
         cap = want;
     }
     *out = buf;
@@ -1596,7 +1604,6 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
     if (slab) {
         double* acc = nullptr;
         if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
-        tr_zero_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(reinterpret_cast<float*>(acc), (size_t)B * groups * 4);
         tr_gn_stats_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, npix, C, groups, acc);
         tr_gn_stats_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, (double)npix * (C / groups), eps,
                                                                            reinterpret_cast<float2*>(stats));
@@ -1623,7 +1630,6 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
     if (slab) {
         double* acc = nullptr;
         if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
-        tr_zero_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(reinterpret_cast<float*>(acc), (size_t)B * groups * 4);
         tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
