@@ -486,6 +486,44 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
     const int cq = 4 * wave + (lane & 3), ppl = lane >> 2;           // staging role
     const int nwc = W >> p.lwc;
     const int sh = p.mode ? 1 : 0;
+    struct WgStage { f32x4 d0, d1, xm, x0, x1, x2; };
+    const float* const dyb = p.dy + n0 + 4 * cq;
+    const float* const xb = p.x + c0 + 4 * cq;
+    const int Win = p.Win, Hin = p.Hin, lwc = p.lwc;
+    auto fetch = [&](int pp, int b, int w0, WgStage& r) __attribute__((always_inline)) {
+        const int k = 2 * pp, h = k >> lwc, wl = k & (WC - 1), hs = h >> sh;
+        const float* src = dyb + ((size_t)(b * W + w0 + wl) * H + h) * N;
+        r.d0 = *reinterpret_cast<const f32x4*>(src);
+        r.d1 = *reinterpret_cast<const f32x4*>(src + (size_t)H * N);
+        r.x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + ((w0 + wl) >> sh)) * Hin + hs) * Cin);
+        r.x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + ((w0 + wl + 1) >> sh)) * Hin + hs) * Cin);
+        if (TAPS == 9) {
+            int wm = w0 + wl - 1, w2 = w0 + wl + 2;
+            wm = wm < 0 ? wm + W : wm;
+            w2 = w2 >= W ? w2 - W : w2;
+            r.xm = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + (wm >> sh)) * Hin + hs) * Cin);
+            r.x2 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + (w2 >> sh)) * Hin + hs) * Cin);
+        }
+    };
+    auto stash = [&](int pp, const WgStage& r) __attribute__((always_inline)) {
+        const int k = 2 * pp, h = k >> lwc, wl = k & (WC - 1);
+        uint32_t* da = reinterpret_cast<uint32_t*>(sA + (4 * cq) * pitchA + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) da[e * (pitchA >> 1)] = rldm::pack_bf16x2(r.d0[e], r.d1[e]);
+        if (TAPS == 9) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sB + (4 * cq) * pitchB + (h + 1) * WC + wl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dst[e * (pitchB >> 1)] = rldm::pack_bf16x2(r.xm[e], r.x0[e]);
+                dst[(64 + e) * (pitchB >> 1)] = rldm::pack_bf16x2(r.x0[e], r.x1[e]);
+                dst[(128 + e) * (pitchB >> 1)] = rldm::pack_bf16x2(r.x1[e], r.x2[e]);
+            }
+        } else {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sB + (4 * cq) * pitchB + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * (pitchB >> 1)] = rldm::pack_bf16x2(r.x0[e], r.x1[e]);
+        }
+    };
     const int chunk_end = min((z + 1) * p.cpw, p.nchunks);
     const bool do_sums = (p.rows || p.total) && c0 == 0;
     int sum_b = -1;
@@ -493,41 +531,15 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
     for (int chunk = z * p.cpw; chunk < chunk_end; ++chunk) {
         const int b = chunk / nwc, w0 = (chunk - b * nwc) << p.lwc;
         __syncthreads();                                             // the previous chunk's fragments have been read
-        for (int pp = ppl; 2 * pp < KP; pp += 16) {
-            const int k = 2 * pp, h = k >> p.lwc, wl = k & (WC - 1);
-            {
-                const float* src = p.dy + ((size_t)(b * W + w0 + wl) * H + h) * N + n0 + 4 * cq;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)H * N);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(sA + (4 * cq) * pitchA + k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e * (pitchA >> 1)] = rldm::pack_bf16x2(v0[e], v1[e]);
-            }
-            const int hs = h >> sh;
-            if (TAPS == 9) {
-                int wm = w0 + wl - 1, w2 = w0 + wl + 2;
-                wm = wm < 0 ? wm + W : wm;
-                w2 = w2 >= W ? w2 - W : w2;
-                const float* xb = p.x + c0 + 4 * cq;
-                const f32x4 xm = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + (wm >> sh)) * p.Hin + hs) * Cin);
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl) >> sh)) * p.Hin + hs) * Cin);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl + 1) >> sh)) * p.Hin + hs) * Cin);
-                const f32x4 x2 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + (w2 >> sh)) * p.Hin + hs) * Cin);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(sB + (4 * cq) * pitchB + (h + 1) * WC + wl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dst[e * (pitchB >> 1)] = rldm::pack_bf16x2(xm[e], x0[e]);
-                    dst[(64 + e) * (pitchB >> 1)] = rldm::pack_bf16x2(x0[e], x1[e]);
-                    dst[(128 + e) * (pitchB >> 1)] = rldm::pack_bf16x2(x1[e], x2[e]);
-                }
-            } else {
-                const float* xb = p.x + c0 + 4 * cq;
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl) >> sh)) * p.Hin + hs) * Cin);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * p.Win + ((w0 + wl + 1) >> sh)) * p.Hin + hs) * Cin);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(sB + (4 * cq) * pitchB + k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e * (pitchB >> 1)] = rldm::pack_bf16x2(x0[e], x1[e]);
-            }
+        // two staging iterations' global loads are requested before the first is converted and stored (a chunk is 1 - 4
+        // iterations of 6 loads per thread: issued one iteration at a time each paid a full memory latency)
+        for (int pp0 = ppl; 2 * pp0 < KP; pp0 += 32) {
+            WgStage r0, r1;
+            const bool two = 2 * (pp0 + 16) < KP;
+            fetch(pp0, b, w0, r0);
+            if (two) fetch(pp0 + 16, b, w0, r1);
+            stash(pp0, r0);
+            if (two) stash(pp0 + 16, r1);
         }
         __syncthreads();
         if (do_sums) {                                               // thread (row n = tid >> 2, quarter of the chunk's pixels)

@@ -604,16 +604,34 @@ class UNetTrainer:
         return st
 
 
+def encode_ahead(vae, clean_images, stream, generator=None):
+    """The VAE half of the loop body (ldm/train_unconditional.py:480-481) for the NEXT batch, enqueued on `stream` so that it
+    runs beside the current step's many small UNet launches.  Returns (latents, event): wait for the event on the training
+    stream, then pass `latents=` to training_step."""
+    cur = torch.cuda.current_stream(clean_images.device if clean_images.is_cuda else None)
+    stream.wait_stream(cur)                                    # the images were produced on the caller's stream
+    with torch.cuda.stream(stream):
+        latents = vae.encode(clean_images).latent_dist.sample(generator=generator, scale=vae.config.scaling_factor)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    latents.record_stream(cur)
+    return latents, ev
+
+
 def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, pos_encoding=True, snr_gamma=None,
-                  noise=None, timesteps=None, condition=None, graphed=False):
+                  noise=None, timesteps=None, condition=None, graphed=False, latents=None):
     """One iteration of the reference's loop body (ldm/train_unconditional.py:479-556) with `with_vae: True`:
     latents = vae.encode(x).latent_dist.sample() * scaling_factor; eps ~ N(0, 1); t ~ U{0..T-1}; add_noise; pos-encoding
     channel; epsilon-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA.
     condition (B, Cc, W, H): the conditional twin (ldm/train_conditional.py:418-447) -- the encoded low-resolution image
     (`condition_encoder(batch["down"])`) or `cat([masked latents, mask])`, concatenated to the noisy latents.
-    graphed: replay the UNet forward / backward / optimizer from captured HIP graphs (UNetTrainer.train_step_graphed)."""
+    graphed: replay the UNet forward / backward / optimizer from captured HIP graphs (UNetTrainer.train_step_graphed).
+    latents: `vae.encode(clean_images).latent_dist.sample() * scaling_factor` computed by the caller (input pipelining:
+    `encode_ahead`); clean_images is ignored then."""
     dev = trainer.device
-    if vae is not None:
+    if latents is not None:                 # encoded ahead of time (e.g. on a second stream while the previous step ran)
+        latents = latents.to(dev).float()
+    elif vae is not None:
         latents = vae.encode(clean_images.to(dev)).latent_dist.sample(generator=generator, scale=vae.config.scaling_factor)
     else:
         latents = clean_images.to(dev).float()

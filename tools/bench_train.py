@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--overlap-vae", action="store_true", help="encode batch i + 1 on a second stream while batch i trains (measured: 4 % slower than in-step)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured step graphs")
     ap.add_argument("--seed", type=int, default=20240310)
     a = ap.parse_args()
@@ -37,7 +38,7 @@ def main():
     from rangeldm_amd.params import unet_param_shapes, vae_param_shapes
     from rangeldm_amd.schedulers import DDPMSchedulerHIP
     from rangeldm_amd.synth import synth_state_dict, normal
-    from rangeldm_amd.training import UNetTrainer, training_step
+    from rangeldm_amd.training import UNetTrainer, training_step, encode_ahead
     from rangeldm_amd.vae import AutoencoderKLHIP
     rank, world, local = D.init_from_env("nccl")
     torch.cuda.set_device(local)
@@ -58,8 +59,21 @@ def main():
     imgs = [torch.from_numpy(normal(a.seed, f"train/{rank}/{i}", shape)).mul_(0.5).to(dev) for i in range(n_iter)]
     losses = []
 
+    side = torch.cuda.Stream(dev) if (vae is not None and a.overlap_vae) else None
+    ahead = {}
+
     def one(i):
-        losses.append(training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True, graphed=not a.eager))
+        if side is None:
+            losses.append(training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True, graphed=not a.eager))
+            return
+        # input pipelining: batch i + 1 is encoded on a second stream while batch i trains (every step still encodes one batch)
+        if i not in ahead:
+            ahead[i] = encode_ahead(vae, imgs[i], side, generator=gen)
+        lat, ev = ahead.pop(i)
+        torch.cuda.current_stream(dev).wait_event(ev)
+        if i + 1 < n_iter:
+            ahead[i + 1] = encode_ahead(vae, imgs[i + 1], side, generator=gen)
+        losses.append(training_step(tr, None, sched, imgs[i], generator=gen, pos_encoding=True, graphed=not a.eager, latents=lat))
 
     for i in range(a.warmup):
         one(i)
@@ -78,6 +92,7 @@ def main():
                           "data": "synthetic", "config": {"workload": f"train_unconditional step, batch {B} per GPU, "
                                                           f"{'VAE encode + ' if vae is not None else ''}UNet fwd+bwd, AdamW, EMA",
                                                           "launch": "eager" if a.eager else "captured HIP graphs",
+                                                          "vae_encode": "in step" if side is None else "one batch ahead on a second stream",
                                                           "global_batch": B * world},
                           "gflop_per_sample": gflop, "end_to_end_tflops": sps * gflop / 1e3,
                           "loss_first_last": [float(losses[0]), float(losses[-1])]}))
