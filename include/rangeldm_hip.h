@@ -293,6 +293,9 @@ typedef struct rldm_pack_desc {
     int32_t N, Cin, taps, pad_;
 } rldm_pack_desc;
 int rldm_train_pack_weights_all(const float* params, const rldm_pack_desc* descs, int num_layers, int64_t total, void* stream);
+/* the same as a tiled transpose (coalesced reads and writes): descs[i].first = cumulative count of 64 x 64 (N, Cin) tiles,
+ * total_tiles = their sum = the grid. */
+int rldm_train_pack_weights_tiled(const float* params, const rldm_pack_desc* descs, int num_layers, int64_t total_tiles, void* stream);
 
 /* ---- introspection used by bench.py / tests ----------------------------------------------------------------- */
 /* algorithmic FLOPs (2*MACs of conv/linear/QK^T/PV) of one UNet forward / VAE decode / encode for batch B */

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "rldm_train_hyper_step": (C.c_int, [_P, C.POINTER(HyperConfigC), _P, _P]),
     "rldm_train_pack_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_pack_weights_all": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
+    "rldm_train_pack_weights_tiled": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
     "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),

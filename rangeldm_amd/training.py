@@ -161,27 +161,30 @@ class UNetTrainer:
     def _view(self, flat, n):
         return flat[self.offsets[n]:self.offsets[n] + self.sizes[n]].view(self.shapes[n])
 
-    def repack(self):
-        """Refresh the bf16 operand copies of every conv / linear weight from the fp32 masters: one launch."""
+    def repack(self, tiled=True):
+        """Refresh the bf16 operand copies of every conv / linear weight from the fp32 masters: one launch (tiled: a 64 x 64
+        tile transpose per workgroup; False: the element-wise kernel, kept as the cross-check)."""
         import ctypes as C
         if getattr(self, "_pack_table", None) is None:
-            descs = (_lib.PackDescC * len(self.wf))()
-            first = 0
-            for i, (n, wf) in enumerate(self.wf.items()):
-                N, Cin, _, offset, _ = self.layers[n]
-                wt = self.wt[n]
-                d = descs[i]
-                d.first, d.param_offset = first, offset
-                d.w_forward = wf.data_ptr()
-                d.w_transposed = wt.data_ptr() if wt is not None else None
-                d.N, d.Cin, d.taps = N, Cin, wf.shape[1]
-                first += max(wf.numel(), wt.numel() if wt is not None else 0)
-            raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
-            self._pack_table, self._pack_total = raw, first
-        _lib.check(_lib.lib().rldm_train_pack_weights_all(C.c_void_p(self.params.data_ptr()),
-                                                          C.c_void_p(self._pack_table.data_ptr()), len(self.wf),
-                                                          self._pack_total, _lib.stream_ptr(self.device)),
-                   "rldm_train_pack_weights_all")
+            tables = []
+            for per_tile in (False, True):
+                descs = (_lib.PackDescC * len(self.wf))()
+                first = 0
+                for i, (n, wf) in enumerate(self.wf.items()):
+                    N, Cin, _, offset, _ = self.layers[n]
+                    wt = self.wt[n]
+                    d = descs[i]
+                    d.first, d.param_offset = first, offset
+                    d.w_forward = wf.data_ptr()
+                    d.w_transposed = wt.data_ptr() if wt is not None else None
+                    d.N, d.Cin, d.taps = N, Cin, wf.shape[1]
+                    first += (((N + 63) // 64) * ((Cin + 63) // 64)) if per_tile else max(wf.numel(), wt.numel() if wt is not None else 0)
+                tables.append((torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device), first))
+            self._pack_table = tables
+        table, total = self._pack_table[1 if tiled else 0]
+        fn = _lib.lib().rldm_train_pack_weights_tiled if tiled else _lib.lib().rldm_train_pack_weights_all
+        _lib.check(fn(C.c_void_p(self.params.data_ptr()), C.c_void_p(table.data_ptr()), len(self.wf), total,
+                      _lib.stream_ptr(self.device)), "rldm_train_pack_weights")
 
     def state_dict(self, ema=False):
         flat = (self.ema if ema else self.params).cpu()

@@ -188,6 +188,30 @@ def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
     assert torch.isfinite(m(x, 10).sample).all()
 
 
+@pytest.mark.gpu
+def test_operand_repack_tiled_equals_elementwise():
+    """The tiled transpose (one launch, all layers incl. the fused groups and the 5- / 4-channel ends with their zero pads)
+    writes exactly the bytes of the per-layer kernel."""
+    from rangeldm_amd import train_ops as T
+    cfg = UNetConfig(**SMALL)
+    tr = TR.UNetTrainer(cfg, synth_state_dict(unet_param_shapes(cfg), prefix="tr."), use_ema=False)
+    for wf in tr.wf.values():
+        wf.fill_(7.0)
+    for wt in tr.wt.values():
+        if wt is not None:
+            wt.fill_(7.0)
+    tr.repack(tiled=True)
+    got = {n: (tr.wf[n].clone(), None if tr.wt[n] is None else tr.wt[n].clone()) for n in tr.wf}
+    tr.repack(tiled=False)
+    for n, (N, Cin, taps, off, need_t) in tr.layers.items():
+        w = tr.params[off:off + N * Cin * taps].view(N, Cin, taps)
+        wf, wt = T.pack_weights(w, taps)
+        assert torch.equal(got[n][0].view(torch.int16), wf.view(torch.int16)), n
+        assert torch.equal(tr.wf[n].view(torch.int16), wf.view(torch.int16)), n
+        if need_t:
+            assert torch.equal(got[n][1].view(torch.int16), wt.view(torch.int16)), n
+
+
 def _adam_close(a, b, lr, what):
     """parameters of two runs agree: a sign flip of a near-zero gradient moves an Adam parameter by 2 lr, nothing else may"""
     d = torch.cat([(a[k] - b[k]).reshape(-1) for k in a]).abs()
