@@ -696,6 +696,29 @@ __global__ __launch_bounds__(256) void tr_gn_stats_kernel(const float* __restric
     }
 }
 
+// 4 channels per thread for 4 | channels-per-group <= 16: thread (pixel lane t / Q, channel quad t % Q), Q = cpg / 4
+__global__ __launch_bounds__(256) void tr_gn_stats_vec_kernel(const float* __restrict__ x, int npix, int C, int groups, float eps,
+                                                              float2* __restrict__ stats) {
+    __shared__ double sh[4];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups, Q = cpg >> 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q, step = 256 / Q;
+    const float* base = x + (size_t)b * npix * C + g * cpg + 4 * q;
+    double s = 0.0, ss = 0.0;
+    for (int p = pl; p < npix; p += step) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += v[e]; ss += (double)v[e] * v[e]; }
+    }
+    s = block_sum_d(s, sh);
+    ss = block_sum_d(ss, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)npix * cpg, mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        stats[b * groups + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
+}
+
 // Large tensors: the one-block-per-(image, group) kernels above read 16-byte pieces 2 KB apart.  These variants give a
 // block a slab of 64 pixels x all channels (fully coalesced float4 rows); a thread's channel quad is the same in every
 // iteration when C divides 1024, so it accumulates in registers and ends with one LDS atomic per group it touched.
@@ -843,6 +866,52 @@ __global__ __launch_bounds__(256) void tr_gn_bwd_reduce_kernel(const float* __re
     if (threadIdx.x < cpg) {
         float tg = 0.f, tb = 0.f;
         for (int t = threadIdx.x; t < TT; t += cpg) { tg += shg[t]; tb += shb[t]; }
+        unsafeAtomicAdd(dgamma + g * cpg + threadIdx.x, tg);
+        unsafeAtomicAdd(dbeta + g * cpg + threadIdx.x, tb);
+    }
+    if (threadIdx.x == 0) sums[b * groups + g] = make_float2((float)s1, (float)s2);
+}
+
+__global__ __launch_bounds__(256) void tr_gn_bwd_reduce_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, int npix, int C, int groups, int silu,
+                                                                   float2* __restrict__ sums, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
+    __shared__ double sh[4];
+    __shared__ float shg[4][256], shb[4][256];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups, Q = cpg >> 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q, step = 256 / Q;
+    const float2 st = stats[b * groups + g];
+    const size_t base = (size_t)b * npix * C + g * cpg + 4 * q;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * cpg + 4 * q), be = *reinterpret_cast<const f32x4*>(beta + g * cpg + 4 * q);
+    double s1 = 0.0, s2 = 0.0;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pl; p < npix; p += step) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - st.x) * st.y;
+            float dz = dv[e];
+            if (silu) {
+                const float z = xh * ga[e] + be[e], sg = sigmoid_f(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            s1 += (double)(dz * ga[e]);
+            s2 += (double)(dz * ga[e] * xh);
+            dg[e] += dz * xh;
+            db[e] += dz;
+        }
+    }
+    s1 = block_sum_d(s1, sh);
+    s2 = block_sum_d(s2, sh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { shg[e][threadIdx.x] = dg[e]; shb[e][threadIdx.x] = db[e]; }
+    __syncthreads();
+    if (threadIdx.x < cpg) {                                          // channel ci = 4 q' + e: threads t = q' (mod Q)
+        const int qq = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float tg = 0.f, tb = 0.f;
+        for (int t = qq; t < 256; t += Q) { tg += shg[e][t]; tb += shb[e][t]; }
         unsafeAtomicAdd(dgamma + g * cpg + threadIdx.x, tg);
         unsafeAtomicAdd(dbeta + g * cpg + threadIdx.x, tb);
     }
@@ -1665,7 +1734,9 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
         tr_gn_stats_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, npix, C, groups, acc);
         tr_gn_stats_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, (double)npix * (C / groups), eps,
                                                                            reinterpret_cast<float2*>(stats));
-    } else
+    } else if ((C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
+        tr_gn_stats_vec_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
+    else
         tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
     const size_t total = (size_t)B * npix * C;
     const int cpg = C / groups;
@@ -1691,7 +1762,10 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
         tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
-    } else
+    } else if ((C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
+        tr_gn_bwd_reduce_vec_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
+                                                                 groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
+    else
         tr_gn_bwd_reduce_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
                                                                  groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
     const size_t total = (size_t)B * npix * C;

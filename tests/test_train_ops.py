@@ -91,7 +91,7 @@ def test_conv_forward_dgrad_wgrad(B, Cin, N, W, H, taps, stride, mode):
 
 
 @pytest.mark.parametrize("B,C,W,H,silu", [(2, 64, 16, 8, True), (3, 32, 8, 4, False), (1, 128, 4, 2, True), (2, 512, 4, 2, True),
-                                            (2, 96, 8, 4, True), (2, 160, 4, 2, False),       # 3 / 5 channels per group
+                                            (2, 96, 8, 4, True), (2, 160, 4, 2, False), (2, 256, 16, 8, True),       # 3 / 5 / 8 channels per group
                                             (2, 128, 256, 16, True), (1, 512, 64, 8, False)])  # slab kernels (large tensors)
 def test_group_norm_forward_backward(B, C, W, H, silu):
     from rangeldm_amd import train_ops as T

@@ -76,6 +76,29 @@ def test_bucketed_gradient_average_world2_gloo():
     assert out[0] and out[1]
 
 
+def test_parameter_order_makes_fused_groups_contiguous():
+    """plan_parameter_order: a permutation of the state-dict names in which the weights (and the biases) of every fused group
+    -- all time_emb_proj layers, to_q / to_k / to_v of each attention block -- are consecutive, so one [sum N][K] matrix in
+    the flat fp32 buffers is the stacked Linear; bucket planning still covers every parameter once."""
+    for cfg in (UNetConfig(), UNetConfig(**SMALL)):
+        shapes = unet_param_shapes(cfg)
+        names, fused = TR.plan_parameter_order(list(shapes), shapes)
+        assert sorted(names) == sorted(shapes) and len(set(names)) == len(names)
+        assert "time_emb_proj_all" in fused and len(fused) == 1 + sum(n.endswith("to_q.weight") for n in shapes)
+        for key, grp in fused.items():
+            for members in (grp["weights"], grp["biases"]):
+                i = names.index(members[0])
+                assert names[i:i + len(members)] == members, key
+            assert len({shapes[m][1] for m in grp["weights"]}) == 1                    # one K for the stacked matrix
+            assert [shapes[w][0] for w in grp["weights"]] == [shapes[b][0] for b in grp["biases"]]
+        sizes = [int(np.prod(shapes[n])) for n in names]
+        buckets = TR.plan_buckets(sizes, 1 << 20)
+        assert buckets[0][0] == 0 and buckets[-1][1] == len(names) and sum(b[3] for b in buckets) == sum(sizes)
+        assert all(buckets[i][1] == buckets[i + 1][0] for i in range(len(buckets) - 1))
+        # the stacked time_emb_proj comes before the blocks that use it: its bucket is among the last to complete in backward
+        assert names.index(fused["time_emb_proj_all"]["weights"][0]) < names.index("down_blocks.0.resnets.0.norm1.weight")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw,B,weights", [
     (dict(**SMALL), 2, None),
