@@ -136,7 +136,18 @@ def main():
     ap.add_argument("--preset", default="RangeLDM")
     ap.add_argument("--seed", type=int, default=20240310)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 5 instead of the headline: the data-parallel training step (tools/bench_train.py, same "
+                         "--gpus / --steps / --warmup contract, metric training samples/sec)")
+    args, rest = ap.parse_known_args()
+    if args.train:
+        sys.argv = [os.path.join(ROOT, "tools", "bench_train.py"), "--gpus", str(args.gpus), "--steps", str(args.steps),
+                    "--warmup", str(args.warmup)] + rest
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        return bench_train.main()
+    if rest:
+        ap.error("unrecognized arguments: " + " ".join(rest))
 
     from rangeldm_amd import distributed as D
     from rangeldm_amd.pipelines import LDMPipelineRange, DDIMPipelineRange
@@ -203,7 +214,7 @@ def main():
                        "global_batch": B * world, "batch_per_gpu": B, "inference_steps": S, "sampler": args.sampler,
                        "parallelism": f"sample-sharded x{world}, RCCL all-gather of finished images"},
         }
-        if world == 1:
+        if True:                                        # (per-GPU figures, measured on rank 0's GPU for every N)
             h = pipe._fused.get(unet, vae, sched, B, S, 0 if args.sampler == "ddim" else 1, p["pos_encoding"], 0)
             rl, kernels = roofline(pipe, h, xs[0], S)
             gflop_per_image = (S * unet.flops(B) + (vae.decode_flops(B, *lat_shape[1:]) if vae else 0.0)) / B / 1e9
@@ -211,9 +222,9 @@ def main():
             res["kernels"] = kernels
             res["gflop_per_image"] = round(gflop_per_image, 1)
             res["end_to_end_tflops"] = round(res["value"] * gflop_per_image / 1e3, 1)
-            res["end_to_end_frac_of_mfma_peak"] = round(res["value"] * gflop_per_image / 1e3 / PEAK_BF16_TFLOPS, 4)
+            res["end_to_end_frac_of_mfma_peak"] = round(res["value"] / world * gflop_per_image / 1e3 / PEAK_BF16_TFLOPS, 4)
             res["unet_launches_per_step"] = unet.num_launches(B)
-            if not args.no_cpu_baseline:
+            if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(p, usd, vsd, B, S)
         print(json.dumps(res), flush=True)
     D.barrier()
