@@ -36,6 +36,11 @@ int tr_attention_backward_mfma(const float* q, const float* k, const float* v, i
 
 namespace {
 
+inline bool gn_vec_reduce_env() {
+    static const bool v = getenv("RLDM_TR_GN_VEC_REDUCE") != nullptr;
+    return v;
+}
+
 // RLDM_TR_ATTN=scalar: the fp32 one-thread-per-query kernels of this file (A/B runs)
 inline bool attention_scalar() {
     static const bool v = getenv("RLDM_TR_ATTN") && std::string(getenv("RLDM_TR_ATTN")) == "scalar";
@@ -1762,7 +1767,9 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
         tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
-    } else if ((C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
+    } else if (gn_vec_reduce_env() && (C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
+        // (measured 14.0 us against 10.1 us for the channel-pinned kernel below: four sigmoids per iteration and the wider LDS
+        //  epilogue cost more than the 16-byte loads save; kept for A/B runs)
         tr_gn_bwd_reduce_vec_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
                                                                  groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
     else
