@@ -214,6 +214,10 @@ typedef struct rldm_train_conv_desc {
  * rldm_train_pack_weights (forward copy, or the transposed copy with Cin/N swapped for the data gradient). */
 int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* rowadd,
                     int rowadd_ld, const float* res, float* y, int accumulate, void* stream);
+/* How many K splits rldm_train_conv uses for this shape (1: none).  A split launch adds its partial tiles to y atomically
+ * after zero-filling it; with accumulate != 0 it adds onto what y holds, so a caller that owns pre-zeroed outputs (one fill
+ * for all of a step's split launches) passes accumulate = 1 and saves the per-launch fill. */
+int rldm_train_conv_splits(const rldm_train_conv_desc* d, int rowadd_ld);
 /* dw[N][Cin][taps] += sum over pixels of dy (x) x  (torch weight layout; dw must be zeroed by the caller). */
 int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, void* stream);
 /* The same plus the bias / per-image row gradients of rldm_train_colsum from the same pass over dy (rows / total may be NULL);

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "rldm_hist_spectral_sq": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_hist_mmd": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), _P]),
     "rldm_train_conv": (C.c_int, [C.POINTER(TrainConvDescC), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "rldm_train_conv_splits": (C.c_int, [C.POINTER(TrainConvDescC), C.c_int]),
     "rldm_train_wgrad": (C.c_int, [C.POINTER(TrainConvDescC), _P, _P, _P, _P]),
     "rldm_train_wgrad_bias": (C.c_int, [C.POINTER(TrainConvDescC), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "rldm_train_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P]),

@@ -1536,6 +1536,38 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 extern "C" {
 
+// launch shape of the LDS-staged conv: narrow (64-channel) tile? how many K splits?  (shared by rldm_train_conv and
+// rldm_train_conv_splits, which lets the host hand out pre-zeroed outputs to the split launches)
+static void conv_lds_plan(int P, int N, int Cin, int taps, bool* narrow_out, int* ksplit_out) {
+    const long long gx = (P + 63) / 64;
+    long long gy = (N + 127) / 128;
+    // 128-channel tiles stage the pixel operand half as often; 64-channel tiles double the workgroups in flight, which
+    // is what hides a stage's load latency when the launch has fewer than ~2 workgroups per CU (3x3 levels 1-3: 10-20 %
+    // faster; the 512-workgroup level 0 and the two-stage 1x1 convs are faster with the wide tile)
+    static const int bn_env = getenv("RLDM_TR_BN") ? atoi(getenv("RLDM_TR_BN")) : 0;
+    const bool narrow = bn_env ? bn_env == 64 : (taps == 9 && gx * gy < 512);   // (measured per level)
+    if (narrow) gy = (N + 63) / 64;
+    // split K when the launch cannot fill the chip (see the kernel): aim at >= 512 workgroups, >= 3 stages each
+    static const int ks_env = getenv("RLDM_TR_KSPLIT") ? atoi(getenv("RLDM_TR_KSPLIT")) : -1;
+    const int niter = taps * (Cin / (Cin % 64 == 0 ? 64 : 32));
+    const long long wgs = gx * gy;
+    int ksplit = wgs > 192 ? 1 : (int)std::min<long long>((512 + wgs - 1) / wgs, niter / 3);
+    if (ks_env >= 0) ksplit = ks_env;
+    *narrow_out = narrow;
+    *ksplit_out = std::max(1, std::min(ksplit, niter));
+}
+
+int rldm_train_conv_splits(const rldm_train_conv_desc* d, int rowadd_ld) {
+    if (!d || d->stride < 1) return 1;
+    const int sh = d->mode ? 1 : 0;
+    const int P = d->B * ((d->Win << sh) / d->stride) * ((d->Hin << sh) / d->stride);
+    if (!(P >= 64 && (rowadd_ld & 3) == 0 && d->Cin % 32 == 0)) return 1;
+    bool narrow;
+    int ksplit;
+    conv_lds_plan(P, d->N, d->Cin, d->taps, &narrow, &ksplit);
+    return ksplit;
+}
+
 int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* rowadd,
                     int rowadd_ld, const float* res, float* y, int accumulate, void* stream) {
     RLDM_REQUIRE(d && x && w_packed && y, "null argument");
@@ -1554,19 +1586,10 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
     const bool lds = P >= 64 && aligned;               // Linear layers on a handful of rows: the direct kernel
     hipStream_t st = (hipStream_t)stream;
     if (lds && p.Cin % 32 == 0) {
-        // 128-channel tiles stage the pixel operand half as often; 64-channel tiles double the workgroups in flight, which
-        // is what hides a stage's load latency when the launch has fewer than ~2 workgroups per CU (3x3 levels 1-3: 10-20 %
-        // faster; the 512-workgroup level 0 and the two-stage 1x1 convs are faster with the wide tile)
-        static const int bn_env = getenv("RLDM_TR_BN") ? atoi(getenv("RLDM_TR_BN")) : 0;
-        const bool narrow = bn_env ? bn_env == 64 : (p.taps == 9 && (long long)grid.x * grid.y < 512);   // (measured per level)
+        bool narrow;
+        int ksplit;
+        conv_lds_plan(P, p.N, p.Cin, p.taps, &narrow, &ksplit);
         if (narrow) grid.y = (p.N + 63) / 64;
-        // split K when the launch cannot fill the chip (see the kernel): aim at >= 512 workgroups, >= 3 stages each
-        static const int ks_env = getenv("RLDM_TR_KSPLIT") ? atoi(getenv("RLDM_TR_KSPLIT")) : -1;
-        const int niter = p.taps * (p.Cin / (p.Cin % 64 == 0 ? 64 : 32));
-        const long long wgs = (long long)grid.x * grid.y;
-        int ksplit = wgs > 192 ? 1 : (int)std::min<long long>((512 + wgs - 1) / wgs, niter / 3);
-        if (ks_env >= 0) ksplit = ks_env;
-        ksplit = std::max(1, std::min(ksplit, niter));
         if (ksplit > 1) {
             if (!accumulate) tr_zero_kernel<<<nblk((size_t)P * p.N / 4 + 1), 256, 0, st>>>(y, (size_t)P * p.N);   // (a kernel, not a memset node: see tr_zero_kernel)
             grid.z = ksplit;

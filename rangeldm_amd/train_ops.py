@@ -48,11 +48,55 @@ def pack_weights(w, taps, want_transposed=True):
     return wf, wt
 
 
+class ZeroArena:
+    """Pre-zeroed outputs for the split-K conv launches of one step: every such launch gets its own slice (handed out in call
+    order, the same every step), and ONE fill at the start of the step replaces a fill launch per conv (75 per step at the
+    RangeLDM size).  `begin()` zeroes what the previous step used and rewinds; `take(shape)` returns the next slice."""
+
+    def __init__(self, device, nbytes=64 << 20):
+        self.device, self.buf, self.pos, self.high = device, None, 0, 0
+        self.cap = nbytes // 4
+
+    def begin(self):
+        if self.buf is None:
+            self.buf = torch.zeros(self.cap, dtype=torch.float32, device=self.device)
+        elif self.high:
+            self.buf[:self.high].zero_()
+        self.pos = 0
+
+    def take(self, shape):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n4 = (n + 3) // 4 * 4
+        if self.buf is None or self.pos + n4 > self.cap:
+            return None                                  # arena full: the launch zero-fills its own output
+        t = self.buf[self.pos:self.pos + n].view(shape)
+        self.pos += n4
+        self.high = max(self.high, self.pos)
+        return t
+
+
+_arena = None
+
+
+def set_zero_arena(arena):
+    """Install (or remove, None) the arena `conv` draws split-K outputs from."""
+    global _arena
+    _arena = arena
+
+
 def conv(x, w_packed, N, taps, stride=1, mode=0, bias=None, rowadd=None, res=None, out=None, accumulate=False):
     """y = conv(x) + bias + rowadd[b] + res.  x (B, W, H, Cin) -> (B, Wo, Ho, N)."""
     d = conv_desc(x, N, taps, stride, mode)
     Wo, Ho = out_size(x.shape[1], x.shape[2], stride, mode)
-    y = out if out is not None else empty((x.shape[0], Wo, Ho, N), x)
+    y = out
+    if y is None and _arena is not None and \
+            _lib.lib().rldm_train_conv_splits(C.byref(d), 0 if rowadd is None else rowadd.stride(0)) > 1:
+        y = _arena.take((x.shape[0], Wo, Ho, N))        # pre-zeroed: the split launch only adds
+        accumulate = y is not None
+    if y is None:
+        y = empty((x.shape[0], Wo, Ho, N), x)
     _chk(_lib.lib().rldm_train_conv(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(rowadd),
                                     0 if rowadd is None else rowadd.stride(0), _p(res), _p(y), 1 if accumulate else 0, _s(x)),
          "rldm_train_conv")

@@ -149,6 +149,7 @@ class UNetTrainer:
         self.buckets = plan_buckets([self.sizes[n] for n in self.names], bucket_mb * (1 << 20) // 4)
         self._tape, self._grad, self._keep = [], {}, []
         self._rows, self._row_parent = {}, {}
+        self._arena = T.ZeroArena(self.device, 256 << 20)
         self._pending, self._ready = [], None
         self.last_grad_norm = None
         # captured step graphs (train_step_graphed): device-side step counter + per-step optimizer scalars
@@ -258,10 +259,11 @@ class UNetTrainer:
                     drow = T.empty(rowadd.shape, rowadd)
                 else:                                   # a slice of the fused time_emb_proj output: write its slice of the gradient
                     rows, off = parent
-                    if id(rows) not in self._grad:
-                        self._grad[id(rows)] = (T.empty(rows.shape, rows), True)
+                    if id(rows) not in self._grad:       # zeroed once for all 22 slices (they accumulate into it)
+                        self._grad[id(rows)] = (torch.zeros(rows.shape, dtype=torch.float32, device=rows.device), True)
                     drow = self._grad[id(rows)][0][:, off:off + rowadd.shape[1]]
-            T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"])
+            T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"],
+                         rows_accumulate=rowadd is not None and self._row_parent.get(id(rowadd)) is not None)
             self._done(*done)
             if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)
@@ -405,6 +407,8 @@ class UNetTrainer:
         timesteps (B,) int64 -> model_output (B, W, H, out_channels) NHWC.  Records the tape for `backward`."""
         cfg = self.cfg
         self._tape, self._grad = [], {}
+        T.set_zero_arena(self._arena)                   # split-K conv outputs of this step: pre-zeroed slices, one fill
+        self._arena.begin()
         x = T.pack_input(sample_nchw.float().contiguous(), pos_encoding)
         if x.shape[3] != cfg.in_channels:
             raise ValueError(f"sample has {x.shape[3]} channels (incl. pos-encoding), the UNet expects {cfg.in_channels}")
@@ -472,6 +476,7 @@ class UNetTrainer:
         for fn in reversed(self._tape):
             fn()
         self._tape, self._grad = [], {}
+        T.set_zero_arena(None)
         if launch_collectives:
             for w in self._pending:
                 w.wait()
