@@ -462,7 +462,7 @@ struct TrWgrad2 {
 };
 
 template <int TAPS>
-__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
+__global__ __launch_bounds__(256, 2) void tr_wgrad2_kernel(const TrWgrad2 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
     constexpr int NC = TAPS == 9 ? 3 : 1;
     const int tid = threadIdx.x, lane = tid & 63;
