@@ -332,6 +332,139 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
         }
 }
 
+// Halo variant for the stride-1, mode-0 3x3 convs whose launch fills the chip (levels 0 / 1: forward and data gradient): the
+// kernel above re-stages its 64-pixel tile for every tap (9 x 16 KB of fp32 per 64-channel chunk and workgroup -- at level 0
+// 302 MB through L2 in 26 us, which is what bounds it).  Here a 64-channel chunk's tile is staged ONCE with its halo --
+// (64 / H + 2) azimuth columns x (H + 2) beams, circular in azimuth, zero rows above and below -- and the nine taps read
+// their B fragments from it at a uniform row offset dw * (H + 2) + dh; only the weight tile is staged per tap.  x traffic
+// and fp32->bf16 conversions drop 5x.  Stage order: chunk-major, tap fastest.
+template <int BN>
+__global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
+    static_assert(BN == 64 || BN == 128, "channel tile");
+    constexpr int CK = 64;
+    constexpr int TPR = 256 / BN, NR = BN / 64;
+    constexpr int PITCH = CK + 8;
+    constexpr int WV = CK / (8 * TPR);
+    constexpr int MAXHP = 136;                      // (64 / H + 2) * (H + 2) for H = 2 .. 32
+    __shared__ __attribute__((aligned(16))) bf16_t sXh[MAXHP * PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t sW[BN * PITCH];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int Cin = p.Cin, Cin_pad = p.Cin_pad, W = p.Wout, H = p.Hout, N = p.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int px0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
+    const int WCt = 64 / H, HP2 = H + 2, HP = (WCt + 2) * HP2;
+    const int b = px0 / (W * H), w0 = (px0 / H) % W;                 // the tile = WCt whole columns of image b
+    // halo staging roles: pass j: halo pixel hp = 64 j + (tid >> 2), quarter (tid & 3) of the chunk's 64 channels
+    const int sq = tid & 3;
+    const float* hsrc[3];
+    bool hlive[3], hin[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int hp = 64 * j + (tid >> 2);
+        hin[j] = hp < HP;
+        const int wc = hp / HP2, hr = hp - wc * HP2;
+        int w = w0 - 1 + wc;
+        w = w < 0 ? w + W : (w >= W ? w - W : w);
+        const int h = hr - 1;
+        hlive[j] = hin[j] && h >= 0 && h < H;
+        hsrc[j] = p.x + ((size_t)(b * W + w) * H + (hlive[j] ? h : 0)) * Cin + sq * 16;
+    }
+    const int npass = (HP + 63) >> 6;                                // 2 (H = 16, 8, 4) or 3 (H = 2)
+    const int swr = tid / TPR, shalf = tid % TPR;
+    const int wrow = n0 + swr;
+    const bf16_t* wptr = p.w + (size_t)(wrow < N ? wrow : 0) * 9 * Cin_pad + shalf * (CK / TPR);
+    const int nck = Cin / CK;
+    f32x4 xr[3][4];
+    u32x4 wr[WV];
+    auto fetch_x = [&](int cc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < npass && hin[j]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xr[j][q] = reinterpret_cast<const f32x4*>(hsrc[j] + cc * CK)[q];
+            }
+    };
+    auto stash_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < npass && hin[j]) {
+                const float lv = hlive[j] ? 1.f : 0.f;
+                bf16_t* dst = sXh + (64 * j + (tid >> 2)) * PITCH + sq * 16;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 a = xr[j][2 * q], c = xr[j][2 * q + 1];
+                    u32x4 u;
+                    u.x = rldm::pack_bf16x2(a.x * lv, a.y * lv); u.y = rldm::pack_bf16x2(a.z * lv, a.w * lv);
+                    u.z = rldm::pack_bf16x2(c.x * lv, c.y * lv); u.w = rldm::pack_bf16x2(c.z * lv, c.w * lv);
+                    *reinterpret_cast<u32x4*>(dst + 8 * q) = u;
+                }
+            }
+    };
+    auto fetch_w = [&](int tap, int cc) __attribute__((always_inline)) {
+        const bf16_t* src = wptr + (size_t)tap * Cin_pad + cc * CK;
+#pragma unroll
+        for (int q = 0; q < WV; ++q) wr[q] = reinterpret_cast<const u32x4*>(src)[q];
+    };
+    auto stash_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / TPR) + 8 * q) = wr[q];
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // this lane's pixel of the tile -> its row in the halo image
+    const int lp = (wave & 1) * 32 + l31;
+    const int r0 = (lp / H + 1) * HP2 + (lp % H) + 1;
+    const bf16_t* bx0 = sXh + r0 * PITCH + 8 * kg;
+    const bf16_t* aw0 = sW + ((wave >> 1) * (BN / 2) + l31) * PITCH + 8 * kg;
+    const bf16_t* aw1 = aw0 + (NR == 2 ? 32 : 0) * PITCH;
+    fetch_x(0);
+    fetch_w(0, 0);
+    for (int cc = 0; cc < nck; ++cc) {
+        for (int tap = 0; tap < 9; ++tap) {
+            __syncthreads();                        // everyone is done reading the previous stage (and, at tap 0, the halo tile)
+            if (tap == 0) stash_x();
+            stash_w();
+            __syncthreads();
+            if (tap < 8) fetch_w(tap + 1, cc);
+            else if (cc + 1 < nck) fetch_w(0, cc + 1);
+            if (tap == 2 && cc + 1 < nck) fetch_x(cc + 1);          // the next chunk's halo rides in registers for six taps
+            const int toff = ((tap / 3) - 1) * HP2 + (tap % 3) - 1;
+            const bf16_t* bx = bx0 + toff * PITCH;
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aw0 + 16 * ks);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
+                if (NR == 2) {
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int px = px0 + lp;
+    const int nb = n0 + (wave >> 1) * (BN / 2);
+    float* yrow = p.y + (size_t)px * N;
+    const float* rrow = p.res ? p.res + (size_t)px * N : nullptr;
+#pragma unroll
+    for (int h = 0; h < NR; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const int ch = nb + 32 * h + 8 * (r >> 2) + 4 * kg;       // 4 consecutive channels per register quad (N % 4 == 0 here)
+            if (ch >= N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h ? acc1[r + e] : acc0[r + e];
+            if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (p.rowadd) { const float4 t = *reinterpret_cast<const float4*>(p.rowadd + (size_t)b * p.rowadd_ld + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (rrow) { const float4 t = *reinterpret_cast<const float4*>(rrow + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(yrow + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            *reinterpret_cast<float4*>(yrow + ch) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+}
+
 // ---- weight gradient --------------------------------------------------------------------------------------------------
 struct TrWgrad {
     const float* dy; const float* x; float* dw;   // dw: partial sums [taps][slices][N][Cin], slices = grid.z * 4 waves
@@ -1594,7 +1727,14 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
             if (!accumulate) tr_zero_kernel<<<nblk((size_t)P * p.N / 4 + 1), 256, 0, st>>>(y, (size_t)P * p.N);   // (a kernel, not a memset node: see tr_zero_kernel)
             grid.z = ksplit;
         }
-        if (p.Cin % 64 == 0) {
+        static const bool nohalo_env = getenv("RLDM_TR_NO_HALO") != nullptr;           // A/B: the per-tap staging kernel
+        const int H = p.Hout;
+        const bool halo = !nohalo_env && ksplit == 1 && p.taps == 9 && p.stride == 1 && p.mode == 0 && p.Cin % 64 == 0 && p.N % 4 == 0 &&
+                          H >= 2 && H <= 32 && (H & (H - 1)) == 0 && (p.Wout * H) % 64 == 0 && p.Wout % (64 / H) == 0 && p.Wout >= 64 / H + 2;
+        if (halo) {
+            if (narrow) tr_conv_halo_kernel<64><<<grid, 256, 0, st>>>(p);
+            else tr_conv_halo_kernel<128><<<grid, 256, 0, st>>>(p);
+        } else if (p.Cin % 64 == 0) {
             if (narrow) tr_conv_lds_kernel<64, 64><<<grid, 256, 0, st>>>(p);
             else tr_conv_lds_kernel<64, 128><<<grid, 256, 0, st>>>(p);
         } else {

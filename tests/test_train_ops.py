@@ -44,6 +44,8 @@ def rnd(*shape, seed=0):
     # several chunks per workgroup, the nearest-x2 index map, 1x1
     (2, 64, 64, 16, 8, 9, 1, 0), (1, 128, 64, 32, 16, 9, 1, 0), (3, 64, 128, 32, 4, 9, 1, 0), (2, 192, 64, 64, 2, 9, 1, 0),
     (2, 64, 64, 8, 4, 9, 1, 1), (2, 128, 64, 16, 8, 1, 1, 0), (9, 64, 64, 64, 16, 9, 1, 0), (2, 64, 64, 24, 8, 9, 1, 0),
+    # launches large enough for the halo-tile conv (no K split): H = 16 (wide tile), 8 / 4 / 2 (narrow tile; 2: three halo passes)
+    (4, 64, 128, 256, 16, 9, 1, 0), (8, 128, 128, 128, 8, 9, 1, 0), (16, 64, 256, 64, 4, 9, 1, 0), (32, 64, 256, 64, 2, 9, 1, 0),
 ])
 def test_conv_forward_dgrad_wgrad(B, Cin, N, W, H, taps, stride, mode):
     from rangeldm_amd import train_ops as T
