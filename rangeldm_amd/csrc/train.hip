@@ -338,30 +338,32 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
 // (64 / H + 2) azimuth columns x (H + 2) beams, circular in azimuth, zero rows above and below -- and the nine taps read
 // their B fragments from it at a uniform row offset dw * (H + 2) + dh; only the weight tile is staged per tap.  x traffic
 // and fp32->bf16 conversions drop 5x.  Stage order: chunk-major, tap fastest.
-template <int BN>
-__global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
+template <int BN, int PT>
+__global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
     static_assert(BN == 64 || BN == 128, "channel tile");
     constexpr int CK = 64;
-    constexpr int TPR = 256 / BN, NR = BN / 64;
+    static_assert(PT == 64 || PT == 128, "pixel tile");
+    constexpr int NT = PT * 4;                      // threads: PT / 32 pixel groups x 2 channel halves of waves
+    constexpr int TPR = NT / BN, NR = BN / 64;
     constexpr int PITCH = CK + 8;
     constexpr int WV = CK / (8 * TPR);
-    constexpr int MAXHP = 136;                      // (64 / H + 2) * (H + 2) for H = 2 .. 32
+    constexpr int MAXHP = PT == 64 ? 136 : 264;     // (PT / H + 2) * (H + 2) for H = 2 .. 32
     __shared__ __attribute__((aligned(16))) bf16_t sXh[MAXHP * PITCH];
     __shared__ __attribute__((aligned(16))) bf16_t sW[BN * PITCH];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int Cin = p.Cin, Cin_pad = p.Cin_pad, W = p.Wout, H = p.Hout, N = p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
-    const int px0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
-    const int WCt = 64 / H, HP2 = H + 2, HP = (WCt + 2) * HP2;
+    const int px0 = blockIdx.x * PT, n0 = blockIdx.y * BN;
+    const int WCt = PT / H, HP2 = H + 2, HP = (WCt + 2) * HP2;
     const int b = px0 / (W * H), w0 = (px0 / H) % W;                 // the tile = WCt whole columns of image b
-    // halo staging roles: pass j: halo pixel hp = 64 j + (tid >> 2), quarter (tid & 3) of the chunk's 64 channels
+    // halo staging roles: pass j: halo pixel hp = PT j + (tid >> 2), quarter (tid & 3) of the chunk's 64 channels
     const int sq = tid & 3;
     const float* hsrc[3];
     bool hlive[3], hin[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int hp = 64 * j + (tid >> 2);
+        const int hp = PT * j + (tid >> 2);
         hin[j] = hp < HP;
         const int wc = hp / HP2, hr = hp - wc * HP2;
         int w = w0 - 1 + wc;
@@ -370,13 +372,14 @@ __global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
         hlive[j] = hin[j] && h >= 0 && h < H;
         hsrc[j] = p.x + ((size_t)(b * W + w) * H + (hlive[j] ? h : 0)) * Cin + sq * 16;
     }
-    const int npass = (HP + 63) >> 6;                                // 2 (H = 16, 8, 4) or 3 (H = 2)
+    const int npass = (HP + PT - 1) / PT;                            // 2, or 3 (H = 2)
     const int swr = tid / TPR, shalf = tid % TPR;
     const int wrow = n0 + swr;
     const bf16_t* wptr = p.w + (size_t)(wrow < N ? wrow : 0) * 9 * Cin_pad + shalf * (CK / TPR);
     const int nck = Cin / CK;
+    constexpr int D = 3;                            // weight stages in flight (one L2 latency = about three stage times)
     f32x4 xr[3][4];
-    u32x4 wr[WV];
+    u32x4 wr[D][WV];
     auto fetch_x = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
         for (int j = 0; j < 3; ++j)
             if (j < npass && hin[j]) {
                 const float lv = hlive[j] ? 1.f : 0.f;
-                bf16_t* dst = sXh + (64 * j + (tid >> 2)) * PITCH + sq * 16;
+                bf16_t* dst = sXh + (PT * j + (tid >> 2)) * PITCH + sq * 16;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 a = xr[j][2 * q], c = xr[j][2 * q + 1];
@@ -401,34 +404,37 @@ __global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
                 }
             }
     };
-    auto fetch_w = [&](int tap, int cc) __attribute__((always_inline)) {
-        const bf16_t* src = wptr + (size_t)tap * Cin_pad + cc * CK;
-#pragma unroll
-        for (int q = 0; q < WV; ++q) wr[q] = reinterpret_cast<const u32x4*>(src)[q];
-    };
-    auto stash_w = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / TPR) + 8 * q) = wr[q];
-    };
+#define HALO_FETCH_W(SLOT, TAP, CC)                                                                      \
+    {                                                                                                    \
+        const bf16_t* src_ = wptr + (size_t)(TAP) * Cin_pad + (CC) * CK;                                 \
+        _Pragma("unroll") for (int q = 0; q < WV; ++q) wr[SLOT][q] = reinterpret_cast<const u32x4*>(src_)[q]; \
+    }
+#define HALO_STASH_W(SLOT)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < WV; ++q)                                                       \
+        *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / TPR) + 8 * q) = wr[SLOT][q];
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     // this lane's pixel of the tile -> its row in the halo image
-    const int lp = (wave & 1) * 32 + l31;
+    constexpr int PG = PT / 32;                     // pixel groups of 32
+    const int lp = (wave % PG) * 32 + l31;
     const int r0 = (lp / H + 1) * HP2 + (lp % H) + 1;
     const bf16_t* bx0 = sXh + r0 * PITCH + 8 * kg;
-    const bf16_t* aw0 = sW + ((wave >> 1) * (BN / 2) + l31) * PITCH + 8 * kg;
+    const bf16_t* aw0 = sW + ((wave / PG) * (BN / 2) + l31) * PITCH + 8 * kg;
     const bf16_t* aw1 = aw0 + (NR == 2 ? 32 : 0) * PITCH;
     fetch_x(0);
-    fetch_w(0, 0);
+    HALO_FETCH_W(0, 0, 0)
+    HALO_FETCH_W(1, 1, 0)
+    HALO_FETCH_W(2, 2, 0)
     for (int cc = 0; cc < nck; ++cc) {
-        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {         // (unrolled: the ring slot tap % D is a compile-time register set)
             __syncthreads();                        // everyone is done reading the previous stage (and, at tap 0, the halo tile)
             if (tap == 0) stash_x();
-            stash_w();
+            HALO_STASH_W(tap % D)
             __syncthreads();
-            if (tap < 8) fetch_w(tap + 1, cc);
-            else if (cc + 1 < nck) fetch_w(0, cc + 1);
+            if (tap + D < 9) HALO_FETCH_W(tap % D, tap + D, cc)
+            else if (cc + 1 < nck) HALO_FETCH_W(tap % D, tap + D - 9, cc + 1)
             if (tap == 2 && cc + 1 < nck) fetch_x(cc + 1);          // the next chunk's halo rides in registers for six taps
             const int toff = ((tap / 3) - 1) * HP2 + (tap % 3) - 1;
             const bf16_t* bx = bx0 + toff * PITCH;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
         }
     }
     const int px = px0 + lp;
-    const int nb = n0 + (wave >> 1) * (BN / 2);
+    const int nb = n0 + (wave / PG) * (BN / 2);
     float* yrow = p.y + (size_t)px * N;
     const float* rrow = p.res ? p.res + (size_t)px * N : nullptr;
 #pragma unroll
@@ -463,6 +469,8 @@ __global__ __launch_bounds__(256) void tr_conv_halo_kernel(const TrConv p) {
             if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(yrow + ch); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
             *reinterpret_cast<float4*>(yrow + ch) = make_float4(v[0], v[1], v[2], v[3]);
         }
+#undef HALO_FETCH_W
+#undef HALO_STASH_W
 }
 
 // ---- weight gradient --------------------------------------------------------------------------------------------------
@@ -1731,9 +1739,14 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
         const int H = p.Hout;
         const bool halo = !nohalo_env && ksplit == 1 && p.taps == 9 && p.stride == 1 && p.mode == 0 && p.Cin % 64 == 0 && p.N % 4 == 0 &&
                           H >= 2 && H <= 32 && (H & (H - 1)) == 0 && (p.Wout * H) % 64 == 0 && p.Wout % (64 / H) == 0 && p.Wout >= 64 / H + 2;
-        if (halo) {
-            if (narrow) tr_conv_halo_kernel<64><<<grid, 256, 0, st>>>(p);
-            else tr_conv_halo_kernel<128><<<grid, 256, 0, st>>>(p);
+        static const int pt_env = getenv("RLDM_TR_PT") ? atoi(getenv("RLDM_TR_PT")) : 0;
+        const bool wide_px = pt_env == 128 && halo && !narrow && (p.Wout * H) % 128 == 0 && p.Wout % (128 / H) == 0 && p.Wout >= 128 / H + 2;
+        if (halo && wide_px) {
+            grid.x = P / 128;
+            tr_conv_halo_kernel<128, 128><<<grid, 512, 0, st>>>(p);
+        } else if (halo) {
+            if (narrow) tr_conv_halo_kernel<64, 64><<<grid, 256, 0, st>>>(p);
+            else tr_conv_halo_kernel<128, 64><<<grid, 256, 0, st>>>(p);
         } else if (p.Cin % 64 == 0) {
             if (narrow) tr_conv_lds_kernel<64, 64><<<grid, 256, 0, st>>>(p);
             else tr_conv_lds_kernel<64, 128><<<grid, 256, 0, st>>>(p);
