@@ -603,7 +603,7 @@ struct TrWgrad2 {
 };
 
 template <int TAPS>
-__global__ __launch_bounds__(256, 2) void tr_wgrad2_kernel(const TrWgrad2 p) {
+__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
     constexpr int NC = TAPS == 9 ? 3 : 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void tr_wgrad2_kernel(const TrWgrad2 p) {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int cq = 4 * wave + (lane & 3), ppl = lane >> 2;           // staging role
+    // staging role: 4 channel quads x 16 pixel pairs per wave (8 quads x 8 pairs = whole 128-byte lines measured the same)
+    const int cq = 4 * wave + (lane & 3), ppl = lane >> 2;
     const int nwc = W >> p.lwc;
     const int sh = p.mode ? 1 : 0;
     struct WgStage { f32x4 d0, d1, xm, x0, x1, x2; };
@@ -674,19 +675,19 @@ __global__ __launch_bounds__(256, 2) void tr_wgrad2_kernel(const TrWgrad2 p) {
     const bool do_sums = (p.rows || p.total) && c0 == 0;
     int sum_b = -1;
     float sum_img = 0.f, sum_all = 0.f;
+    WgStage R[4];                                                    // one chunk of staging data (1 - 4 iterations of 6 loads)
+    if (z * p.cpw < chunk_end) {
+        const int c0_ = z * p.cpw, b0_ = c0_ / nwc, w00 = (c0_ - b0_ * nwc) << p.lwc;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (2 * (ppl + 16 * it) < KP) fetch(ppl + 16 * it, b0_, w00, R[it]);
+    }
     for (int chunk = z * p.cpw; chunk < chunk_end; ++chunk) {
         const int b = chunk / nwc, w0 = (chunk - b * nwc) << p.lwc;
         __syncthreads();                                             // the previous chunk's fragments have been read
-        // two staging iterations' global loads are requested before the first is converted and stored (a chunk is 1 - 4
-        // iterations of 6 loads per thread: issued one iteration at a time each paid a full memory latency)
-        for (int pp0 = ppl; 2 * pp0 < KP; pp0 += 32) {
-            WgStage r0, r1;
-            const bool two = 2 * (pp0 + 16) < KP;
-            fetch(pp0, b, w0, r0);
-            if (two) fetch(pp0 + 16, b, w0, r1);
-            stash(pp0, r0);
-            if (two) stash(pp0 + 16, r1);
-        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (2 * (ppl + 16 * it) < KP) stash(ppl + 16 * it, R[it]);
         __syncthreads();
         if (do_sums) {                                               // thread (row n = tid >> 2, quarter of the chunk's pixels)
             const bf16_t* r = sA + (tid >> 2) * pitchA + (tid & 3) * (KP >> 2);
@@ -704,6 +705,12 @@ __global__ __launch_bounds__(256, 2) void tr_wgrad2_kernel(const TrWgrad2 p) {
             }
             sum_img += sacc;
             sum_all += sacc;
+        }
+        if (chunk + 1 < chunk_end) {                                 // the next chunk's loads fly during this chunk's MFMAs
+            const int nb_ = (chunk + 1) / nwc, nw0 = ((chunk + 1) - nb_ * nwc) << p.lwc;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (2 * (ppl + 16 * it) < KP) fetch(ppl + 16 * it, nb_, nw0, R[it]);
         }
         const bf16_t* fa = sA + (32 * wi + l31) * pitchA + 8 * kg;
         const bf16_t* fb = sB + (32 * wj + l31) * pitchB + 8 * kg;
@@ -754,6 +761,29 @@ __global__ __launch_bounds__(256, 2) void tr_wgrad2_kernel(const TrWgrad2 p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[t][r];
     }
+}
+
+// four channels per thread, eight slices in flight (Cin % 4 == 0): the scalar kernel below ran at 2 TB/s over 38 MB of partials
+__global__ __launch_bounds__(256) void tr_wgrad_reduce_vec_kernel(const float* __restrict__ part, int slices, int N, int Cin, int taps,
+                                                                  float* __restrict__ dw) {
+    const size_t nc = (size_t)N * Cin, nc4 = nc >> 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc4 * taps) return;
+    const int t = (int)(i / nc4);
+    const size_t e = (i - (size_t)t * nc4) * 4;
+    const float* src = part + (size_t)t * slices * nc + e;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int sidx = 0;
+    for (; sidx + 8 <= slices; sidx += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(sidx + j) * nc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+    for (; sidx < slices; ++sidx) acc += *reinterpret_cast<const f32x4*>(src + (size_t)sidx * nc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dw[(e + q) * taps + t] += acc[q];
 }
 
 // dw[n][c][t] += sum over slices of part[t][slice][n][c]   (one thread per (t, n, c); reads coalesced along c)
@@ -1798,7 +1828,10 @@ int rldm_train_wgrad_bias(const rldm_train_conv_desc* d, const float* dy, const 
             w2.nchunks = p.B * (W / WC);
             const int tiles2 = (p.N / 64) * (p.Cin / 64);
             static const int wg_env = getenv("RLDM_TR_WG_BLOCKS") ? atoi(getenv("RLDM_TR_WG_BLOCKS")) : 256;
-            int Z = std::max(1, std::min(w2.nchunks, (wg_env + tiles2 - 1) / tiles2));
+            // (few chunks -- the 32 x 2 level -- : two per workgroup halve the partial tiles for the same kernel time)
+            static const int cpw_env = getenv("RLDM_TR_WG_CPW") ? atoi(getenv("RLDM_TR_WG_CPW")) : 0;
+            const int cpw_min = cpw_env ? cpw_env : (w2.nchunks <= 16 ? 2 : 1);
+            int Z = std::max(1, std::min(std::max(1, w2.nchunks / cpw_min), (wg_env + tiles2 - 1) / tiles2));
             w2.cpw = (w2.nchunks + Z - 1) / Z;
             Z = (w2.nchunks + w2.cpw - 1) / w2.cpw;
             w2.pitchA = WC * H + 8;
@@ -1838,7 +1871,7 @@ int rldm_train_wgrad_bias(const rldm_train_conv_desc* d, const float* dy, const 
         if (p.taps == 9) tr_wgrad2_kernel<9><<<grid, 256, smem, st>>>(w2);
         else tr_wgrad2_kernel<1><<<grid, 256, smem, st>>>(w2);
         TR_LAUNCH_CHECK();
-        if (!w2.dw) tr_wgrad_reduce_kernel<<<nblk((size_t)p.N * p.Cin * p.taps), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
+        if (!w2.dw) tr_wgrad_reduce_vec_kernel<<<nblk((size_t)p.N * p.Cin * p.taps / 4), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
         TR_LAUNCH_CHECK();
         return 0;
     }
