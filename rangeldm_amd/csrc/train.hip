@@ -1104,7 +1104,8 @@ __global__ __launch_bounds__(256) void tr_gn_bwd_reduce_slab_kernel(const float*
     __shared__ double s1[64], s2[64];
     __shared__ float sg[1024], sb[1024];
     const int b = blockIdx.y, cpg = C / groups;
-    const int p0 = blockIdx.x * 64, p1 = min(p0 + 64, npix);
+    const int SP = gridDim.z ? (npix + gridDim.x - 1) / gridDim.x : 64;   // pixels per block (the launcher's slab size)
+    const int p0 = blockIdx.x * SP, p1 = min(p0 + SP, npix);
     if (threadIdx.x < groups) { s1[threadIdx.x] = 0.0; s2[threadIdx.x] = 0.0; }
     for (int c = threadIdx.x; c < C; c += 256) { sg[c] = 0.f; sb[c] = 0.f; }
     __syncthreads();
@@ -1973,7 +1974,8 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
     if (slab) {
         double* acc = nullptr;
         if (gn_accumulators((size_t)B * groups * 2, st, &acc)) return 1;
-        tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
+        static const int slab_env = getenv("RLDM_TR_GN_SLAB") ? atoi(getenv("RLDM_TR_GN_SLAB")) : 64;
+        tr_gn_bwd_reduce_slab_kernel<<<dim3((npix + slab_env - 1) / slab_env, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma,
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
     } else if (gn_vec_reduce_env() && (C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
