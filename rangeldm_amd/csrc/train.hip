@@ -895,6 +895,48 @@ __global__ __launch_bounds__(256) void tr_gn_stats_vec_kernel(const float* __res
     }
 }
 
+__device__ inline float sigmoid_f(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// Statistics AND apply in one launch for the small tensors (levels 1-3): the block of (image, group) re-reads its own slab
+// (it is 2-32 KB: L1 / L2 hits) and writes y.  Saves a launch per GroupNorm where a launch costs more than the work.
+__global__ __launch_bounds__(256) void tr_gn_fwd_fused_vec_kernel(const float* __restrict__ x, int npix, int C, int groups, float eps,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int silu, float2* __restrict__ stats, float* __restrict__ y) {
+    __shared__ double sh[4];
+    __shared__ float2 sst;
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups, Q = cpg >> 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q, step = 256 / Q;
+    const size_t off = (size_t)b * npix * C + g * cpg + 4 * q;
+    double s = 0.0, ss = 0.0;
+    for (int p = pl; p < npix; p += step) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off + (size_t)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += v[e]; ss += (double)v[e] * v[e]; }
+    }
+    s = block_sum_d(s, sh);
+    ss = block_sum_d(ss, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)npix * cpg, mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        sst = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+        stats[b * groups + g] = sst;
+    }
+    __syncthreads();
+    const float2 st = sst;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * cpg + 4 * q), be = *reinterpret_cast<const f32x4*>(beta + g * cpg + 4 * q);
+    for (int p = pl; p < npix; p += step) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off + (size_t)p * C);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = (v[e] - st.x) * st.y * ga[e] + be[e];
+            out[e] = silu ? z * sigmoid_f(z) : z;
+        }
+        *reinterpret_cast<f32x4*>(y + off + (size_t)p * C) = out;
+    }
+}
+
 // Large tensors: the one-block-per-(image, group) kernels above read 16-byte pieces 2 KB apart.  These variants give a
 // block a slab of 64 pixels x all channels (fully coalesced float4 rows); a thread's channel quad is the same in every
 // iteration when C divides 1024, so it accumulates in registers and ends with one LDS atomic per group it touched.
@@ -942,7 +984,6 @@ __global__ __launch_bounds__(256) void tr_gn_stats_finish_kernel(double* __restr
     stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
 }
 
-__device__ inline float sigmoid_f(float z) { return 1.f / (1.f + __expf(-z)); }
 
 __global__ __launch_bounds__(256) void tr_gn_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int npix,
@@ -1949,9 +1990,16 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
         tr_gn_stats_slab_kernel<<<dim3((npix + 63) / 64, B), 256, 0, st>>>(x, npix, C, groups, acc);
         tr_gn_stats_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, (double)npix * (C / groups), eps,
                                                                            reinterpret_cast<float2*>(stats));
-    } else if ((C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
+    } else if ((C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0) {
+        static const bool nofuse = getenv("RLDM_TR_GN_NOFUSE") != nullptr;
+        if (!nofuse) {
+            tr_gn_fwd_fused_vec_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, gamma, beta, silu,
+                                                                        reinterpret_cast<float2*>(stats), y);
+            TR_LAUNCH_CHECK();
+            return 0;
+        }
         tr_gn_stats_vec_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
-    else
+    } else
         tr_gn_stats_kernel<<<dim3(groups, B), 256, 0, st>>>(x, npix, C, groups, eps, reinterpret_cast<float2*>(stats));
     const size_t total = (size_t)B * npix * C;
     const int cpg = C / groups;
@@ -1979,8 +2027,8 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
                                                                                beta, npix, C, groups, silu, acc, dgamma, dbeta);
         tr_gn_sums_finish_kernel<<<nblk((size_t)B * groups), 256, 0, st>>>(acc, B * groups, reinterpret_cast<float2*>(scratch));
     } else if (gn_vec_reduce_env() && (C / groups) % 4 == 0 && C / groups <= 16 && (C / groups & (C / groups - 1)) == 0)
-        // (measured 14.0 us against 10.1 us for the channel-pinned kernel below: four sigmoids per iteration and the wider LDS
-        //  epilogue cost more than the 16-byte loads save; kept for A/B runs)
+        // (A/B only: measured 14.0 us against 10.1 us for the channel-pinned kernel below -- four sigmoids per iteration and the
+        //  wider LDS epilogue cost more than the 16-byte loads save; fusing the apply pass into it was no faster either)
         tr_gn_bwd_reduce_vec_kernel<<<dim3(groups, B), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats), gamma, beta, npix, C,
                                                                  groups, silu, reinterpret_cast<float2*>(scratch), dgamma, dbeta);
     else
