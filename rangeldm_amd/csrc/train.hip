@@ -714,16 +714,31 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
         }
         const bf16_t* fa = sA + (32 * wi + l31) * pitchA + 8 * kg;
         const bf16_t* fb = sB + (32 * wj + l31) * pitchB + 8 * kg;
-#pragma unroll 2
-        for (int k = 0; k < KP; k += 16) {
-            const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + k));
-            if (TAPS == 9) {
+        // fragments of k-step k + 1 are requested before the MFMAs of k-step k (one wave per SIMD: nothing else hides the LDS latency)
+        if (TAPS == 9) {
+            uint4 Ac = *reinterpret_cast<const uint4*>(fa), Bc[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const bf16x8 Bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + (t / 3) * 64 * pitchB + k + (t % 3) * WC));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) Bc[t] = *reinterpret_cast<const uint4*>(fb + (t / 3) * 64 * pitchB + (t % 3) * WC);
+            for (int k = 0; k < KP; k += 16) {
+                uint4 An = Ac, Bn[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) Bn[t] = Bc[t];
+                if (k + 16 < KP) {
+                    An = *reinterpret_cast<const uint4*>(fa + k + 16);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) Bn[t] = *reinterpret_cast<const uint4*>(fb + (t / 3) * 64 * pitchB + k + 16 + (t % 3) * WC);
                 }
-            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ac), __builtin_bit_cast(bf16x8, Bc[t]), acc[t], 0, 0, 0);
+                Ac = An;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) Bc[t] = Bn[t];
+            }
+        } else {
+#pragma unroll 2
+            for (int k = 0; k < KP; k += 16) {
+                const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + k));
                 const bf16x8 Bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + k));
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[0], 0, 0, 0);
             }
