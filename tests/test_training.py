@@ -333,6 +333,22 @@ def test_graphed_steps_cut_at_gradient_buckets_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--eager", "--graphed"])
+def test_two_data_parallel_ranks_on_one_gpu(mode):
+    """tools/dp_probe.py: two real ranks (gloo on device tensors; RCCL refuses two ranks per device) through the eager and the
+    captured, bucket-cut step: identical parameters on both ranks, equal to one process trained on the concatenated batch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29541 + (mode == "--graphed")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "dp_probe.py")] + ([mode] if mode == "--eager" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "max |rank0 - rank1| = 0.000e+00" in r.stdout, r.stdout[-1000:]
+
+
+@pytest.mark.gpu
 def test_training_step_loop_body_unconditional_and_conditional():
     """`training_step` = the loop body of ldm/train_unconditional.py:479-556 (VAE encode + sample, add_noise, pos-encoding,
     min-SNR weights) and its conditional twin (ldm/train_conditional.py:418-447, upsample: 4 + 8 folded-condition channels)."""
