@@ -14,7 +14,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()              # (more ranks than visible devices: the one-GPU rehearsal of an N-rank run)
     if world > 1 and not dist.is_initialized():
+        backend = os.environ.get("RLDM_DIST_BACKEND", backend)      # e.g. gloo: RCCL refuses two ranks on one device
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
