@@ -114,6 +114,14 @@ struct GnStatsParams {
 };
 int launch_gn_stats(const GnStatsParams& p, hipStream_t stream);
 
+// [B][P][C] partials -> [B][2][C]: the per-image double-precision total as float head + tail (see gn_fold_kernel).
+struct GnFoldParams {
+    const float2* part;     // [B][P][C]
+    float2* out;            // [B][2][C]
+    int B, P, C;
+};
+int launch_gn_fold(const GnFoldParams& p, hipStream_t stream);
+
 // y = silu?( GroupNorm( cat[x0, x1] ) ) as one bf16 tensor [B][npix][C0 + C1], from the producers' per-channel partials.
 // Used in front of conv_small.hip where every 32/64-channel tile of a conv would otherwise redo the whole activation.
 struct GnApplyParams {

@@ -68,6 +68,53 @@ int launch_gn_stats(const GnStatsParams& p, hipStream_t stream) {
     return 0;
 }
 
+// Fold of the [B][P][C] partials of a tensor with many pixel tiles per image (the 512x32 / 1024x64 levels of the VAE and of
+// the pixel-space UNet: P = 64 / 256) into [B][2][C] -- the per-image total in double precision, stored as its float head
+// and tail, so that a consumer that adds its "partials" in double gets the same 48 bits back.  Without it every workgroup
+// of the consuming conv re-reads P * Cin * 8 bytes of statistics (131 KB for a 43 KB activation tile at the 64-channel
+// level) in a serial chain of P / 16 round trips.  A block = (image, 16 channels): 16 slices of P summed in a fixed order.
+__global__ void __launch_bounds__(256) gn_fold_kernel(const GnFoldParams p) {
+    __shared__ double sS[16][17], sQ[16][17];
+    const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4;
+    const int b = blockIdx.y, c = blockIdx.x * 16 + cl;
+    const float2* src = p.part + (size_t)b * p.P * p.C + c;
+    double S = 0.0, Q = 0.0;
+    if (c < p.C) {
+        int q = sl;
+        for (; q + 48 < p.P; q += 64) {
+            float2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = src[(size_t)(q + 16 * j) * p.C];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { S += (double)v[j].x; Q += (double)v[j].y; }
+        }
+        for (; q < p.P; q += 16) {
+            const float2 v = src[(size_t)q * p.C];
+            S += (double)v.x;
+            Q += (double)v.y;
+        }
+    }
+    sS[sl][cl] = S;
+    sQ[sl][cl] = Q;
+    __syncthreads();
+    if (sl == 0 && c < p.C) {
+        S = 0.0; Q = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { S += sS[j][cl]; Q += sQ[j][cl]; }
+        const float Sh = (float)S, Qh = (float)Q;
+        float2* dst = p.out + (size_t)b * 2 * p.C + c;
+        dst[0] = make_float2(Sh, Qh);
+        dst[p.C] = make_float2((float)(S - (double)Sh), (float)(Q - (double)Qh));
+    }
+}
+
+int launch_gn_fold(const GnFoldParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(p.P > 0 && p.C > 0, "gn_fold: empty statistics");
+    hipLaunchKernelGGL(gn_fold_kernel, dim3((p.C + 15) / 16, p.B), dim3(256), 0, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // GroupNorm (+SiLU) of cat[x0, x1] from the producers' per-channel partials -> one activated bf16 tensor.
 // A block owns GSL consecutive groups (1/8 of the channels) of `ppb` pixels of one image: it folds just those channels'
 // partials into the affine (a few hundred floats, double accumulation as in the conv prologue of conv_igemm.hip) and then

@@ -878,8 +878,32 @@ struct Builder {
         return 0;
     }
 
+    // Statistics of a tensor with many pixel tiles per image are folded once, by one small launch, instead of by every
+    // workgroup of every consumer (gn_fold_kernel); RLDM_DBG_FLAGS=262144 keeps the raw partials for A/B runs.
+    static constexpr int kFoldAboveP = 32;
+    int fold_stats(Tensor& y) {
+        if (!y.valid() || y.P <= kFoldAboveP || (g_dbg_flags & 262144)) return 0;
+        const size_t raw_off = y.st_off, raw_bytes = y.st_bytes();
+        const int rawP = y.P;
+        add_stats(y, 2);
+        ++launches;
+        if (!dry) {
+            GnFoldParams g;
+            g.part = ptr<float2>(raw_off);
+            g.out = ptr<float2>(y.st_off);
+            g.B = y.B; g.P = rawP; g.C = y.C;
+            plan->ops.push_back({[g](hipStream_t s) { return launch_gn_fold(g, s); }, "gn_fold_kernel", 0.0, (double)raw_bytes});
+        }
+        arena.release(raw_off, raw_bytes);
+        return 0;
+    }
+
     // y = conv(...) ; consumes nothing (callers release inputs)
     int conv(const ConvArgs& a, Tensor* out) {
+        if (conv_route(a, out)) return 1;
+        return fold_stats(*out);
+    }
+    int conv_route(const ConvArgs& a, Tensor* out) {
         ConvLayer* L = a.layer;
         RLDM_REQUIRE(L != nullptr, "internal: missing conv layer");
         const Tensor& x0 = a.x0;
