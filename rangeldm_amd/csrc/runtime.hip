@@ -2006,10 +2006,12 @@ int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_
 
 // ---- sampler ------------------------------------------------------------------------------------------------------
 static int sampler_num_lanes(int batch) {
-    // Default ONE chain: on MI355X / ROCm 7.2 graph launches on separate streams did not overlap usefully -- at batch 16
-    // two chains of 8 measured 105 img/s and four chains of 4 measured 67 img/s against 122 img/s for a single chain
-    // (every launch pays its fixed cost again and the workgroups use most of a CU's LDS).  RLDM_LANES=n overrides.
-    int want = 1;
+    // ONE chain up to batch 31: chains of fewer than 16 samples lose more to the fixed cost of every launch than they gain
+    // from running side by side (batch 16: two chains of 8 measured 165 img/s against 194 for a single chain).  From batch
+    // 32 on, chains of >= 16 samples overlap usefully (the launches of one chain fill the CUs the other leaves idle in its
+    // prologues / low-resolution levels): 2 x 16 = 241 img/s against 229 for one chain of 32, 3 x 16 = 264 against 1 x 48,
+    // 2 x 32 = 267 against 264 for one chain of 64; four chains were slower again (238).  RLDM_LANES=n overrides.
+    int want = batch >= 32 ? std::min(3, batch / 16) : 1;
     if (const char* e = getenv("RLDM_LANES")) want = atoi(e);
     if (want <= 0) want = 1;
     want = std::max(1, std::min(want, batch));

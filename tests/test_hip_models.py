@@ -239,3 +239,28 @@ def test_full_config_sampler_properties():
     assert torch.equal(a, b)                                           # no atomics anywhere: bit-reproducible
     solo = pipe(batch_size=1, num_inference_steps=6, latents=x_T[1:], output_type="torch").cpu()
     assert rel_l2(solo[0], a[1]) < 2e-2                                 # GroupNorm / attention never mix samples
+
+
+def test_concurrent_chains_match_single_chain(monkeypatch):
+    """The sampler splits a batch >= 32 into chains of >= 16 samples on separate streams (sampler_num_lanes, runtime.hip);
+    RLDM_LANES forces the split at a small batch here.  Samples never interact, so the chains must reproduce the
+    single-chain images (up to the tile routing, which depends on the chain's batch) -- for DDIM and for the DDPM mode,
+    whose step noise is sliced per chain."""
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
+    cfg = UNetConfig()
+    vae, _, _ = hip_vae()
+    x_T = T(normal(11, "xT", (4, 4, 256, 16)))
+    for sched in (DDIMSchedulerHIP, DDPMSchedulerHIP):
+        out = {}
+        for lanes in ("1", "2", "4"):
+            monkeypatch.setenv("RLDM_LANES", lanes)
+            unet, _ = hip_unet(cfg, "")
+            pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=sched(), pos_encoding=True)
+            zs = T(normal(12, "zs", (4, 4, 4, 256, 16)))               # [step][B, C, W, H] ancestral noise (DDPM mode only)
+            out[lanes] = pipe(batch_size=4, num_inference_steps=4, latents=x_T, step_noise=zs, output_type="torch").cpu()
+            assert torch.isfinite(out[lanes]).all()
+        assert rel_l2(out["2"], out["1"]) < 2e-2, sched.__name__
+        assert rel_l2(out["4"], out["1"]) < 2e-2, sched.__name__
+        for j in range(4):                                              # every sample, not just the average
+            assert rel_l2(out["2"][j], out["1"][j]) < 3e-2
