@@ -8,7 +8,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/${TAG}_gpu_tests.txt
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python tools/bench_train.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_train.json 2>> $OUT/${TAG}_bench.err
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
