@@ -338,6 +338,7 @@ int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int wa
                     char* kernel_name, size_t name_cap, void* stream);
 int rldm_debug_force_tile(int BM, int BN, int ksplit);
 int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
+int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLATE builds: [start, end] (100 MHz) of every workgroup of the last conv_stream launch */
 int rldm_debug_set_flags(int flags);
 /* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */

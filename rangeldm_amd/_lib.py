@@ -136,6 +136,7 @@ PROTOTYPES = {
     "rldm_debug_set_flags": (C.c_int, [C.c_int]),
     "rldm_debug_graph_trace": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t]),
     "rldm_debug_timestamps": (C.c_int, [_P]),
+    "rldm_debug_block_times": (C.c_int, [_P, C.c_int]),
     "rldm_test_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
 }
 

@@ -67,6 +67,9 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 #define RLDM_STAMP()
 #endif
     RLDM_STAMP();
+#ifdef RLDM_ABLATE
+    const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- which tile: grid = (channel tiles, pixel tiles of an image, images) -------------------------------------------
     const int tiles_h = p.tiles_h, tiles_img = p.tiles_img;       // tiles_h is a power of two
@@ -490,6 +493,13 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 #ifdef RLDM_ABLATE
     if (p.ts && blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z == 0 && tid == 0)
         for (int i = 0; i < 12; ++i) p.ts[blockIdx.y * 64 + i] = i < tsn ? tsv[i] : 0ull;
+    {
+        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (p.ts && tid == 0 && lin < 2048) {
+            p.ts[256 + 2 * lin] = t_real0;
+            p.ts[257 + 2 * lin] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 #endif
 #undef RLDM_STAMP
 }

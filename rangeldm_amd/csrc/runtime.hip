@@ -2324,16 +2324,27 @@ int rldm_debug_set_flags(int flags) {
 }
 
 // enable (host_out == NULL: allocate + zero) or read back (host_out = 256 x u64) the in-kernel timestamps of the conv kernel
+static constexpr int kTsBlocks = 2048;          // per-workgroup [start, end] s_memrealtime pairs behind the 256 stamps
 int rldm_debug_timestamps(unsigned long long* host_out) {
     if (!g_ts_buf) {
-        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_ts_buf), 256 * 8));
-        RLDM_HIP_CHECK(hipMemset(g_ts_buf, 0, 256 * 8));
+        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_ts_buf), (256 + 2 * kTsBlocks) * 8));
+        RLDM_HIP_CHECK(hipMemset(g_ts_buf, 0, (256 + 2 * kTsBlocks) * 8));
     }
     if (host_out) {
         RLDM_HIP_CHECK(hipDeviceSynchronize());
         RLDM_HIP_CHECK(hipMemcpy(host_out, g_ts_buf, 256 * 8, hipMemcpyDeviceToHost));
         RLDM_HIP_CHECK(hipMemset(g_ts_buf, 0, 256 * 8));
     }
+    return 0;
+}
+// ABLATE builds of conv_stream.hip: [start, end] of every workgroup (first 2048) of the last launch on the 100 MHz
+// s_memrealtime counter, which all XCDs share -- the spread of the starts / ends is the launch's dispatch and tail skew
+int rldm_debug_block_times(unsigned long long* host_out, int nblocks) {
+    RLDM_REQUIRE(host_out && nblocks >= 1 && nblocks <= kTsBlocks, "block times: 1..2048 blocks");
+    RLDM_REQUIRE(g_ts_buf != nullptr, "block times: call rldm_debug_timestamps(NULL) first");
+    RLDM_HIP_CHECK(hipDeviceSynchronize());
+    RLDM_HIP_CHECK(hipMemcpy(host_out, g_ts_buf + 256, (size_t)nblocks * 16, hipMemcpyDeviceToHost));
+    RLDM_HIP_CHECK(hipMemset(g_ts_buf + 256, 0, 2 * kTsBlocks * 8));
     return 0;
 }
 

@@ -181,6 +181,18 @@ def main():
                 if a.ts:
                     buf = (C.c_ulonglong * 256)()
                     _lib.lib().rldm_debug_timestamps(buf)
+                    if "conv_stream" in kn or "256,128,c64t9" in kn or True:
+                        nb = 2048
+                        bt = (C.c_ulonglong * (2 * nb))()
+                        if _lib.lib().rldm_debug_block_times(bt, nb) == 0:
+                            st = [bt[2 * i] for i in range(nb) if bt[2 * i]]
+                            en = [bt[2 * i + 1] for i in range(nb) if bt[2 * i]]
+                            if st:
+                                t0 = min(st)
+                                life = sorted((e - s_) * 0.01 for s_, e in zip(st, en))
+                                print(f"    {len(st)} workgroups: starts spread {(max(st) - t0) * 0.01:.2f} us, ends {(min(en) - t0) * 0.01:.2f} .. "
+                                      f"{(max(en) - t0) * 0.01:.2f} us after the first start; lifetime min / median / max "
+                                      f"{life[0]:.2f} / {life[len(life) // 2]:.2f} / {life[-1]:.2f} us", file=sys.stderr)
                     for blk in range(2):
                         v = [buf[blk * 64 + i] for i in range(64)]
                         v = [x for x in v if x]
