@@ -57,9 +57,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     const int wn = wave % NWN, kg = wave / NWN;
     const int kh = lane >> 5, l31 = lane & 31;
 #ifdef RLDM_ABLATE
-    unsigned long long tsv[8];
+    unsigned long long tsv[12];
     int tsn = 0;
-#define RLDM_STAMP() tsv[tsn++] = __builtin_amdgcn_s_memtime()
+#define RLDM_STAMP() if (tsn < 12) tsv[tsn++] = __builtin_amdgcn_s_memtime()
 #else
 #define RLDM_STAMP()
 #endif
@@ -158,9 +158,13 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
             bool rowok[KB], inimg[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const int vhl = (k0 + kb) * SPI + rsub;
+                // slot -> halo row, rotated by one (3x3): a wave instruction moves SPI consecutive slots, and with rows
+                // 1, 2, ... first the zero rows above and below a full-height tile (32x2 / 64x4 images: rows 0 and THv - 1)
+                // share an instruction instead of each wasting half of one on lanes that skip the GroupNorm + SiLU math
+                const int slot = (k0 + kb) * SPI + rsub;
+                const int vhl = HALO ? (slot + 1 >= THv ? slot + 1 - THv : slot + 1) : slot;
                 const int vh = h0 - HALO + vhl;                 // row / column of the (nearest-x2: virtual) input image
-                rowok[kb] = laneok && (k0 + kb) < KC && vhl < THv;
+                rowok[kb] = laneok && (k0 + kb) < KC && slot < THv;
                 inimg[kb] = rowok[kb] && vh >= 0 && vh < (p.Hin << ups);
                 const unsigned goff = (unsigned)((vh >> ups) * (CIN * 2) + c8 * 16);
                 ldo[kb] = vhl * RSM + c8 * 16;
@@ -177,6 +181,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     }
                 }
             }
+            if (k0 == 0) { RLDM_STAMP(); }      // tile loads issued
             if (gn && k0 == 0) {
                 // per-channel sums -> (every channel's thread folds its own group: no serial phase) mean / rstd -> a*x + s
                 double* sD = reinterpret_cast<double*>(smem + abytes + 64);      // [2*CIN], behind the image
@@ -208,6 +213,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     for (int e = 0; e < 8; ++e) { ga[e] = sG[c8 * 8 + e]; gs[e] = sG[CIN + c8 * 8 + e]; }
                 }
             }
+            if (k0 == 0) { RLDM_STAMP(); }      // affine ready
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -229,6 +235,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     if (col < TWv && rowok[kb]) *reinterpret_cast<uint4*>(sA + col * colb + ldo[kb]) = o;
                 }
         }
+        RLDM_STAMP();                           // tile normalised and stored
         // residual-phase input: raw cat[r0, r1], the tile's own pixels only; a wave instruction moves 64 / LPR pixels
         if (R8 > 0) {
             const int lgr = R8 <= 16 ? 4 : (R8 <= 32 ? 5 : 6);          // log2(lanes per pixel)
@@ -473,7 +480,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     RLDM_STAMP();
 #ifdef RLDM_ABLATE
     if (p.ts && blockIdx.x < 4 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
-        for (int i = 0; i < 8; ++i) p.ts[blockIdx.x * 64 + i] = i < tsn ? tsv[i] : 0ull;
+        for (int i = 0; i < 12; ++i) p.ts[blockIdx.x * 64 + i] = i < tsn ? tsv[i] : 0ull;
     {
         const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (p.ts && tid == 0 && lin < 2048) {
