@@ -101,7 +101,15 @@ def roofline(pipe, sampler_handle, x_T, steps):
             for f in t:
                 t[f] += v[f] * mult
     all_ms = sum(v["ms"] for v in tot.values())
+    # dominant kernel = largest share of the kernel time.  conv_stream<256,128> (26.6 % in the rocprofv3 trace,
+    # profiles/round1_v25_rocprof_kernel_stats.txt) and the fused attention (21.9 % there; VALU-bound, its MFMAs carry 8 useful
+    # rows of 32) are within a percent of each other under this function's per-launch HIP events, so the choice is pinned to
+    # the trace's order unless another kernel leads by more than 10 %: the roofline object then describes the same kernel run
+    # after run.  Every kernel's own TFLOP/s is in `kernels`.
     dom = max(tot, key=lambda k: tot[k]["ms"])
+    pinned = "conv_stream_kernel<256,128,CK64,taps9>"
+    if pinned in tot and tot[pinned]["ms"] >= tot[dom]["ms"] / 1.1:
+        dom = pinned
     d = tot[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     kernels = {k: {"share": round(v["ms"] / all_ms, 4), "launches_per_batch": v["launches"],
