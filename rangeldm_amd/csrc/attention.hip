@@ -11,7 +11,8 @@
 //         all-ones, so the MFMA also produces the softmax denominator for free.  The kernel is VALU(exp)-bound, not
 //         MFMA-bound, so the idle MFMA rows cost nothing -- and the VALU work per score is cut to max + exp2 + pack: the
 //         running maximum rides in the S^T MFMA's C operand and is only raised (with a rescale) when a score beats it by
-//         more than 2^8.
+//         more than 2^8.  (A two-pass version -- exact maxima first, then exp2 + pack only -- measured 23 % slower in the
+//         key loop and -0.6 % end to end: the second S^T MFMA and its LDS reads cost more than the max / ballot they remove.)
 // Data: qkv [B][L][3C] bf16 straight out of the fused GroupNorm+QKV GEMM (q pre-multiplied by log2(e)/sqrt(8) through
 // the packed Wq).  A workgroup owns one (image, head): it stages that head's K rows (16 B each) and V TRANSPOSED
 // ([d][key], so the PV "A" fragments are 8-byte LDS reads) into LDS once -- 32 bytes per key -- and each of its waves
@@ -160,6 +161,15 @@ __global__ void __launch_bounds__(512) attention_d8_kernel(const AttnParams p, c
 __global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvParams p, const int waves, const int Lp) {
     constexpr int TPW = 4;                                // query tiles per wave (L <= 1024)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef RLDM_ABLATE
+    unsigned long long tsv[8];
+    int tsn = 0;
+    const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
+#define RLDM_ASTAMP() if (tsn < 8) tsv[tsn++] = __builtin_amdgcn_s_memtime()
+#else
+#define RLDM_ASTAMP()
+#endif
+    RLDM_ASTAMP();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = waves * 64;
@@ -218,6 +228,7 @@ __global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvPar
         __syncthreads();
     }
 
+    RLDM_ASTAMP();                                        // GroupNorm affine in LDS
     // ---- the GroupNorm affine folded into the head's weights: W' = W_h * diag(a) (bf16, A-fragment order, LDS),
     // b' = b_h + W_h * s -- the pixel fragments then go from global memory into the MFMA untouched -----------------------
     const int nks = C >> 4;
@@ -245,6 +256,7 @@ __global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvPar
     }
     __syncthreads();
 
+    RLDM_ASTAMP();                                        // W', b' in LDS
     // ---- projection of this wave's pixel tiles T = wave, wave + waves, ...: one tile at a time, its rows of x requested
     // whole (a lane's 16-byte pieces of one 128-byte line are issued back to back: every line is fetched once) ------------
     float binit[12];
@@ -293,13 +305,27 @@ __global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvPar
             vcol[9 * vst] = (bf16_t)0;
         }
     }
+    RLDM_ASTAMP();                                        // this wave's tiles projected
     __syncthreads();
+    RLDM_ASTAMP();                                        // ... everyone's
     bf16_t* out_bh = p.out + ((size_t)b * L) * C + h * 8;
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
         const int q0 = (wave + ti * waves) * 32;
         if (q0 < L) attention_tile(sK, sVt, vst, L, Lp, C, q0, qf[ti], out_bh, l31, hh);
     }
+    RLDM_ASTAMP();                                        // attention of this wave's tiles
+#ifdef RLDM_ABLATE
+    if (p.ts && p.L == p.ts_L && tid == 0) {
+        if (blockIdx.x == 0)
+            for (int i = 0; i < 8; ++i) p.ts[i] = i < tsn ? tsv[i] : 0ull;
+        if (blockIdx.x < 2048) {
+            p.ts[256 + 2 * blockIdx.x] = t_real0;
+            p.ts[257 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
+#undef RLDM_ASTAMP
 }
 
 int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream) {

@@ -170,6 +170,8 @@ struct AttnQkvParams {
     const float* bias;
     bf16_t* out;
     int B, L, C;
+    unsigned long long* ts;     // ABLATE builds: phase stamps of workgroup 0 + [start, end] of every workgroup, launches with L == ts_L
+    int ts_L;
 };
 int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream);
 

@@ -728,7 +728,7 @@ struct Builder {
         bool epi_res = false;
         RLDM_REQUIRE(small_params(a, Cin_t, R_t, taps, Wout, Hout, &p, &epi_res), "conv " + L->name + ": conv_small route lost");
         p.dbg = g_dbg_flags;
-        p.ts = g_ts_buf;
+        p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         const int BN = small_bn(p, taps, gn_fused);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
         p.ntile_n = N / BN;
@@ -832,7 +832,7 @@ struct Builder {
             RLDM_REQUIRE(x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
         }
         p.dbg = g_dbg_flags;
-        p.ts = g_ts_buf;
+        p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         p.ntile_n = N / conv_stream_bn(p);
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img);
@@ -957,7 +957,7 @@ struct Builder {
         p.silu = a.silu;
         p.gn_eps = a.eps;
         p.dbg = g_dbg_flags;
-        p.ts = g_ts_buf;
+        p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         p.gn_groups = a.groups;
         p.ksplit = tc.ksplit;
         const int tiles_img = (Wout / p.TW) * (Hout / p.TH);
@@ -1157,6 +1157,8 @@ struct NetCommon {
                 ap.bias = f->bias.as<float>();
                 ap.out = b.tptr(o);
                 ap.B = x.B; ap.L = Lt; ap.C = x.C;
+                ap.ts = g_ts_buf;
+                ap.ts_L = getenv("RLDM_TS_ATTN_L") ? atoi(getenv("RLDM_TS_ATTN_L")) : 0;
                 b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl,
                                        (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0});
             }
