@@ -2007,13 +2007,18 @@ int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_
 }
 
 // ---- sampler ------------------------------------------------------------------------------------------------------
-static int sampler_num_lanes(int batch) {
+static int sampler_num_lanes(int batch, int W, int H) {
     // ONE chain up to batch 31: chains of fewer than 16 samples lose more to the fixed cost of every launch than they gain
     // from running side by side (batch 16: two chains of 8 measured 165 img/s against 194 for a single chain).  From batch
     // 32 on, chains of >= 16 samples overlap usefully (the launches of one chain fill the CUs the other leaves idle in its
     // prologues / low-resolution levels): 2 x 16 = 241 img/s against 229 for one chain of 32, 3 x 16 = 264 against 1 x 48,
     // 2 x 32 = 267 against 264 for one chain of 64; four chains were slower again (238).  RLDM_LANES=n overrides.
-    int want = batch >= 32 ? std::min(3, batch / 16) : 1;
+    // The unit is WORK, not samples: a chain wants >= 16 x 4096 network-input pixels (16 KITTI latents of 256 x 16).  nuScenes
+    // latents are 256 x 8: 32 of them as 2 x 16 measured 301 img/s against 358 for one chain, so they split from 64 on.
+    const long long px = (long long)batch * W * H, unit = 16LL * 4096;
+    // Pixel-space networks (RangeDM, 1024 x 64 per sample) fill the chip with every launch of a single sample: 2 chains of 2
+    // measured 91 img/s against 93.5 for one chain of 4, so only latent-space samplers split.
+    int want = (px >= 2 * unit && W * H <= 8192) ? (int)std::min<long long>(3, px / unit) : 1;
     if (const char* e = getenv("RLDM_LANES")) want = atoi(e);
     if (want <= 0) want = 1;
     want = std::max(1, std::min(want, batch));
@@ -2054,7 +2059,7 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
     if (s->temb_tab.alloc((size_t)cfg->num_steps * unet->net.temb_ld * 4)) return 1;
     if (unet_temb(unet, s->t_dev.as<float>(), cfg->num_steps, s->temb_tab.as<float>(), nullptr)) return 1;
     RLDM_HIP_CHECK(hipStreamSynchronize(nullptr));
-    const int nl = sampler_num_lanes(B);
+    const int nl = sampler_num_lanes(B, W, H);
     for (int l = 0; l < nl; ++l) {
         auto ln = std::make_unique<SamplerLane>();
         ln->nb = B / nl;
