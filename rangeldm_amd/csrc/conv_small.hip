@@ -29,7 +29,7 @@ __device__ __forceinline__ void lds_barrier_s() {
     __builtin_amdgcn_s_barrier();
 }
 
-// BM = 32 * MI pixels (64: the 64x4 / 32x2 levels and the pointwise convs; 128: the 128x8 level), BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
+// BM = 32 * MI pixels (64: the 64x4 / 32x2 levels and the pointwise convs; 128: the 128x8 level; 32: 32x1 images -- the lowest nuScenes level), BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
 // TAPS == 9: 3x3 over a pre-activated input.  TAPS == 1: pointwise (attention q/k/v and output projections); there the
 // GroupNorm affine (no separate launch: one FMA per element while the tile is on its way to LDS) is folded in.
 template <int NWN, int CPT, int TAPS, int MI>
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     constexpr int PFX = (G % 3 == 0) ? 3 : 2;  // pixel fragments read ahead (LDS); divides G
     constexpr int RMAX = G < 8 ? G : 8;        // residual-phase steps per k-group (<= G: they arrive in the ring)
     constexpr int AS = MI >= 4 ? 1 : 2;        // accumulator sets: consecutive MFMAs never share an accumulator
-    constexpr int HB = 64;                     // epilogue half-tile: pixels exchanged through LDS at a time
+    constexpr int HB = BM < 64 ? BM : 64;      // epilogue half-tile: pixels exchanged through LDS at a time (32-pixel tiles: all of it)
     constexpr int FRS = BN * 4 + 16, NC8 = BN / 8;    // fp32 partial-sum image: [k-group][HB pixels][FRS bytes]
     constexpr int LPS = C8 <= 16 ? 16 : (C8 <= 32 ? 32 : 64), SPI = 64 / LPS;   // lanes per halo slot, slots per instruction
     // staging batch: columns per wave x row groups in flight (128-pixel tiles are 16 wide: 18 halo columns, 3 per wave,
@@ -250,20 +250,20 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
             const unsigned ld2 = (unsigned)(first ? nR0 : nR1) * 2u;
             const int pix0 = (b * p.Win + w0) * p.Hin + h0;
             constexpr int NBR = 8;              // <= 8 instructions per wave and 64 pixels (R <= 512)
-            for (int hp = 0; hp < BM / 64; ++hp) {
+            for (int hp = 0; hp < (BM + 63) / 64; ++hp) {
                 uint4 rv[NBR];
 #pragma unroll
                 for (int u = 0; u < NBR; ++u) {
                     const int pl = (wave + 8 * u) * ppi + psub, pidx = hp * 64 + pl;
                     const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
                     rv[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (pl < 64 && rc8 < R8)
+                    if (pl < HB && rc8 < R8)
                         rv[u] = *reinterpret_cast<const uint4*>(lbase + (size_t)(unsigned)(pix0 + pw * p.Hin + ph) * ld2);
                 }
 #pragma unroll
                 for (int u = 0; u < NBR; ++u) {
                     const int pl = (wave + 8 * u) * ppi + psub, pidx = hp * 64 + pl;
-                    if (pl < 64 && rc8 < R8) *reinterpret_cast<uint4*>(sR + pidx * RSR + rc8 * 16) = rv[u];
+                    if (pl < HB && rc8 < R8) *reinterpret_cast<uint4*>(sR + pidx * RSR + rc8 * 16) = rv[u];
                 }
             }
         }
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     for (int hp = 0; hp < NHALF; ++hp) {
         if (hp > 0) lds_barrier_s();            // the previous half-tile has been consumed
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
+        for (int m2 = 0; m2 < (MI < 2 ? 1 : 2); ++m2) {
             const int mi = hp * 2 + m2, pl = m2 * 32 + l31;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -537,7 +537,9 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     const int G = (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;
     if (R / (16 * KG) > std::min(G, 8)) return false;
     const int BMpx = p.TW * p.TH;
-    if ((BMpx != 64 && BMpx != 128) || p.TH < 2 || p.TW + 2 > 40 || p.Win * p.up < 2) return false;
+    if ((BMpx != 32 && BMpx != 64 && BMpx != 128) || (p.TH < 2 && BMpx != 32) || p.TW + 2 > 40 || p.Win * p.up < 2) return false;
+    // 32-pixel tiles (32x1 images): the 256- / 512-channel 3x3 convs and the 256-channel pointwise conv, 32-channel tiles
+    if (BMpx == 32 && (BN != 32 || p.up != 1 || !((taps == 9 && (cpt == 2 || cpt == 4)) || (taps == 1 && cpt == 2)))) return false;
     if (BMpx == 128 && (taps != 9 || BN != 64 || p.TW + 2 > 24 || (cpt != 2 && cpt != 4 && cpt != 6))) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
     return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;
@@ -570,6 +572,7 @@ int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream)
     RLDM_SMALL(2, 2, 1) RLDM_SMALL(2, 4, 1) RLDM_SMALL(2, 8, 1)
     RLDM_SMALL(4, 4, 1) RLDM_SMALL(4, 8, 1)
     RLDM_SMALL4(2, 2, 9, 4) RLDM_SMALL4(2, 4, 9, 4) RLDM_SMALL4(2, 6, 9, 4)
+    RLDM_SMALL4(1, 2, 9, 1) RLDM_SMALL4(1, 4, 9, 1) RLDM_SMALL4(1, 2, 1, 1)
 #undef RLDM_SMALL
 #undef RLDM_SMALL4
     RLDM_REQUIRE(false, "conv_small: no instance");

@@ -25,6 +25,9 @@ CONV_CASES = [
     (2, 128, 128, 32, 16, 3, 1, 0, False),     # L0-like, CK=64
     (1, 128, 128, 256, 16, 3, 1, 0, False),    # full L0 width (wrap seam across many tiles)
     (2, 256, 256, 32, 2, 3, 1, 0, False),      # L3: H=2, mostly zero padding
+    (4, 256, 256, 32, 1, 3, 1, 0, False),      # nuScenes L3: 32x1 images (conv_small.hip's 32-pixel tiles), H=1: only zero rows above / below
+    (3, 512, 256, 32, 1, 3, 1, 0, False),      # ... its up-block input width
+    (2, 256, 256, 32, 1, 1, 1, 0, False),      # ... pointwise
     (2, 256, 256, 64, 4, 3, 1, 0, False),      # L2
     (3, 128, 256, 16, 8, 3, 1, 0, False),      # odd batch
     (2, 16, 128, 32, 16, 3, 1, 0, False),      # conv_in (padded 16-ch input), CK=16
@@ -92,7 +95,7 @@ def test_conv_wrap_seam_exact():
     assert y[0, 2].abs().sum() == 0                             # beam -1 does not exist: zero padding
 
 
-GN_CASES = [(128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
+GN_CASES = [(256, 256, 256, 32, 1), (128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
             (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8),
             (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16)]
 
@@ -132,7 +135,8 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H, conv_flags):
 
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
                                                 (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3),
-                                                (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1), (2, 128, 128, 128, 8, 3)])
+                                                (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1), (2, 128, 128, 128, 8, 3),
+                                                (4, 256, 256, 32, 1, 3), (2, 256, 256, 32, 1, 1)])
 def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
     the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
@@ -152,6 +156,7 @@ def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
                                                 (16, 128, 384, 128, 8, True, False),   # L1 q/k/v at the bench batch (128-ch tiles)
                                                 (4, 256, 768, 64, 4, True, False),     # L2 q/k/v
                                                 (2, 256, 256, 32, 2, False, True),     # L3 attention output projection + x
+                                                (4, 256, 256, 32, 1, False, True),     # nuScenes L3 output projection (32-pixel tiles)
                                                 (16, 128, 128, 128, 8, False, True),   # L1 output projection + x
                                                 (3, 512, 256, 16, 4, True, True)])
 def test_conv_pointwise_small_route(B, C, N, W, H, gn, res):

@@ -72,6 +72,18 @@ def test_unet_forward_small(kw, B):
     assert rel_l2(m(x.cuda(), ts).sample.cpu(), ref_ps) < TOL_FWD
 
 
+def test_unet_forward_nuscenes_config():
+    """BASELINE config 3 (ldm/configs/nuscenes.yaml: 256 x 8 latents, full channel widths): its lowest level has 32 x 1 images,
+    which run on conv_small.hip's 32-pixel tiles (3x3 over 256 / 512 channels and the attention output projection)."""
+    cfg = UNetConfig(sample_size=(256, 8))
+    m, sd = hip_unet(cfg, "nu.")
+    x = T(normal(5, "x", (2, cfg.in_channels, *cfg.sample_size)))
+    ref = o_unet.OracleUNet(cfg, sd)(x, 333).sample
+    out = m(x.cuda(), 333).sample.cpu()
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    assert rel_l2(out, ref) < TOL_FWD
+
+
 def test_unet_forward_full_config_golden(golden):
     """RangeLDM KITTI-360 config (30.1 M params, 256x16 latents) against the committed oracle output."""
     g = golden("unet")
