@@ -630,8 +630,10 @@ struct Builder {
         const bool few_px = (long long)a.x0.B * Wout * Hout <= 4096 && !(g_dbg_flags & 65536);
         if (taps == 9 && (a.pad_mode != 0 || (Wout * Hout > ((g_dbg_flags & 1024) ? 1024 : 256) && !few_px))) return false;
         // pixel tile: 64; 128 for the 3x3 convs of the 128x8 level (each weight fragment then feeds 4 MFMAs)
-        // (32 for 32x1 images: the lowest nuScenes level, which otherwise runs as 8 workgroups of the generic kernel)
-        const int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : (Wout * Hout == 32 && a.up == 1 ? 32 : 64);
+        // (32 for 32x1 images: the lowest nuScenes level, which otherwise runs as 8 workgroups of the generic kernel; and for
+        //  32x2 images, as two tiles each: twice the workgroups, half the staging / epilogue per workgroup -- level-3 convs
+        //  13.4-14.2 -> 13.0 us, +0.5-1 % end to end; rldm_debug_set_flags(524288) keeps the 64-pixel tile: A/B runs, tests)
+        const int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : ((Wout * Hout == 32 || (Wout * Hout == 64 && Hout == 2 && !(g_dbg_flags & 524288))) && a.up == 1 ? 32 : 64);
         if (taps == 1 && a.x1.valid()) return false;
         if (!a.gn && a.x1.valid()) return false;
         if (a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
