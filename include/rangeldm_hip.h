@@ -46,6 +46,9 @@ typedef struct rldm_unet_config {
     int32_t norm_num_groups;                    /* 32                                                    */
     float norm_eps;                             /* 1e-5                                                  */
     int32_t mid_attention;                      /* add_attention                                         */
+    int32_t flip_sin_to_cos;                    /* Timesteps(..., flip_sin_to_cos): 1 for UNet2DModel    */
+    int32_t freq_shift;                         /* Timesteps(..., downscale_freq_shift): 0; (0, 1) is the
+                                                   sinusoid of vae/sgm/modules/diffusionmodules/model.py:28-46 */
 } rldm_unet_config;
 
 /* sgm Encoder/Decoder kwargs: vae/configs/kitti360.yaml:30-62 (== AutoencoderKL after ldm/convert_vae.py:123-189). */
@@ -73,7 +76,10 @@ void rldm_unet_destroy(rldm_unet* m);
 /* replaces load_state_dict / safetensors.load_model (ldm/inference.py:120): one call per diffusers key,
  * `data` = HOST fp32, `numel` elements in the reference's (C_out, C_in, kh, kw) / (out, in) order. */
 int rldm_unet_set_param(rldm_unet* m, const char* name, const float* data, int64_t numel);
-/* checks every key was supplied, packs bf16 MFMA-ordered weights to HBM */
+/* checks every key was supplied, packs bf16 MFMA-ordered weights to HBM.  May be called again after further
+ * rldm_unet_set_param calls (load_state_dict on a live model, e.g. periodic EMA evaluation): it frees and rebuilds the
+ * device weights and bumps the model's generation; every rldm_sampler built on the model notices at its next
+ * rldm_sample and re-plans / re-captures its graphs (between set_param and finalize the model refuses to run). */
 int rldm_unet_finalize(rldm_unet* m);
 /* replaces `unet(sample, timestep).sample` (ldm/pipelines.py:103,239,360,500; train: ldm/train_unconditional.py:512).
  * sample: device fp32 [B, in_channels, W, H]; timesteps: HOST int64, nt == 1 (broadcast) or nt == B;
@@ -348,6 +354,12 @@ int rldm_test_conv_stats(const rldm_conv_desc* d, const float* x0, const float* 
                          void* stream);
 /* multi-head (d=8) self-attention core: qkv device fp32 [B][L][3C] -> out device fp32 [B][L][C] */
 int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void* stream);
+/* the launch every attention block of the UNet actually runs -- GroupNorm -> to_q / to_k / to_v -> softmax(q k^T/sqrt 8) v
+ * (diffusers Attention before to_out; reference analogue vae/sgm/modules/attention.py:194-284 behind a GroupNorm):
+ * x device fp32 [B][L][C] token-major, gamma / beta host [C], wqkv host [3C][C] (q | k | v rows), bqkv host [3C]
+ * -> out device fp32 [B][L][C], heads concatenated. */
+int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, float eps, const float* gamma, const float* beta,
+                            const float* wqkv, const float* bqkv, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,10 +37,13 @@ def group_norm_silu(x, w, b, groups, eps, silu=True):
     return F.silu(h) if silu else h
 
 
-def timestep_embedding(t, dim=128, max_period=10000.0):
-    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) [3P; SURVEY.md A.2]:
-    f_i = exp(-ln(1e4) * i / half);  e = [cos(t f), sin(t f)]."""
+def timestep_embedding(t, dim=128, max_period=10000.0, flip_sin_to_cos=True, freq_shift=0):
+    """diffusers get_timestep_embedding / Timesteps(dim, flip_sin_to_cos, downscale_freq_shift) [3P; SURVEY.md A.2]:
+    f_i = exp(-ln(1e4) * i / (half - freq_shift));  e = [sin(t f), cos(t f)], halves swapped when flip_sin_to_cos.
+    UNet2DModel uses (True, 0).  (False, 1) is the reference's own vae/sgm/modules/diffusionmodules/model.py:28-46
+    (`[sin, cos]`, divisor `half_dim - 1`), which pins this formula (oracle/validate_unet_against_reference.py)."""
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
     emb = t.float()[:, None] * torch.exp(exponent)[None, :]
-    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+    s, c = torch.sin(emb), torch.cos(emb)
+    return torch.cat([c, s] if flip_sin_to_cos else [s, c], dim=-1)

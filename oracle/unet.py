@@ -52,7 +52,7 @@ def time_embedding(sd, cfg: UNetConfig, timestep, batch):
     elif timestep.dim() == 0:
         timestep = timestep[None]
     t = timestep * torch.ones(batch, dtype=timestep.dtype)
-    e = ops.timestep_embedding(t, cfg.block_out_channels[0])
+    e = ops.timestep_embedding(t, cfg.block_out_channels[0], flip_sin_to_cos=cfg.flip_sin_to_cos, freq_shift=cfg.freq_shift)
     e = F.linear(e, _t(sd, "time_embedding.linear_1.weight"), _t(sd, "time_embedding.linear_1.bias"))
     return F.linear(F.silu(e), _t(sd, "time_embedding.linear_2.weight"), _t(sd, "time_embedding.linear_2.bias"))
 

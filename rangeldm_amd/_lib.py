@@ -14,7 +14,8 @@ class UNetConfigC(C.Structure):
                 ("out_channels", C.c_int32), ("layers_per_block", C.c_int32), ("num_levels", C.c_int32),
                 ("block_out_channels", C.c_int32 * RLDM_MAX_LEVELS), ("down_attn", C.c_int32 * RLDM_MAX_LEVELS),
                 ("up_attn", C.c_int32 * RLDM_MAX_LEVELS), ("attention_head_dim", C.c_int32),
-                ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float), ("mid_attention", C.c_int32)]
+                ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float), ("mid_attention", C.c_int32),
+                ("flip_sin_to_cos", C.c_int32), ("freq_shift", C.c_int32)]
 
 
 class VAEConfigC(C.Structure):
@@ -138,6 +139,7 @@ PROTOTYPES = {
     "rldm_debug_timestamps": (C.c_int, [_P]),
     "rldm_debug_block_times": (C.c_int, [_P, C.c_int]),
     "rldm_test_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_test_attention_qkv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -22,7 +22,7 @@ SCHEDULER_CONFIG_NAME = "scheduler_config.json"
 
 # diffusers UNet2DModel defaults the kernels implement; any other value in a config.json is refused loudly
 _UNET_FIXED = {
-    "act_fn": "silu", "time_embedding_type": "positional", "freq_shift": 0, "flip_sin_to_cos": True,
+    "act_fn": "silu", "time_embedding_type": "positional",
     "resnet_time_scale_shift": "default", "downsample_type": "conv", "upsample_type": "conv", "dropout": 0.0,
     "mid_block_scale_factor": 1, "downsample_padding": 1, "center_input_sample": False, "class_embed_type": None,
     "num_class_embeds": None, "attn_norm_num_groups": None,
@@ -50,7 +50,8 @@ def unet_config_from_diffusers(d):
               layers_per_block=d.get("layers_per_block", 2), block_out_channels=tuple(d["block_out_channels"]),
               down_block_types=tuple(d["down_block_types"]), up_block_types=tuple(d["up_block_types"]),
               attention_head_dim=d.get("attention_head_dim", 8) or 8, norm_num_groups=d.get("norm_num_groups", 32),
-              norm_eps=d.get("norm_eps", 1e-5), add_attention=bool(d.get("add_attention", True)))
+              norm_eps=d.get("norm_eps", 1e-5), add_attention=bool(d.get("add_attention", True)),
+              flip_sin_to_cos=bool(d.get("flip_sin_to_cos", True)), freq_shift=int(d.get("freq_shift", 0)))
     return UNetConfig(**kw)
 
 
@@ -59,7 +60,8 @@ def unet_config_to_diffusers(cfg):
          "in_channels": cfg.in_channels, "out_channels": cfg.out_channels, "layers_per_block": cfg.layers_per_block,
          "block_out_channels": list(cfg.block_out_channels), "down_block_types": list(cfg.down_block_types),
          "up_block_types": list(cfg.up_block_types), "attention_head_dim": cfg.attention_head_dim,
-         "norm_num_groups": cfg.norm_num_groups, "norm_eps": cfg.norm_eps}
+         "norm_num_groups": cfg.norm_num_groups, "norm_eps": cfg.norm_eps,
+         "flip_sin_to_cos": bool(cfg.flip_sin_to_cos), "freq_shift": int(cfg.freq_shift)}
     d.update(_UNET_FIXED)
     d["add_attention"] = bool(cfg.add_attention)
     return d
@@ -198,7 +200,11 @@ def load_vae_dir(path):
     sd = _load_safetensors(os.path.join(path, WEIGHTS_NAME))
     if "quant_conv.weight" in sd:                     # ldm/inference.py:89-91 keeps them only when present
         raise NotImplementedError("VAE checkpoint with quant_conv / post_quant_conv")
-    sd = {k: v for k, v in sd.items() if ".attentions." not in k}      # attention-free VAE (ldm/inference.py:94-95)
+    attn = [k for k in sd if ".attentions." in k]
+    if attn:
+        # ldm/inference.py:94-95 replaces attention by identity only when 'encoder.mid_block.attentions.0.to_q.weight' is
+        # ABSENT; a checkpoint that carries attention weights was trained with it and must not be run attention-free
+        raise NotImplementedError(f"VAE checkpoint {path} holds mid-block attention weights ({attn[0]}, ...): not implemented")
     check_state_dict(sd, vae_param_shapes(cfg), f"VAE checkpoint {path}")
     return cfg, sd
 

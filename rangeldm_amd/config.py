@@ -28,6 +28,11 @@ class UNetConfig:
     norm_eps: float = 1e-5
     time_embed_dim_mult: int = 4                       # time_embed_dim = block_out_channels[0] * 4
     add_attention: bool = True                         # mid-block attention
+    # diffusers UNet2DModel kwargs of the positional time embedding (Timesteps(block_out_channels[0], flip_sin_to_cos,
+    # freq_shift)); (False, 1) is the sinusoid of sgm's get_timestep_embedding (vae/sgm/.../model.py:28-46)
+    flip_sin_to_cos: bool = True
+    freq_shift: int = 0
+    downsample_padding: int = 1                        # the only value the reference's UNets use (ldm/utils.py:92-93)
     # reference surgery (ldm/utils.py:125-203 via `all_circonv`): every conv wraps W and zero-pads H
     all_circonv: bool = True
 
@@ -37,6 +42,8 @@ class UNetConfig:
         self.down_block_types = tuple(self.down_block_types)
         self.up_block_types = tuple(self.up_block_types)
         assert len(self.block_out_channels) == len(self.down_block_types) == len(self.up_block_types)
+        if self.downsample_padding != 1:
+            raise NotImplementedError("UNet downsamplers use downsample_padding=1 (circular 3x3 stride 2)")
         if not self.all_circonv:
             raise NotImplementedError("only the all_circonv surgery of the reference configs is supported "
                                       "(sub_circonv, ldm/inference.py:105-118, is out of scope)")

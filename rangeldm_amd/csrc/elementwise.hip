@@ -65,52 +65,87 @@ int launch_nhwc_bf16_to_nchw_f32(const bf16_t* src, float* dst, int B, int C, in
     return 0;
 }
 
-// ---- time embedding + every resnet's time_emb_proj, one block per timestep row -------------------------------------
-// diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0) + TimestepEmbedding + ResnetBlock2D.time_emb_proj(SiLU(emb))
+// ---- time embedding + every resnet's time_emb_proj ------------------------------------------------------------------
+// diffusers Timesteps(flip_sin_to_cos, freq_shift) + TimestepEmbedding + ResnetBlock2D.time_emb_proj(SiLU(emb))
 // [3P; SURVEY.md A.2]; analogue vae/sgm/modules/diffusionmodules/model.py:28-46,349.  fp32 throughout.
-__global__ void __launch_bounds__(256) temb_kernel(const TembParams p) {
-    extern __shared__ float sm[];
-    float* e = sm;                  // dim0
-    float* h1 = sm + p.dim0;        // D
-    float* h2 = h1 + p.D;           // D   (SiLU(emb))
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const float t = p.t[row];
-    const int half = p.dim0 / 2;
-    for (int i = tid; i < half; i += 256) {
-        const float f = expf(-9.210340371976184f * (float)i / (float)half);   // ln(10000)
-        const float a = t * f;
-        e[i] = cosf(a);
-        e[half + i] = sinf(a);
-    }
-    __syncthreads();
-    for (int o = tid; o < p.D; o += 256) {
-        float acc = p.b1[o];
-        const float* w = p.w1 + (size_t)o * p.dim0;
-        for (int k = 0; k < p.dim0; ++k) acc += w[k] * e[k];
-        h1[o] = silu_f(acc);
-    }
-    __syncthreads();
-    for (int o = tid; o < p.D; o += 256) {
-        float acc = p.b2[o];
-        const float* w = p.w2 + (size_t)o * p.D;
-        for (int k = 0; k < p.D; ++k) acc += w[k] * h1[k];
-        h2[o] = silu_f(acc);
-    }
-    __syncthreads();
-    // projections: one wave per output, lanes stride the D inputs (coalesced weight rows)
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int o = wave; o < p.total; o += 4) {
-        const float* w = p.wp + (size_t)o * p.D;
-        float acc = 0.f;
-        for (int k = lane; k < p.D; k += 64) acc += w[k] * h2[k];
+// Three launches of one row-batched Linear: out[r][o] = act(b[o] + sum_k w[o][k] * in[r][k]).  A workgroup owns 16
+// outputs for ALL rows (its 16 weight rows are read once), lane = row, the K loop runs over 128-wide chunks staged in
+// LDS (pitch 132 floats: 16-byte reads of 8 consecutive lanes cover the 32 banks), weights are LDS broadcasts.
+// The [50][4352] table of a 50-step sampler is 272 + 32 + 32 workgroups instead of 50 (3.3 ms -> tens of us).
+constexpr int TL_OB = 16, TL_KC = 128, TL_PITCH = TL_KC + 4;
+struct RowsLinearParams {
+    const float* in;        // [rows][K], or null: the sinusoid of t
+    const float* t;         // [rows] (sinusoid mode)
+    int flip, shift;
+    const float* w; const float* b;   // [O][K], [O]
+    float* out; int ldo;
+    int rows, K, O, act;
+};
+__global__ void __launch_bounds__(256) rows_linear_kernel(const RowsLinearParams p) {
+    __shared__ float xs[64 * TL_PITCH];
+    __shared__ float ws[TL_OB * TL_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o0 = blockIdx.x * TL_OB;
+    const int half = p.K / 2;
+    for (int r0 = 0; r0 < p.rows; r0 += 64) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < p.K; kc += TL_KC) {
+            __syncthreads();
+            for (int i = tid; i < 64 * TL_KC; i += 256) {
+                const int r = i / TL_KC, k = i % TL_KC, kk = kc + k;
+                float v = 0.f;
+                if (r0 + r < p.rows && kk < p.K) {
+                    if (p.in) v = p.in[(size_t)(r0 + r) * p.K + kk];
+                    else {
+                        const int j = kk % half;
+                        const float f = expf(-9.210340371976184f * (float)j / (float)(half - p.shift));   // ln(10000)
+                        const float a = p.t[r0 + r] * f;
+                        const bool first = kk < half;
+                        v = (first == (p.flip != 0)) ? cosf(a) : sinf(a);      // [sin, cos]; halves swapped when flip
+                    }
+                }
+                xs[r * TL_PITCH + k] = v;
+            }
+            for (int i = tid; i < TL_OB * TL_KC; i += 256) {
+                const int o = i / TL_KC, k = i % TL_KC;
+                ws[o * TL_PITCH + k] = (o0 + o < p.O && kc + k < p.K) ? p.w[(size_t)(o0 + o) * p.K + kc + k] : 0.f;
+            }
+            __syncthreads();
+            const float4* xr = reinterpret_cast<const float4*>(xs + lane * TL_PITCH);
+#pragma unroll 4
+            for (int k4 = 0; k4 < TL_KC / 4; ++k4) {
+                const float4 x = xr[k4];
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-        if (lane == 0) p.out[(size_t)row * p.total + o] = acc + p.bp[o];
+                for (int j = 0; j < 4; ++j) {
+                    const float4 w = reinterpret_cast<const float4*>(ws + (wave * 4 + j) * TL_PITCH)[k4];
+                    acc[j] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+                }
+            }
+        }
+        if (r0 + lane < p.rows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = o0 + wave * 4 + j;
+                if (o < p.O) {
+                    float v = acc[j] + p.b[o];
+                    if (p.act) v = silu_f(v);
+                    p.out[(size_t)(r0 + lane) * p.ldo + o] = v;
+                }
+            }
+        }
     }
 }
 int launch_temb(const TembParams& p, hipStream_t stream) {
-    const size_t lds = (size_t)(p.dim0 + 2 * p.D) * sizeof(float);
-    hipLaunchKernelGGL(temb_kernel, dim3(p.rows), dim3(256), lds, stream, p);
+    float* h1 = p.scratch;
+    float* h2 = p.scratch + (size_t)p.rows * p.D;
+    RowsLinearParams a{};
+    a.in = nullptr; a.t = p.t; a.flip = p.flip_sin_to_cos; a.shift = p.freq_shift;
+    a.w = p.w1; a.b = p.b1; a.out = h1; a.ldo = p.D; a.rows = p.rows; a.K = p.dim0; a.O = p.D; a.act = 1;
+    hipLaunchKernelGGL(rows_linear_kernel, dim3((a.O + TL_OB - 1) / TL_OB), dim3(256), 0, stream, a);
+    a.in = h1; a.w = p.w2; a.b = p.b2; a.out = h2; a.K = p.D;        // h2 = SiLU(emb): what every time_emb_proj reads
+    hipLaunchKernelGGL(rows_linear_kernel, dim3((a.O + TL_OB - 1) / TL_OB), dim3(256), 0, stream, a);
+    a.in = h2; a.w = p.wp; a.b = p.bp; a.out = p.out; a.ldo = p.total; a.O = p.total; a.act = 0;
+    hipLaunchKernelGGL(rows_linear_kernel, dim3((a.O + TL_OB - 1) / TL_OB), dim3(256), 0, stream, a);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

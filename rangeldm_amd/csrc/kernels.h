@@ -199,6 +199,8 @@ struct TembParams {
     const float* w2; const float* b2;   // [D][D]
     const float* wp; const float* bp;   // [total][D] concatenated time_emb_proj
     float* out;              // [rows][total]
+    float* scratch;          // [2][rows][D] (the two hidden layers)
+    int flip_sin_to_cos, freq_shift;   // diffusers Timesteps arguments: UNet2DModel (1, 0); sgm get_timestep_embedding (0, 1)
 };
 int launch_temb(const TembParams& p, hipStream_t stream);
 

@@ -425,6 +425,22 @@ struct Layers {
     }
 };
 
+// Per-head MFMA A fragments of the merged q|k|v Linear for attention_qkv_d8_kernel: w [3C][C] (q rows already scaled by
+// log2(e)/sqrt(8)), b [3C] -> img [heads][C/16][64 lanes][8] bf16 (row = lane & 31: 0-7 q, 8-15 k, 16-23 v, 24-31 zero;
+// channels 16*ks + 8*(lane >> 5) ..+8), bias [heads][32].
+static void pack_attn_head_frags(const float* w, const float* b, int C, std::vector<bf16_t>& img, std::vector<float>& bias) {
+    const int heads = C / 8, nks = C / 16;
+    img.assign((size_t)heads * nks * 512, 0);
+    bias.assign((size_t)heads * 32, 0.f);
+    for (int h = 0; h < heads; ++h)
+        for (int row = 0; row < 24; ++row) {
+            const int src = (row / 8) * C + h * 8 + row % 8;            // q | k | v rows of the merged Linear
+            bias[(size_t)h * 32 + row] = b[src];
+            for (int c = 0; c < C; ++c)
+                img[(((size_t)h * nks + c / 16) * 64 + ((c % 16) / 8) * 32 + row) * 8 + c % 8] = f32_to_bf16(w[(size_t)src * C + c]);
+        }
+}
+
 struct ConvArgs {
     ConvLayer* layer = nullptr;
     Tensor x0, x1;                 // x1 optional concat
@@ -1114,16 +1130,9 @@ struct NetCommon {
         }
         ConvLayer* L = layers.get_conv(p + ".qkv");
         RLDM_REQUIRE(L && L->Cin == C && L->Cout == 3 * C, "attention " + p + ": unexpected q/k/v shapes");
-        const int heads = C / 8, nks = C / 16;
-        std::vector<bf16_t> img((size_t)heads * nks * 512, 0);
-        std::vector<float> bias((size_t)heads * 32, 0.f);
-        for (int h = 0; h < heads; ++h)
-            for (int row = 0; row < 24; ++row) {
-                const int src = (row / 8) * C + h * 8 + row % 8;            // q | k | v rows of the merged Linear
-                bias[(size_t)h * 32 + row] = L->b[src];
-                for (int c = 0; c < C; ++c)
-                    img[(((size_t)h * nks + c / 16) * 64 + ((c % 16) / 8) * 32 + row) * 8 + c % 8] = f32_to_bf16(L->w[(size_t)src * C + c]);
-            }
+        std::vector<bf16_t> img;
+        std::vector<float> bias;
+        pack_attn_head_frags(L->w.data(), L->b.data(), C, img, bias);
         auto f = std::make_unique<AttnFused>();
         if (upload(f->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
         if (upload(f->bias, bias.data(), bias.size() * sizeof(float))) return 1;
@@ -1254,6 +1263,8 @@ struct rldm_unet {
     DevBuf w1, b1, w2, b2, wp, bp;                  // fp32 time-embedding weights
     std::map<int, std::unique_ptr<Plan>> plans;     // per batch size
     DevBuf t_dev, temb_tab;                         // scratch for rldm_unet_forward
+    DevBuf temb_scratch;                            // hidden layers of the time-embedding MLP (launch_temb)
+    uint64_t generation = 0;                        // bumped whenever the device weights are (re)built: samplers re-plan
     int temb_rows_cap = 0;
     std::vector<std::string> resnet_order;
 
@@ -1498,6 +1509,10 @@ static int unet_temb(rldm_unet* m, const float* t_dev, int rows, float* tab, hip
     p.w2 = m->w2.as<float>(); p.b2 = m->b2.as<float>();
     p.wp = m->wp.as<float>(); p.bp = m->bp.as<float>();
     p.out = tab;
+    const size_t need = (size_t)2 * rows * m->temb_dim * sizeof(float);
+    if (m->temb_scratch.bytes < need && m->temb_scratch.alloc(need)) return 1;
+    p.scratch = m->temb_scratch.as<float>();
+    p.flip_sin_to_cos = m->cfg.flip_sin_to_cos; p.freq_shift = m->cfg.freq_shift;
     return launch_temb(p, s);
 }
 
@@ -1505,6 +1520,7 @@ static int unet_temb(rldm_unet* m, const float* t_dev, int rows, float* tab, hip
 // VAE
 // =================================================================================================================
 struct rldm_vae {
+    uint64_t generation = 0;                        // see rldm_unet::generation
     rldm_vae_config cfg;
     ParamStore params;
     NetCommon net;
@@ -1750,6 +1766,7 @@ struct rldm_sampler {
     std::vector<std::unique_ptr<SamplerLane>> lanes;
     hipEvent_t ev_in = nullptr;
     long long n_latent = 0, n_image = 0;            // whole batch
+    uint64_t unet_gen = 0, vae_gen = 0;             // generations of the weights the lanes' plans and graphs were built on
     ~rldm_sampler() {
         lanes.clear();
         if (ev_in) (void)hipEventDestroy(ev_in);
@@ -1781,6 +1798,54 @@ static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* n
     sp.n = ln->n_latent;
     if (launch_sched_step(sp, st)) return 1;
     return launch_step_counter(ln->step.as<int>(), 0, 1, st);
+}
+
+// (Re)build everything of a sampler that is baked on the models' device weights: the time-embedding table, every lane's
+// UNet / decode plan (weight pointers, packed images) and -- by dropping them -- the captured graphs.  Called at creation
+// and again by rldm_sample when rldm_unet_finalize / rldm_vae_finalize ran since (load_state_dict on a model a pipeline
+// already sampled with: the old graphs would replay over freed weight buffers).
+static int sampler_build_plans(rldm_sampler* s) {
+    rldm_unet* unet = s->unet;
+    rldm_vae* vae = s->vae;
+    RLDM_REQUIRE(unet->params.finalized, "unet not finalized (set_param without rldm_unet_finalize)");
+    RLDM_REQUIRE(!vae || vae->params.finalized, "vae not finalized (set_param without rldm_vae_finalize)");
+    const auto& uc = unet->cfg;
+    const int W = uc.sample_w, H = uc.sample_h;
+    for (auto& lnp : s->lanes) RLDM_HIP_CHECK(hipStreamSynchronize(lnp->stream));
+    if (s->temb_tab.alloc((size_t)s->cfg.num_steps * unet->net.temb_ld * 4)) return 1;
+    if (unet_temb(unet, s->t_dev.as<float>(), s->cfg.num_steps, s->temb_tab.as<float>(), nullptr)) return 1;
+    RLDM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    for (auto& lnp : s->lanes) {
+        SamplerLane* ln = lnp.get();
+        if (ln->step_graph) { (void)hipGraphExecDestroy(ln->step_graph); ln->step_graph = nullptr; }
+        if (ln->decode_graph) { (void)hipGraphExecDestroy(ln->decode_graph); ln->decode_graph = nullptr; }
+        ln->captured_noise = nullptr;
+        ln->uplan.reset();
+        ln->dplan.reset();
+        if (unet_make_plan(unet, ln->nb, &ln->uplan)) return 1;
+        PlanIO& io = ln->uplan->io;
+        io.sample = ln->x.as<float>();
+        io.sample_channels = uc.out_channels;
+        io.pos_encoding = s->cfg.pos_encoding;
+        io.cond = s->cfg.cond_channels ? ln->cond.as<float>() : nullptr;
+        io.cond_channels = s->cfg.cond_channels;
+        io.out = ln->eps.as<float>();
+        io.temb = s->temb_tab.as<float>();
+        io.step_ptr = ln->step.as<int>();
+        io.temb_rows_per_step = 1;
+        io.temb_per_sample = 0;
+        if (vae) {
+            if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan)) return 1;
+            PlanIO& d = ln->dplan->io;
+            d.sample = ln->x.as<float>();
+            d.sample_channels = vae->cfg.z_channels;
+            d.sample_scale = 1.0f / vae->cfg.scaling_factor;      // latents / scaling_factor, ldm/pipelines.py:365
+            d.out = ln->image.as<float>();
+        }
+    }
+    s->unet_gen = unet->generation;
+    s->vae_gen = vae ? vae->generation : 0;
+    return 0;
 }
 
 static int capture(hipStream_t st, const std::function<int()>& body, hipGraphExec_t* exec) {
@@ -1850,6 +1915,7 @@ void rldm_unet_destroy(rldm_unet* m) { delete m; }
 int rldm_unet_set_param(rldm_unet* m, const char* name, const float* data, int64_t numel) {
     RLDM_REQUIRE(m && name && data, "null argument");
     m->plans.clear();
+    m->params.finalized = false;                    // a live sampler refuses to run until rldm_unet_finalize rebuilt the weights
     return m->params.set(name, data, numel);
 }
 
@@ -1860,6 +1926,7 @@ int rldm_unet_finalize(rldm_unet* m) {
     m->plans.clear();
     if (unet_build_layers(m)) return 1;
     m->params.finalized = true;
+    ++m->generation;
     return 0;
 }
 
@@ -1936,6 +2003,7 @@ void rldm_vae_destroy(rldm_vae* m) { delete m; }
 int rldm_vae_set_param(rldm_vae* m, const char* name, const float* data, int64_t numel) {
     RLDM_REQUIRE(m && name && data, "null argument");
     m->plans.clear();
+    m->params.finalized = false;
     return m->params.set(name, data, numel);
 }
 int rldm_vae_finalize(rldm_vae* m) {
@@ -1944,6 +2012,7 @@ int rldm_vae_finalize(rldm_vae* m) {
     m->plans.clear();
     if (vae_build_layers(m)) return 1;
     m->params.finalized = true;
+    ++m->generation;
     return 0;
 }
 
@@ -2059,9 +2128,6 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
     std::vector<float> tf(cfg->num_steps);
     for (int i = 0; i < cfg->num_steps; ++i) tf[i] = (float)cfg->timesteps[i];
     if (upload(s->t_dev, tf.data(), tf.size() * 4)) return 1;
-    if (s->temb_tab.alloc((size_t)cfg->num_steps * unet->net.temb_ld * 4)) return 1;
-    if (unet_temb(unet, s->t_dev.as<float>(), cfg->num_steps, s->temb_tab.as<float>(), nullptr)) return 1;
-    RLDM_HIP_CHECK(hipStreamSynchronize(nullptr));
     const int nl = sampler_num_lanes(B, W, H);
     for (int l = 0; l < nl; ++l) {
         auto ln = std::make_unique<SamplerLane>();
@@ -2074,29 +2140,10 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
         RLDM_HIP_CHECK(hipEventCreateWithFlags(&ln->ev_out, hipEventDisableTiming));
         if (ln->x.alloc(ln->n_latent * 4) || ln->eps.alloc(ln->n_latent * 4) || ln->step.alloc(64)) return 1;
         if (cfg->cond_channels && ln->cond.alloc((size_t)ln->n_cond * 4)) return 1;
-        if (unet_make_plan(unet, ln->nb, &ln->uplan)) return 1;
-        PlanIO& io = ln->uplan->io;
-        io.sample = ln->x.as<float>();
-        io.sample_channels = uc.out_channels;
-        io.pos_encoding = cfg->pos_encoding;
-        io.cond = cfg->cond_channels ? ln->cond.as<float>() : nullptr;
-        io.cond_channels = cfg->cond_channels;
-        io.out = ln->eps.as<float>();
-        io.temb = s->temb_tab.as<float>();
-        io.step_ptr = ln->step.as<int>();
-        io.temb_rows_per_step = 1;
-        io.temb_per_sample = 0;
-        if (vae) {
-            if (ln->image.alloc(ln->n_image * 4)) return 1;
-            if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan)) return 1;
-            PlanIO& d = ln->dplan->io;
-            d.sample = ln->x.as<float>();
-            d.sample_channels = vae->cfg.z_channels;
-            d.sample_scale = 1.0f / vae->cfg.scaling_factor;      // latents / scaling_factor, ldm/pipelines.py:365
-            d.out = ln->image.as<float>();
-        }
+        if (vae && ln->image.alloc(ln->n_image * 4)) return 1;
         s->lanes.push_back(std::move(ln));
     }
+    if (sampler_build_plans(s.get())) return 1;
     *out = s.release();
     return 0;
 }
@@ -2109,6 +2156,10 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
     RLDM_REQUIRE((s->cfg.cond_channels == 0) == (cond == nullptr), "cond tensor does not match sampler.cond_channels");
     RLDM_REQUIRE(s->cfg.mode == RLDM_SAMPLER_DDIM || step_noise != nullptr, "DDPM sampling needs step_noise");
     hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
+    if (s->unet_gen != s->unet->generation || (s->vae && s->vae_gen != s->vae->generation) || !s->unet->params.finalized ||
+        (s->vae && !s->vae->params.finalized)) {
+        if (sampler_build_plans(s)) return 1;       // the models were reloaded since the graphs were captured
+    }
     RLDM_HIP_CHECK(hipEventRecord(s->ev_in, caller));
     // per lane: inputs, (first call) eager warm step + graph capture
     for (auto& lnp : s->lanes) {
@@ -2467,6 +2518,62 @@ int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void*
     std::vector<float> hf(ho.size());
     for (size_t i = 0; i < ho.size(); ++i) hf[i] = bf16_to_f32(ho[i]);
     RLDM_HIP_CHECK(hipMemcpy(out, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// The fused GroupNorm -> to_q/to_k/to_v -> softmax(q k^T / sqrt(8)) v launch on its own (what runs inside every
+// attention block of the UNet): x device fp32 [B][L][C] (token-major), gamma/beta host [C], wqkv host [3C][C] (rows
+// q | k | v, torch Linear layout), bqkv host [3C] -> out device fp32 [B][L][C] (heads concatenated, before to_out).
+int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, float eps, const float* gamma, const float* beta,
+                            const float* wqkv, const float* bqkv, float* out, void* stream) {
+    RLDM_REQUIRE(x && gamma && beta && wqkv && bqkv && out, "null argument");
+    RLDM_REQUIRE(C % 16 == 0 && C % groups == 0, "attention_qkv: channels must be a multiple of 16 and of the group count");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = (size_t)B * L * C;
+    std::vector<float> hx(n);
+    RLDM_HIP_CHECK(hipMemcpy(hx.data(), x, n * 4, hipMemcpyDeviceToHost));
+    std::vector<bf16_t> hb(n);
+    std::vector<float> stats((size_t)B * C * 2, 0.f);      // one partial row per image: (sum, sum of squares) of the bf16 values
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            double S = 0.0, SS = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const size_t i = ((size_t)b * L + l) * C + c;
+                hb[i] = f32_to_bf16(hx[i]);
+                const double v = bf16_to_f32(hb[i]);
+                S += v;
+                SS += v * v;
+            }
+            stats[((size_t)b * C + c) * 2] = (float)S;
+            stats[((size_t)b * C + c) * 2 + 1] = (float)SS;
+        }
+    std::vector<float> w((size_t)3 * C * C), bb((size_t)3 * C);
+    const float qs = 1.4426950408889634f / std::sqrt(8.0f);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = wqkv[i] * (i < (size_t)C * C ? qs : 1.f);
+    for (int i = 0; i < 3 * C; ++i) bb[i] = bqkv[i] * (i < C ? qs : 1.f);
+    std::vector<bf16_t> img;
+    std::vector<float> bias;
+    pack_attn_head_frags(w.data(), bb.data(), C, img, bias);
+    DevBuf dx, dst, dg, dbt, dw, dbias, dout;
+    if (upload(dx, hb.data(), n * 2) || upload(dst, stats.data(), stats.size() * 4) || upload(dg, gamma, C * 4) ||
+        upload(dbt, beta, C * 4) || upload(dw, img.data(), img.size() * 2) || upload(dbias, bias.data(), bias.size() * 4))
+        return 1;
+    if (dout.alloc(n * 2)) return 1;
+    AttnQkvParams ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.x = dx.as<bf16_t>(); ap.st = dst.as<float2>(); ap.P = 1;
+    ap.gamma = dg.as<float>(); ap.beta = dbt.as<float>(); ap.eps = eps; ap.groups = groups;
+    const int cpg = C / groups;
+    ap.inv_n = (float)(1.0 / ((double)L * cpg));
+    ap.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+    ap.wfrag = dw.as<bf16_t>(); ap.bias = dbias.as<float>(); ap.out = dout.as<bf16_t>();
+    ap.B = B; ap.L = L; ap.C = C;
+    if (launch_attention_qkv(ap, st)) return 1;
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<bf16_t> ho(n);
+    RLDM_HIP_CHECK(hipMemcpy(ho.data(), dout.p, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) hx[i] = bf16_to_f32(ho[i]);
+    RLDM_HIP_CHECK(hipMemcpy(out, hx.data(), n * 4, hipMemcpyHostToDevice));
     return 0;
 }
 

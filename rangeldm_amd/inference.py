@@ -49,14 +49,51 @@ def load_config(cfg):
         y = yaml.safe_load(f)
     mc = dict(y["model_config"])
     mc["sample_size"] = tuple(mc["sample_size"])
+    # ldm/inference.py:99-118: `all_circonv` swaps every conv / downsampler for the circular ones; `sub_circonv` only part of
+    # the net; neither: a plain zero-padded UNet.  Only the first is built -- refuse the others loudly.
+    if y.get("sub_circonv", False) and not y.get("all_circonv", False):
+        raise NotImplementedError("sub_circonv (ldm/inference.py:105-118) is not supported; use all_circonv")
+    if not y.get("all_circonv", False):
+        raise NotImplementedError("configs without all_circonv (zero-padded convolutions) are not supported")
     unet = UNetConfig(**{k: v for k, v in mc.items() if k in UNetConfig.__dataclass_fields__})
     vae = None
     if y.get("with_vae", False):
-        f = 4                                   # vae/configs/kitti360.yaml:35-41: ch_mult [1,2,4] -> 4x
-        vae = VAEConfig(sample_size=(unet.sample_size[0] * f, unet.sample_size[1] * f))
+        vae = vae_config_for(y, unet, os.path.dirname(os.path.abspath(cfg)))
     return dict(unet=unet, vae=vae, pos_encoding=bool(y.get("pos_encoding", False)), cond_channels=0,
                 steps=int(y.get("ddpm_num_inference_steps", 50)), ddim=bool(y.get("ddim", False)),
                 batch=int(y.get("eval_batch_size", 16)))
+
+
+def vae_config_for(y, unet, base_dir):
+    """VAE geometry of a reference yaml: `vae_config` names the sgm yaml the VAE was trained with
+    (ldm/configs/RangeLDM.yaml: ../vae/configs/kitti360.yaml; ldm/train_unconditional.py:250-271 reads it).  When that file
+    is reachable its ddconfig is used; otherwise the shipped default (ch 64, ch_mult [1, 2, 4], 4x) -- a `--weights`
+    directory always overrides both with the checkpoint's own config.json."""
+    from .checkpoint import vae_config_from_sgm_yaml
+    path = y.get("vae_config")
+    if path:
+        path = path if os.path.isabs(path) else os.path.normpath(os.path.join(base_dir, path))
+        if os.path.isfile(path):
+            import yaml
+            with open(path) as f:
+                v = vae_config_from_sgm_yaml(yaml.safe_load(f))
+            f_ = v.downscale
+            v.sample_size = (unet.sample_size[0] * f_, unet.sample_size[1] * f_)
+            return v
+    f_ = VAEConfig().downscale                      # vae/configs/kitti360.yaml:35-41: ch_mult [1,2,4] -> 4x
+    return VAEConfig(sample_size=(unet.sample_size[0] * f_, unet.sample_size[1] * f_))
+
+
+def device_step_noise(seed, global_indices, steps, lat_shape, device):
+    """[steps][B, C, W, H] ancestral noise, drawn ON THE DEVICE from one generator per GLOBAL sample index (seed and index
+    only: independent of rank, world size and batch composition).  The reference draws it from the unseeded global device RNG
+    (ldm/pipelines.py:362 passes no generator), which is not reproducible across runs or GPU counts."""
+    out = torch.empty((steps, len(global_indices), *lat_shape), device=device, dtype=torch.float32)
+    for b, gidx in enumerate(global_indices):
+        g = torch.Generator(device=device)
+        g.manual_seed((int(seed) * 1000003 + int(gidx)) & 0x7fffffffffffffff)
+        out[:, b] = torch.randn((steps, *lat_shape), generator=g, device=device, dtype=torch.float32)
+    return out
 
 
 def save_png(pixels_u8, path):
@@ -116,7 +153,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
 
     from .params import unet_param_shapes, vae_param_shapes
-    from .pipelines import DDIMPipelineRange, LDMPipelineRange
+    from .pipelines import DDIMPipelineRange, DDPMPipelineRange, LDMPipelineRange
     from .schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
     from .synth import latent_noise, synth_state_dict
     from .unet import UNet2DModelHIP
@@ -151,20 +188,28 @@ def main(argv=None):
         # ldm/inference.py:131-136: the LDM branch keeps the DDPM scheduler (strided ancestral sampling)
         pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDPMSchedulerHIP(sched_cfg),
                                 pos_encoding=cfg["pos_encoding"])
-    else:
+    elif cfg.get("ddim", True):
         pipe = DDIMPipelineRange(unet=unet, scheduler=DDIMSchedulerHIP(sched_cfg), pos_encoding=cfg["pos_encoding"])
-    lat_shape = (cfg["unet"].out_channels, *cfg["unet"].sample_size)
+    else:
+        # ldm/inference.py:141-145: ddim False -> DDPMPipelineRange (ancestral sampling in pixel space; it takes no
+        # pos_encoding argument in the reference either: ldm/pipelines.py:27-31)
+        pipe = DDPMPipelineRange(unet=unet, scheduler=DDPMSchedulerHIP(sched_cfg))
+    ddpm = isinstance(pipe.scheduler, DDPMSchedulerHIP)
+    lat_ch = cfg["unet"].in_channels if isinstance(pipe, DDPMPipelineRange) else cfg["unet"].out_channels
+    lat_shape = (lat_ch, *cfg["unet"].sample_size)
     to_range = None
 
     for i in range(plan_iterations(a.samples, B, world)):
         keep = image_indices(i, B, rank, world, a.samples)
         if not keep:
             continue
-        # x_T is a function of the GLOBAL image index: any GPU count produces the same images
+        # x_T AND the ancestral step noise are functions of the GLOBAL image index: any GPU count produces the same images
         idx = D.global_sample_indices(i, B, rank, world)
         x_T = torch.from_numpy(np.stack([latent_noise(a.seed, j, lat_shape) for j in idx])).to(dev)
-        gen = torch.Generator().manual_seed(a.seed + 1000 * rank + i)       # DDPM step noise
-        image = pipe(batch_size=B, generator=gen, num_inference_steps=steps, output_type="torch", latents=x_T)
+        kw = {}
+        if ddpm:
+            kw["step_noise"] = device_step_noise(a.seed, idx, steps, lat_shape, dev)
+        image = pipe(batch_size=B, num_inference_steps=steps, output_type="torch", latents=x_T, **kw)
         if to_range is None:
             to_range = sensor_for(image.shape[3])
         points, counts, bev_u8, range_u8 = postprocess(to_range, image)

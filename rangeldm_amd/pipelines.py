@@ -29,10 +29,13 @@ class _FusedSampler:
         self._cache = {}
 
     def get(self, unet, vae, scheduler, batch, steps, mode, pos_encoding, cond_channels, eta=0.0):
+        # keyed by the model objects themselves (kept alive by the cache entry, so an id is never reused for another
+        # model); weights reloaded through load_state_dict are picked up by the library: rldm_sample re-plans and
+        # re-captures when the model's generation counter moved (include/rangeldm_hip.h, rldm_unet_finalize)
         key = (id(unet), id(vae), batch, steps, mode, bool(pos_encoding), cond_channels, float(eta))
-        h = self._cache.get(key)
-        if h is not None:
-            return h
+        ent = self._cache.get(key)
+        if ent is not None:
+            return ent[0]
         scheduler.set_timesteps(steps)
         ts = scheduler.timesteps.numpy().astype(np.int64)
         if mode == 0:
@@ -50,7 +53,7 @@ class _FusedSampler:
         h = C.c_void_p()
         _lib.check(_lib.lib().rldm_sampler_create(unet._h, vae._h if vae is not None else None, C.byref(cfg),
                                                   C.byref(h)), "rldm_sampler_create")
-        self._cache[key] = h
+        self._cache[key] = (h, unet, vae)
         return h
 
     def run(self, h, x_T, step_noise, cond, out, latents_out=None):
@@ -61,8 +64,8 @@ class _FusedSampler:
 
     def __del__(self):
         try:
-            for h in self._cache.values():
-                _lib.lib().rldm_sampler_destroy(h)
+            for ent in self._cache.values():
+                _lib.lib().rldm_sampler_destroy(ent[0])
         except Exception:
             pass
 
@@ -123,7 +126,10 @@ class _PipelineBase:
         return ImagePipelineOutput(images=image)
 
     def _draw_step_noise(self, n_steps, timesteps, shape, generator, device):
-        """One randn per step with t > 0, in loop order, from the same RNG the reference's scheduler.step would use."""
+        """One randn per step with t > 0, in loop order.  The reference's latent pipelines call `scheduler.step` without a
+        generator (ldm/pipelines.py:362,502), i.e. they draw from the unseeded global RNG of the device; here the caller's
+        `generator` seeds the step noise as well (after x_T, in loop order), so a seeded call is reproducible.  With
+        generator=None the global device RNG is used, as in the reference."""
         zs = torch.zeros((n_steps, *shape), device=device, dtype=torch.float32)
         for i, t in enumerate(timesteps):
             if int(t) > 0:
@@ -140,22 +146,32 @@ class DDPMPipelineRange(_PipelineBase):
 
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, num_inference_steps=1000, output_type="torch", return_dict=True,
-                 fused=True):
+                 fused=True, latents=None, step_noise=None):
+        """`latents` / `step_noise` (not in the reference signature): x_T and the [steps][B, C, W, H] ancestral noise
+        already on the device, instead of drawing them from `generator`."""
         cfg = self.unet.config
         ss = cfg.sample_size if not isinstance(cfg.sample_size, int) else (cfg.sample_size, cfg.sample_size)
         shape = (batch_size, cfg.in_channels, *ss)
-        image = randn_tensor(shape, generator=generator, device=self.device, dtype=torch.float32)
+        if latents is not None:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"latents shape {tuple(latents.shape)} != {shape}")
+            image = latents.to(device=self.device, dtype=torch.float32)
+        else:
+            image = randn_tensor(shape, generator=generator, device=self.device, dtype=torch.float32)
         self.scheduler.set_timesteps(num_inference_steps)
         if fused and isinstance(self.scheduler, DDPMSchedulerHIP):
-            zs = self._draw_step_noise(num_inference_steps, self.scheduler.timesteps, shape, generator, self.device)
+            zs = step_noise if step_noise is not None else self._draw_step_noise(
+                num_inference_steps, self.scheduler.timesteps, shape, generator, self.device)
+            zs = zs.to(self.device, torch.float32).contiguous()
             h = self._fused.get(self.unet, None, self.scheduler, batch_size, num_inference_steps, 1, False, 0)
             out = torch.empty_like(image)
             self._fused.run(h, image.contiguous(), zs, None, out)
             image = out
         else:
-            for t in self.progress_bar(self.scheduler.timesteps):
+            for i, t in enumerate(self.progress_bar(self.scheduler.timesteps)):
                 model_output = self.unet(image, t).sample
-                image = self.scheduler.step(model_output, t, image, generator=generator).prev_sample
+                kw = {"noise": step_noise[i]} if step_noise is not None else {"generator": generator}
+                image = self.scheduler.step(model_output, t, image, **kw).prev_sample
         return self._finish(image, output_type, return_dict)
 
 
@@ -233,7 +249,7 @@ class LDMPipelineRange(_PipelineBase):
             zs = None
             if mode == 1:
                 zs = step_noise if step_noise is not None else self._draw_step_noise(
-                    num_inference_steps, self.scheduler.timesteps, shape, None, self.device)
+                    num_inference_steps, self.scheduler.timesteps, shape, generator, self.device)
                 zs = zs.to(self.device, torch.float32).contiguous()
             h = self._fused.get(self.unet, self.vae, self.scheduler, batch_size, num_inference_steps, mode,
                                 self.pos_encoding, 0)
@@ -275,9 +291,12 @@ class LDMUpscalePipelineRange(_PipelineBase):
         super().__init__()
         self.register_modules(vae=vae, unet=unet, scheduler=scheduler)
 
-    def encode_masked_image(self, image, mask, generator=None):
+    def encode_masked_image(self, image, mask, generator=None, noise=None):
+        """ldm/pipelines.py:406-412.  `generator` / `noise` (not in the reference signature) seed or inject the draw of
+        `latent_dist.sample()`."""
         image = image.to(self.unet.device)
-        image = self.vae.encode(image).latent_dist.sample(generator=generator)
+        dist = self.vae.encode(image).latent_dist
+        image = dist.sample(noise=noise) if noise is not None else dist.sample(generator=generator)
         image = image * self.vae.config.scaling_factor
         mask = mask.to(self.unet.device)
         mask = torch.nn.functional.interpolate(mask, size=image.shape[-2:])
@@ -286,7 +305,7 @@ class LDMUpscalePipelineRange(_PipelineBase):
     @torch.no_grad()
     def __call__(self, image, mask=None, condition_encoder=None, batch_size=1, generator=None, eta=0.0,
                  num_inference_steps=50, output_type="torch", return_dict=True, fused=True, latents=None,
-                 step_noise=None, **kwargs):
+                 step_noise=None, encode_noise=None, **kwargs):
         if image is None:
             raise ValueError("`image` input cannot be undefined.")
         cfg = self.unet.config
@@ -298,7 +317,7 @@ class LDMUpscalePipelineRange(_PipelineBase):
             assert condition_encoder is not None
             image = condition_encoder(image)
         else:
-            image = self.encode_masked_image(image, mask)
+            image = self.encode_masked_image(image, mask, generator=generator, noise=encode_noise)
         image = image.to(dtype=latents.dtype, device=self.unet.device)
         height, width = image.shape[2:]
         assert cfg.in_channels == cfg.out_channels + image.shape[1]
@@ -313,7 +332,7 @@ class LDMUpscalePipelineRange(_PipelineBase):
             zs = None
             if mode == 1:
                 zs = step_noise if step_noise is not None else self._draw_step_noise(
-                    num_inference_steps, self.scheduler.timesteps, shape, None, self.device)
+                    num_inference_steps, self.scheduler.timesteps, shape, generator, self.device)
                 zs = zs.to(self.device, torch.float32).contiguous()
             h = self._fused.get(self.unet, self.vae, self.scheduler, batch_size, num_inference_steps, mode, False,
                                 image.shape[1])

@@ -97,6 +97,9 @@ class UNetTrainer:
                  max_grad_norm=1.0, use_ema=True, ema_max_decay=0.9999, ema_inv_gamma=1.0, ema_power=0.75,
                  lr_warmup_steps=500, total_steps=100000, bucket_mb=32):
         self.cfg = config if isinstance(config, UNetConfig) else UNetConfig(**config)
+        if not self.cfg.flip_sin_to_cos or self.cfg.freq_shift != 0:
+            raise NotImplementedError("the training step implements UNet2DModel's default time embedding "
+                                      "(flip_sin_to_cos=True, freq_shift=0) only")
         _lib.require_gpu()
         self.device = torch.device(device)
         self.shapes = unet_param_shapes(self.cfg)

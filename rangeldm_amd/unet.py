@@ -57,6 +57,7 @@ class UNet2DModelHIP:
         c.norm_num_groups = config.norm_num_groups
         c.norm_eps = config.norm_eps
         c.mid_attention = 1 if config.add_attention else 0
+        c.flip_sin_to_cos, c.freq_shift = int(bool(config.flip_sin_to_cos)), int(config.freq_shift)
         self._h = C.c_void_p()
         _lib.check(L.rldm_unet_create(C.byref(c), C.byref(self._h)), "rldm_unet_create")
         self._shapes = unet_param_shapes(config)

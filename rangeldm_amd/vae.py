@@ -121,7 +121,12 @@ class AutoencoderKLHIP:
                 dk = sgm_to_diffusers_vae_key(k, len(self._cfg.ch_mult))
                 if dk is not None and dk in self._shapes:
                     sd[dk] = v
-                elif strict and (k.startswith("encoder.") or k.startswith("decoder.")) and "attn" not in k:
+                elif ".attentions." in k or ".attn_" in k or ".attn." in k:
+                    # ldm/inference.py:94-95 swaps attention for identity only when the checkpoint has NO attention
+                    # weights; one that has them was trained with mid-block attention and would decode wrongly here
+                    raise NotImplementedError(f"VAE checkpoint holds attention weights ({k}): mid-block attention is not "
+                                              "implemented (the reference's range-image VAEs use attn_type none)")
+                elif strict and (k.startswith("encoder.") or k.startswith("decoder.")):
                     raise RuntimeError(f"unexpected VAE key {k}")
         missing = [k for k in self._shapes if k not in sd]
         if strict and missing:

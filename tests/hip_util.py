@@ -85,3 +85,26 @@ def hip_conv_stats(x0, weight, bias, stride=1):
                                                _lib.stream_ptr(dev)), "rldm_test_conv_stats")
     torch.cuda.synchronize()
     return st.cpu()
+
+
+def hip_attention_qkv(x, gamma, beta, wqkv, bqkv, groups=32, eps=1e-5):
+    """rldm_test_attention_qkv: the fused GroupNorm -> q/k/v -> softmax.V launch of every UNet attention block.
+    x (B, L, C) token-major fp32 -> (B, L, C) heads concatenated (before to_out)."""
+    dev = torch.device("cuda")
+    B, L, C_ = x.shape
+    xs = x.to(dev, torch.float32).contiguous()
+    out = torch.empty((B, L, C_), device=dev, dtype=torch.float32)
+
+    def hostp(t):
+        a = np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    hg, pg = hostp(gamma)
+    hb, pb = hostp(beta)
+    hw, pw = hostp(wqkv)
+    hq, pq = hostp(bqkv)
+    _lib.check(_lib.lib().rldm_test_attention_qkv(C.c_void_p(xs.data_ptr()), B, L, C_, groups, eps, pg, pb, pw, pq,
+                                                  C.c_void_p(out.data_ptr()), _lib.stream_ptr(dev)),
+               "rldm_test_attention_qkv")
+    torch.cuda.synchronize()
+    return out.cpu()

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from rangeldm_amd import _lib
-    assert ctypes.sizeof(_lib.UNetConfigC) == 4 * (6 + 3 * 8 + 4)
+    assert ctypes.sizeof(_lib.UNetConfigC) == 4 * (6 + 3 * 8 + 6)
     assert ctypes.sizeof(_lib.VAEConfigC) == 4 * (4 + 8 + 6)
     assert ctypes.sizeof(_lib.ConvDescC) == 4 * 13
     assert ctypes.sizeof(_lib.TrainConvDescC) == 4 * 8 and ctypes.sizeof(_lib.AdamWConfigC) == 4 * 8
@@ -125,11 +125,29 @@ def test_inference_driver_index_arithmetic():
 def test_inference_driver_reads_reference_yaml(tmp_path):
     from rangeldm_amd.inference import load_config
     y = tmp_path / "RangeLDM.yaml"
-    y.write_text("eval_batch_size: 16\nddpm_num_inference_steps: 50\nwith_vae: True\npos_encoding: True\n"
+    y.write_text("eval_batch_size: 16\nddpm_num_inference_steps: 50\nwith_vae: True\npos_encoding: True\nall_circonv: True\n"
+                 "ddim: True\nvae_config: ../vae/configs/kitti360.yaml\n"
                  "model_config:\n  sample_size: [256, 16]\n  in_channels: 5\n  out_channels: 4\n  layers_per_block: 2\n"
                  "  block_out_channels: [128, 128, 256, 256]\n"
                  "  down_block_types: [DownBlock2D, AttnDownBlock2D, AttnDownBlock2D, AttnDownBlock2D]\n"
                  "  up_block_types: [AttnUpBlock2D, AttnUpBlock2D, AttnUpBlock2D, UpBlock2D]\n")
     c = load_config(str(y))
     assert c["unet"].sample_size == (256, 16) and c["unet"].in_channels == 5 and c["vae"].sample_size == (1024, 64)
-    assert c["steps"] == 50 and c["batch"] == 16 and c["pos_encoding"] is True
+    assert c["steps"] == 50 and c["batch"] == 16 and c["pos_encoding"] is True and c["ddim"] is True
+    # ldm/inference.py:99-118: only the all_circonv surgery is built; anything else must refuse, not run with other padding
+    import pytest
+    txt = y.read_text()
+    (tmp_path / "plain.yaml").write_text(txt.replace("all_circonv: True\n", ""))
+    with pytest.raises(NotImplementedError):
+        load_config(str(tmp_path / "plain.yaml"))
+    (tmp_path / "sub.yaml").write_text(txt.replace("all_circonv: True\n", "sub_circonv: True\n"))
+    with pytest.raises(NotImplementedError):
+        load_config(str(tmp_path / "sub.yaml"))
+    # the VAE geometry comes from the sgm yaml `vae_config` points at when it is reachable (here: an 8x VAE)
+    vdir = tmp_path / "vae"
+    vdir.mkdir()
+    (vdir / "v.yaml").write_text("model:\n  params:\n    ddconfig:\n      attn_type: none\n      double_z: true\n      z_channels: 4\n"
+                                 "      in_channels: 2\n      out_ch: 2\n      ch: 32\n      ch_mult: [1, 2, 4, 4]\n      num_res_blocks: 2\n")
+    (tmp_path / "v8.yaml").write_text(txt.replace("../vae/configs/kitti360.yaml", "vae/v.yaml"))
+    c8 = load_config(str(tmp_path / "v8.yaml"))
+    assert c8["vae"].ch == 32 and c8["vae"].downscale == 8 and c8["vae"].sample_size == (2048, 128)

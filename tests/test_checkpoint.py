@@ -112,6 +112,16 @@ def test_checkpoint_errors(tmp_path):
         ck.load_unet_dir(str(tmp_path / "unet"))
     with pytest.raises(FileNotFoundError):
         ck.load_output_dir(str(tmp_path / "nope"))
+    # a VAE trained WITH mid-block attention must not load as an attention-free one (ldm/inference.py:94-95 swaps attention
+    # for identity only when the checkpoint has no attention weights)
+    vsd = synth_state_dict(vae_param_shapes(SMALL_VAE), prefix="v.")
+    vsd["encoder.mid_block.attentions.0.to_q.weight"] = np.zeros((128, 128), np.float32)
+    ck.save_model_dir(str(tmp_path / "vae"), ck.vae_config_to_diffusers(SMALL_VAE), vsd)
+    with pytest.raises(NotImplementedError, match="attention"):
+        ck.load_vae_dir(str(tmp_path / "vae"))
+    # flip_sin_to_cos / freq_shift are UNet2DModel kwargs that change the arithmetic: they round-trip through config.json
+    cfg = UNetConfig(sample_size=(32, 8), block_out_channels=(32, 32, 64, 64), flip_sin_to_cos=False, freq_shift=1)
+    assert ck.unet_config_from_diffusers(ck.unet_config_to_diffusers(cfg)) == cfg
 
 
 @pytest.mark.gpu

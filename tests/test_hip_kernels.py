@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ops
-from tests.hip_util import bf16r, rel_l2, hip_conv, hip_attention, hip_conv_stats
+from tests.hip_util import bf16r, rel_l2, hip_conv, hip_attention, hip_attention_qkv, hip_conv_stats
 
 pytestmark = pytest.mark.gpu
 TOL_Q, TOL_F = 4e-3, 2e-2
@@ -215,3 +215,72 @@ def test_attention_large_logits():
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 3e-2
+
+
+def _attn_qkv_ref(x, gamma, beta, wqkv, bqkv, eps=1e-5, rounded=True):
+    """oracle.unet.attention_block's arithmetic up to (not including) to_out, on token-major x (B, L, C)."""
+    B, L, C = x.shape
+    r = bf16r if rounded else (lambda t: t)
+    y = F.group_norm(r(x).transpose(1, 2), 32, gamma, beta, eps).transpose(1, 2)
+    q, k, v = (F.linear(y, r(wqkv[i * C:(i + 1) * C]), bqkv[i * C:(i + 1) * C]) for i in range(3))
+    qh, kh, vh = (t.view(B, L, C // 8, 8).transpose(1, 2) for t in (q, k, v))
+    return F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, L, C)
+
+
+# every (L, C) of SURVEY.md A.4 (RangeLDM: 1024 x 128, 256 x 256, 64 x 256; RangeDM: 256 x 512, 64 x 512; nuScenes: 512 x 128,
+# 128 x 256, 32 x 256) plus ragged token counts and the small-config widths
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 128), (2, 256, 256), (3, 64, 256), (1, 256, 512), (1, 64, 512), (2, 512, 128),
+                                   (2, 128, 256), (4, 32, 256), (2, 100, 64), (1, 8, 32), (2, 1000, 128), (1, 48, 16)])
+def test_attention_qkv_fused_kernel(B, L, C):
+    """attention_qkv_d8_kernel alone (the kernel the UNet runs; rldm_test_attention above is the unfused fallback)."""
+    if C % 32:
+        pytest.skip("GroupNorm(32) needs C % 32 == 0")
+    x = _rand(B, L, C, seed=30) * 1.5 + 0.3
+    gamma, beta = 1 + 0.2 * _rand(C, seed=31), 0.2 * _rand(C, seed=32)
+    wqkv = _rand(3 * C, C, seed=33, scale=2.0 * C ** -0.5)          # sharper softmax than unit-variance logits
+    bqkv = _rand(3 * C, seed=34, scale=0.1)
+    out = hip_attention_qkv(x, gamma, beta, wqkv, bqkv)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, _attn_qkv_ref(x, gamma, beta, wqkv, bqkv)) < 1e-2
+    assert rel_l2(out, _attn_qkv_ref(x, gamma, beta, wqkv, bqkv, rounded=False)) < TOL_F
+    # per head, not just on average: a wrong head would hide in a whole-tensor norm
+    ref = _attn_qkv_ref(x, gamma, beta, wqkv, bqkv)
+    for h in range(C // 8):
+        assert rel_l2(out[..., 8 * h:8 * h + 8], ref[..., 8 * h:8 * h + 8]) < 2e-2, h
+
+
+def test_attention_qkv_dominant_key():
+    """one key far outside the first tiles dominates every query (running-maximum / rescale path of the key loop)."""
+    B, L, C = 1, 256, 64
+    x = _rand(B, L, C, seed=35)
+    x[0, 200] *= 6.0
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    wqkv = _rand(3 * C, C, seed=36, scale=4.0 * C ** -0.5)
+    bqkv = torch.zeros(3 * C)
+    out = hip_attention_qkv(x, gamma, beta, wqkv, bqkv)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, _attn_qkv_ref(x, gamma, beta, wqkv, bqkv)) < 3e-2
+
+
+def test_attention_block_matches_reference_crossattention(golden):
+    """GroupNorm + the REFERENCE's multi-head CrossAttention(heads=C/8, dim_head=8) + x (tests/golden/mha.npz, produced by
+    vae/sgm/modules/attention.py:194-284): fused attention launch + to_out projection + residual on the GPU."""
+    from rangeldm_amd.synth import synth_state_dict
+    import numpy as np
+    g = golden("mha")
+    for C, L in ((128, 64), (256, 64), (128, 1024), (256, 1024)):
+        tag = f"C{C}_L{L}"
+        shapes = {"a.group_norm.weight": (C,), "a.group_norm.bias": (C,), "a.to_out.0.weight": (C, C), "a.to_out.0.bias": (C,)}
+        for n in ("to_q", "to_k", "to_v"):
+            shapes[f"a.{n}.weight"] = (C, C)
+        sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(shapes, prefix=f"mha/{tag}/").items()}
+        x = torch.from_numpy(np.asarray(g[f"mha_{tag}_x"], dtype=np.float32))
+        ref = torch.from_numpy(np.asarray(g[f"mha_{tag}_y"], dtype=np.float32))
+        B, _, W, H = x.shape
+        wqkv = torch.cat([sd[f"a.{n}.weight"] * 2.0 for n in ("to_q", "to_k", "to_v")], 0)
+        o = hip_attention_qkv(x.view(B, C, W * H).transpose(1, 2).contiguous(), sd["a.group_norm.weight"],
+                              sd["a.group_norm.bias"], wqkv, torch.zeros(3 * C))
+        o = o.transpose(1, 2).reshape(B, C, W, H)
+        y = hip_conv(o, sd["a.to_out.0.weight"].view(C, C, 1, 1), sd["a.to_out.0.bias"], res=x)
+        assert rel_l2(y - x, ref - x) < TOL_F, tag          # the attention branch itself, not hidden behind the residual
+        assert rel_l2(y, ref) < 5e-3, tag

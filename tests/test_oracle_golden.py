@@ -177,3 +177,125 @@ def test_timestep_embedding_closed_form():
     for i in (0, 1, 63):
         f = math.exp(-math.log(10000.0) * i / 64)
         assert abs(float(e[0, i]) - math.cos(980 * f)) < 1e-4 and abs(float(e[0, 64 + i]) - math.sin(980 * f)) < 1e-4
+
+
+# ---- vectors produced by oracle/validate_unet_against_reference.py from code that IS in the reference: the multi-head
+# CrossAttention (vae/sgm/modules/attention.py:194-284), get_timestep_embedding and the skip-concat / temb UNet `Model`
+# (vae/sgm/modules/diffusionmodules/model.py:28-46, 521-704) after the reference's own surgery, and the reference's
+# LDMPipelineRange / LDMUpscalePipelineRange loops driving them for 50 steps -----------------------------------------
+def _zero_qkv_bias(sd):
+    for k in sd:
+        if any(k.endswith(f".{n}.bias") for n in ("to_q", "to_k", "to_v")):
+            sd[k] = np.zeros_like(sd[k])
+    return sd
+
+
+def ref_unet_sd(cfg, prefix):
+    """the weights of the reference-composed Model: synthetic, q/k/v biases zero (CrossAttention has none)."""
+    return _zero_qkv_bias(synth_state_dict(unet_param_shapes(cfg), prefix=prefix))
+
+
+SGM_SINUSOID = dict(flip_sin_to_cos=False, freq_shift=1)      # get_timestep_embedding of the reference (model.py:28-46)
+REF_UNETS = {
+    "small": dict(sample_size=(64, 8), block_out_channels=(32, 32, 64, 64)),
+    "rangedm_topology": dict(sample_size=(128, 32), in_channels=3, out_channels=2, block_out_channels=(32, 32, 64, 64, 96, 96),
+                             down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+                             up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4),
+}
+
+
+def test_multihead_attention_matches_reference_crossattention(golden):
+    g = golden("mha")
+    for C, L, tol in ((128, 64, 3e-5), (256, 64, 3e-5), (128, 1024, 3e-3), (256, 1024, 3e-3)):     # L=1024 stored as fp16
+        tag = f"C{C}_L{L}"
+        shapes = {"a.group_norm.weight": (C,), "a.group_norm.bias": (C,), "a.to_out.0.weight": (C, C), "a.to_out.0.bias": (C,)}
+        for n in ("to_q", "to_k", "to_v"):
+            shapes[f"a.{n}.weight"] = (C, C)
+        sd = synth_state_dict(shapes, prefix=f"mha/{tag}/")
+        for n in ("to_q", "to_k", "to_v"):
+            sd[f"a.{n}.weight"] = sd[f"a.{n}.weight"] * 2.0
+            sd[f"a.{n}.bias"] = np.zeros(C, np.float32)
+        y = o_unet.attention_block({k: T(v) for k, v in sd.items()}, "a", T(g[f"mha_{tag}_x"]).float(), 32, 1e-5, 8)
+        assert (y - T(g[f"mha_{tag}_y"]).float()).abs().max() < tol, tag
+
+
+@pytest.mark.parametrize("name", list(REF_UNETS))
+@pytest.mark.parametrize("sinus", ["sgm", "unet2d"])
+def test_unet_wiring_matches_reference_model(golden, name, sinus):
+    g = golden("unetref")
+    cfg = UNetConfig(**REF_UNETS[name], **(SGM_SINUSOID if sinus == "sgm" else {}))
+    sd = {k: T(v) for k, v in ref_unet_sd(cfg, f"ref/{name}.").items()}
+    eps = o_unet.unet_forward(sd, cfg, T(g[f"unetref_{name}_{sinus}_x"]), T(g[f"unetref_{name}_{sinus}_t"]))
+    ref = T(g[f"unetref_{name}_{sinus}_eps"])
+    assert (eps - ref).abs().max() < 2e-5 * float(ref.abs().max())
+
+
+def test_unet_full_width_matches_reference_model(golden):
+    g = golden("unetref")
+    cfg = UNetConfig(**SGM_SINUSOID)
+    sd = {k: T(v) for k, v in ref_unet_sd(cfg, "ref/full.").items()}
+    eps = o_unet.unet_forward(sd, cfg, T(g["unetref_full_x"]), int(g["unetref_full_t"][0]))
+    ref = T(g["unetref_full_sgm_eps"])
+    assert (eps - ref).abs().max() < 2e-5 * float(ref.abs().max())
+
+
+def test_other_presets_match_reference_modules(golden):
+    from rangeldm_amd.config import PRESETS
+    g = golden("presets")
+    cfg = UNetConfig(in_channels=12, **SGM_SINUSOID)
+    sd = {k: T(v) for k, v in ref_unet_sd(cfg, "ref/up.").items()}
+    ref = T(g["presets_up_eps"])
+    assert (o_unet.unet_forward(sd, cfg, T(g["presets_up_x"]), 700) - ref).abs().max() < 2e-5 * float(ref.abs().max())
+    vcfg = VAEConfig()
+    vsd = {k: T(v) for k, v in synth_state_dict(vae_param_shapes(vcfg), prefix="vae.").items()}
+    img = o_vae.vae_decode(vsd, vcfg, T(g["presets_nusc_z"]))
+    assert (img - T(g["presets_nusc_image_f16"]).float()).abs().max() < 3e-3
+    kw = {k: v for k, v in PRESETS["RangeDM"]["unet"].to_dict().items() if k not in SGM_SINUSOID}
+    rcfg = UNetConfig(**kw, **SGM_SINUSOID)
+    rsd = {k: T(v) for k, v in ref_unet_sd(rcfg, "ref/rangedm.").items()}
+    ref = T(g["presets_rangedm_eps"])
+    eps = o_unet.unet_forward(rsd, rcfg, T(g["presets_rangedm_x_f16"]).float(), 900)
+    assert (eps - ref).abs().max() < 2e-5 * float(ref.abs().max())
+
+
+def test_inpainting_mask_path_matches_reference(golden):
+    """LDMUpscalePipelineRange.encode_masked_image + loop (ldm/pipelines.py:406-412, 466-507) on sgm Encoder/Decoder."""
+    import torch.nn.functional as F
+    g = golden("inpaint")
+    vcfg = VAEConfig()
+    vae = o_vae.OracleVAE(vcfg, synth_state_dict(vae_param_shapes(vcfg), prefix="vae."))
+    img, mask = T(g["inpaint_image"]), T(g["inpaint_mask"])
+    lat = vae.encode(img * mask).latent_dist.sample(noise=T(g["inpaint_enc_noise"])) * vcfg.scaling_factor
+    cond = torch.cat([lat, F.interpolate(mask, size=lat.shape[-2:])], 1)
+    assert (cond - T(g["inpaint_cond_ref"])).abs().max() < 5e-5
+    lat = vae.encode(img * mask).latent_dist.sample(noise=T(g["inpaint_enc_noise2"])) * vcfg.scaling_factor
+    cond = torch.cat([lat, F.interpolate(mask, size=lat.shape[-2:])], 1)
+    zs = [z for z in T(g["inpaint_step_noise"])] + [None]
+    out = o_pipe.ldm_pipeline(vae, _small(9, 4, "smallinp."), o_sched.OracleDDPMScheduler(), T(g["inpaint_x_T"]), 3,
+                              pos_encoding=False, step_noise=zs, cond=cond)
+    assert (out - T(g["inpaint_image_ref"])).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("sched", ["ddim", "ddpm"])
+def test_50_step_full_width_sampler_matches_reference_loop(golden, sched):
+    """The headline workload at batch 1: 50 steps of the full-width RangeLDM UNet + VAE decode.  The golden is the
+    reference's LDMPipelineRange.__call__ (ldm/pipelines.py:282-383) driving the reference-composed Model and the sgm Decoder."""
+    from rangeldm_amd.synth import normal
+    g = golden("traj")
+    cfg = UNetConfig(**SGM_SINUSOID)
+    unet = o_unet.OracleUNet(cfg, ref_unet_sd(cfg, "ref/full."))
+    vcfg = VAEConfig()
+    vae = o_vae.OracleVAE(vcfg, synth_state_dict(vae_param_shapes(vcfg), prefix="vae."))
+    x_T = T(normal(51, f"traj/{sched}/x_T", (1, 4, 256, 16)))
+    zs = None if sched == "ddim" else [T(normal(52, f"traj/z/{i}", (1, 4, 256, 16))) for i in range(49)] + [None]
+    s = o_sched.OracleDDIMScheduler() if sched == "ddim" else o_sched.OracleDDPMScheduler()
+    traj = []
+    lat = o_pipe.ldm_pipeline(vae, unet, s, x_T, 50, pos_encoding=True, step_noise=zs, trajectory=traj, decode=False)
+    ref = T(g[f"traj_{sched}_latent_ref"])
+    assert float((lat - ref).norm() / ref.norm()) < 1e-4
+    for i in (1, 10, 25, 40, 49):
+        r = T(g[f"traj_{sched}_x_step{i}"])
+        assert float((traj[i][0] - r).norm() / r.norm()) < 1e-4, i
+    img = vae.decode(lat / vcfg.scaling_factor).sample
+    r = T(g[f"traj_{sched}_image_ref_f16"]).float()
+    assert float((img - r).norm() / r.norm()) < 2e-3
