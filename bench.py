@@ -7,8 +7,10 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch: x_T (already resident in HBM) -> 50 x [UNet forward + DDIM step]
--> VAE decode -> (N>1: RCCL all-gather of the finished range images).  Weak scaling: every GPU samples its own batch
-of 16 (whole samples are sharded; no collective on the data path except the final all-gather).  Weights are synthetic
+-> VAE decode -> (N>1: RCCL all-gather of the finished range images).  Weak scaling (default): every GPU samples its own
+batch of 16 (whole samples are sharded; no collective on the data path except the final all-gather).
+`--scaling strong --batch 32 --preset nuscenes` is BASELINE config 3: ONE global batch of 32 split over the ranks
+(4 images per GPU at N = 8), same all-gather; `value` is then global-batch images / time.  Weights are synthetic
 (rangeldm_amd.synth), the architecture and sizes are the reference's.
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
@@ -101,15 +103,10 @@ def roofline(pipe, sampler_handle, x_T, steps):
             for f in t:
                 t[f] += v[f] * mult
     all_ms = sum(v["ms"] for v in tot.values())
-    # dominant kernel = largest share of the kernel time.  conv_stream<256,128> (26.6 % in the rocprofv3 trace,
-    # profiles/round1_v25_rocprof_kernel_stats.txt) and the fused attention (21.9 % there; VALU-bound, its MFMAs carry 8 useful
-    # rows of 32) are within a percent of each other under this function's per-launch HIP events, so the choice is pinned to
-    # the trace's order unless another kernel leads by more than 10 %: the roofline object then describes the same kernel run
-    # after run.  Every kernel's own TFLOP/s is in `kernels`.
+    # dominant kernel = the measured leader of this run's per-launch HIP-event times (no name is pinned: conv_stream<256,128>
+    # and the fused attention trade places between runs, and whichever leads is reported; every kernel's own figures are in
+    # `kernels`)
     dom = max(tot, key=lambda k: tot[k]["ms"])
-    pinned = "conv_stream_kernel<256,128,CK64,taps9>"
-    if pinned in tot and tot[pinned]["ms"] >= tot[dom]["ms"] / 1.1:
-        dom = pinned
     d = tot[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     kernels = {k: {"share": round(v["ms"] / all_ms, 4), "launches_per_batch": v["launches"],
@@ -118,12 +115,15 @@ def roofline(pipe, sampler_handle, x_T, steps):
                    "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")       # HBM bytes per launch from the rocprofv3 --pmc passes
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom)
-        except (OSError, ValueError):
-            traffic = None
+    for name in ("round2_traffic.json", "round1_traffic.json"):          # HBM bytes per launch from the rocprofv3 --pmc passes
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except (OSError, ValueError):
+                traffic = None
+            if traffic is not None:
+                break
     rl = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
           "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
@@ -138,7 +138,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (weak) / global batch (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch images on EVERY GPU; strong: ONE global batch of --batch images sharded over the GPUs "
+                         "(BASELINE config 3: --preset nuscenes --batch 32 --scaling strong)")
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--sampler", choices=["ddim", "ddpm"], default="ddim")
     ap.add_argument("--preset", default="RangeLDM")
@@ -173,18 +176,27 @@ def main():
         pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
     else:
         pipe = DDIMPipelineRange(unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
-    B, S = args.batch, args.inference_steps
+    S = args.inference_steps
+    strong = args.scaling == "strong"
+    if strong:
+        if args.batch % world:
+            ap.error(f"--scaling strong needs --batch ({args.batch}) divisible by the number of GPUs ({world})")
+        lo, hi = D.shard_range(args.batch, rank, world)      # this rank's contiguous slice of every global batch
+        B = hi - lo
+    else:
+        B = args.batch
     lat_shape = (p["unet"].out_channels, *p["unet"].sample_size)
     n_iter = args.warmup + args.steps
 
     # inputs resident in HBM before the timed region; x_T is a function of the GLOBAL sample index
     xs = []
     for i in range(n_iter):
-        idx = D.global_sample_indices(i, B, rank, world)
+        idx = ([i * args.batch + j for j in range(lo, hi)] if strong else D.global_sample_indices(i, B, rank, world))
         xs.append(torch.from_numpy(np.stack([latent_noise(args.seed, j, lat_shape) for j in idx])).to(dev))
     zs = None
     if args.sampler == "ddpm":
-        zs = torch.from_numpy(np.stack([np.stack([step_noise(args.seed, j, s, lat_shape) for j in range(B)])
+        first = lo if strong else 0
+        zs = torch.from_numpy(np.stack([np.stack([step_noise(args.seed, first + j, s, lat_shape) for j in range(B)])
                                         for s in range(S)])).to(dev)
 
     def one_step(i):
@@ -212,13 +224,15 @@ def main():
     if rank == 0:
         total_images = world * B * args.steps
         res = {
-            "metric": "range-images/sec, KITTI-360 64x1024 50-step DDIM @ batch16, 1/2/4/8 GPU",
+            "metric": ("range-images/sec, KITTI-360 64x1024 50-step DDIM @ batch16, 1/2/4/8 GPU" if args.preset == "RangeLDM"
+                       else f"range-images/sec, {args.preset} {S}-step {args.sampler.upper()}"),
             "value": total_images / dt, "unit": "range-images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.preset} KITTI-360 64x1024 (latent {lat_shape[0]}x{lat_shape[1]}x{lat_shape[2]}), "
-                                   f"{S}-step {args.sampler.upper()} + VAE decode (4x), batch {B} per GPU, "
-                                   f"synthetic weights, x_T resident in HBM",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.preset} (latent {lat_shape[0]}x{lat_shape[1]}x{lat_shape[2]}), "
+                                   f"{S}-step {args.sampler.upper()}" + (" + VAE decode (4x)" if vae is not None else "") +
+                                   (f", global batch {args.batch} sharded {B} per GPU" if strong else f", batch {B} per GPU") +
+                                   ", synthetic weights, x_T resident in HBM",
                        "global_batch": B * world, "batch_per_gpu": B, "inference_steps": S, "sampler": args.sampler,
                        "parallelism": f"sample-sharded x{world}, RCCL all-gather of finished images"},
         }

@@ -37,10 +37,15 @@ def _worker(rank, world, port, q):
         x = torch.from_numpy(np.stack([latent_noise(7, j, shape) for j in idx]))
         outs.append(D.all_gather_images(_fake_sampler(x)))
     full = torch.cat(outs)
+    # strong scaling (bench.py --scaling strong, BASELINE config 3): ONE global batch split into contiguous per-rank slices
+    GB = 4
+    lo, hi = D.shard_range(GB, rank, world)
+    xs = torch.from_numpy(np.stack([latent_noise(7, 100 + j, shape) for j in range(lo, hi)]))
+    strong = D.all_gather_images(_fake_sampler(xs))
     t = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
     D.barrier()
     if rank == 0:
-        q.put((full.numpy(), t))
+        q.put((full.numpy(), t, strong.numpy()))
     dist.destroy_process_group()
 
 
@@ -51,7 +56,7 @@ def test_two_rank_sharding_and_allgather():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, tmax = q.get(timeout=120)
+    full, tmax, strong = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -61,6 +66,9 @@ def test_two_rank_sharding_and_allgather():
     B, shape = 3, (4, 8, 2)
     ref = torch.from_numpy(np.stack([latent_noise(7, j, shape) for j in range(2 * world * B)]))
     assert np.array_equal(full, _fake_sampler(ref).numpy())
+    # strong split: the gathered batch is the global batch in global order, whatever the rank count
+    ref = torch.from_numpy(np.stack([latent_noise(7, 100 + j, shape) for j in range(4)]))
+    assert np.array_equal(strong, _fake_sampler(ref).numpy())
 
 
 def test_index_arithmetic_single_process():

@@ -2,9 +2,9 @@
 CPU oracle and the golden vectors captured from the reference's own modules (tests/golden, see
 oracle/validate_against_reference.py).
 
-Tolerances: bf16 storage + fp32 accumulation => rel-L2 <= 2e-2 per network forward
-(teacher-forced), <= 3e-2 on free-running trajectories with injected noise (3-5 steps of the small networks and the full
-50 steps of the full-width RangeLDM sampler alike); fp32 elementwise kernels <= 1e-6."""
+Tolerances: bf16 storage + fp32 accumulation => rel-L2 <= 2e-2 per network forward (teacher-forced)
+and per decoded image of a free-running trajectory with injected noise; <= 1e-2 on the final latent x_0 of the full 50-step
+full-width sampler (measured on MI355X: 1.9e-3 DDIM, 2.4e-3 strided DDPM; decoded image 7e-3); fp32 elementwise kernels <= 1e-6."""
 import numpy as np
 import pytest
 import torch
@@ -17,7 +17,8 @@ from tests.hip_util import rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL_FWD = 2e-2
-TOL_TRAJ = 3e-2
+TOL_TRAJ = 2e-2      # decoded image at the end of a free-running trajectory
+TOL_X0 = 1e-2        # final latent of the 50-step full-width sampler
 
 
 def T(a):
@@ -353,7 +354,7 @@ def test_50_step_full_width_sampler_matches_reference_loop(golden, sched):
     e_lat = rel_l2(lat.cpu(), T(g[f"traj_{sched}_latent_ref"]))
     e_img = rel_l2(img.cpu(), T(g[f"traj_{sched}_image_ref_f16"]).float())
     print(f"50-step {sched}: final latent rel-L2 {e_lat:.3e}, decoded image rel-L2 {e_img:.3e}")
-    assert e_lat < TOL_TRAJ and e_img < TOL_TRAJ
+    assert e_lat < TOL_X0 and e_img < TOL_TRAJ
     # the public call gives the same image
     img2 = pipe(batch_size=1, num_inference_steps=50, latents=x_T, step_noise=zs, output_type="torch")
     assert torch.equal(img2, img)
