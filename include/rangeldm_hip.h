@@ -360,6 +360,8 @@ int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void*
  * -> out device fp32 [B][L][C], heads concatenated. */
 int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, float eps, const float* gamma, const float* beta,
                             const float* wqkv, const float* bqkv, float* out, void* stream);
+/* HIP-event time of that launch alone on synthetic data (tools/bench_attn.py) */
+int rldm_bench_attention_qkv(int B, int L, int C, int warmup, int iters, float* avg_us, void* stream);
 
 #ifdef __cplusplus
 }

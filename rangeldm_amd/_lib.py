@@ -140,6 +140,7 @@ PROTOTYPES = {
     "rldm_debug_block_times": (C.c_int, [_P, C.c_int]),
     "rldm_test_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_test_attention_qkv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "rldm_bench_attention_qkv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
 }
 
 _lib = None

@@ -2524,23 +2524,21 @@ int rldm_test_attention(const float* qkv, int B, int L, int C, float* out, void*
 // The fused GroupNorm -> to_q/to_k/to_v -> softmax(q k^T / sqrt(8)) v launch on its own (what runs inside every
 // attention block of the UNet): x device fp32 [B][L][C] (token-major), gamma/beta host [C], wqkv host [3C][C] (rows
 // q | k | v, torch Linear layout), bqkv host [3C] -> out device fp32 [B][L][C] (heads concatenated, before to_out).
-int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, float eps, const float* gamma, const float* beta,
-                            const float* wqkv, const float* bqkv, float* out, void* stream) {
-    RLDM_REQUIRE(x && gamma && beta && wqkv && bqkv && out, "null argument");
-    RLDM_REQUIRE(C % 16 == 0 && C % groups == 0, "attention_qkv: channels must be a multiple of 16 and of the group count");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+namespace {
+struct AttnCase {
+    DevBuf dx, dst, dg, dbt, dw, dbias, dout;
+    AttnQkvParams ap;
+};
+// x_bf16 host [B][L][C]; builds the per-image statistics row, the per-head fragments and the launch parameters
+int make_attn_case(AttnCase& ac, const std::vector<bf16_t>& hb, int B, int L, int C, int groups, float eps, const float* gamma,
+                   const float* beta, const float* wqkv, const float* bqkv) {
     const size_t n = (size_t)B * L * C;
-    std::vector<float> hx(n);
-    RLDM_HIP_CHECK(hipMemcpy(hx.data(), x, n * 4, hipMemcpyDeviceToHost));
-    std::vector<bf16_t> hb(n);
     std::vector<float> stats((size_t)B * C * 2, 0.f);      // one partial row per image: (sum, sum of squares) of the bf16 values
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c) {
             double S = 0.0, SS = 0.0;
             for (int l = 0; l < L; ++l) {
-                const size_t i = ((size_t)b * L + l) * C + c;
-                hb[i] = f32_to_bf16(hx[i]);
-                const double v = bf16_to_f32(hb[i]);
+                const double v = bf16_to_f32(hb[((size_t)b * L + l) * C + c]);
                 S += v;
                 SS += v * v;
             }
@@ -2554,26 +2552,75 @@ int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, flo
     std::vector<bf16_t> img;
     std::vector<float> bias;
     pack_attn_head_frags(w.data(), bb.data(), C, img, bias);
-    DevBuf dx, dst, dg, dbt, dw, dbias, dout;
-    if (upload(dx, hb.data(), n * 2) || upload(dst, stats.data(), stats.size() * 4) || upload(dg, gamma, C * 4) ||
-        upload(dbt, beta, C * 4) || upload(dw, img.data(), img.size() * 2) || upload(dbias, bias.data(), bias.size() * 4))
+    if (upload(ac.dx, hb.data(), n * 2) || upload(ac.dst, stats.data(), stats.size() * 4) || upload(ac.dg, gamma, C * 4) ||
+        upload(ac.dbt, beta, C * 4) || upload(ac.dw, img.data(), img.size() * 2) || upload(ac.dbias, bias.data(), bias.size() * 4))
         return 1;
-    if (dout.alloc(n * 2)) return 1;
-    AttnQkvParams ap;
+    if (ac.dout.alloc(n * 2)) return 1;
+    AttnQkvParams& ap = ac.ap;
     memset(&ap, 0, sizeof(ap));
-    ap.x = dx.as<bf16_t>(); ap.st = dst.as<float2>(); ap.P = 1;
-    ap.gamma = dg.as<float>(); ap.beta = dbt.as<float>(); ap.eps = eps; ap.groups = groups;
+    ap.x = ac.dx.as<bf16_t>(); ap.st = ac.dst.as<float2>(); ap.P = 1;
+    ap.gamma = ac.dg.as<float>(); ap.beta = ac.dbt.as<float>(); ap.eps = eps; ap.groups = groups;
     const int cpg = C / groups;
     ap.inv_n = (float)(1.0 / ((double)L * cpg));
     ap.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
-    ap.wfrag = dw.as<bf16_t>(); ap.bias = dbias.as<float>(); ap.out = dout.as<bf16_t>();
+    ap.wfrag = ac.dw.as<bf16_t>(); ap.bias = ac.dbias.as<float>(); ap.out = ac.dout.as<bf16_t>();
     ap.B = B; ap.L = L; ap.C = C;
-    if (launch_attention_qkv(ap, st)) return 1;
+    ap.ts = g_ts_buf;                                  // ABLATE builds: phase stamps (rldm_debug_timestamps)
+    ap.ts_L = L;
+    return 0;
+}
+}  // namespace
+
+int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, float eps, const float* gamma, const float* beta,
+                            const float* wqkv, const float* bqkv, float* out, void* stream) {
+    RLDM_REQUIRE(x && gamma && beta && wqkv && bqkv && out, "null argument");
+    RLDM_REQUIRE(C % 16 == 0 && C % groups == 0, "attention_qkv: channels must be a multiple of 16 and of the group count");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = (size_t)B * L * C;
+    std::vector<float> hx(n);
+    RLDM_HIP_CHECK(hipMemcpy(hx.data(), x, n * 4, hipMemcpyDeviceToHost));
+    std::vector<bf16_t> hb(n);
+    for (size_t i = 0; i < n; ++i) hb[i] = f32_to_bf16(hx[i]);
+    AttnCase ac;
+    if (make_attn_case(ac, hb, B, L, C, groups, eps, gamma, beta, wqkv, bqkv)) return 1;
+    if (launch_attention_qkv(ac.ap, st)) return 1;
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
     std::vector<bf16_t> ho(n);
-    RLDM_HIP_CHECK(hipMemcpy(ho.data(), dout.p, n * 2, hipMemcpyDeviceToHost));
+    RLDM_HIP_CHECK(hipMemcpy(ho.data(), ac.dout.p, n * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i) hx[i] = bf16_to_f32(ho[i]);
     RLDM_HIP_CHECK(hipMemcpy(out, hx.data(), n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// times the fused attention launch alone (HIP events on `stream`) on synthetic data of the given geometry
+int rldm_bench_attention_qkv(int B, int L, int C, int warmup, int iters, float* avg_us, void* stream) {
+    RLDM_REQUIRE(avg_us && iters >= 1 && C % 32 == 0, "bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = (size_t)B * L * C;
+    uint32_t rng = 4242u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    std::vector<bf16_t> hb(n);
+    for (auto& v : hb) v = f32_to_bf16(rnd() * 1.7f + 0.2f);
+    std::vector<float> gamma(C, 1.f), beta(C, 0.f), w((size_t)3 * C * C), bb((size_t)3 * C, 0.f);
+    const float ws = 2.0f / std::sqrt((float)C);
+    for (auto& v : w) v = rnd() * ws;
+    AttnCase ac;
+    if (make_attn_case(ac, hb, B, L, C, 32, 1e-5f, gamma.data(), beta.data(), w.data(), bb.data())) return 1;
+    for (int i = 0; i < warmup; ++i)
+        if (launch_attention_qkv(ac.ap, st)) return 1;
+    hipEvent_t e0, e1;
+    RLDM_HIP_CHECK(hipEventCreate(&e0));
+    RLDM_HIP_CHECK(hipEventCreate(&e1));
+    RLDM_HIP_CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i)
+        if (launch_attention_qkv(ac.ap, st)) return 1;
+    RLDM_HIP_CHECK(hipEventRecord(e1, st));
+    RLDM_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    RLDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = ms * 1000.0f / iters;
     return 0;
 }
 

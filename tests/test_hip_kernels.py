@@ -230,7 +230,9 @@ def _attn_qkv_ref(x, gamma, beta, wqkv, bqkv, eps=1e-5, rounded=True):
 # every (L, C) of SURVEY.md A.4 (RangeLDM: 1024 x 128, 256 x 256, 64 x 256; RangeDM: 256 x 512, 64 x 512; nuScenes: 512 x 128,
 # 128 x 256, 32 x 256) plus ragged token counts and the small-config widths
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 128), (2, 256, 256), (3, 64, 256), (1, 256, 512), (1, 64, 512), (2, 512, 128),
-                                   (2, 128, 256), (4, 32, 256), (2, 100, 64), (1, 8, 32), (2, 1000, 128), (1, 48, 16)])
+                                   (2, 128, 256), (4, 32, 256), (2, 100, 64), (1, 8, 32), (2, 1000, 128), (1, 48, 16),
+                                   # the bench batch: heads of one image share a workgroup there (HG = 2)
+                                   (16, 256, 256), (16, 64, 256), (16, 32, 256), (16, 128, 128)])
 def test_attention_qkv_fused_kernel(B, L, C):
     """attention_qkv_d8_kernel alone (the kernel the UNet runs; rldm_test_attention above is the unfused fallback)."""
     if C % 32:
