@@ -144,6 +144,25 @@ void rldm_sampler_destroy(rldm_sampler* s);
 int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, const float* cond, float* images,
                 float* latents_out, void* stream);
 
+/* ---- multi-GPU exchange steps: RCCL over xGMI on the caller's stream (rangeldm_amd/csrc/collective.hip) --
+ * One process per GPU.  Rank 0 makes the id and hands its RLDM_UNIQUE_ID_BYTES bytes to the other ranks by any side channel
+ * (MPI, a file, torch.distributed's store); every rank then calls rldm_comm_create with its current HIP device set.  RCCL is
+ * bound at run time (dlopen): the copy already loaded in the process (PyTorch's) if there is one, else RLDM_RCCL_LIB, else
+ * the system librccl. */
+#define RLDM_UNIQUE_ID_BYTES 128
+typedef struct rldm_comm rldm_comm;
+int rldm_comm_unique_id(void* id_out, size_t cap);
+int rldm_comm_create(const void* unique_id, int rank, int world, rldm_comm** out);     /* collective over all ranks */
+void rldm_comm_destroy(rldm_comm* c);
+int rldm_comm_info(const rldm_comm* c, int* rank, int* world, char* rccl_origin, size_t cap);
+/* replaces the per-rank file writing of ldm/inference.py:159-183 as the hand-over of a sample-sharded batch: every rank
+ * contributes `count` floats (its finished (B_local, 2, W, H) images, or the x_0 latents) and receives all ranks' buffers in
+ * rank order in `all` (world * count floats).  Stream-ordered behind rldm_sample when given the same stream. */
+int rldm_allgather_images(rldm_comm* c, const float* local, float* all, int64_t count, void* stream);
+/* replaces DDP's gradient exchange (accelerate.prepare(model), ldm/train_unconditional.py:402-404; backward :545): in-place
+ * sum (average != 0: mean) over the ranks of `count` floats -- one contiguous bucket of the flat gradient buffer. */
+int rldm_allreduce_grads(rldm_comm* c, float* grads, int64_t count, int average, void* stream);
+
 /* ---- range image <-> point cloud (rangeldm_amd/csrc/lidar.hip) ------------------------- */
 typedef struct rldm_lidar rldm_lidar;     /* point_cloud_to_range_image replacement, ldm/dataset.py:135-294 */
 

@@ -85,6 +85,12 @@ PROTOTYPES = {
     "rldm_sampler_create": (C.c_int, [_P, _P, C.POINTER(SamplerConfigC), C.POINTER(_P)]),
     "rldm_sampler_destroy": (None, [_P]),
     "rldm_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rldm_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "rldm_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "rldm_comm_destroy": (None, [_P]),
+    "rldm_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "rldm_allgather_images": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "rldm_allreduce_grads": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "rldm_lidar_create": (C.c_int, [C.POINTER(LidarConfigC), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_P)]),
     "rldm_lidar_destroy": (None, [_P]),
     "rldm_lidar_to_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -39,11 +39,91 @@ def shard_range(total, rank, world):
     return lo, min(total, lo + per)
 
 
+class Communicator:
+    """RCCL communicator behind the C ABI (include/rangeldm_hip.h: rldm_comm_*).  The 128-byte unique id is made by rank 0
+    and handed to the other ranks through torch.distributed's object broadcast (any backend; gloo is enough -- it carries 128
+    bytes once) or, without a process group, through a TCPStore at MASTER_ADDR:MASTER_PORT.  Collectives are issued on the
+    CURRENT torch stream of the device, i.e. stream-ordered behind the sampler / trainer launches."""
+
+    def __init__(self, rank=None, world=None, store=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank, self.world = rank, world
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(_lib.lib().rldm_comm_unique_id(uid, 128), "rldm_comm_unique_id")
+        if world > 1:
+            if dist.is_initialized():
+                box = [uid.raw if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = C.create_string_buffer(box[0], 128)
+            else:
+                store = store or dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                               int(os.environ.get("MASTER_PORT", "29500")) + 1, world, rank == 0)
+                if rank == 0:
+                    store.set("rldm_comm_uid", uid.raw)
+                uid = C.create_string_buffer(store.get("rldm_comm_uid"), 128)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rldm_comm_create(uid, rank, world, C.byref(self._h)), "rldm_comm_create")
+
+    def rccl_origin(self):
+        buf = self._C.create_string_buffer(256)
+        self._lib.check(self._lib.lib().rldm_comm_info(self._h, None, None, buf, 256), "rldm_comm_info")
+        return buf.value.decode()
+
+    def all_gather_images(self, local_images):
+        x = local_images.contiguous().float()
+        out = torch.empty((self.world * x.shape[0], *x.shape[1:]), dtype=torch.float32, device=x.device)
+        self._lib.check(self._lib.lib().rldm_allgather_images(self._h, self._C.c_void_p(x.data_ptr()),
+                                                              self._C.c_void_p(out.data_ptr()), x.numel(),
+                                                              self._lib.stream_ptr(x.device)), "rldm_allgather_images")
+        return out
+
+    def all_reduce_grads(self, flat, average=True):
+        """in place over a contiguous fp32 slice of the flat gradient buffer (one bucket)"""
+        assert flat.is_contiguous() and flat.dtype == torch.float32
+        self._lib.check(self._lib.lib().rldm_allreduce_grads(self._h, self._C.c_void_p(flat.data_ptr()), flat.numel(),
+                                                             1 if average else 0, self._lib.stream_ptr(flat.device)),
+                        "rldm_allreduce_grads")
+        return flat
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.lib().rldm_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_COMM = None
+
+
+def cabi_communicator():
+    """The process-wide Communicator when RLDM_COLLECTIVE=cabi asks for the C-ABI path (default: torch.distributed, whose
+    "nccl" backend is the same RCCL).  Both move the same bytes with the same collective; the C-ABI one is what a non-Python
+    host uses and runs on the sampler's stream without torch's NCCL stream hand-off."""
+    global _COMM
+    if os.environ.get("RLDM_COLLECTIVE", "torch") != "cabi" or not torch.cuda.is_available():
+        return None
+    if _COMM is None:
+        _COMM = Communicator()
+    return _COMM
+
+
 def all_gather_images(local_images, world=None):
     """All-gather finished (B_local, C, W, H) tensors along dim 0; every rank gets the full batch in rank order.
     One collective per batch: 8 x 1 MiB for BASELINE config 2/3 -- latency-bound, negligible vs the sampling time."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return local_images
+    comm = cabi_communicator() if local_images.is_cuda else None
+    if comm is not None:
+        return comm.all_gather_images(local_images)
     world = dist.get_world_size()
     local_images = local_images.contiguous()
     out = torch.empty((world * local_images.shape[0], *local_images.shape[1:]), dtype=local_images.dtype,

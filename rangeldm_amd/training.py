@@ -243,7 +243,27 @@ class UNetTrainer:
 
     def _reduce_bucket(self, b):
         _, _, off, cnt = self.buckets[b]
-        self._pending.append(torch.distributed.all_reduce(self.grads[off:off + cnt], op=self._reduce_op, async_op=True))
+        self._pending.append(self._launch_reduce(off, cnt, self._reduce_op))
+
+    def _launch_reduce(self, off, cnt, op):
+        """All-reduce of one gradient bucket, asynchronous to the stream that goes on with backward; returns an object whose
+        wait() makes the current stream wait for it.  RLDM_COLLECTIVE=cabi: rldm_allreduce_grads (RCCL through the C ABI,
+        include/rangeldm_hip.h) on a side stream; default: torch.distributed (backend "nccl" is the same RCCL)."""
+        from . import distributed as D
+        comm = D.cabi_communicator()
+        if comm is None:
+            return torch.distributed.all_reduce(self.grads[off:off + cnt], op=op, async_op=True)
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(self.device)
+        side = self._comm_stream
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            comm.all_reduce_grads(self.grads[off:off + cnt], average=(op == torch.distributed.ReduceOp.AVG))
+
+        class _Work:
+            def wait(_self):
+                torch.cuda.current_stream(self.device).wait_stream(side)
+        return _Work()
 
     # ---- ops --------------------------------------------------------------------------------------------------
     def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True, done=None):
@@ -473,7 +493,9 @@ class UNetTrainer:
         if reduce:
             self._pidx = {n: i for i, n in enumerate(self.names)}
             self._ready = [hi - lo for lo, hi, _, _ in self.buckets]
-            avg = torch.distributed.get_backend() == "nccl"          # RCCL averages in the collective; gloo sums
+            from . import distributed as D
+            # RCCL (torch's "nccl" backend, or the C-ABI communicator) averages in the collective; gloo sums
+            avg = torch.distributed.get_backend() == "nccl" or D.cabi_communicator() is not None
             self._reduce_op = torch.distributed.ReduceOp.AVG if avg else torch.distributed.ReduceOp.SUM
         self._acc(self._out, dpred, False)
         for fn in reversed(self._tape):
@@ -560,7 +582,7 @@ class UNetTrainer:
                     w.wait()
             elif action is not None:
                 _, _, off, cnt = self.buckets[action]
-                pending.append(torch.distributed.all_reduce(self.grads[off:off + cnt], op=st["reduce_op"], async_op=True))
+                pending.append(self._launch_reduce(off, cnt, st["reduce_op"]))
         self.global_step += 1
         self._step_dev_mirror += 1
         self.last_grad_norm = st["sqnorm"]

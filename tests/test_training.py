@@ -212,6 +212,46 @@ def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cabi_collectives_on_one_gpu(monkeypatch):
+    """rldm_comm_* / rldm_allgather_images / rldm_allreduce_grads (RCCL bound at run time behind the C ABI) with world size 1:
+    the communicator comes up on the RCCL copy the process already holds, the collectives run on the current stream, and the
+    trainer's bucketed path gives the single-process gradients when it goes through them (RLDM_COLLECTIVE=cabi)."""
+    from rangeldm_amd import distributed as D, train_ops as T
+    comm = D.Communicator(rank=0, world=1)
+    assert "rccl" in comm.rccl_origin()
+    img = torch.randn(3, 2, 64, 8, device="cuda")
+    out = comm.all_gather_images(img)
+    g = torch.randn(1000, device="cuda")
+    ref = g.clone()
+    comm.all_reduce_grads(g, average=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, img) and torch.equal(g, ref)
+    del comm
+    cfg = UNetConfig(**SMALL)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    x = torch.randn(2, 5, 32, 8, generator=torch.Generator().manual_seed(1)).cuda()
+    target = torch.randn(2, 4, 32, 8, generator=torch.Generator().manual_seed(2)).cuda()
+    t = torch.tensor([5, 900]).cuda()
+    a = TR.UNetTrainer(cfg, sd, use_ema=False, bucket_mb=1)
+    a.backward(T.mse(a.forward(x, t), target)[1], reduce=False)
+    monkeypatch.setenv("RLDM_COLLECTIVE", "cabi")
+    monkeypatch.setattr(D, "_COMM", None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", RANK="0", WORLD_SIZE="1")
+    torch.distributed.init_process_group("gloo", rank=0, world_size=1)      # (rendezvous only: the bytes go through the C ABI)
+    try:
+        b = TR.UNetTrainer(cfg, sd, use_ema=False, bucket_mb=1)
+        world = b.backward(T.mse(b.forward(x, t), target)[1], reduce=True)
+        torch.cuda.synchronize()
+        assert world == 1 and D._COMM is not None                    # averaged inside the collective, on the C-ABI communicator
+        assert rel(b.grads, a.grads) < 1e-5
+        full = D.all_gather_images(img)                               # world 1: returned as is
+        assert full is img
+    finally:
+        torch.distributed.destroy_process_group()
+        D._COMM = None
+
+
+@pytest.mark.gpu
 def test_operand_repack_tiled_equals_elementwise():
     """The tiled transpose (one launch, all layers incl. the fused groups and the 5- / 4-channel ends with their zero pads)
     writes exactly the bytes of the per-layer kernel."""
