@@ -371,7 +371,10 @@ __global__ void __launch_bounds__(1024) attention_qkv2_d8_kernel(const AttnQkvPa
     const int NT = waves * 64;
     const int heads = p.C >> 3;
     const int hgroups = heads / HG;
-    const int hg = blockIdx.x % hgroups, b = blockIdx.x / hgroups;
+    // workgroups land on XCD (blockIdx % 8): give every XCD a contiguous range of (image, head group) ids, so all the heads of
+    // an image read its x rows through ONE L2 instead of eight (HBM-side fetch of an L = 1024 launch: 38 MB -> one copy of x)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int hg = bid % hgroups, b = bid / hgroups;
     const int l31 = lane & 31, hh = lane >> 5;
     const int C = p.C, L = p.L;
     const int vst = Lp + 8;
