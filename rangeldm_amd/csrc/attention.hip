@@ -701,11 +701,8 @@ int launch_attention_qkv2(const AttnQkvParams& p, hipStream_t stream) {
     const size_t lds = (size_t)HG * Lp * 16 + (size_t)HG * 10 * (Lp + 8) * 2 + 16 + (size_t)p.C * 8 +
                        std::max((size_t)2 * p.C * 8, (size_t)HG * (p.C / 16) * 64 * 4) + (size_t)HG * p.C * 64 + (size_t)HG * 128 + 128;
     auto kern = pair ? attention_qkv2_d8_kernel<1> : attention_qkv2_d8_kernel<0>;
-    static size_t max_set[2] = {0, 0};
-    if (lds > max_set[pair]) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        max_set[pair] = lds;
-    }
+    static DynLdsLimit lds_limit[2];             // per instantiation, per device
+    RLDM_HIP_CHECK(lds_limit[pair].ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(p.B * (heads / HG)), dim3(64 * waves), lds, stream, p, waves, Lp, HG);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -723,12 +720,8 @@ int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream) {
     // up to 16 waves per (image, head): with 1024 tokens that is 4 waves per SIMD on one workgroup per CU
     const int waves = ntiles <= 4 ? 4 : (ntiles <= 8 ? ntiles : 16);       // (>= 4: the affine / weight fold uses every thread)
     const size_t lds = (size_t)Lp * 16 + (size_t)10 * (Lp + 8) * 2 + (size_t)p.C * 8 + (size_t)2 * p.C * 8 + (size_t)p.C * 64 + 128;
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qkv_d8_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        max_set = lds;
-    }
+    static DynLdsLimit lds_limit;                // per device, thread safe
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(attention_qkv_d8_kernel), lds));
     hipLaunchKernelGGL(attention_qkv_d8_kernel, dim3(p.B * (p.C / 8)), dim3(64 * waves), lds, stream, p, waves, Lp);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -743,12 +736,8 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     const int qblocks = (qtiles + wpb - 1) / wpb;
     const int grid = p.B * (p.C / 8) * qblocks;
     const size_t lds = (size_t)Lp * 16 + (size_t)10 * (Lp + 8) * 2;
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_d8_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        max_set = lds;
-    }
+    static DynLdsLimit lds_limit;                // per device, thread safe
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(attention_d8_kernel), lds));
     hipLaunchKernelGGL(attention_d8_kernel, dim3(grid), dim3(64 * wpb), lds, stream, p, wpb, Lp);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;

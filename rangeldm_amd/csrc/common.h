@@ -1,6 +1,7 @@
 // Shared device helpers and host-side error plumbing for librangeldm_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -36,6 +37,29 @@ void set_error(const std::string& msg);
             return 1;                                                                               \
         }                                                                                           \
     } while (0)
+
+// Largest dynamic-LDS size a kernel has been enabled for, PER DEVICE (hipFuncSetAttribute is a per-device setting) and
+// safe to call from several host threads.  One object per kernel instantiation (function-local static at the launch site).
+struct DynLdsLimit {
+    static constexpr int kMaxDevices = 16;
+    std::atomic<size_t> set[kMaxDevices];
+    DynLdsLimit() { for (auto& v : set) v.store(0); }
+    // returns hipSuccess without a runtime call when `bytes` is already covered on the current device
+    hipError_t ensure(const void* kernel, size_t bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const bool tracked = dev >= 0 && dev < kMaxDevices;
+        if (tracked && bytes <= set[dev].load(std::memory_order_acquire)) return hipSuccess;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        if (tracked) {                                   // monotone maximum; racing threads at worst repeat the call
+            size_t cur = set[dev].load(std::memory_order_relaxed);
+            while (cur < bytes && !set[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+        }
+        return hipSuccess;
+    }
+};
 
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------------------
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {

@@ -842,12 +842,8 @@ size_t conv_lds_bytes(const ConvTile& t, const ConvParams& p) {
 template <int NW, int BM, int BN, int WM, int WN, int KG, int CK, int TAPS, int TG, int ACH>
 static int launch_inst(const ConvParams& p, int grid, size_t lds, hipStream_t stream) {
     auto kern = conv_igemm_kernel<NW, BM, BN, WM, WN, KG, CK, TAPS, TG, ACH>;
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        max_set = lds;
-    }
+    static DynLdsLimit lds_limit;                // per device, thread safe
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, p);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -536,11 +536,8 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
 template <int WM, int WN>
 static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
     auto kern = conv_stream_kernel<WM, WN>;
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        max_set = lds;
-    }
+    static DynLdsLimit lds_limit;                // per device, thread safe
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(p.N / (32 * WN), p.tiles_img, p.B), dim3(512), lds, stream, p);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
