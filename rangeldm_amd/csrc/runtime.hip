@@ -2465,15 +2465,17 @@ int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int wa
     cc.plan.io.temb_per_sample = 1;
     RLDM_REQUIRE(!cc.plan.ops.empty(), "internal: empty plan");
     // the timed unit: the conv launch, plus the GroupNorm+SiLU launch in front of it on the conv_small.hip route
-    size_t first = cc.plan.ops.size() - 1;
+    size_t last = cc.plan.ops.size() - 1;           // the conv itself: the last op whose name starts with "conv_" (a gn_fold of
+    while (last > 0 && cc.plan.ops[last].name.rfind("conv_", 0) != 0) --last;      // its output statistics may follow it)
+    size_t first = last;
     if (first > 0 && cc.plan.ops[first - 1].name == "gn_apply_kernel") --first;
     auto run_unit = [&]() {
-        for (size_t o = first; o < cc.plan.ops.size(); ++o)
+        for (size_t o = first; o <= last; ++o)
             if (cc.plan.ops[o].fn(st)) return 1;
         return 0;
     };
     if (kernel_name && name_cap) {
-        const std::string nm = (first + 1 < cc.plan.ops.size() ? "gn_apply+" : "") + cc.plan.ops.back().name;
+        const std::string nm = (first < last ? "gn_apply+" : "") + cc.plan.ops[last].name;
         strncpy(kernel_name, nm.c_str(), name_cap - 1);
         kernel_name[name_cap - 1] = 0;
     }

@@ -176,7 +176,7 @@ def main():
             try:
                 us, kn = bench_case(c, iters=a.iters)
                 tf = flops(c) / us / 1e6
-                cols.append(f"{us:8.1f}us {tf:6.0f}TF {kn.split('<')[1].rstrip('>').replace(',taps', 't').replace('CK', 'c'):>14s}")
+                cols.append(f"{us:8.1f}us {tf:6.0f}TF {(kn.split('<')[1].rstrip('>') if '<' in kn else kn).replace(',taps', 't').replace('CK', 'c'):>14s}")
                 tot[t] += us * n
                 if a.ts:
                     buf = (C.c_ulonglong * 256)()
