@@ -73,7 +73,19 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 
     // ---- which tile: grid = (channel tiles, pixel tiles of an image, images) -------------------------------------------
     const int tiles_h = p.tiles_h, tiles_img = p.tiles_img;       // tiles_h is a power of two
-    const int nt = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
+    // Workgroups are dispatched x-fastest and land on XCD (linear id % 8).  Re-number them so that every XCD owns a contiguous
+    // run of (image, pixel tile, channel tile) ids: the tiles of an image then share ONE L2, and the halo rows two neighbouring
+    // tiles both read (34 x 10 positions for 32 x 8 pixels: 1.33x the tile) are fetched from HBM / Infinity Cache once.
+    int nt, mt, b;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int rid = (p.dbg & (1 << 21)) ? lin : xcd_remap(lin, gx * gy * (int)gridDim.z);
+        const int q = rid / gx;
+        nt = rid - q * gx;
+        b = q / gy;
+        mt = q - b * gy;
+    }
     const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
     const int w0 = tw * p.TW, h0 = th * p.TH;
 
