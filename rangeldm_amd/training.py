@@ -95,7 +95,7 @@ def snr_weights(alphas_cumprod, timesteps, snr_gamma):
 class UNetTrainer:
     def __init__(self, config, state_dict, device="cuda", lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8,
                  max_grad_norm=1.0, use_ema=True, ema_max_decay=0.9999, ema_inv_gamma=1.0, ema_power=0.75,
-                 lr_warmup_steps=500, total_steps=100000, bucket_mb=32):
+                 lr_warmup_steps=500, total_steps=100000, bucket_mb=32, gradient_accumulation_steps=1):
         self.cfg = config if isinstance(config, UNetConfig) else UNetConfig(**config)
         if not self.cfg.flip_sin_to_cos or self.cfg.freq_shift != 0:
             raise NotImplementedError("the training step implements UNet2DModel's default time embedding "
@@ -149,6 +149,10 @@ class UNetTrainer:
                        ema_max_decay=ema_max_decay, ema_inv_gamma=ema_inv_gamma, ema_power=ema_power,
                        lr_warmup_steps=lr_warmup_steps, total_steps=total_steps)
         self.global_step = 0
+        # `gradient_accumulation_steps` of the reference's yaml (accelerator.accumulate(model), ldm/train_unconditional.py:
+        # 466,509): the optimizer runs on every k-th train_step over the mean of the k micro-batch gradients
+        self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+        self._micro = 0
         self.buckets = plan_buckets([self.sizes[n] for n in self.names], bucket_mb * (1 << 20) // 4)
         self._tape, self._grad, self._keep = [], {}, []
         self._rows, self._row_parent = {}, {}
@@ -202,6 +206,33 @@ class UNetTrainer:
         save_model_dir(os.path.join(output_dir, "unet"), unet_config_to_diffusers(self.cfg), self.state_dict())
         if self.ema is not None:
             save_model_dir(os.path.join(output_dir, "unet_ema"), unet_config_to_diffusers(self.cfg), self.state_dict(ema=True))
+
+    def save_state(self, path):
+        """`accelerator.save_state(checkpoint-N)` counterpart (ldm/train_unconditional.py:560-584): everything a resumed run
+        needs besides the weights -- AdamW moments, EMA copy, step counter (lr schedule, bias corrections, EMA warm-up)."""
+        torch.save({"params": self.params.cpu(), "ema": None if self.ema is None else self.ema.cpu(),
+                    "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "global_step": self.global_step,
+                    "micro": self._micro, "names": list(self.names), "hp": dict(self.hp)}, path)
+
+    def load_state(self, path):
+        """`accelerator.load_state` (resume_from_checkpoint, ldm/train_unconditional.py:449-463): restores the buffers IN PLACE
+        (captured step graphs keep pointing at them) and resynchronises the device-side step counter."""
+        st = torch.load(path, map_location="cpu", weights_only=False)
+        if list(st["names"]) != list(self.names):
+            raise RuntimeError("training state was saved for a different parameter layout")
+        self.params.copy_(st["params"])
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        if self.ema is not None:
+            if st["ema"] is None:
+                raise RuntimeError("training state holds no EMA copy")
+            self.ema.copy_(st["ema"])
+        self.global_step = int(st["global_step"])
+        self._micro = int(st.get("micro", 0))
+        self.grads.zero_()
+        self._step_dev.fill_(self.global_step)
+        self._step_dev_mirror = self.global_step
+        self.repack()
 
     # ---- tape -------------------------------------------------------------------------------------------------
     def _acc(self, t, g, owned):
@@ -544,8 +575,16 @@ class UNetTrainer:
         Returns the loss (0-d float64 device tensor; no host sync)."""
         pred = self.forward(noisy_nchw, timesteps, pos_encoding)
         loss, dpred = T.mse(pred, target_nchw.float().contiguous(), loss_weights)
+        k = self.gradient_accumulation_steps
+        self._micro += 1
+        if self._micro < k:
+            # a micro-batch inside the accumulation window: gradients add up in the flat buffer, no exchange with the other
+            # ranks (accelerate's no_sync) and no optimizer step
+            self.backward(dpred, reduce=False)
+            return loss
+        self._micro = 0
         world = self.backward(dpred)
-        self.optimizer_step(world)
+        self.optimizer_step(world * k)                   # mean over ranks and over the k micro-batches
         return loss
 
     # ---- captured step graphs ---------------------------------------------------------------------------------
@@ -556,6 +595,9 @@ class UNetTrainer:
         step is cut into one graph per gradient bucket: after each, the bucket's RCCL all-reduce is launched eagerly on
         the communication stream and overlaps the next segment of backward; the optimizer segment waits for all of them.
         Returns the loss (0-d float64 device tensor, a copy)."""
+        if self.gradient_accumulation_steps != 1:
+            raise NotImplementedError("train_step_graphed captures one optimizer step per call; use train_step with "
+                                      "gradient_accumulation_steps > 1")
         dist = torch.distributed
         if reduce is None:
             reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

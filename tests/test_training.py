@@ -212,6 +212,45 @@ def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_save_state_resume_and_gradient_accumulation(tmp_path):
+    """accelerator.save_state / load_state and gradient_accumulation_steps (ldm/train_unconditional.py:449-463,466,560-584):
+    a resumed trainer continues exactly where the saved one was (moments, EMA, lr / EMA warm-up position), and two
+    half-batches accumulated give the step of the whole batch."""
+    cfg = UNetConfig(**SMALL)
+    sd = synth_state_dict(unet_param_shapes(cfg), prefix="tr.")
+    lr = 1e-3
+    kw = dict(lr=lr, lr_warmup_steps=3, total_steps=40, use_ema=True)
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(4, 5, 32, 8, generator=g).cuda(), torch.randint(0, 1000, (4,), generator=g).cuda(),
+                torch.randn(4, 4, 32, 8, generator=g).cuda()) for _ in range(4)]
+    a = TR.UNetTrainer(cfg, sd, **kw)
+    for x, t, y in batches[:2]:
+        a.train_step(x, t, y)
+    a.save_state(str(tmp_path / "state.pt"))
+    for x, t, y in batches[2:]:
+        a.train_step(x, t, y)
+    b = TR.UNetTrainer(cfg, synth_state_dict(unet_param_shapes(cfg), prefix="other."), **kw)      # different weights: all restored
+    b.load_state(str(tmp_path / "state.pt"))
+    assert b.global_step == 2
+    for x, t, y in batches[2:]:
+        b.train_step_graphed(x, t, y)                                # (and the device-side step counter was resynchronised)
+    _adam_close(a.state_dict(), b.state_dict(), lr, "resumed parameters")
+    _adam_close(a.state_dict(ema=True), b.state_dict(ema=True), lr, "resumed ema")
+    # accumulation: 2 x (batch 2) == 1 x (batch 4)
+    c = TR.UNetTrainer(cfg, sd, **kw)
+    d = TR.UNetTrainer(cfg, sd, gradient_accumulation_steps=2, **kw)
+    for x, t, y in batches[:2]:
+        c.train_step(x, t, y)
+        d.train_step(x[:2], t[:2], y[:2])
+        assert d.global_step == c.global_step - 1                    # no optimizer step inside the window
+        d.train_step(x[2:], t[2:], y[2:])
+    assert d.global_step == c.global_step == 2
+    _adam_close(c.state_dict(), d.state_dict(), lr, "accumulated parameters")
+    with pytest.raises(NotImplementedError):
+        d.train_step_graphed(*batches[0])
+
+
+@pytest.mark.gpu
 def test_cabi_collectives_on_one_gpu(monkeypatch):
     """rldm_comm_* / rldm_allgather_images / rldm_allreduce_grads (RCCL bound at run time behind the C ABI) with world size 1:
     the communicator comes up on the RCCL copy the process already holds, the collectives run on the current stream, and the
