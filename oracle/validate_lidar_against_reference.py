@@ -161,10 +161,38 @@ def main():
         gold[f"lidar_proj_{tag}_car_ref"] = car_ref.T
         gold[f"lidar_proj_{tag}_width"] = np.array([width])
 
+    print("== conditions of the conditional path: RangeDataset.__getitem__ (ldm/dataset.py:340-362)")
+    import tempfile
+    from rangeldm_amd.conditional import downsample_range_image, inpainting_inputs
+    cgold = {}
+    with tempfile.TemporaryDirectory() as td:
+        jpg = torch.from_numpy(rng.standard_normal((2, 64, 16)).astype(np.float32))
+        pth = os.path.join(td, "item.pth")
+        torch.save({"jpg": jpg, "mask": torch.ones(64, 16), "car_window_mask": torch.ones(64, 16)}, pth)
+        for tag, kw in (("up4", dict(downsample=4)), ("up24", dict(downsample=[2, 4])), ("inp", dict(inpainting=0.0625)),
+                        ("inpwrap", dict(inpainting=1.25))):
+            item = ds.RangeDataset(**kw)
+            item.file_paths = ["item"]
+            item.get_pth_path = lambda p_: pth                       # the cached-.pth branch of __getitem__ (:321-322)
+            ret = item[0]
+            if "downsample" in kw:
+                check(f"RangeDataset down {kw['downsample']}", downsample_range_image(jpg, kw["downsample"]).numpy(), ret["down"].numpy(), 0.0)
+                cgold[f"condds_{tag}_down_ref"] = ret["down"].numpy()
+            else:
+                m, mi = inpainting_inputs(jpg, kw["inpainting"])
+                check(f"RangeDataset inpainting_mask {kw['inpainting']}", m.numpy(), ret["inpainting_mask"].numpy(), 0.0)
+                check(f"RangeDataset masked_image {kw['inpainting']}", mi.numpy(), ret["masked_image"].numpy(), 0.0)
+                cgold[f"condds_{tag}_mask_ref"] = ret["inpainting_mask"].numpy()
+                cgold[f"condds_{tag}_masked_ref"] = ret["masked_image"].numpy()
+        cgold["condds_jpg"] = jpg.numpy()
+
     print(f"\n{'all checks passed' if not FAILS else 'FAILED: ' + ', '.join(FAILS)}")
     if FAILS:
         sys.exit(1)
     if not args.check:
+        cpath = os.path.join(GOLD, "condds.npz")
+        np.savez_compressed(cpath, **{k: np.ascontiguousarray(v) for k, v in cgold.items()})
+        print(f"wrote {cpath} ({os.path.getsize(cpath) / 1024:.0f} KiB)")
         path = os.path.join(GOLD, "lidar.npz")
         np.savez_compressed(path, **{k: np.ascontiguousarray(v) for k, v in gold.items()})
         print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")

@@ -151,3 +151,46 @@ def test_inference_driver_reads_reference_yaml(tmp_path):
     (tmp_path / "v8.yaml").write_text(txt.replace("../vae/configs/kitti360.yaml", "vae/v.yaml"))
     c8 = load_config(str(tmp_path / "v8.yaml"))
     assert c8["vae"].ch == 32 and c8["vae"].downscale == 8 and c8["vae"].sample_size == (2048, 128)
+
+
+def test_conditional_inputs_match_reference_dataset(golden):
+    """`down` / `inpainting_mask` / `masked_image` as RangeDataset.__getitem__ builds them (ldm/dataset.py:340-362; vectors from
+    the reference class, oracle/validate_lidar_against_reference.py) and the sparse-input picture of the conditional driver."""
+    import numpy as np
+    import torch
+    from rangeldm_amd.conditional import downsample_range_image, inpainting_inputs, sparse_input_image, encode_condition
+    g = golden("condds")
+    jpg = torch.from_numpy(g["condds_jpg"])
+    assert np.array_equal(downsample_range_image(jpg, 4).numpy(), g["condds_up4_down_ref"])
+    assert np.array_equal(downsample_range_image(jpg, [2, 4]).numpy(), g["condds_up24_down_ref"])
+    for tag, frac in (("inp", 0.0625), ("inpwrap", 1.25)):
+        m, mi = inpainting_inputs(jpg, frac)
+        assert np.array_equal(m.numpy(), g[f"condds_{tag}_mask_ref"]) and np.array_equal(mi.numpy(), g[f"condds_{tag}_masked_ref"])
+    # batched form + the -1-filled picture of ldm/inference_conditional.py:176-182
+    xb = torch.stack([jpg, jpg * 2])
+    down = downsample_range_image(xb, 4)
+    assert down.shape == (2, 2, 64, 4) and torch.equal(down[1], downsample_range_image(jpg * 2, 4))
+    shown = sparse_input_image(xb, down, 4)
+    assert torch.equal(shown[..., 2::4], down) and float(shown[..., 0::4].max()) == -1.0
+    # the up-sampling condition is the folded low-resolution image (ldm/train_conditional.py:419-421)
+    cond = encode_condition({"down": down})
+    assert cond.shape == (2, 8, 16, 4)
+
+
+def test_conditional_driver_reads_reference_yaml(tmp_path):
+    from rangeldm_amd.inference_conditional import load_conditional_config
+    import pytest
+    y = tmp_path / "upsample.yaml"
+    y.write_text("ddim: True\nddpm_num_inference_steps: 50\nwith_vae: True\nvae_config: ../vae/configs/kitti360.yaml\n"
+                 "block_out_channels: [128, 128, 256, 256]\ninpainting: null\nupsample: 4\nall_circonv: True\nmodel_config: null\n"
+                 "resolution: [1024, 64]\neval_batch_size: 16\n")
+    c = load_conditional_config(str(y))
+    assert c["task"] == "upsample" and c["rate"] == 4 and c["unet"].in_channels == 12 and c["unet"].sample_size == (256, 16)
+    assert c["cond_channels"] == 8 and c["vae"].sample_size == (1024, 64) and c["range_limit"] == 70.0
+    (tmp_path / "inp.yaml").write_text(y.read_text().replace("inpainting: null", "inpainting: 0.0625").replace("upsample: 4", "upsample: null"))
+    c = load_conditional_config(str(tmp_path / "inp.yaml"))
+    assert c["task"] == "inpainting" and c["unet"].in_channels == 9 and abs(c["fraction"] - 0.0625) < 1e-9
+    (tmp_path / "both.yaml").write_text(y.read_text().replace("inpainting: null", "inpainting: 0.1"))
+    with pytest.raises(ValueError):
+        load_conditional_config(str(tmp_path / "both.yaml"))
+    assert load_conditional_config("upsample")["unet"].in_channels == 12

@@ -281,3 +281,22 @@ def test_inference_driver_writes_reference_outputs(tmp_path):
         assert np.array_equal(np.array(Image.open(out / f"{i}_range.png")), LidarOracle.render_u8(img))
         bev = np.array(Image.open(out / f"{i}.png"))
         assert bev.shape == (1024, 1024)
+
+
+@pytest.mark.gpu
+def test_conditional_inference_driver_writes_reference_layout(tmp_path):
+    """python -m rangeldm_amd.inference_conditional (ldm/inference_conditional.py counterpart, BASELINE config 4 shapes, batch 2):
+    `<j>_seed_<seed>.bin / .png` in densification_result/, and target / input pictures for seed 0."""
+    import os
+    from rangeldm_amd import inference_conditional as IC
+    out = str(tmp_path / "generated")
+    IC.main(["--cfg", "upsample", "--batch_size", "2", "--samples", "2", "--out", out])
+    for d in ("densification_result", "densification_target", "densification_input"):
+        for j in range(2):
+            for ext in ("bin", "png"):
+                assert os.path.getsize(os.path.join(out, d, f"{j}_seed_0.{ext}")) > 0, (d, j, ext)
+    assert os.path.exists(os.path.join(out, "densification_result", "1_seed_1.bin"))      # samples // B // world + 1 iterations
+    pts = np.fromfile(os.path.join(out, "densification_target", "0_seed_0.bin"), dtype=np.float32).reshape(-1, 4)
+    assert len(pts) > 1000 and float(np.linalg.norm(pts[:, :3], axis=1).max()) < 70.0      # KITTI-360 range limit of the driver
+    sparse = np.fromfile(os.path.join(out, "densification_input", "0_seed_0.bin"), dtype=np.float32).reshape(-1, 4)
+    assert 0 < len(sparse) < len(pts)                                                       # a quarter of the beams carry returns
