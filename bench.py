@@ -161,9 +161,9 @@ def main():
         ap.error("unrecognized arguments: " + " ".join(rest))
 
     from rangeldm_amd import distributed as D
-    from rangeldm_amd.pipelines import LDMPipelineRange, DDIMPipelineRange
+    from rangeldm_amd.pipelines import LDMPipelineRange, DDIMPipelineRange, LDMUpscalePipelineRange
     from rangeldm_amd.schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
-    from rangeldm_amd.synth import latent_noise, step_noise
+    from rangeldm_amd.synth import latent_noise, step_noise, sparse_range_condition
 
     rank, world, local = D.init_from_env("nccl")
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
@@ -172,7 +172,14 @@ def main():
 
     p, unet, vae, usd, vsd = build_models(args.preset, args.seed)
     sched = DDIMSchedulerHIP() if args.sampler == "ddim" else DDPMSchedulerHIP()
-    if vae is not None:
+    cond_enc = None
+    if p["cond_channels"] == 8:                          # BASELINE config 4: up-sampling 16 -> 64 beams (ldm/configs/upsample.yaml)
+        from rangeldm_amd.encoders import SparseRangeImageEncoder2
+        pipe = LDMUpscalePipelineRange(vae=vae, unet=unet, scheduler=sched)
+        cond_enc = SparseRangeImageEncoder2()
+    elif p["cond_channels"]:
+        ap.error(f"--preset {args.preset}: no synthetic condition for this preset")
+    elif vae is not None:
         pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
     else:
         pipe = DDIMPipelineRange(unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
@@ -199,10 +206,19 @@ def main():
         zs = torch.from_numpy(np.stack([np.stack([step_noise(args.seed, first + j, s, lat_shape) for j in range(B)])
                                         for s in range(S)])).to(dev)
 
+    conds = None
+    if cond_enc is not None:                             # the low-resolution images, resident in HBM like x_T
+        W4, H4 = p["unet"].sample_size
+        conds = [torch.from_numpy(np.stack([sparse_range_condition(args.seed, (i * B + j) if not strong else j,
+                                                                    (2, 4 * W4, H4)) for j in range(B)])).to(dev)
+                 for i in range(n_iter)]
+
     def one_step(i):
         kw = dict(batch_size=B, num_inference_steps=S, latents=xs[i], output_type="torch")
         if zs is not None:
             kw["step_noise"] = zs
+        if conds is not None:
+            kw.update(image=conds[i], condition_encoder=cond_enc)
         img = pipe(**kw)
         return D.all_gather_images(img)
 
@@ -237,7 +253,7 @@ def main():
                        "parallelism": f"sample-sharded x{world}, RCCL all-gather of finished images"},
         }
         if True:                                        # (per-GPU figures, measured on rank 0's GPU for every N)
-            h = pipe._fused.get(unet, vae, sched, B, S, 0 if args.sampler == "ddim" else 1, p["pos_encoding"], 0)
+            h = pipe._fused.get(unet, vae, sched, B, S, 0 if args.sampler == "ddim" else 1, p["pos_encoding"], p["cond_channels"])
             rl, kernels = roofline(pipe, h, xs[0], S)
             gflop_per_image = (S * unet.flops(B) + (vae.decode_flops(B, *lat_shape[1:]) if vae else 0.0)) / B / 1e9
             res["roofline"] = rl
