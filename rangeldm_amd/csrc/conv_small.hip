@@ -161,24 +161,28 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                 // slot -> halo row, rotated by one (3x3): a wave instruction moves SPI consecutive slots, and with rows
                 // 1, 2, ... first the zero rows above and below a full-height tile (32x2 / 64x4 images: rows 0 and THv - 1)
                 // share an instruction instead of each wasting half of one on lanes that skip the GroupNorm + SiLU math
+                rowok[kb] = false;
+                inimg[kb] = false;
+                ldo[kb] = 0;
+                if ((k0 + kb) >= KC) continue;              // (uniform: a row group this tile does not have costs a branch,
+                                                            //  not the predicate / zero-fill code of its NCW slots)
                 const int slot = (k0 + kb) * SPI + rsub;
                 const int vhl = HALO ? (slot + 1 >= THv ? slot + 1 - THv : slot + 1) : slot;
                 const int vh = h0 - HALO + vhl;                 // row / column of the (nearest-x2: virtual) input image
-                rowok[kb] = laneok && (k0 + kb) < KC && slot < THv;
+                rowok[kb] = laneok && slot < THv;
                 inimg[kb] = rowok[kb] && vh >= 0 && vh < (p.Hin << ups);
                 const unsigned goff = (unsigned)((vh >> ups) * (CIN * 2) + c8 * 16);
                 ldo[kb] = vhl * RSM + c8 * 16;
 #pragma unroll
                 for (int j = 0; j < NCW; ++j) {
                     const int col = wave + 8 * j;
+                    if (col >= TWv) continue;               // (uniform per wave)
                     v[kb][j] = make_uint4(0u, 0u, 0u, 0u);
-                    if (col < TWv && (k0 + kb) < KC) {
-                        int vw = w0 - HALO + col;
-                        const int Wv = p.Win << ups;
-                        vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
-                        const unsigned char* cbase = xg + (size_t)((b * p.Win + (vw >> ups)) * p.Hin) * (CIN * 2);     // uniform
-                        if (inimg[kb]) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
-                    }
+                    int vw = w0 - HALO + col;
+                    const int Wv = p.Win << ups;
+                    vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
+                    const unsigned char* cbase = xg + (size_t)((b * p.Win + (vw >> ups)) * p.Hin) * (CIN * 2);     // uniform
+                    if (inimg[kb]) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
                 }
             }
             if (k0 == 0) { RLDM_STAMP(); }      // tile loads issued
@@ -215,10 +219,12 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
             }
             if (k0 == 0) { RLDM_STAMP(); }      // affine ready
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb) {
+                if ((k0 + kb) >= KC) continue;
 #pragma unroll
                 for (int j = 0; j < NCW; ++j) {
                     const int col = wave + 8 * j;
+                    if (col >= TWv) continue;
                     uint4 o = v[kb][j];
                     if (gn && inimg[kb]) {
                         float f0 = bf16lo(o.x) * ga[0] + gs[0], f1 = bf16hi(o.x) * ga[1] + gs[1];
@@ -232,8 +238,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                         o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
                         o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);
                     }
-                    if (col < TWv && rowok[kb]) *reinterpret_cast<uint4*>(sA + col * colb + ldo[kb]) = o;
+                    if (rowok[kb]) *reinterpret_cast<uint4*>(sA + col * colb + ldo[kb]) = o;
                 }
+            }
         }
         RLDM_STAMP();                           // tile normalised and stored
         // residual-phase input: raw cat[r0, r1], the tile's own pixels only; a wave instruction moves 64 / LPR pixels
