@@ -181,8 +181,10 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                     int vw = w0 - HALO + col;
                     const int Wv = p.Win << ups;
                     vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
-                    const unsigned char* cbase = xg + (size_t)((b * p.Win + (vw >> ups)) * p.Hin) * (CIN * 2);     // uniform
-                    if (inimg[kb]) v[kb][j] = *reinterpret_cast<const uint4*>(cbase + goff);
+                    // 32-bit byte offset of the column (uniform; the tensors on this route are far below 4 GiB): scalar base +
+                    // one VGPR offset per load instead of a 64-bit pointer per column
+                    const unsigned coff = (unsigned)((b * p.Win + (vw >> ups)) * p.Hin) * (unsigned)(CIN * 2);
+                    if (inimg[kb]) v[kb][j] = *reinterpret_cast<const uint4*>(xg + (coff + goff));
                 }
             }
             if (k0 == 0) { RLDM_STAMP(); }      // tile loads issued
