@@ -263,6 +263,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                 uint4 rv[NBR];
 #pragma unroll
                 for (int u = 0; u < NBR; ++u) {
+                    if ((wave + 8 * u) * ppi >= HB) continue;       // (uniform: instructions past the half-tile cost a branch)
                     const int pl = (wave + 8 * u) * ppi + psub, pidx = hp * 64 + pl;
                     const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
                     rv[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -271,6 +272,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
                 }
 #pragma unroll
                 for (int u = 0; u < NBR; ++u) {
+                    if ((wave + 8 * u) * ppi >= HB) continue;
                     const int pl = (wave + 8 * u) * ppi + psub, pidx = hp * 64 + pl;
                     if (pl < HB && rc8 < R8) *reinterpret_cast<uint4*>(sR + pidx * RSR + rc8 * 16) = rv[u];
                 }
