@@ -201,7 +201,11 @@ def test_bucketed_allreduce_path_on_one_gpu(tmp_path):
         assert len(b.buckets) >= 3
         b.backward(T.mse(b.forward(x, t), target)[1], reduce=True)
         assert all(r == 0 for r in [0])                               # (buckets all fired: pending handles were waited)
-        assert rel(b.grads, a.grads) < 1e-5                           # fp32 atomics reorder sums, nothing else differs
+        # a bucket reduced too early or twice would be off by O(1).  Run to run the gradients agree to ~6e-9 (split-K fp32 atomics
+        # reorder sums) -- except that in about 1 run of 100 that last-bit noise flips the bf16 rounding of one activation on its way
+        # into a conv (a 0.2 % change of that operand), which shows as 1e-4 .. 2.5e-3 of the gradient norm, with or without a
+        # collective (tools/flaky_probe.py finds the runs, tools/flaky_bisect.py the op and the pixel)
+        assert rel(b.grads, a.grads) < 5e-3
         b.optimizer_step()
     finally:
         torch.distributed.destroy_process_group()
@@ -282,7 +286,7 @@ def test_cabi_collectives_on_one_gpu(monkeypatch):
         world = b.backward(T.mse(b.forward(x, t), target)[1], reduce=True)
         torch.cuda.synchronize()
         assert world == 1 and D._COMM is not None                    # averaged inside the collective, on the C-ABI communicator
-        assert rel(b.grads, a.grads) < 1e-5
+        assert rel(b.grads, a.grads) < 5e-3                           # (see test_bucketed_allreduce_path_on_one_gpu)
         full = D.all_gather_images(img)                               # world 1: returned as is
         assert full is img
     finally:
