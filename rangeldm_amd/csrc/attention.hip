@@ -189,7 +189,10 @@ __global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvPar
     float* sBp = reinterpret_cast<float*>(sW + (size_t)(C >> 4) * 512);    // [32]: b_h + W_h * s
 
     // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic) ----------------------------------------------------
-    {
+    if (p.st == nullptr) {                                // x arrives normalised (producer-side GroupNorm): W' = W, b' = b
+        for (int t = tid; t < C; t += NT) { sGa[t] = 1.f; sGs[t] = 0.f; }
+        __syncthreads();
+    } else {
         const int cpg = C / p.groups;
         for (int t = tid; t < C; t += NT) {
             const float2* src = p.st + (size_t)b * p.P * C + t;
@@ -409,7 +412,8 @@ __global__ void __launch_bounds__(1024) attention_qkv2_d8_kernel(const AttnQkvPa
     }
     const bool own_ch = tid < C;                          // (C <= 512 <= NT is not guaranteed: channels beyond NT loop below)
     float g_pre = 0.f, b_pre = 0.f;
-    if (own_ch) { g_pre = p.gamma[tid]; b_pre = p.beta[tid]; }
+    const bool prenorm = p.st == nullptr;                 // x arrives normalised (producer-side GroupNorm): W' = W, b' = b
+    if (own_ch && !prenorm) { g_pre = p.gamma[tid]; b_pre = p.beta[tid]; }
     const bf16_t* wf_ptr = p.wfrag + (size_t)(hg * HG) * nks * 512;
     const int npieces = HG * nks * 64;
     constexpr int NPW = 2;                                // weight pieces held per thread up front (more: loaded in the loop)
@@ -421,7 +425,11 @@ __global__ void __launch_bounds__(1024) attention_qkv2_d8_kernel(const AttnQkvPa
     if (tid < 32 * HG && (tid & 31) < 24) bias_pre = p.bias[(hg * HG + (tid >> 5)) * 32 + (tid & 31)];
 
     // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic; one fold per workgroup) ----------------------------------
-    {
+    if (prenorm) {
+        for (int t = tid; t < C; t += NT) { sGa[t] = 1.f; sGs[t] = 0.f; }
+        if (tid < 8) sC[tid] = tid == 0 ? (bf16_t)0x3f80 : (bf16_t)0;
+        __syncthreads();
+    } else {
         const int cpg = C / p.groups;
         for (int t = tid; t < C; t += NT) {
             const float2* src = p.st + (size_t)b * p.P * C + t;

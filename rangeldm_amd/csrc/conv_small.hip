@@ -38,7 +38,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     constexpr int CIN = 16 * KG * CPT, C8 = CIN / 8;
     constexpr int RSM = CIN * 2 + 16;          // image row stride (bytes): C8 + 1 16-byte slots, odd
     constexpr int HALO = TAPS == 9 ? 1 : 0;
-    constexpr int TPG = TAPS == 1 ? 1 : (CPT <= 4 ? 3 : 1);   // taps per unrolled group (a tap row, or one tap for wide inputs)
+    // taps per unrolled group: all nine when a k-group has <= 2 steps per tap (the ring then holds the wave's WHOLE main stream --
+    // 9 / 18 fragments requested at kernel entry, no weight wait inside the K loop), a tap row, or one tap for wide inputs
+    constexpr int TPG = TAPS == 1 ? 1 : ((CPT <= 2 && MI <= 2) ? 9 : (CPT <= 4 ? 3 : 1));
     constexpr int G = TPG * CPT;               // k-steps per group = weight fragments in flight per wave
     constexpr int NGRP = TAPS / TPG;
     constexpr int PFX = (G % 3 == 0) ? 3 : 2;  // pixel fragments read ahead (LDS); divides G
@@ -87,15 +89,20 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     float* sBias = reinterpret_cast<float*>(sR + npx * RSR);    // BN
 
     // ---- bias (+ time embedding row): fetched now, parked in LDS after the staging loop ---------------------------------
+    // (the sampler's step index selects the time-embedding row: a uniform load at the top level -- a scalar load that does not sit
+    //  in the vector-memory queue -- instead of a dependent vector load in wave 0 ahead of its weight ring)
+    const int temb_step = (p.temb && p.step_ptr) ? *p.step_ptr : 0;
     float bias_v = 0.f, temb_v = 0.f;
-    if (tid < BN) {
-        const int ch = nt * BN + tid;
-        bias_v = p.bias[ch];
-        if (p.temb) {
-            const int step = p.step_ptr ? *p.step_ptr : 0;
-            temb_v = p.temb[(size_t)(step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld + ch];
+    if (tid < BN) bias_v = p.bias[nt * BN + tid];
+
+    // ---- producer-side GroupNorm: the consumers' gamma / beta of channel tid % BN (view tid / BN), requested now ---------
+    float nv_gamma = 0.f, nv_beta = 0.f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v)         // (constant indices: a run-time index into the by-value argument would copy it to scratch)
+        if (v < p.nviews && tid / BN == v) {
+            nv_gamma = p.nv[v].gamma[nt * BN + tid % BN];
+            nv_beta = p.nv[v].beta[nt * BN + tid % BN];
         }
-    }
 
     // ---- TAPS == 1: the GroupNorm inputs of channel `tid` (statistics partials of the producer, gamma, beta), requested now
     const bool gn = p.st0 != nullptr;       // (3x3: single-input convs only; concatenated inputs come pre-activated)
@@ -140,12 +147,55 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
         __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the K loop's counted waits rely on it
     }
 
+    if (p.temb && tid < BN)
+        temb_v = p.temb[(size_t)(temb_step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld + nt * BN + tid];
+
     RLDM_STAMP();
     // ---- the input tile, once: global -> LDS; wrap on W, zeros on H.  Wave w copies halo columns w, w + 8, ...; a wave
     // instruction moves SPI rows x C8 16-byte pieces of a column, so a lane's row, channel and both offsets never change.
     // TAPS == 1 with statistics: the GroupNorm affine of the image is derived while the first loads are in flight and
     // applied on the way into LDS ----
-    {
+    const bool whole_image = tiles_img == 1 && p.up == 1 && !gn && p.TW == p.Win && p.TH == p.Hin && 2 * p.TH * C8 <= NT;
+    if (whole_image) {
+        // the tile IS the image and arrives ready (pre-activated, or no norm): [npx][CIN] is one contiguous block -- a linear copy
+        // (thread-constant piece index -> pixel / channel by constant divisions, no per-piece predicates), the two wrap-around halo
+        // columns re-read from the image's last / first column, zero rows written without a load
+        constexpr int NPIECE = BM * C8, NLD = (NPIECE + NT - 1) / NT;
+        const unsigned char* img = reinterpret_cast<const unsigned char*>(p.x0) + (size_t)b * npx * (CIN * 2);
+        uint4 v[NLD], hv[HALO ? 1 : 1];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = tid + i * NT;
+            if (NPIECE % NT == 0 || q < NPIECE) v[i] = *reinterpret_cast<const uint4*>(img + (size_t)q * 16);
+        }
+        // halo columns (3x3): piece hq = (side, row, c8); side 0 -> LDS column 0 <- image column W - 1, side 1 -> column TW + 1 <- 0
+        const int nhalo = HALO ? 2 * p.TH * C8 : 0;
+        const int hside = tid / (p.TH * C8), hrem = tid - hside * (p.TH * C8);
+        if (HALO && tid < nhalo)
+            hv[0] = *reinterpret_cast<const uint4*>(img + ((size_t)(hside ? 0 : (p.TW - 1) * p.TH) * C8 + hrem) * 16);
+        RLDM_STAMP();                           // tile loads issued
+        if (HALO) {                             // zero rows 0 and TH + 1 of every halo column
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            for (int q = tid; q < TWv * 2 * C8; q += NT) {
+                const int col = q / (2 * C8), r = q - col * (2 * C8);
+                const int row = r < C8 ? 0 : THv - 1, c8 = r < C8 ? r : r - C8;
+                *reinterpret_cast<uint4*>(sA + col * colb + row * RSM + c8 * 16) = z;
+            }
+        }
+        RLDM_STAMP();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = tid + i * NT;
+            const int pix = q / C8, c8 = q - pix * C8;
+            const int pw = pix >> p.th_shift, ph = pix - (pw << p.th_shift);
+            if (NPIECE % NT == 0 || q < NPIECE)
+                *reinterpret_cast<uint4*>(sA + (pw + HALO) * colb + (ph + HALO) * RSM + c8 * 16) = v[i];
+        }
+        if (HALO && tid < nhalo) {
+            const int row = hrem / C8, c8 = hrem - row * C8;
+            *reinterpret_cast<uint4*>(sA + (hside ? TWv - 1 : 0) * colb + (row + 1) * RSM + c8 * 16) = hv[0];
+        }
+    } else {
         const int c8 = lane & (LPS - 1), rsub = lane / LPS;
         const bool laneok = c8 < C8;
         const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x0);
@@ -245,6 +295,8 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
             }
         }
         RLDM_STAMP();                           // tile normalised and stored
+    }
+    {
         // residual-phase input: raw cat[r0, r1], the tile's own pixels only; a wave instruction moves 64 / LPR pixels
         if (R8 > 0) {
             const int lgr = R8 <= 16 ? 4 : (R8 <= 32 ? 5 : 6);          // log2(lanes per pixel)
@@ -326,8 +378,8 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
         const int x0 = pw * colb + ph * RSM + kh * 16 + kg * 32;
 #pragma unroll
         for (int t = 0; t < TPG; ++t) {
-            xa[mi][t] = x0 + t * RSM;                                      // group 0: taps (0, t)
-            xn[mi][t] = TPG == 3 ? x0 + colb + t * RSM : x0 + RSM;         // group 1: taps (1, t) | tap (0, 1)
+            xa[mi][t] = TPG == 9 ? x0 + (t / 3) * colb + (t % 3) * RSM : x0 + t * RSM;   // group 0: all taps | taps (0, t)
+            xn[mi][t] = TPG == 3 ? x0 + colb + t * RSM : x0 + RSM;         // group 1: taps (1, t) | tap (0, 1) (TPG == 9: none)
         }
         xres[mi] = abytes + pidx * RSR + kh * 16 + kg * 32;
     }
@@ -470,6 +522,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     if (p.y_stats) {
         // the pixel groups of one wave fold by lane shuffles, the 8 waves through LDS
         float* sS = reinterpret_cast<float*>(sT + HB * TRS);                // [8 waves][2][BN]
+        float* sC = sS + 16 * BN;                                           // [2][BN]: the tile's per-channel (sum, sumsq)
 #pragma unroll
         for (int d = NCP; d < 64; d <<= 1) {
             s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d);
@@ -486,6 +539,59 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
 #pragma unroll
             for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
             reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
+            sC[tid] = S;
+        }
+        // ---- the tile IS the image (one tile per image): the statistics of its channels' groups are complete here, so the
+        // GroupNorm (+ SiLU) of every consumer is applied now, once, to the rounded tile still in LDS, instead of by each of
+        // the consumer's channel tiles on its way into LDS (statistics round trip + fold + 9 VALU instructions per element
+        // in front of every consumer's K loop).  Same arithmetic as the consumer-side fold: per-channel fp32 sums of the
+        // rounded values -> group sums in double -> a = gamma * rsq(var + eps), s = beta - mean * a -> a * x + s (-> SiLU) ----
+        RLDM_STAMP();                           // output and statistics written
+        if (NHALF == 1 && p.nviews > 0) {
+            float* sAff = sC + 2 * BN;                                      // [view][2][BN]
+            lds_barrier_s();
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                if (v >= p.nviews || tid / BN != v) continue;
+                const NormView nv = p.nv[v];
+                const int c = tid % BN, cpg = 1 << nv.cpg_shift, g0 = (c >> nv.cpg_shift) << nv.cpg_shift;
+                double S = 0.0, SS = 0.0;
+                for (int i = 0; i < cpg; ++i) {
+                    S += (double)sC[g0 + i];
+                    SS += (double)sC[BN + g0 + i];
+                }
+                const double inv_n = (double)nv.inv_n;
+                const double mean = S * inv_n;
+                double var = SS * inv_n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const float a = nv_gamma * __builtin_amdgcn_rsqf((float)var + nv.eps);
+                sAff[(v * 2 + 0) * BN + c] = a;
+                sAff[(v * 2 + 1) * BN + c] = nv_beta - (float)mean * a;
+            }
+            lds_barrier_s();
+            // item = (pixel, 4 channels): 8-byte pieces, 64-byte rows per pixel
+            constexpr int NC4 = BN / 4, VPASS = (HB * NC4 + NT - 1) / NT;
+#pragma unroll
+            for (int q = 0; q < VPASS; ++q) {
+                const int pl = tid / NC4 + q * (NT / NC4), c4 = tid % NC4;
+                if (pl >= HB) break;
+                const uint2 rq = *reinterpret_cast<const uint2*>(sT + pl * TRS + c4 * 8);
+                const float x[4] = {bf16lo(rq.x), bf16hi(rq.x), bf16lo(rq.y), bf16hi(rq.y)};
+                const int pw = pl >> p.th_shift, ph = pl - (pw << p.th_shift);
+                const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    if (v >= p.nviews) continue;
+                    const NormView nv = p.nv[v];
+                    const float4 av = *reinterpret_cast<const float4*>(sAff + (v * 2 + 0) * BN + c4 * 4);
+                    const float4 sv = *reinterpret_cast<const float4*>(sAff + (v * 2 + 1) * BN + c4 * 4);
+                    float f0 = x[0] * av.x + sv.x, f1 = x[1] * av.y + sv.y, f2 = x[2] * av.z + sv.z, f3 = x[3] * av.w + sv.w;
+                    if (nv.silu) { f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3); }
+                    uint2 o;
+                    o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
+                    *reinterpret_cast<uint2*>(nv.y + pix * nv.ld + nt * BN + c4 * 4) = o;
+                }
+            }
         }
     }
     RLDM_STAMP();
@@ -522,7 +628,7 @@ size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN) {
     const size_t r = (size_t)p.TW * p.TH * (R * 2 + 16);
     const size_t main_bytes = a + r + BN * 4 + 3072;            // + read-ahead slack past the residual image
     const size_t gn_bytes = a + 64 + (size_t)2 * Cin * 8 + (size_t)2 * Cin * 4;    // GroupNorm scratch behind the image
-    const size_t epi = (size_t)KG * BM * (BN * 4 + 16) + (size_t)BM * (BN * 2 + 16) + (size_t)8 * 2 * BN * 4;
+    const size_t epi = (size_t)KG * BM * (BN * 4 + 16) + (size_t)BM * (BN * 2 + 16) + (size_t)(8 * 2 + 2 + 6) * BN * 4;
     return std::max(std::max(main_bytes, gn_bytes), epi);
 }
 
@@ -553,6 +659,10 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     if (BMpx == 32 && (BN != 32 || p.up != 1 || !((taps == 9 && (cpt == 2 || cpt == 4)) || (taps == 1 && cpt == 2)))) return false;
     if (BMpx == 128 && (taps != 9 || BN != 64 || p.TW + 2 > 24 || (cpt != 2 && cpt != 4 && cpt != 6))) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
+    // normalised copies for the consumers: the tile owns the image, statistics on, whole groups inside a 32-channel tile
+    if (p.nviews < 0 || p.nviews > 3 || (p.nviews > 0 && (p.tiles_img != 1 || BMpx > 64))) return false;
+    for (int v = 0; v < p.nviews; ++v)
+        if (p.nv[v].cpg_shift < 0 || p.nv[v].cpg_shift > 5) return false;
     return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;
 }
 

@@ -115,14 +115,6 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     auto w_load = [&](const unsigned char* base, int idx) __attribute__((always_inline)) {      // fragment idx in [0, 16)
         return *reinterpret_cast<const bf16x8*>(base + (idx / 8) * 8192 + woff + ((idx % 8) * 1024 - 4096));
     };
-    bf16x8 wr[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        wr[j] = w_load(wptr, j);
-        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the counted waits below rely on it
-    }
-    wptr += G * 1024;                           // -> the fragments the first row of taps refills
-
     RLDM_STAMP();
     // ---- halo staging: thread-constant source pixel of each of its ACH 16-byte pieces ---------------------------------
     const int atotal = TWv * THv * C8;
@@ -223,6 +215,16 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     }
     float bias_v = 0.f;
     if (tid < BN) bias_v = p.bias[nt * BN + tid];
+    // the weight ring is requested BEHIND the statistics partials: s_waitcnt vmcnt counts in order, so the fold below would otherwise
+    // wait for the ring's 12 KB per wave (96 KB per CU through a 64 B/clk L1) before it sees its few hundred bytes
+    bf16x8 wr[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        wr[j] = w_load(wptr, j);
+        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the counted waits below rely on it
+    }
+    wptr += G * 1024;                           // -> the fragments the first row of taps refills
+
     RLDM_STAMP();
     // (address arithmetic of the halo pieces: integer multiplies, done while the requests above are in flight)
 #pragma unroll

@@ -11,6 +11,21 @@ namespace rldm {
 //   v(wrap(w*stride + i - pad_lo), h*stride + j - pad_lo) for taps i (azimuth), j (beams); h out of range -> 0.
 // Reference arithmetic: ldm/utils.py:40-55,107-116; vae/sgm/modules/diffusionmodules/model.py:93-125,164-172.
 // ---------------------------------------------------------------------------------------------------------------
+// A normalised (+ activated) copy of a conv's output, written by the PRODUCER's epilogue for one consuming GroupNorm
+// (conv_small.hip, tiles that own a whole image: the statistics of its 32 channels are complete inside the workgroup).
+// y = silu?( gamma * (x - mean_g) * rstd_g + beta ) on the bf16-rounded output, stored at channel offset of the consumer's
+// (possibly concatenated) input tensor.
+struct NormView {
+    bf16_t* y;              // consumer's pre-activated input [B][W][H][ld], already offset to this producer's first channel
+    const float* gamma;     // consumer's GroupNorm affine, offset the same way
+    const float* beta;
+    int ld;
+    int cpg_shift;          // log2(channels per group) of the CONSUMER's norm (<= 5: a 32-channel tile holds whole groups)
+    float inv_n;            // 1 / (pixels per image * channels per group)
+    float eps;
+    int silu;
+};
+
 struct ConvParams {
     // main phase: TAPS taps per CK-channel chunk over cat[x0, x1], GroupNorm (+SiLU) applied on the way into LDS
     const bf16_t* x0;
@@ -66,6 +81,8 @@ struct ConvParams {
     const bf16_t* res;       // conv_small.hip: identity residual [B][Wout][Hout][N] added in the epilogue (or null)
     unsigned long long* ts;  // tuning: s_memtime stamps of blocks 0..3, wave 0 ([4][64]) or null
     int dbg;                // tuning ablations (rldm_debug_set_flags): 1 skip stores, 2 skip main loop, 4 skip GN finalize
+    int nviews;             // conv_small.hip, image-owning tiles: normalised copies of the output for up to 3 consumers
+    NormView nv[3];
 };
 
 struct ConvTile {

@@ -294,6 +294,7 @@ struct Tensor {
     int id = -1;
     size_t st_off = 0;     // per-channel partial statistics [B][P][C] float2 (P == 0: none)
     int P = 0;
+    int prod = -1;         // ordinal of the Builder::conv call that produced it (-1: something else)
     size_t st_bytes() const { return (size_t)B * P * C * sizeof(float2); }
     size_t bytes() const { return (size_t)B * W * H * C * sizeof(bf16_t); }
     bool valid() const { return id >= 0; }
@@ -453,6 +454,44 @@ struct ConvArgs {
     Tensor r0, r1;                 // residual-phase sources (layer->R channels in total), at output resolution
     bool want_stats = false;       // emit per-channel statistics of the output (a GroupNorm will read it)
     bool out_f32_nchw = false;     // conv_out: write plan->io.out
+    bool own_image = false;        // conv_small route with ONE tile per image (the producer normalises for its consumers)
+};
+
+// Producer-side GroupNorm: which convs write a normalised (+ activated) copy of their output for which
+// consuming GroupNorm.  Filled by a recording pass over the network walk (the walk is the same in every pass, so a conv is
+// identified by its ordinal), read by the sizing and the real pass.
+struct ViewPlan {
+    struct Part { int prod; int ch_off; };
+    struct Cons {
+        std::vector<Part> parts;
+        int Ctot = 0, silu = 0, groups = 32;
+        float eps = 1e-5f;
+        bool ok = false;               // the consumer can read a pre-activated tensor (conv_small 3x3, fused attention)
+        bool use = false;              // decided: ok and every part's producer can emit
+    };
+    struct Emit { const NormParams* norm; int ch_off; int Ctot; int silu; int groups; float eps; };
+    std::vector<char> can_emit;        // by conv ordinal
+    std::vector<int> out_c;            // output channels, by conv ordinal (tuning aid below)
+    std::map<const NormParams*, Cons> cons;
+    std::map<int, std::vector<Emit>> emit;
+    void decide() {
+        std::map<int, int> nper;
+        for (auto& kv : cons) {
+            Cons& c = kv.second;
+            bool good = c.ok && c.groups > 0 && c.Ctot % c.groups == 0;
+            const int cpg = good ? c.Ctot / c.groups : 0;
+            good = good && cpg >= 1 && cpg <= 32 && (cpg & (cpg - 1)) == 0;
+            for (auto& pt : c.parts)
+                good = good && pt.prod >= 0 && pt.prod < (int)can_emit.size() && can_emit[pt.prod] && pt.ch_off % cpg == 0 &&
+                       nper[pt.prod] < 3;
+            c.use = good;
+            if (!good) continue;
+            for (auto& pt : c.parts) {
+                emit[pt.prod].push_back({kv.first, pt.ch_off, c.Ctot, c.silu, c.groups, c.eps});
+                nper[pt.prod]++;
+            }
+        }
+    }
 };
 
 // routing / ablation switches (rldm_debug_set_flags); RLDM_DBG_FLAGS seeds them for A/B runs of unmodified drivers
@@ -578,6 +617,37 @@ struct Builder {
     int temb_ld = 0;               // row stride of the time-embedding table (0: network has none)
     int* ticket_ptr = nullptr;     // split-K arrival counters (plan->tickets, zeroed at allocation; null in the dry pass)
     int tickets = 0;
+    ViewPlan* vp = nullptr;        // producer-side GroupNorm plan (null: off)
+    bool recording = false;        // the pass that fills *vp (a dry pass)
+    int conv_ord = 0;
+    int groups_hint = 32;
+    std::map<const NormParams*, Tensor> view_tensors;      // consumer norm -> its pre-activated input (alive until consumed)
+    const std::vector<ViewPlan::Emit>* cur_emit = nullptr; // of the conv being built
+
+    // recording pass: GroupNorm `n` over cat[x0, x1] is consumed by something that could read a pre-activated tensor instead
+    void record_consumer(const NormParams* n, const Tensor& x0, const Tensor& x1, int silu, bool ok, int groups, float eps) {
+        if (!vp || !recording || !n) return;
+        ViewPlan::Cons c;
+        c.parts.push_back({x0.prod, 0});
+        if (x1.valid()) c.parts.push_back({x1.prod, x0.C});
+        c.Ctot = x0.C + (x1.valid() ? x1.C : 0);
+        c.silu = silu;
+        c.groups = groups;
+        c.eps = eps;
+        c.ok = ok && x0.W * x0.H == (x1.valid() ? x1.W * x1.H : x0.W * x0.H);
+        vp->cons[n] = c;
+    }
+    // sizing / real pass: the pre-activated input of the consumer that owns norm `n`, if the plan has one
+    bool take_view(const NormParams* n, Tensor* v) {
+        if (!vp || recording || !n) return false;
+        auto it = vp->cons.find(n);
+        if (it == vp->cons.end() || !it->second.use) return false;
+        auto vt = view_tensors.find(n);
+        if (vt == view_tensors.end()) return false;
+        *v = vt->second;
+        view_tensors.erase(vt);
+        return true;
+    }
 
     Tensor make(int B, int W, int H, int C) {
         Tensor t;
@@ -649,7 +719,11 @@ struct Builder {
         // (32 for 32x1 images: the lowest nuScenes level, which otherwise runs as 8 workgroups of the generic kernel; and for
         //  32x2 images, as two tiles each: twice the workgroups, half the staging / epilogue per workgroup -- level-3 convs
         //  13.4-14.2 -> 13.0 us, +0.5-1 % end to end; rldm_debug_set_flags(524288) keeps the 64-pixel tile: A/B runs, tests)
-        const int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : ((Wout * Hout == 32 || (Wout * Hout == 64 && Hout == 2 && !(g_dbg_flags & 524288))) && a.up == 1 ? 32 : 64);
+        int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : ((Wout * Hout == 32 || (Wout * Hout == 64 && Hout == 2 && !(g_dbg_flags & 524288))) && a.up == 1 ? 32 : 64);
+        if (a.own_image) {                      // one tile per image (<= 64 pixels), or not this route
+            if (Wout * Hout > 64 || a.up != 1) return false;
+            bm = Wout * Hout;
+        }
         if (taps == 1 && a.x1.valid()) return false;
         if (!a.gn && a.x1.valid()) return false;
         if (a.layer->Cout % 32 != 0 || (g_force_bm && g_force_bm != 64)) return false;
@@ -683,10 +757,11 @@ struct Builder {
     // 3x3: 64 channels when that fills the chip, else 32 (twice the blocks, half the weight stream per block).
     // 1x1: the work per block is a few MFMAs and the launch is one latency chain per block, so the route is taken only if
     // the grid fits one round of 256 workgroups -- with the narrowest tile that does (most blocks); else the generic kernel.
-    static int small_bn(const ConvParams& q, int taps, bool gn_fused) {
+    static int small_bn(const ConvParams& q, int taps, bool gn_fused, bool own = false) {
         ConvParams t = q;
         if (gn_fused) t.st0 = reinterpret_cast<const float2*>(&t);      // (only its presence matters to the shape check)
         const long long tiles = (long long)q.B * q.tiles_img;
+        if (own) return (q.tiles_img == 1 && conv_small_supported(t, taps, 32)) ? 32 : 0;      // whole groups per 32-channel tile
         if (g_force_bn && conv_small_supported(t, taps, g_force_bn)) return g_force_bn;
         if (taps == 9 && q.TW * q.TH == 128)    // one round of workgroups, or the generic kernel
             return (conv_small_supported(t, 9, 64) && tiles * (q.N / 64) <= 256) ? 64 : 0;
@@ -709,7 +784,7 @@ struct Builder {
         ConvParams q;
         bool epi;
         if (!small_params(a, Cin_t, R_t, taps, Wout, Hout, &q, &epi)) return false;
-        return small_bn(q, taps, small_gn_fused(a, taps)) != 0;
+        return small_bn(q, taps, small_gn_fused(a, taps), a.own_image) != 0;
     }
 
     int conv_small(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, Tensor* out) {
@@ -748,12 +823,23 @@ struct Builder {
         RLDM_REQUIRE(small_params(a, Cin_t, R_t, taps, Wout, Hout, &p, &epi_res), "conv " + L->name + ": conv_small route lost");
         p.dbg = g_dbg_flags;
         p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
-        const int BN = small_bn(p, taps, gn_fused);
+        const int BN = small_bn(p, taps, gn_fused, a.own_image);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
         p.ntile_n = N / BN;
 
         Tensor y = make(x0.B, Wout, Hout, N);
-        if (a.want_stats) add_stats(y, p.tiles_img);
+        if (a.want_stats || a.own_image) add_stats(y, p.tiles_img);
+        // normalised copies for the consumers (producer-side GroupNorm): the consumer's input tensor is created by the first
+        // producer that writes a part of it and released by the consumer
+        std::vector<Tensor> vts;
+        if (a.own_image && cur_emit) {
+            RLDM_REQUIRE(p.tiles_img == 1 && cur_emit->size() <= 3, "conv " + L->name + ": producer-side GroupNorm lost its tile");
+            for (const auto& e : *cur_emit) {
+                auto it = view_tensors.find(e.norm);
+                if (it == view_tensors.end()) it = view_tensors.emplace(e.norm, make(x0.B, Wout, Hout, e.Ctot)).first;
+                vts.push_back(it->second);
+            }
+        }
         const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
         plan->flops += fl;
         ++launches;
@@ -776,10 +862,25 @@ struct Builder {
             p.y_ld = N;
             p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
             p.temb_ld = temb_ld;
+            for (size_t v = 0; v < vts.size(); ++v) {
+                const auto& e = (*cur_emit)[v];
+                NormView& nv = p.nv[v];
+                nv.y = tptr(vts[v]) + e.ch_off;
+                nv.gamma = e.norm->gamma.as<float>() + e.ch_off;
+                nv.beta = e.norm->beta.as<float>() + e.ch_off;
+                nv.ld = e.Ctot;
+                const int cpg = e.Ctot / e.groups;
+                nv.cpg_shift = 0;
+                while ((1 << nv.cpg_shift) < cpg) ++nv.cpg_shift;
+                nv.inv_n = (float)(1.0 / ((double)Wout * Hout * cpg));
+                nv.eps = e.eps;
+                nv.silu = e.silu;
+            }
+            p.nviews = (int)vts.size();
             Plan* pl = plan;
             const int temb_off = a.temb_off;
             const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * taps + L->R) * 2.0 +
-                              (double)x0.B * Wout * Hout * N * 2.0 + (double)x0.B * Wout * Hout * R_t * 2.0;
+                              (double)x0.B * Wout * Hout * N * 2.0 * (1.0 + (double)vts.size()) + (double)x0.B * Wout * Hout * R_t * 2.0;
             const std::string kname = "conv_small_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(BN) + ",taps" + std::to_string(taps) + ">";
             plan->ops.push_back({[p, BN, taps, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
@@ -918,8 +1019,42 @@ struct Builder {
     }
 
     // y = conv(...) ; consumes nothing (callers release inputs)
-    int conv(const ConvArgs& a, Tensor* out) {
+    int conv(const ConvArgs& a0, Tensor* out) {
+        ConvArgs a = a0;
+        const int ord = conv_ord++;
+        ConvLayer* L = a.layer;
+        RLDM_REQUIRE(L != nullptr, "internal: missing conv layer");
+        const int taps = L->ksize * L->ksize;
+        const int Cin_t = a.x0.C + (a.x1.valid() ? a.x1.C : 0);
+        const int R_t = (a.r0.valid() ? a.r0.C : 0) + (a.r1.valid() ? a.r1.C : 0);
+        const int Wout = a.x0.W * a.up / a.stride, Hout = a.x0.H * a.up / a.stride;
+        Tensor view;
+        if (recording && vp) {
+            // as a consumer: could this conv read cat[x0, x1] already normalised + activated?  (3x3 on the conv_small route)
+            ConvArgs c = a;
+            c.x0.C = Cin_t; c.x1 = Tensor(); c.gn = nullptr; c.silu = 0;
+            if (a.gn) record_consumer(a.gn, a.x0, a.x1, a.silu, taps == 9 && small_route(c, Cin_t, R_t, taps, Wout, Hout), a.groups, a.eps);
+            // as a producer: with one tile per image, whether its own input arrives raw (statistics) or pre-activated
+            ConvArgs o = a, oc = c;
+            o.own_image = oc.own_image = true;
+            if ((int)vp->can_emit.size() <= ord) vp->can_emit.resize(ord + 1, 0);
+            if ((int)vp->out_c.size() <= ord) vp->out_c.resize(ord + 1, 0);
+            vp->out_c[ord] = L->Cout;
+            vp->can_emit[ord] = !(g_dbg_flags & 1048576) && !a.out_f32_nchw && small_route(o, Cin_t, R_t, taps, Wout, Hout) &&
+                                (!a.gn || small_route(oc, Cin_t, R_t, taps, Wout, Hout));
+        } else if (vp) {
+            if (take_view(a.gn, &view)) {
+                a.x0 = view; a.x1 = Tensor(); a.gn = nullptr; a.silu = 0;
+            }
+            auto it = vp->emit.find(ord);
+            cur_emit = (it != vp->emit.end() && !it->second.empty()) ? &it->second : nullptr;
+            a.own_image = cur_emit != nullptr;
+        }
         if (conv_route(a, out)) return 1;
+        cur_emit = nullptr;
+        if (view.valid()) release(view);
+        out->prod = ord;
+        if (out->valid()) live[out->id] = *out;
         return fold_stats(*out);
     }
     int conv_route(const ConvArgs& a, Tensor* out) {
@@ -1057,10 +1192,45 @@ struct Builder {
 // Two passes over the same walk: a dry one sizes the activation arena (and the split-K counters), the real one bakes
 // device pointers into the launch list.
 static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)>& walk, int* launches = nullptr) {
+    // pass 0 records which GroupNorms could be applied by the producers of their inputs (ViewPlan)
+    ViewPlan vplan;
+    {
+        Builder rec;
+        rec.plan = plan;
+        rec.dry = true;
+        rec.recording = true;
+        rec.vp = &vplan;
+        rec.temb_ld = temb_ld;
+        if (walk(rec)) return 1;
+        vplan.decide();
+        // tuning aid (tools/bench_conv.py on a single conv): RLDM_FAKE_VIEWS=n makes every conv that could normalise for a
+        // consumer write n copies nobody reads (identity affine, SiLU on), so the epilogue's cost can be stamped alone
+        const char* fv = getenv("RLDM_FAKE_VIEWS");
+        if (!fv && (g_dbg_flags & (1 << 22))) fv = "2";     // (tests: the own-image tile + epilogue on single-conv plans)
+        if (fv) {
+            static std::map<int, std::unique_ptr<NormParams>> dummies;
+            for (int ord = 0; ord < (int)vplan.can_emit.size(); ++ord) {
+                if (!vplan.can_emit[ord] || vplan.emit.count(ord) || vplan.out_c[ord] % 32 != 0) continue;
+                const int C = vplan.out_c[ord];
+                for (int i = 0; i < std::min(3, atoi(fv)); ++i) {
+                    auto& d = dummies[C * 4 + i];
+                    if (!d) {
+                        d = std::make_unique<NormParams>();
+                        d->C = C;
+                        std::vector<float> one(C, 1.f), zero(C, 0.f);
+                        if (upload(d->gamma, one.data(), C * 4) || upload(d->beta, zero.data(), C * 4)) return 1;
+                    }
+                    vplan.emit[ord].push_back({d.get(), 0, C, 1, 32, 1e-5f});
+                }
+            }
+        }
+        plan->flops = 0;
+    }
     Builder dry;
     dry.plan = plan;
     dry.dry = true;
     dry.temb_ld = temb_ld;
+    dry.vp = &vplan;
     if (walk(dry)) return 1;
     if (launches) *launches = dry.launches;
     if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
@@ -1074,6 +1244,7 @@ static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)
     real.base = plan->arena.as<char>();
     real.ticket_ptr = plan->tickets.as<int>();
     real.temb_ld = temb_ld;
+    real.vp = &vplan;
     if (walk(real)) return 1;
     return 0;
 }
@@ -1145,6 +1316,10 @@ struct NetCommon {
         const int Lt = x.W * x.H;
         if (!(g_dbg_flags & 32768) && x.C % 16 == 0 && x.C <= 512 && Lt <= 1024 && x.P > 0 && x.C % groups == 0) {
             // GroupNorm + q/k/v projection inside the attention launch: no [B][L][3C] tensor, one launch less
+            NormParams* gnp = layers.get_norm(p + ".group_norm");
+            b.record_consumer(gnp, x, Tensor(), 0, true, groups, eps);
+            Tensor xn;                                  // x already normalised by its producer (producer-side GroupNorm)
+            const bool pre = b.take_view(gnp, &xn);
             Tensor o = b.make(x.B, x.W, x.H, x.C);
             const double fl = 4.0 * (double)x.B * (x.C / 8) * (double)Lt * Lt * 8 + 2.0 * (double)x.B * Lt * 3.0 * x.C * x.C;
             b.plan->flops += fl;
@@ -1152,11 +1327,10 @@ struct NetCommon {
             if (!b.dry) {
                 AttnFused* f = nullptr;
                 if (get_attn_fused(p, x.C, &f)) return 1;
-                NormParams* gnp = layers.get_norm(p + ".group_norm");
                 AttnQkvParams ap;
                 memset(&ap, 0, sizeof(ap));
-                ap.x = b.tptr(x);
-                ap.st = b.sptr(x);
+                ap.x = pre ? b.tptr(xn) : b.tptr(x);
+                ap.st = pre ? nullptr : b.sptr(x);
                 ap.P = x.P;
                 ap.gamma = gnp->gamma.as<float>();
                 ap.beta = gnp->beta.as<float>();
@@ -1174,6 +1348,7 @@ struct NetCommon {
                 b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl,
                                        (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0});
             }
+            if (pre) b.release(xn);
             ConvArgs co;
             co.layer = layers.get_conv(p + ".to_out.0");
             co.x0 = o;
@@ -1978,9 +2153,21 @@ double rldm_unet_flops(rldm_unet* m, int B) {
 int rldm_unet_num_launches(rldm_unet* m, int B) {
     if (!m || !m->params.finalized) return -1;
     Plan tmp;
+    ViewPlan vplan;                     // same three-pass scheme as build_plan, without the real pass
+    {
+        Builder rec;
+        rec.plan = &tmp;
+        rec.dry = true;
+        rec.recording = true;
+        rec.vp = &vplan;
+        rec.temb_ld = m->net.temb_ld;
+        if (unet_walk(m, rec, B)) return -1;
+        vplan.decide();
+    }
     Builder dry;
     dry.plan = &tmp;
     dry.dry = true;
+    dry.vp = &vplan;
     dry.temb_ld = m->net.temb_ld;
     if (unet_walk(m, dry, B)) return -1;
     return dry.launches + 1;   // + time-embedding kernel

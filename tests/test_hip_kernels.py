@@ -100,13 +100,15 @@ GN_CASES = [(256, 256, 256, 32, 1), (128, 128, 128, 32, 16), (256, 128, 256, 16,
             (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16)]
 
 
-@pytest.fixture(params=[0, 1024, 4096, 256 + 2048, 524288],
-                ids=["default", "small-128px-tiles", "stream-any-grid", "generic-only", "level3-64px-tiles"])
+@pytest.fixture(params=[0, 1024, 4096, 256 + 2048, 524288, 1 << 22],
+                ids=["default", "small-128px-tiles", "stream-any-grid", "generic-only", "level3-64px-tiles", "own-image-tiles"])
 def conv_flags(request):
     """Routing of the conv launches: 0 default; 1024 also sends the 128x8 level to conv_small.hip (128-pixel tiles);
     4096 sends every eligible 3x3 to conv_stream.hip regardless of the grid size (by default it needs >= 128 workgroups);
     256 + 2048 keeps everything on the generic implicit-GEMM kernel; 524288 keeps 32x2 images on one 64-pixel conv_small tile
-    (by default they run as two 32-pixel tiles)."""
+    (by default they run as two 32-pixel tiles); 1 << 22 makes every conv that can own a whole image (<= 64 pixels, conv_small.hip)
+    do so and write two normalised copies of its output (producer-side GroupNorm epilogue; the copies are checked at network level:
+    test_producer_side_groupnorm_matches_consumer_side)."""
     from rangeldm_amd import _lib
     _lib.lib().rldm_debug_set_flags(request.param)
     yield request.param

@@ -96,6 +96,31 @@ def test_unet_forward_full_config_golden(golden):
     assert abs(m.flops(1) / 1e9 - 34.071) < 0.35          # 34.071 GFLOP per sample-forward
 
 
+@pytest.mark.parametrize("size", [(256, 16), (256, 8)])
+def test_producer_side_groupnorm_matches_consumer_side(size):
+    """Producer-side GroupNorm (conv_small.hip epilogue: a conv whose tile owns a whole <= 64-pixel image writes the normalised +
+    activated copies its consumers read) against the same network with every GroupNorm applied by the consumer
+    (rldm_debug_set_flags(1048576)): the arithmetic is the same, only the summation split of the statistics (one 64-pixel tile
+    against two 32-pixel tiles) differs, and a last-bit change of a scale flips bf16 roundings downstream -- so the two forwards differ by about what either differs from the oracle."""
+    from rangeldm_amd import _lib
+    cfg = UNetConfig(sample_size=size)
+    x = T(normal(11, "x", (2, cfg.in_channels, *cfg.sample_size))).cuda()
+    outs = []
+    for flags in (0, 1048576):
+        _lib.lib().rldm_debug_set_flags(flags)
+        try:
+            m, _ = hip_unet(cfg, "ps.")
+            outs.append((m(x, 250).sample.cpu(), m.num_launches(2) if hasattr(m, "num_launches") else None))
+        finally:
+            _lib.lib().rldm_debug_set_flags(0)
+    assert torch.isfinite(outs[0][0]).all()
+    d = rel_l2(outs[0][0], outs[1][0])
+    print("producer- vs consumer-side GroupNorm: rel-L2", float(d))
+    assert d < TOL_FWD / 2
+    if outs[0][1] is not None:
+        assert outs[0][1] < outs[1][1]                     # the separate gn_apply launches in front of the up-block convs are gone
+
+
 def test_unet_errors():
     cfg = UNetConfig(**SMALL)
     from rangeldm_amd.unet import UNet2DModelHIP
