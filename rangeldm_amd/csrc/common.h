@@ -90,6 +90,16 @@ __device__ inline float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// The sampler's step index (device int behind a uniform pointer) as a VECTOR load.  As a scalar load it would share lgkmcnt with
+// the kernel-argument loads, which return out of order: the first use of any later argument then waits for it too, and every
+// wave of the launch stalls one cold memory round trip at entry.  The lane offset is an opaque zero, so the compiler keeps the
+// load in the vector queue, where it is the first (in-order) request and its consumer far away waits for nothing.
+__device__ __forceinline__ int load_step_vector(const int* step_ptr) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return step_ptr[z];
+}
+
 // XCD-aware block remap (guide T1): blocks land on XCD (bid % 8); give each XCD a contiguous range of logical ids
 // so neighbouring tiles (which share input halos / weight panels) hit the same private L2.  Bijective for any n.
 __device__ inline int xcd_remap(int bid, int nblocks) {

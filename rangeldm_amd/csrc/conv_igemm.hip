@@ -673,6 +673,16 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     // ---- epilogue ----------------------------------------------------------------------------------------------------
     if (p.y_nchw) {                            // fp32 NCHW (network outputs: few channels), straight from the registers
         if (kg != 0) return;
+        // fused scheduler step (sched_step_kernel's arithmetic on the value just computed)
+        const bool sched = p.sch.coef_table != nullptr;
+        float c0 = 1.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
+        const float* nz = nullptr;
+        if (sched) {
+            const int step = *p.sch.step_ptr;
+            const float* c = p.sch.coef_table + 5 * step;
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4];
+            if (p.sch.noise && c4 != 0.f) nz = p.sch.noise + (size_t)step * p.sch.noise_step_stride;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int pidx = wm * (MI * 32) + mi * 32 + l31;
@@ -684,8 +694,18 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = nt * BN + wn * (NI * 32) + ni * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    if (ch < p.N && !(p.dbg & 1))
-                        p.y_nchw[(((size_t)b * p.N + ch) * p.Wout + ow) * p.Hout + oh] = acc[0][ni][mi][r];
+                    if (ch < p.N && !(p.dbg & 1)) {
+                        const size_t i = (((size_t)b * p.N + ch) * p.Wout + ow) * p.Hout + oh;
+                        const float e = acc[0][ni][mi][r];
+                        p.y_nchw[i] = e;
+                        if (sched) {
+                            const float x = p.sch.x[i];
+                            const float x0 = (x - c1 * e) / c0;
+                            float prev = (p.sch.mode == 0) ? c2 * x0 + c3 * e : c2 * x0 + c3 * x;
+                            if (nz) prev += c4 * nz[i];
+                            p.sch.x_prev[i] = prev;
+                        }
+                    }
                 }
         }
         return;

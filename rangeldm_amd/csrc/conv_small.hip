@@ -59,9 +59,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     const int wn = wave % NWN, kg = wave / NWN;
     const int kh = lane >> 5, l31 = lane & 31;
 #ifdef RLDM_ABLATE
-    unsigned long long tsv[12];
+    unsigned long long tsv[16];
     int tsn = 0;
-#define RLDM_STAMP() if (tsn < 12) tsv[tsn++] = __builtin_amdgcn_s_memtime()
+#define RLDM_STAMP() if (tsn < 16) tsv[tsn++] = __builtin_amdgcn_s_memtime()
 #else
 #define RLDM_STAMP()
 #endif
@@ -74,6 +74,10 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     // grid = (channel tiles, pixel tiles of an image, images).  Workgroups go to the XCDs round-robin in x-fastest order, so
     // with 4 or 8 channel tiles all blocks that stream the same weight slice share an XCD (one L2 copy of it)
     const int tiles_h = p.tiles_h, tiles_img = p.tiles_img;       // tiles_h is a power of two
+#ifdef RLDM_ABLATE
+    asm volatile("s_nop 0" :: "s"(tiles_h));                      // (the stamp below sits behind the kernel-argument wait)
+#endif
+    RLDM_STAMP();                               // kernel arguments arrived
     const int nt = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
     const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
     const int w0 = tw * p.TW, h0 = th * p.TH;
@@ -89,9 +93,9 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     float* sBias = reinterpret_cast<float*>(sR + npx * RSR);    // BN
 
     // ---- bias (+ time embedding row): fetched now, parked in LDS after the staging loop ---------------------------------
-    // (the sampler's step index selects the time-embedding row: a uniform load at the top level -- a scalar load that does not sit
-    //  in the vector-memory queue -- instead of a dependent vector load in wave 0 ahead of its weight ring)
-    const int temb_step = (p.temb && p.step_ptr) ? *p.step_ptr : 0;
+    // (the sampler's step index selects the time-embedding row: requested first, as a vector load -- common.h -- and used behind
+    //  the weight ring; the dependent row load then costs wave 0 nothing ahead of its ring)
+    const int temb_step = (p.temb && p.step_ptr && tid < BN) ? load_step_vector(p.step_ptr) : 0;
     float bias_v = 0.f, temb_v = 0.f;
     if (tid < BN) bias_v = p.bias[nt * BN + tid];
 
@@ -128,6 +132,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
         g_beta = p.gn_beta[tid];
     }
 
+    RLDM_STAMP();                               // small requests (bias, statistics partials, affines) issued
     // ---- this wave's weight stream: [9 * CPT main steps (tap-major)][RPT residual steps], 1 KiB each; lane l holds channel
     // l & 31, k = 8 * (l >> 5) .. + 8 of the step.  The first G fragments are requested before anything else.
     const int RPT = (R >> 4) / KG;              // residual steps of this k-group (<= RMAX)
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) 
     RLDM_STAMP();
 #ifdef RLDM_ABLATE
     if (p.ts && blockIdx.x < 4 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
-        for (int i = 0; i < 12; ++i) p.ts[blockIdx.x * 64 + i] = i < tsn ? tsv[i] : 0ull;
+        for (int i = 0; i < 16; ++i) p.ts[blockIdx.x * 64 + i] = i < tsn ? tsv[i] : 0ull;
     {
         const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (p.ts && tid == 0 && lin < 2048) {

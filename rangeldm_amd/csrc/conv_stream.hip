@@ -78,9 +78,9 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     // tiles both read (34 x 10 positions for 32 x 8 pixels: 1.33x the tile) are fetched from HBM / Infinity Cache once.
     int nt, mt, b;
     {
-        const int gx = gridDim.x, gy = gridDim.y;
+        const int gx = p.ntile_n, gy = tiles_img;      // (== gridDim.x / .y: from the arguments, not a dependent read of the dispatch packet)
         const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        const int rid = (p.dbg & (1 << 21)) ? lin : xcd_remap(lin, gx * gy * (int)gridDim.z);
+        const int rid = (p.dbg & (1 << 21)) ? lin : xcd_remap(lin, gx * gy * p.B);
         const int q = rid / gx;
         nt = rid - q * gx;
         b = q / gy;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
     const int w0 = tw * p.TW, h0 = th * p.TH;
 
     // the sampler's step index selects the time-embedding row: requested first, used after everything else is in flight
-    const int temb_step = (p.temb && p.step_ptr) ? *p.step_ptr : 0;
+    const int temb_step = (p.temb && p.step_ptr && tid < BN) ? load_step_vector(p.step_ptr) : 0;
 
     const int Cin = p.C0 + p.C1;
     const int NCC = Cin / CK;                  // main-phase chunks: 9 taps x 4 k-steps

@@ -10,6 +10,9 @@ namespace rldm {
 __global__ void __launch_bounds__(256) pack_input_kernel(const PackInputParams p) {
     const long long npix = (long long)p.B * p.W * p.H;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the sampler's step index: advanced by the first launch of a step (nothing in this kernel reads it; every later launch of the
+    // step sees the new value across the kernel boundary) instead of by a one-thread launch of its own behind the scheduler step
+    if (i == 0 && p.step_inc) *p.step_inc += 1;
     if (i >= npix) return;
     const int hw = p.W * p.H;
     const int b = (int)(i / hw);

@@ -26,6 +26,19 @@ struct NormView {
     int silu;
 };
 
+// The scheduler step fused into conv_out's fp32 NCHW epilogue (conv_igemm.hip): the thread that produces eps[i] also holds the
+// index of x[i], so x_prev[i] = step(x[i], eps[i], noise[i]) costs one more load and store instead of a launch of its own
+// (DDIMScheduler.step / DDPMScheduler.step; same arithmetic as sched_step_kernel).
+struct SchedFuse {
+    const float* coef_table;  // device [steps][5]; null: not fused
+    const int* step_ptr;
+    const float* x;
+    const float* noise;       // [steps][noise_step_stride] or null
+    long long noise_step_stride;
+    float* x_prev;
+    int mode;                 // 0 ddim, 1 ddpm
+};
+
 struct ConvParams {
     // main phase: TAPS taps per CK-channel chunk over cat[x0, x1], GroupNorm (+SiLU) applied on the way into LDS
     const bf16_t* x0;
@@ -81,6 +94,7 @@ struct ConvParams {
     const bf16_t* res;       // conv_small.hip: identity residual [B][Wout][Hout][N] added in the epilogue (or null)
     unsigned long long* ts;  // tuning: s_memtime stamps of blocks 0..3, wave 0 ([4][64]) or null
     int dbg;                // tuning ablations (rldm_debug_set_flags): 1 skip stores, 2 skip main loop, 4 skip GN finalize
+    SchedFuse sch;          // conv_igemm.hip, y_nchw outputs: the sampler's scheduler step in the epilogue
     int nviews;             // conv_small.hip, image-owning tiles: normalised copies of the output for up to 3 consumers
     NormView nv[3];
 };
@@ -202,6 +216,7 @@ struct PackInputParams {
     const float* cond; int cc;
     int B, W, H, Cpad;
     bf16_t* out;
+    int* step_inc;            // sampler: the device step index is advanced here, by the first launch of a step (or null)
 };
 int launch_pack_input(const PackInputParams& p, hipStream_t stream);
 int launch_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int W, int H, int Cpad, hipStream_t s);

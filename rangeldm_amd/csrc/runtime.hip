@@ -315,6 +315,9 @@ struct PlanIO {
     const int* step_ptr = nullptr;
     int temb_rows_per_step = 1;
     int temb_per_sample = 0;
+    // sampler only: the step index advanced by the step's first launch, the scheduler step in conv_out's epilogue
+    int* step_inc = nullptr;
+    SchedFuse sch = {};
 };
 
 struct Op {
@@ -1179,7 +1182,10 @@ struct Builder {
                     p.temb_rows_per_step = pl->io.temb_rows_per_step;
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
-                if (f32out) p.y_nchw = pl->io.out;
+                if (f32out) {
+                    p.y_nchw = pl->io.out;
+                    p.sch = pl->io.sch;
+                }
                 return launch_conv(tile, p, s);
             }, kname, fl, by});
         }
@@ -1569,12 +1575,13 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
     if (!b.dry) {
         bf16_t* dst = b.tptr(xin);
         plan->ops.push_back({[plan, dst, B, W, H, Cpad](hipStream_t s) {
-            PackInputParams p;
+            PackInputParams p{};
             p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
             p.pos_encoding = plan->io.pos_encoding;
             p.cond = plan->io.cond; p.cc = plan->io.cond_channels;
             p.B = B; p.W = W; p.H = H; p.Cpad = Cpad;
             p.out = dst;
+            p.step_inc = plan->io.step_inc;
             return launch_pack_input(p, s);
         }, "pack_input_kernel", 0.0, (double)B * W * H * (Cpad * 2.0 + 4.0 * 5)});
     }
@@ -1785,7 +1792,7 @@ static void push_pack_input(Builder& b, Tensor xin) {
     bf16_t* dst = b.tptr(xin);
     const int B = xin.B, W = xin.W, H = xin.H, Cpad = xin.C;
     plan->ops.push_back({[plan, dst, B, W, H, Cpad](hipStream_t s) {
-        PackInputParams p;
+        PackInputParams p{};
         p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
         p.pos_encoding = 0; p.cond = nullptr; p.cc = 0;
         p.B = B; p.W = W; p.H = H; p.Cpad = Cpad;
@@ -1923,6 +1930,7 @@ struct SamplerLane {
     hipEvent_t ev_out = nullptr;
     hipGraphExec_t step_graph = nullptr, decode_graph = nullptr;
     int graph_steps = 1;                            // sampler steps captured in step_graph
+    bool fused_tail = true;                         // scheduler step in conv_out's epilogue, step index advanced by pack_input
     const float* captured_noise = nullptr;
     long long n_latent = 0, n_image = 0, n_cond = 0;
     ~SamplerLane() {
@@ -1951,7 +1959,12 @@ struct rldm_sampler {
 static DevBuf g_trace;                 // rldm_debug_graph_trace: 4096 timestamps
 static Plan* g_trace_plan = nullptr;
 
+// (rldm_debug_set_flags(1 << 23) at sampler creation keeps the scheduler step and the step counter as launches of their own)
+static bool sampler_fused_tail() { return !(g_dbg_flags & (1 << 23)); }
+
 static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* noise, hipStream_t st) {
+    const bool fused = ln->fused_tail;
+    if (fused) ln->uplan->io.sch.noise = noise;        // (the rest of io.sch / io.step_inc: sampler_build_plans)
     if (g_dbg_flags & 8192) {
         if (!g_trace.p) {
             if (g_trace.alloc(4096 * 8)) return 1;
@@ -1960,6 +1973,7 @@ static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* n
         g_trace_plan = ln->uplan.get();
         if (ln->uplan->run_stamped(st, g_trace.as<unsigned long long>(), 4096)) return 1;
     } else if (ln->uplan->run(st)) return 1;
+    if (fused) return 0;
     SchedParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
@@ -2009,6 +2023,19 @@ static int sampler_build_plans(rldm_sampler* s) {
         io.step_ptr = ln->step.as<int>();
         io.temb_rows_per_step = 1;
         io.temb_per_sample = 0;
+        ln->fused_tail = sampler_fused_tail();
+        if (ln->fused_tail) {
+            // the scheduler step rides in conv_out's epilogue, the step index is advanced by pack_input: 2 launches per step fewer
+            SchedFuse& f = io.sch;
+            f.coef_table = s->coef.as<float>();
+            f.step_ptr = ln->step.as<int>();
+            f.x = ln->x.as<float>();
+            f.noise = nullptr;                          // per call: sampler_enqueue_step
+            f.noise_step_stride = s->n_latent;
+            f.x_prev = ln->x.as<float>();
+            f.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
+            io.step_inc = ln->step.as<int>();
+        }
         if (vae) {
             if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan)) return 1;
             PlanIO& d = ln->dplan->io;
@@ -2358,14 +2385,14 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
         if (cond)
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->cond.p, cond + (size_t)ln->b0 * (ln->n_cond / ln->nb), ln->n_cond * 4,
                                           hipMemcpyDeviceToDevice, st));
-        if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
+        if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
         const float* noise = s->cfg.mode == RLDM_SAMPLER_DDPM ? step_noise + lat_off : nullptr;
         if (!ln->step_graph || ln->captured_noise != noise) {
             // one eager step first (sets kernel attributes, packs weights), then rewind and capture
             if (sampler_enqueue_step(s, ln, noise, st)) return 1;
             RLDM_HIP_CHECK(hipStreamSynchronize(st));
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
-            if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
+            if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
             // the graph holds `gs` consecutive steps (the step index lives on the device, so the steps are identical launches):
             // fewer, longer graphs keep the queue fed across step boundaries
             int gs = getenv("RLDM_GRAPH_STEPS") ? atoi(getenv("RLDM_GRAPH_STEPS")) : 10;
@@ -2418,7 +2445,7 @@ int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size
     SamplerLane* ln = s->lanes[0].get();
     hipStream_t st = ln->stream;
     RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
-    if (launch_step_counter(ln->step.as<int>(), 0, 0, st)) return 1;
+    if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
     if (ln->uplan->run(st)) return 1;                      // warm
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
     std::map<std::string, KernelStat> unet_stats, vae_stats;
