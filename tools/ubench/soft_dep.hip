@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(NT, 1) layer(const float* __restrict__ w, cons
             const float4* p = reinterpret_cast<const float4*>(act_in + (size_t)src * ACT_PER_WG) + tid + i * NT;
             a[i] = SOFT ? ld_sc1(p) : *p;
         }
-        if (SOFT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SOFT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[0].z), "+v"(a[0].w), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[1].z), "+v"(a[1].w)::"memory");
 #pragma unroll
         for (int i = 0; i < ACT_PER_WG / 4 / NT; ++i) {
             const float want = (float)((idx - 1) * 1000 + src);
