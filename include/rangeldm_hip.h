@@ -362,6 +362,9 @@ int rldm_test_conv(const rldm_conv_desc* d, const float* x0, const float* x1, co
 int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int warmup, int iters, float* avg_us,
                     char* kernel_name, size_t name_cap, void* stream);
 int rldm_debug_force_tile(int BM, int BN, int ksplit);
+/* self-check word of the persistent trunk launches (trunk.hip) of the batch-B plan of a UNet: 0 fine or no trunk, 1 a bounded
+ * wait gave up, 2 a cluster of workgroups was spread over several XCDs; synchronises the device */
+int rldm_unet_trunk_status(rldm_unet* m, int B);
 int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
 int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLATE builds: [start, end] (100 MHz) of every workgroup of the last conv_stream launch */
 int rldm_debug_set_flags(int flags);

@@ -134,6 +134,7 @@ PROTOTYPES = {
     "rldm_unet_flops": (C.c_double, [_P, C.c_int]),
     "rldm_vae_decode_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "rldm_unet_num_launches": (C.c_int, [_P, C.c_int]),
+    "rldm_unet_trunk_status": (C.c_int, [_P, C.c_int]),
     "rldm_sampler_profile": (C.c_int, [_P, _P, C.c_char_p, C.c_size_t]),
     "rldm_test_conv": (C.c_int, [C.POINTER(ConvDescC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rldm_bench_conv": (C.c_int, [C.POINTER(ConvDescC), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),

@@ -132,6 +132,35 @@ size_t conv_stream_lds_bytes(const ConvParams& p);
 bool conv_stream_supported(const ConvParams& p, int taps);
 int launch_conv_stream(const ConvParams& p, hipStream_t stream);
 
+// Persistent trunk launch (trunk.hip): consecutive conv_small launches whose tile owns a whole image (<= 64 pixels, 32-channel
+// tiles) as the phases of ONE launch; the N / 32 workgroups of an image hand their outputs to each other through the L2 of the
+// XCD they share.  `kind`: 0 = 3x3 over 256 channels, 1 = 3x3 over 512, 2 = 1x1 over 256 (conv_small instances <1,2,9,2>,
+// <1,4,9,2>, <1,2,1,2>).
+// A phase record is 64 dwords: ONE vector load per wave (lane l holds word l), requested a phase ahead, and v_readlane puts the
+// fields into SGPRs -- the place the kernel-argument copy of a stand-alone launch lives in.
+enum TrunkWord {
+    TW_X0 = 0, TW_R0 = 2, TW_R1 = 4, TW_WPK = 6, TW_BIAS = 8, TW_Y = 10, TW_YSTATS = 12, TW_RES = 14,    // 64-bit pointers
+    TW_R0C = 16, TW_R1C, TW_WIN, TW_HIN, TW_WOUT, TW_HOUT, TW_TW, TW_TH, TW_COLB, TW_THSHIFT, TW_N, TW_YLD, TW_NVIEWS,
+    TW_KIND, TW_G, TW_NMINE, TW_TEMBOFF,
+    TW_NV0 = 34,            // 2 views x 11 words: y (2), gamma (2), beta (2), ld, cpg_shift, inv_n, eps, silu
+    TW_NVSTRIDE = 11,
+    TW_WORDS = 64
+};
+struct TrunkPhase {
+    unsigned w[TW_WORDS];
+};
+struct TrunkParams {
+    const TrunkPhase* phases;   // device
+    int nphases;
+    int B, ranks;               // images; channel tiles per image (N / 32)
+    unsigned* counters;         // device [B][32] zero-initialised: [0] arrivals (monotonic), [1] rank 0's XCC id + 1, [3] launches so far
+    int* error;                 // device flag: 1 a bounded wait gave up, 2 a cluster is spread over several XCDs
+    const float* temb;          // the plan's time-embedding table (PlanIO), set per launch
+    const int* step_ptr;
+    int temb_rows_per_step, temb_per_sample, temb_ld;
+};
+int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------------------------
 // Per-channel statistics (norm.hip) for tensors that did not come out of a conv epilogue (tests, external inputs):
 // deterministic partial (sum, sumsq) per (b, pixel chunk p, channel).

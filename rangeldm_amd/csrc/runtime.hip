@@ -336,6 +336,8 @@ struct Plan {
     int B = 0, W = 0, H = 0;
     DevBuf arena;
     DevBuf tickets;                // split-K arrival counters of every conv in the plan
+    std::vector<std::unique_ptr<DevBuf>> trunk_bufs;   // phase records / cluster counters of the persistent trunk launches
+    DevBuf trunk_error;            // device int: a trunk launch gave up a wait (1) or found a cluster off its XCD (2)
     PlanIO io;
     std::vector<Op> ops;
     double flops = 0;
@@ -669,12 +671,75 @@ struct Builder {
     void retain(const Tensor& t) { refs[t.id]++; }
     void release(const Tensor& t) {
         if (!t.valid()) return;
+        if (trunk_open) {          // (the memory may not be recycled inside the segment)
+            deferred.push_back(t);
+            return;
+        }
         if (--refs[t.id] == 0) {
             arena.release(t.off, t.bytes());
             if (t.P) arena.release(t.st_off, t.st_bytes());
             live.erase(t.id);
         }
     }
+    // ---- persistent trunk (trunk.hip): consecutive image-owning conv_small launches collected into one launch ----------------
+    struct PendingTrunk {
+        std::vector<TrunkPhase> phases;
+        size_t lds = 0;
+        int B = 0, ranks = 0;
+        double flops = 0, bytes = 0;
+    } pend;
+    bool trunk_open = false;
+    std::vector<Tensor> deferred;  // releases held back while a segment is open (clusters of different images drift apart)
+    // rldm_debug_set_flags: 1 << 24 keeps every phase a launch of its own with the tiles unchanged (tests: identical results);
+    // 1 << 25 also gives the convs back their default tiles (A/B runs of the whole feature)
+    static bool trunk_enabled() { return !(g_dbg_flags & ((1 << 24) | (1 << 25))); }
+    static bool trunk_tiles() { return !(g_dbg_flags & (1 << 25)); }
+    void note_launch() {           // every launch that is not a trunk phase closes the open segment
+        flush_trunk();
+        ++launches;
+    }
+    int flush_trunk() {
+        if (!trunk_open) return 0;
+        trunk_open = false;
+        int rc = 0;
+        if (!dry && !pend.phases.empty()) {
+            auto recs = std::make_unique<DevBuf>();
+            auto ctrs = std::make_unique<DevBuf>();
+            if (upload(*recs, pend.phases.data(), pend.phases.size() * sizeof(TrunkPhase))) return 1;
+            if (ctrs->alloc((size_t)pend.B * 32 * 4)) return 1;
+            RLDM_HIP_CHECK(hipMemset(ctrs->p, 0, ctrs->bytes));
+            if (!plan->trunk_error.p) {
+                if (plan->trunk_error.alloc(64)) return 1;
+                RLDM_HIP_CHECK(hipMemset(plan->trunk_error.p, 0, 64));
+            }
+            TrunkParams tp;
+            memset(&tp, 0, sizeof(tp));
+            tp.phases = recs->as<TrunkPhase>();
+            tp.nphases = (int)pend.phases.size();
+            tp.B = pend.B;
+            tp.ranks = pend.ranks;
+            tp.counters = ctrs->as<unsigned>();
+            tp.error = plan->trunk_error.as<int>();
+            tp.temb_ld = temb_ld;
+            plan->trunk_bufs.push_back(std::move(recs));
+            plan->trunk_bufs.push_back(std::move(ctrs));
+            Plan* pl = plan;
+            const size_t lds = pend.lds;
+            plan->ops.push_back({[tp, lds, pl](hipStream_t st) mutable {
+                tp.temb = pl->io.temb;
+                tp.step_ptr = pl->io.step_ptr;
+                tp.temb_rows_per_step = pl->io.temb_rows_per_step;
+                tp.temb_per_sample = pl->io.temb_per_sample;
+                return launch_trunk(tp, lds, st);
+            }, "trunk_kernel<" + std::to_string(pend.phases.size()) + " phases>", pend.flops, pend.bytes});
+        }
+        pend = PendingTrunk();
+        std::vector<Tensor> d;
+        d.swap(deferred);
+        for (const Tensor& t : d) release(t);
+        return rc;
+    }
+
     template <class T> T* ptr(size_t off) const { return reinterpret_cast<T*>(base + off); }
     bf16_t* tptr(const Tensor& t) const { return t.valid() ? ptr<bf16_t>(t.off) : nullptr; }
     const float2* sptr(const Tensor& t) const { return (t.valid() && t.P) ? ptr<float2>(t.st_off) : nullptr; }
@@ -684,7 +749,7 @@ struct Builder {
         const int npix = x.W * x.H;
         const int P = std::max(1, std::min(16, npix / 64));
         add_stats(x, P);
-        ++launches;
+        note_launch();
         if (!dry) {
             GnStatsParams g;
             g.x = tptr(x);
@@ -803,7 +868,7 @@ struct Builder {
         Tensor act;
         if (preact) {
             act = make(a.x0.B, a.x0.W, a.x0.H, Cin_t);
-            ++launches;
+            note_launch();
             if (!dry) {
                 GnApplyParams g;
                 memset(&g, 0, sizeof(g));
@@ -845,7 +910,26 @@ struct Builder {
         }
         const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
         plan->flops += fl;
-        ++launches;
+        // a phase of the persistent trunk launch (trunk.hip) instead of a launch of its own: the tile owns the image, the input
+        // arrives pre-activated (or needs no norm), one of the three instances the trunk kernel carries
+        const int cpt_t = Cin_t / 128;
+        const int trunk_kind = (taps == 9 && Cin_t == 256) ? 0 : ((taps == 9 && Cin_t == 512) ? 1 : ((taps == 1 && Cin_t == 256) ? 2 : -1));
+        const int ranks_t = N / 32;
+        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && p.TW * p.TH == 64 && !gn_fused && !preact &&
+                        trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && 8 * ranks_t * ((x0.B + 7) / 8) <= 256 &&
+                        2 * p.TH * (Cin_t / 8) <= 512 && vts.size() <= 2;
+        if (in_trunk && trunk_open && (pend.ranks != ranks_t || pend.B != x0.B)) flush_trunk();
+        if (in_trunk) {
+            if (!trunk_open) {
+                ++launches;
+                trunk_open = true;
+                pend.B = x0.B;
+                pend.ranks = ranks_t;
+            }
+        } else {
+            note_launch();
+        }
+        (void)cpt_t;
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
             if (L->get_fragpacked(Cin_t, conv_small_kgroups(BN), epi_res, &pk)) return 1;
@@ -885,6 +969,38 @@ struct Builder {
             const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * taps + L->R) * 2.0 +
                               (double)x0.B * Wout * Hout * N * 2.0 * (1.0 + (double)vts.size()) + (double)x0.B * Wout * Hout * R_t * 2.0;
             const std::string kname = "conv_small_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(BN) + ",taps" + std::to_string(taps) + ">";
+            if (in_trunk) {
+                TrunkPhase ph;
+                memset(&ph, 0, sizeof(ph));
+                auto put64 = [&](int at, const void* ptr) {
+                    const unsigned long long u = (unsigned long long)(uintptr_t)ptr;
+                    ph.w[at] = (unsigned)u;
+                    ph.w[at + 1] = (unsigned)(u >> 32);
+                };
+                auto putf = [&](int at, float f) { memcpy(&ph.w[at], &f, 4); };
+                put64(TW_X0, p.x0); put64(TW_R0, p.r0); put64(TW_R1, p.r1); put64(TW_WPK, p.wpk); put64(TW_BIAS, p.bias);
+                put64(TW_Y, p.y); put64(TW_YSTATS, p.y_stats); put64(TW_RES, p.res);
+                ph.w[TW_R0C] = p.R0; ph.w[TW_R1C] = p.R1; ph.w[TW_WIN] = p.Win; ph.w[TW_HIN] = p.Hin; ph.w[TW_WOUT] = p.Wout;
+                ph.w[TW_HOUT] = p.Hout; ph.w[TW_TW] = p.TW; ph.w[TW_TH] = p.TH; ph.w[TW_COLB] = p.colb; ph.w[TW_THSHIFT] = p.th_shift;
+                ph.w[TW_N] = p.N; ph.w[TW_YLD] = p.y_ld; ph.w[TW_NVIEWS] = p.nviews;
+                const int cpt = Cin_t / 128, KG = 8;
+                const int G = trunk_kind == 0 ? 18 : (trunk_kind == 1 ? 12 : cpt);
+                ph.w[TW_KIND] = trunk_kind;
+                ph.w[TW_G] = std::min(G, 12);       // == kTrunkPrefetch (conv_small_body.h)
+                ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
+                ph.w[TW_TEMBOFF] = (unsigned)temb_off;
+                for (int v = 0; v < p.nviews; ++v) {
+                    const int at = TW_NV0 + v * TW_NVSTRIDE;
+                    put64(at, p.nv[v].y); put64(at + 2, p.nv[v].gamma); put64(at + 4, p.nv[v].beta);
+                    ph.w[at + 6] = p.nv[v].ld; ph.w[at + 7] = p.nv[v].cpg_shift;
+                    putf(at + 8, p.nv[v].inv_n); putf(at + 9, p.nv[v].eps);
+                    ph.w[at + 10] = p.nv[v].silu;
+                }
+                pend.phases.push_back(ph);
+                pend.lds = std::max(pend.lds, conv_small_lds_bytes(p, taps, BN));
+                pend.flops += fl;
+                pend.bytes += by;
+            } else
             plan->ops.push_back({[p, BN, taps, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;
@@ -961,7 +1077,7 @@ struct Builder {
         if (a.want_stats) add_stats(y, p.tiles_img);
         const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
         plan->flops += fl;
-        ++launches;
+        note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
             if (L->get_streampacked(Cin_t, conv_stream_kgroups(p), &pk)) return 1;
@@ -1009,7 +1125,7 @@ struct Builder {
         const size_t raw_off = y.st_off, raw_bytes = y.st_bytes();
         const int rawP = y.P;
         add_stats(y, 2);
-        ++launches;
+        note_launch();
         if (!dry) {
             GnFoldParams g;
             g.part = ptr<float2>(raw_off);
@@ -1051,7 +1167,9 @@ struct Builder {
             }
             auto it = vp->emit.find(ord);
             cur_emit = (it != vp->emit.end() && !it->second.empty()) ? &it->second : nullptr;
-            a.own_image = cur_emit != nullptr;
+            // one tile per image: to normalise for the consumers, and (input ready, nothing to fold) to be a trunk phase
+            a.own_image = cur_emit != nullptr ||
+                          (trunk_tiles() && !a.gn && ord < (int)vp->can_emit.size() && vp->can_emit[ord] && !a.x1.valid());
         }
         if (conv_route(a, out)) return 1;
         cur_emit = nullptr;
@@ -1139,7 +1257,7 @@ struct Builder {
             tickets += (int)tiles;
         }
         plan->flops += 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
-        ++launches;
+        note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
             if (L->get_packed(tile.BN, tile.CK, Cin_t, &pk)) return 1;
@@ -1238,6 +1356,7 @@ static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)
     dry.temb_ld = temb_ld;
     dry.vp = &vplan;
     if (walk(dry)) return 1;
+    if (dry.flush_trunk()) return 1;
     if (launches) *launches = dry.launches;
     if (plan->arena.alloc(dry.arena.peak + 256)) return 1;
     if (plan->tickets.alloc((size_t)std::max(1, dry.tickets) * sizeof(int))) return 1;
@@ -1252,7 +1371,7 @@ static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)
     real.temb_ld = temb_ld;
     real.vp = &vplan;
     if (walk(real)) return 1;
-    return 0;
+    return real.flush_trunk();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1329,7 +1448,7 @@ struct NetCommon {
             Tensor o = b.make(x.B, x.W, x.H, x.C);
             const double fl = 4.0 * (double)x.B * (x.C / 8) * (double)Lt * Lt * 8 + 2.0 * (double)x.B * Lt * 3.0 * x.C * x.C;
             b.plan->flops += fl;
-            ++b.launches;
+            b.note_launch();
             if (!b.dry) {
                 AttnFused* f = nullptr;
                 if (get_attn_fused(p, x.C, &f)) return 1;
@@ -1375,7 +1494,7 @@ struct NetCommon {
         Tensor o = b.make(x.B, x.W, x.H, x.C);
         const int L = x.W * x.H;
         b.plan->flops += 4.0 * (double)x.B * (x.C / 8) * (double)L * L * 8;
-        ++b.launches;
+        b.note_launch();
         if (!b.dry) {
             AttnParams ap;
             ap.qkv = b.tptr(qkv); ap.out = b.tptr(o);
@@ -1571,7 +1690,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
     Plan* plan = b.plan;
 
     Tensor xin = b.make(B, W, H, Cpad);
-    ++b.launches;
+    b.note_launch();
     if (!b.dry) {
         bf16_t* dst = b.tptr(xin);
         plan->ops.push_back({[plan, dst, B, W, H, Cpad](hipStream_t s) {
@@ -1786,7 +1905,7 @@ static int vae_build_layers(rldm_vae* m) {
 }
 
 static void push_pack_input(Builder& b, Tensor xin) {
-    ++b.launches;
+    b.note_launch();
     if (b.dry) return;
     Plan* plan = b.plan;
     bf16_t* dst = b.tptr(xin);
@@ -2177,6 +2296,18 @@ double rldm_unet_flops(rldm_unet* m, int B) {
     return plan->flops;
 }
 
+// self-check word of the persistent trunk launches of the batch-B plan (0 fine / no trunk; 1 a wait gave up; 2 a cluster was spread
+// over several XCDs); synchronises the device
+int rldm_unet_trunk_status(rldm_unet* m, int B) {
+    if (!m) return -1;
+    auto it = m->plans.find(B);
+    if (it == m->plans.end() || !it->second->trunk_error.p) return 0;
+    int terr = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&terr, it->second->trunk_error.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return terr;
+}
+
 int rldm_unet_num_launches(rldm_unet* m, int B) {
     if (!m || !m->params.finalized) return -1;
     Plan tmp;
@@ -2197,6 +2328,7 @@ int rldm_unet_num_launches(rldm_unet* m, int B) {
     dry.vp = &vplan;
     dry.temb_ld = m->net.temb_ld;
     if (unet_walk(m, dry, B)) return -1;
+    dry.flush_trunk();
     return dry.launches + 1;   // + time-embedding kernel
 }
 
@@ -2391,6 +2523,12 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             // one eager step first (sets kernel attributes, packs weights), then rewind and capture
             if (sampler_enqueue_step(s, ln, noise, st)) return 1;
             RLDM_HIP_CHECK(hipStreamSynchronize(st));
+            if (ln->uplan->trunk_error.p) {         // the persistent trunk's self-check (a wait that gave up / a cluster off its XCD)
+                int terr = 0;
+                RLDM_HIP_CHECK(hipMemcpy(&terr, ln->uplan->trunk_error.p, 4, hipMemcpyDeviceToHost));
+                RLDM_REQUIRE(terr == 0, "persistent trunk launch failed its self-check (code " + std::to_string(terr) +
+                                            "): set RLDM_DBG_FLAGS=16777216 to run the levels as separate launches");
+            }
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
             if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
             // the graph holds `gs` consecutive steps (the step index lives on the device, so the steps are identical launches):

@@ -1,0 +1,140 @@
+// Persistent "trunk" launch for the levels whose images fit one workgroup tile (<= 64 pixels: the 32x2 level and the mid block
+// of the KITTI network): a run of consecutive convs -- ResnetBlock conv1 / conv2, attention output projections -- executes as the
+// PHASES of one launch instead of one launch each (ldm/pipelines.py:353-362 -> UNet2DModel.forward).
+//
+// Why this is legal without a grid barrier: with producer-side GroupNorm (conv_small_body.h) a workgroup (image b, 32 output
+// channels) needs, for the next layer, only what the OTHER channel tiles of the SAME image wrote -- GroupNorm statistics never
+// leave the image.  So the dependence between two layers is a cluster of N / 32 workgroups per image, not the grid.  The
+// workgroups of an image are given block ids with equal (id % 8): they land on one XCD and share its L2, where a plain store is
+// visible to an L1-bypassing load once it has been acknowledged.  Measured (tools/ubench/xcd_cluster.hip): publish + arrive + wait
+// for the cluster + gather 32 KB = 1.4 us, against 1.9 us for the same hand-off across a launch boundary -- and the boundary also
+// costs the next launch its argument fetch, its first weight round trip and its address set-up, which here run under the
+// previous phase (the next phase's weight fragments are requested behind the K loop).
+//
+// A phase = conv_small_body<..., TRUNK = true> on a ConvParams record in device memory.  Nothing here orders workgroups of
+// DIFFERENT images: they drift apart freely (so activations of a segment are never recycled inside it: runtime.hip defers the
+// arena releases to the segment's end).
+#include "conv_small_body.h"
+
+namespace rldm {
+
+// A phase record is 64 dwords (kernels.h, TrunkWord): every wave loads it with ONE instruction (lane l = word l) a phase ahead,
+// and v_readlane moves the fields into SGPRs -- where the kernel-argument copy of a stand-alone launch lives.  (Reading the record
+// field by field would be ~60 dependent VECTOR loads per phase: the launch also writes device memory, so the compiler may not use
+// scalar loads for it.)
+__device__ __forceinline__ unsigned rl(unsigned rec, int word) { return (unsigned)__builtin_amdgcn_readlane((int)rec, word); }
+template <class T> __device__ __forceinline__ T* rl_ptr(unsigned rec, int word) {
+    return reinterpret_cast<T*>(((unsigned long long)rl(rec, word + 1) << 32) | rl(rec, word));
+}
+__device__ __forceinline__ void unpack_phase(ConvParams& q, unsigned rec) {
+    q.x0 = rl_ptr<const bf16_t>(rec, TW_X0);
+    q.r0 = rl_ptr<const bf16_t>(rec, TW_R0);
+    q.r1 = rl_ptr<const bf16_t>(rec, TW_R1);
+    q.wpk = rl_ptr<const bf16_t>(rec, TW_WPK);
+    q.bias = rl_ptr<const float>(rec, TW_BIAS);
+    q.y = rl_ptr<bf16_t>(rec, TW_Y);
+    q.y_stats = rl_ptr<float2>(rec, TW_YSTATS);
+    q.res = rl_ptr<const bf16_t>(rec, TW_RES);
+    q.R0 = (int)rl(rec, TW_R0C); q.R1 = (int)rl(rec, TW_R1C);
+    q.Win = (int)rl(rec, TW_WIN); q.Hin = (int)rl(rec, TW_HIN); q.Wout = (int)rl(rec, TW_WOUT); q.Hout = (int)rl(rec, TW_HOUT);
+    q.TW = (int)rl(rec, TW_TW); q.TH = (int)rl(rec, TW_TH); q.colb = (int)rl(rec, TW_COLB); q.th_shift = (int)rl(rec, TW_THSHIFT);
+    q.N = (int)rl(rec, TW_N); q.y_ld = (int)rl(rec, TW_YLD); q.nviews = (int)rl(rec, TW_NVIEWS);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int at = TW_NV0 + v * TW_NVSTRIDE;
+        q.nv[v].y = rl_ptr<bf16_t>(rec, at);
+        q.nv[v].gamma = rl_ptr<const float>(rec, at + 2);
+        q.nv[v].beta = rl_ptr<const float>(rec, at + 4);
+        q.nv[v].ld = (int)rl(rec, at + 6);
+        q.nv[v].cpg_shift = (int)rl(rec, at + 7);
+        q.nv[v].inv_n = __uint_as_float(rl(rec, at + 8));
+        q.nv[v].eps = __uint_as_float(rl(rec, at + 9));
+        q.nv[v].silu = (int)rl(rec, at + 10);
+    }
+    q.nv[2] = q.nv[1];                          // (trunk phases write at most two copies)
+    // what a trunk phase never has / what its tile implies
+    q.x1 = nullptr; q.C0 = 0; q.C1 = 0; q.st0 = nullptr; q.st1 = nullptr; q.P0 = 0; q.P1 = 0; q.temb = nullptr; q.step_ptr = nullptr;
+    q.ts = nullptr; q.up = 1; q.stride = 1; q.tiles_h = 1; q.tiles_img = 1; q.dbg = 0; q.silu = 0; q.B = 0;
+}
+
+__global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
+    // block id -> (image, channel tile): ids with the same (id % 8) share an XCD; an image's `ranks` tiles are 8 apart
+    const int wg = blockIdx.x;
+    const int ranks = tp.ranks;
+    const int t = wg >> 3;
+    const int rank = t % ranks, b = (t / ranks) * 8 + (wg & 7);
+    if (b >= tp.B) return;                      // (batch not a multiple of 8: the surplus workgroups have no cluster)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kg = __builtin_amdgcn_readfirstlane(tid >> 6);        // NWN == 1: wave = k-group
+    unsigned* const counter = tp.counters + b * 32;
+    const unsigned* const recs = reinterpret_cast<const unsigned*>(tp.phases);
+
+    // the cluster's arrival counter is never reset: this launch waits for arrivals past `base` = launches so far x arrivals per
+    // launch ([3] is advanced by rank 0 at the very end: visible to the next launch across the kernel boundary)
+    const unsigned epoch = counter[3];
+    const unsigned base = epoch * (unsigned)(tp.nphases * ranks);
+    // placement check (the protocol's only assumption): rank 0 publishes its XCC id ahead of its first arrive, every other
+    // rank compares once it has waited for that arrive
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (rank == 0 && tid == 0) __hip_atomic_store(counter + 1, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    bf16x8 wpf[kTrunkPrefetch];
+    unsigned rec = recs[lane];                  // phase 0's record
+    auto wave_stream = [&](unsigned r) __attribute__((always_inline)) {
+        return reinterpret_cast<const unsigned char*>(rl_ptr<const bf16_t>(r, TW_WPK)) + ((size_t)(rank * 8 + kg) * rl(r, TW_NMINE)) * 1024;
+    };
+    {
+        const unsigned char* w0 = wave_stream(rec);
+        const int g0 = (int)rl(rec, TW_G);
+#pragma unroll
+        for (int j = 0; j < kTrunkPrefetch; ++j)
+            if (j < g0) wpf[j] = *reinterpret_cast<const bf16x8*>(w0 + (unsigned)(j * 1024 + lane * 16));
+    }
+    for (int i = 0; i < tp.nphases; ++i) {
+        const unsigned nrec = i + 1 < tp.nphases ? recs[(i + 1) * TW_WORDS + lane] : 0u;     // requested a phase ahead
+        ConvParams cp;
+        unpack_phase(cp, rec);
+        TrunkSeam seam;
+        seam.counter = counter;
+        seam.wait_for = base + (unsigned)(i * ranks);
+        seam.has_wait = i != 0;
+        seam.error = tp.error;
+        const int toff = (int)rl(rec, TW_TEMBOFF);
+        seam.temb = toff >= 0 ? tp.temb + toff : nullptr;
+        seam.step_ptr = tp.step_ptr;
+        seam.temb_rows_per_step = tp.temb_rows_per_step;
+        seam.temb_per_sample = tp.temb_per_sample;
+        seam.temb_ld = tp.temb_ld;
+        const int kind = (int)rl(rec, TW_KIND);
+        // (the next record has long arrived when the K loop ends: its weight stream is resolved inside the body, behind the K loop)
+        seam.next_rec = nrec;
+        seam.next_rank_kg = rank * 8 + kg;
+        switch (kind) {
+            case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
+            case 1: conv_small_body<1, 4, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
+            default: conv_small_body<1, 2, 1, 2, true>(cp, rank, 0, b, wpf, seam); break;
+        }
+        if (i == 1 && rank != 0 && tid == 0) {  // (rank 0's first arrive has been waited for: its XCC id is there)
+            const unsigned x0 = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x0 != xcc + 1u) *tp.error = 2;  // not on rank 0's XCD: this workgroup's reads may be stale
+        }
+        rec = nrec;
+    }
+    if (rank == 0 && tid == 0) counter[3] = epoch + 1u;
+}
+
+int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
+    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 && tp.B >= 1, "trunk: bad parameters");
+    RLDM_REQUIRE(lds <= 160 * 1024, "trunk: LDS tile too large");
+    const int groups = (tp.B + 7) / 8;
+    const int grid = 8 * tp.ranks * groups;
+    RLDM_REQUIRE(grid <= 256, "trunk: the grid must be co-resident (one workgroup per CU)");
+    static DynLdsLimit lds_limit;                // per device, thread safe
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(trunk_kernel), lds));
+    hipLaunchKernelGGL(trunk_kernel, dim3(grid), dim3(512), lds, stream, tp);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rldm

@@ -156,6 +156,10 @@ class UNet2DModelHIP:
     def num_launches(self, batch):
         return int(_lib.lib().rldm_unet_num_launches(self._h, batch))
 
+    def trunk_status(self, batch):
+        """Self-check of the persistent trunk launches of the batch's plan (0: fine or none); synchronises the device."""
+        return int(_lib.lib().rldm_unet_trunk_status(self._h, batch))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

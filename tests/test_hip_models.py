@@ -111,6 +111,7 @@ def test_producer_side_groupnorm_matches_consumer_side(size):
         try:
             m, _ = hip_unet(cfg, "ps.")
             outs.append((m(x, 250).sample.cpu(), m.num_launches(2) if hasattr(m, "num_launches") else None))
+            assert m.trunk_status(2) == 0
         finally:
             _lib.lib().rldm_debug_set_flags(0)
     assert torch.isfinite(outs[0][0]).all()
@@ -119,6 +120,33 @@ def test_producer_side_groupnorm_matches_consumer_side(size):
     assert d < TOL_FWD / 2
     if outs[0][1] is not None:
         assert outs[0][1] < outs[1][1]                     # the separate gn_apply launches in front of the up-block convs are gone
+
+
+@pytest.mark.parametrize("B", [2, 16, 5])
+def test_persistent_trunk_matches_separate_launches(B):
+    """The persistent trunk launch (trunk.hip: the convs of the 32x2 level and the mid block as phases of one launch, the channel
+    tiles of an image handing over through their XCD's L2) against the same plan as separate launches
+    (rldm_debug_set_flags(1 << 24)): the SAME kernels' code on the SAME operands in the same order, so the outputs are identical,
+    and repeated forwards (the cluster counters re-arm themselves) stay identical."""
+    from rangeldm_amd import _lib
+    cfg = UNetConfig()
+    x = T(normal(13, "x", (B, cfg.in_channels, *cfg.sample_size))).cuda()
+    outs, launches = [], []
+    for flags in (0, 1 << 24):
+        _lib.lib().rldm_debug_set_flags(flags)
+        try:
+            m, _ = hip_unet(cfg, "tk.")
+            o1 = m(x, 250).sample.cpu()
+            o2 = m(x, 250).sample.cpu()
+            o3 = m(x, 731).sample.cpu()
+            assert m.trunk_status(B) == 0
+            assert torch.equal(o1, o2)
+            outs.append((o1, o3))
+            launches.append(m.num_launches(B))
+        finally:
+            _lib.lib().rldm_debug_set_flags(0)
+    assert launches[0] < launches[1]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_unet_errors():
