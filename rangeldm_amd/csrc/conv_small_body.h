@@ -24,6 +24,7 @@ struct TrunkSeam {
     unsigned next_rec;              // lane l: word l of the next phase's record (kernels.h TrunkWord), or 0 behind the last phase
     int next_rank_kg;               // this wave's weight stream of a layer = (channel tile * k-groups + k-group)
     int* error;                     // device flag: a bounded poll gave up (the host refuses the plan's results)
+    unsigned long long* ts;         // ABLATE builds: 16 stamp slots of this phase (workgroup 0) or null
     // the phase's time-embedding row (the launch's arguments, not the phase record: the table belongs to the caller of the plan)
     const float* temb;              // table + this layer's channel offset, or null
     const int* step_ptr;
@@ -151,7 +152,11 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         }
 
     // ---- persistent trunk: everything above is independent of the previous phase; everything below reads what it published ----
-    if constexpr (TRUNK) trunk_wait(seam, tid);
+    if constexpr (TRUNK) {
+        RLDM_STAMP();                           // (trunk) small requests issued, waiting for the cluster
+        trunk_wait(seam, tid);
+        RLDM_STAMP();                           // (trunk) the previous phase has been published
+    }
 
     // ---- TAPS == 1: the GroupNorm inputs of channel `tid` (statistics partials of the producer, gamma, beta), requested now
     // (3x3: single-input convs only; concatenated inputs come pre-activated.  Trunk phases: pre-activated inputs only)
@@ -668,6 +673,10 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
             if (j < next_g) wpf[j] = *reinterpret_cast<const bf16x8*>(next_w + (unsigned)(j * 1024 + lane * 16));
     }
 #ifdef RLDM_ABLATE
+    if (TRUNK && seam.ts && tid == 0) {
+        RLDM_STAMP();
+        for (int i = 0; i < 16; ++i) seam.ts[i] = i < tsn ? tsv[i] : 0ull;
+    }
     if (!TRUNK && p.ts && blockIdx.x < 4 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
         for (int i = 0; i < 16; ++i) p.ts[blockIdx.x * 64 + i] = i < tsn ? tsv[i] : 0ull;
     {

@@ -158,6 +158,7 @@ struct TrunkParams {
     const float* temb;          // the plan's time-embedding table (PlanIO), set per launch
     const int* step_ptr;
     int temb_rows_per_step, temb_per_sample, temb_ld;
+    unsigned long long* ts;     // ABLATE builds: [phase][16] s_memtime stamps of workgroup 0 (rldm_debug_timestamps buffer) or null
 };
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream);
 

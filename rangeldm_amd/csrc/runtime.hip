@@ -730,6 +730,7 @@ struct Builder {
                 tp.step_ptr = pl->io.step_ptr;
                 tp.temb_rows_per_step = pl->io.temb_rows_per_step;
                 tp.temb_per_sample = pl->io.temb_per_sample;
+                tp.ts = (getenv("RLDM_TS_TRUNK") && tp.nphases == atoi(getenv("RLDM_TS_TRUNK"))) ? g_ts_buf : nullptr;
                 return launch_trunk(tp, lds, st);
             }, "trunk_kernel<" + std::to_string(pend.phases.size()) + " phases>", pend.flops, pend.bytes});
         }
@@ -890,7 +891,7 @@ struct Builder {
         bool epi_res = false;
         RLDM_REQUIRE(small_params(a, Cin_t, R_t, taps, Wout, Hout, &p, &epi_res), "conv " + L->name + ": conv_small route lost");
         p.dbg = g_dbg_flags;
-        p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
+        p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         const int BN = small_bn(p, taps, gn_fused, a.own_image);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
         p.ntile_n = N / BN;
@@ -1071,7 +1072,7 @@ struct Builder {
             RLDM_REQUIRE(x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
         }
         p.dbg = g_dbg_flags;
-        p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
+        p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         p.ntile_n = N / conv_stream_bn(p);
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img);
@@ -1232,7 +1233,7 @@ struct Builder {
         p.silu = a.silu;
         p.gn_eps = a.eps;
         p.dbg = g_dbg_flags;
-        p.ts = getenv("RLDM_TS_ATTN_L") ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
+        p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         p.gn_groups = a.groups;
         p.ksplit = tc.ksplit;
         const int tiles_img = (Wout / p.TW) * (Hout / p.TH);
@@ -1468,7 +1469,7 @@ struct NetCommon {
                 ap.bias = f->bias.as<float>();
                 ap.out = b.tptr(o);
                 ap.B = x.B; ap.L = Lt; ap.C = x.C;
-                ap.ts = g_ts_buf;
+                ap.ts = getenv("RLDM_TS_TRUNK") ? nullptr : g_ts_buf;
                 ap.ts_L = getenv("RLDM_TS_ATTN_L") ? atoi(getenv("RLDM_TS_ATTN_L")) : 0;
                 b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl,
                                        (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0});
@@ -2919,7 +2920,7 @@ int make_attn_case(AttnCase& ac, const std::vector<bf16_t>& hb, int B, int L, in
     ap.magic_cpg = ((1 << 20) + cpg - 1) / cpg;
     ap.wfrag = ac.dw.as<bf16_t>(); ap.bias = ac.dbias.as<float>(); ap.out = ac.dout.as<bf16_t>();
     ap.B = B; ap.L = L; ap.C = C;
-    ap.ts = g_ts_buf;                                  // ABLATE builds: phase stamps (rldm_debug_timestamps)
+    ap.ts = getenv("RLDM_TS_TRUNK") ? nullptr : g_ts_buf;                                  // ABLATE builds: phase stamps (rldm_debug_timestamps)
     ap.ts_L = L;
     return 0;
 }

@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
         seam.wait_for = base + (unsigned)(i * ranks);
         seam.has_wait = i != 0;
         seam.error = tp.error;
+        seam.ts = (tp.ts && wg == 0 && i < 16) ? tp.ts + i * 16 : nullptr;
         const int toff = (int)rl(rec, TW_TEMBOFF);
         seam.temb = toff >= 0 ? tp.temb + toff : nullptr;
         seam.step_ptr = tp.step_ptr;

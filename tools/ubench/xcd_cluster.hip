@@ -25,9 +25,14 @@ __device__ __forceinline__ u32x4 ld_sc1(const void* p) {
 __device__ __forceinline__ void st_wt(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
 __device__ __forceinline__ void cluster_ids(int wg, int* cluster, int* rank) {
+#ifdef CROSS_XCD      // 16 consecutive block ids = one cluster: two workgroups on each of the 8 XCDs
+    *cluster = wg >> 4;
+    *rank = wg & 15;
+#else
     const int x = wg & 7, j = wg >> 3;
     *cluster = x * 2 + (j >> 4);
     *rank = j & 15;
+#endif
 }
 __device__ __forceinline__ unsigned pattern(int phase, int cluster, int rank, int i) { return (unsigned)(phase * 65536 + cluster * 1024 + rank * 32 + (i & 31)); }
 
