@@ -17,89 +17,9 @@
 // the packed Wq).  A workgroup owns one (image, head): it stages that head's K rows (16 B each) and V TRANSPOSED
 // ([d][key], so the PV "A" fragments are 8-byte LDS reads) into LDS once -- 32 bytes per key -- and each of its waves
 // then runs 32 queries against all keys out of LDS.  out [B][L][C] bf16.
-#include "kernels.h"
+#include "attention_body.h"
 
 namespace rldm {
-
-// One 32-query tile against all Lp keys staged in LDS (sK rows, sVt = V^T in consumption order + ones + zero rows).
-// qf: B operand of S^T for lane (query l31, half hh) = q[query][4*hh .. 4*hh+3] (pre-scaled by log2(e)/sqrt(8)).
-__device__ __forceinline__ void attention_tile(const bf16_t* sK, const bf16_t* sVt, int vst, int L, int Lp, int C, int q0,
-                                               s16x4 qf, bf16_t* out_bh, int l31, int hh) {
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-
-    // A operand rows of the PV MFMA: row l31 < 8 -> V^T[d = l31], row 8 -> ones, rows 9..31 -> the zero row (one address)
-    const bf16_t* vrow_ptr = sVt + min(l31, 9) * vst + 8 * hh;
-    const bf16_t* krow_ptr = sK + l31 * 8 + 4 * hh;
-    const bool ragged = (L & 31) != 0;
-
-    // Running maximum m of the query (log2 units), kept as the MFMA's C operand: s = k.q - m comes out of the matrix core.
-    // m is exact after the first tile and afterwards only raised when some score of the wave exceeds it by more than 8
-    // (p <= 2^8 then: harmless in fp32 / bf16), so the rescale of o, the subtraction and the refresh of C are rare.
-    f32x16 cn;
-    {
-        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr);
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, s, 0, 0, 0);
-        if (ragged && 32 > L) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -1e30f;
-        }
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cn[r] = -tmax;
-    }
-
-    for (int k0 = 0; k0 < Lp; k0 += 32) {
-        const s16x4 kf = *reinterpret_cast<const s16x4*>(krow_ptr + k0 * 8);
-        const uint4 v0 = *reinterpret_cast<const uint4*>(vrow_ptr + k0);
-        const uint4 v1 = *reinterpret_cast<const uint4*>(vrow_ptr + k0 + 16);
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(kf, qf, cn, 0, 0, 0);
-        // lane (query l31, half hh), register r <-> key k0 + (r&3) + 8*(r>>2) + 4*hh ; scores are in log2 units, relative to m
-        if (ragged && k0 + 32 > L) {                        // last tile: keys >= L get -inf scores
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -1e30f;
-        }
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        if (__builtin_amdgcn_ballot_w64(tmax > 8.0f) != 0ull) {
-            // raise m (both halves of a query agree on it), rescale what has been accumulated
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float d = fmaxf(tmax, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] -= d; cn[r] -= d; }
-#pragma unroll
-            for (int r = 0; r < 5; ++r) o[r] *= alpha;      // rows 0..8 only: V rows and the ones row (others stay 0)
-        }
-        uint32_t pk[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1]));
-        // PV: MFMA t (t = 0, 1) contracts over the 16 keys {k0 + 16t + 4hh' + (e&3) + 8(e>>2)}, e = 0..7, hh' = 0, 1
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0),
-                                                    __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])), o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1),
-                                                    __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7])), o, 0, 0, 0);
-    }
-    // o rows: reg r of half hh <-> row (r&3) + 8*(r>>2) + 4*hh.  d = 4*hh + r for r < 4; denominator = row 8 = reg 4 of hh 0
-    float denom = __shfl(o[4], l31);
-    const float inv = 1.0f / denom;
-    uint2 ov;
-    ov.x = pack_bf16x2(o[0] * inv, o[1] * inv);
-    ov.y = pack_bf16x2(o[2] * inv, o[3] * inv);
-    if (q0 + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0 + l31) * C + 4 * hh) = ov;
-}
 
 __global__ void __launch_bounds__(512) attention_d8_kernel(const AttnParams p, const int waves_per_block, const int Lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,362 +252,14 @@ __global__ void __launch_bounds__(1024) attention_qkv_d8_kernel(const AttnQkvPar
 }
 
 
-// =====================================================================================================================
-// Second generation of the fused launch (round 2).  Same contract as attention_qkv_d8_kernel; what changed and why
-// (per-wave s_memtime stamps of both generations: tools/attn_timeline2.py, profiles/round2_attn_timeline.txt):
-//   * The prologue of the first generation was FIVE dependent global round trips of ~2 us each (statistics partials ->
-//     gamma / beta -> the head's weight fragments -> its bias -> the x rows of the wave's second query tile): 12 of the 44 us of
-//     an L = 1024 launch, 6 of the 7 us of an L = 64 one.  None of them depends on another: every one is now requested in the
-//     first instructions of the kernel and consumed from registers.
-//   * S^T rides on v_mfma_f32_32x32x16_bf16 with the contraction padded from 8 to 16: slot 8 of the key side is 1.0 and slot 8 of
-//     the query side is -m (the softmax stabiliser of that query, rounded to bf16 -- the SAME rounded value for every key, so it
-//     cancels in the normalisation).  The matrix core then delivers s - m directly with a zero C operand: no 16-register copy of
-//     -m per query tile, no per-tile maximum, ballot, branch or rescale in the key loop -- per 32 x 32 score tile the VALU work is
-//     16 v_exp_f32 + 8 v_cvt_pk_bf16_f32.
-//   * m = the exact maximum over the first 32 keys.  Later keys may beat it by up to ~2^100 before an fp32 accumulator overflows
-//     (bf16 has fp32's exponent range, so P = 2^(s-m) > 1 is representable); a wave whose denominators are not finite afterwards
-//     (a score beat the first tile's maximum by more than ~100 in log2 units) redoes its tiles with the running-maximum loop of
-//     attention_tile.  The denominator is >= 1 by construction (the maximal key of the first tile contributes exactly 1).
-//   * a wave runs TWO query tiles against each key tile (L = 1024): the K fragment and the two V^T fragments are read from LDS
-//     once for both, and the loop is ROTATED -- S(i+1) of a chain is issued right behind its PV(i) MFMAs, so it executes on the
-//     matrix pipe while the VALU does the other chain's exponentials.  In the first generation the oldest wave of a SIMD spent
-//     ~240 of its 560 cycles per iteration waiting on its own LDS -> S -> exp -> PV chain, and the younger waves only got the
-//     leftover issue slots (the four waves of a SIMD finished one after the other, 12 k cycles apart).
-//   * HG heads of one image share a workgroup when a head alone has fewer than 16 query tiles: the GroupNorm fold is done once
-//     per workgroup and the heads' x rows come from the CU's L1 after the first head fetched them.
-// Layouts (LDS): sK [HG][Lp][8] bf16 (16 B per key), sVt [HG][10][Lp + 8] (as above), sC = one 16-byte row {1.0, 0, ...} (slots
-// 8..15 of every key), sW [HG][C/16][64][8], sBp [HG][32].
 template <int PAIR>
 __global__ void __launch_bounds__(1024) attention_qkv2_d8_kernel(const AttnQkvParams p, const int waves, const int Lp, const int HG) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef RLDM_ABLATE
-    unsigned long long tsv[8];
-    int tsn = 0;
-    const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
-#define RLDM_ASTAMP() if (tsn < 8) tsv[tsn++] = __builtin_amdgcn_s_memtime()
-#else
-#define RLDM_ASTAMP()
-#endif
-    RLDM_ASTAMP();
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NT = waves * 64;
-    const int heads = p.C >> 3;
-    const int hgroups = heads / HG;
     // workgroups land on XCD (blockIdx % 8): give every XCD a contiguous range of (image, head group) ids, so all the heads of
     // an image read its x rows through ONE L2 instead of eight (HBM-side fetch of an L = 1024 launch: 38 MB -> one copy of x)
+    const int hgroups = (p.C >> 3) / HG;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int hg = bid % hgroups, b = bid / hgroups;
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int C = p.C, L = p.L;
-    const int vst = Lp + 8;
-    const int ntiles = Lp >> 5;
-    const int nks = C >> 4;
-    const int wph = waves / HG;                           // waves per head
-    const int hl = wave / wph, wl = wave % wph;           // this wave's head (local) and its index among the head's waves
-    const int h = hg * HG + hl;
-
-    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);                       // [HG][Lp][8]
-    bf16_t* sVt = sK + (size_t)HG * Lp * 8;                             // [HG][10][vst]
-    bf16_t* sC = sVt + (size_t)HG * 10 * vst;                           // [8]: {1, 0, 0, 0, 0, 0, 0, 0}
-    float* sGa = reinterpret_cast<float*>(sC + 8);                      // [C]
-    float* sGs = sGa + C;
-    double* sD = reinterpret_cast<double*>(sGs + C);                    // [2][C] scratch (>= HG * nks * 64 floats)
-    const int scratch = max(2 * C * 8, HG * nks * 64 * 4);              // bytes of sD / sPart (the partial sums of b' need more for HG > 1)
-    bf16_t* sW = reinterpret_cast<bf16_t*>(reinterpret_cast<unsigned char*>(sD) + scratch);    // [HG][C/16][64 lanes][8]
-    float* sBp = reinterpret_cast<float*>(sW + (size_t)HG * nks * 512); // [HG][32]
-
-    // ---- every global read of the prologue, requested up front (one memory round trip instead of five) ----------------------
-    constexpr int TPW = PAIR ? 2 : 1;
-    constexpr int KB = 8;                                 // k-steps (16 channels each) of x held in registers per tile
-    const int T0 = wl;                                    // query tiles of this wave: T0 (and T0 + wph)
-    bf16x8 xpre[TPW][KB];
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int px = min((T0 + ti * wph) * 32 + l31, L - 1);
-        const bf16_t* xrow = p.x + ((size_t)b * L + px) * C + 8 * hh;
-#pragma unroll
-        for (int j = 0; j < KB; ++j)
-            if (j < nks) xpre[ti][j] = *reinterpret_cast<const bf16x8*>(xrow + j * 16);
-    }
-    const bool own_ch = tid < C;                          // (C <= 512 <= NT is not guaranteed: channels beyond NT loop below)
-    float g_pre = 0.f, b_pre = 0.f;
-    const bool prenorm = p.st == nullptr;                 // x arrives normalised (producer-side GroupNorm): W' = W, b' = b
-    if (own_ch && !prenorm) { g_pre = p.gamma[tid]; b_pre = p.beta[tid]; }
-    const bf16_t* wf_ptr = p.wfrag + (size_t)(hg * HG) * nks * 512;
-    const int npieces = HG * nks * 64;
-    constexpr int NPW = 2;                                // weight pieces held per thread up front (more: loaded in the loop)
-    uint4 wpre[NPW];
-#pragma unroll
-    for (int j = 0; j < NPW; ++j)
-        if (tid + j * NT < npieces) wpre[j] = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)(tid + j * NT) * 8);
-    float bias_pre = 0.f;
-    if (tid < 32 * HG && (tid & 31) < 24) bias_pre = p.bias[(hg * HG + (tid >> 5)) * 32 + (tid & 31)];
-
-    // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic; one fold per workgroup) ----------------------------------
-    if (prenorm) {
-        for (int t = tid; t < C; t += NT) { sGa[t] = 1.f; sGs[t] = 0.f; }
-        if (tid < 8) sC[tid] = tid == 0 ? (bf16_t)0x3f80 : (bf16_t)0;
-        __syncthreads();
-    } else {
-        const int cpg = C / p.groups;
-        for (int t = tid; t < C; t += NT) {
-            const float2* src = p.st + (size_t)b * p.P * C + t;
-            double S = 0.0, SS = 0.0;
-            int q = 0;
-            for (; q + 8 <= p.P; q += 8) {
-                float2 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(q + j) * C];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
-            }
-            for (; q < p.P; ++q) {
-                const float2 v = src[(size_t)q * C];
-                S += (double)v.x;
-                SS += (double)v.y;
-            }
-            sD[t] = S;
-            sD[C + t] = SS;
-        }
-        if (tid < 8) sC[tid] = tid == 0 ? (bf16_t)0x3f80 : (bf16_t)0;
-        __syncthreads();
-        for (int t = tid; t < C; t += NT) {
-            const int g0 = ((t * p.magic_cpg) >> 20) * cpg;
-            double S = 0.0, SS = 0.0;
-            for (int i = 0; i < cpg; ++i) {
-                S += sD[g0 + i];
-                SS += sD[C + g0 + i];
-            }
-            const double mean = S * (double)p.inv_n;
-            double var = SS * (double)p.inv_n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            const float gm = t == tid ? g_pre : p.gamma[t], bt = t == tid ? b_pre : p.beta[t];
-            const float a = gm * __builtin_amdgcn_rsqf((float)var + p.eps);
-            sGa[t] = a;
-            sGs[t] = bt - (float)mean * a;
-        }
-        __syncthreads();
-    }
-    RLDM_ASTAMP();                                        // 1: GroupNorm affine in LDS
-
-    // ---- W' = W_h * diag(a) (bf16, A-fragment order), b' = b_h + W_h * s for the HG heads of this workgroup -----------------
-    float* sPart = reinterpret_cast<float*>(sD);
-    for (int q = tid, j = 0; q < npieces; q += NT, ++j) { // piece q = (head, k-step, lane): row q & 31, channels 16*ks + 8*(lane >> 5) ..
-        const int c0 = ((q >> 6) % nks) * 16 + ((q >> 5) & 1) * 8;
-        uint4 w;
-        if (j == 0) w = wpre[0];
-        else if (j == 1) w = wpre[1];
-        else w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);
-        const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
-        const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
-        uint4 n;
-        n.x = pack_bf16x2(bf16lo(w.x) * a0.x, bf16hi(w.x) * a0.y);
-        n.y = pack_bf16x2(bf16lo(w.y) * a0.z, bf16hi(w.y) * a0.w);
-        n.z = pack_bf16x2(bf16lo(w.z) * a1.x, bf16hi(w.z) * a1.y);
-        n.w = pack_bf16x2(bf16lo(w.w) * a1.z, bf16hi(w.w) * a1.w);
-        *reinterpret_cast<uint4*>(sW + (size_t)q * 8) = n;
-        sPart[q] = bf16lo(w.x) * s0.x + bf16hi(w.x) * s0.y + bf16lo(w.y) * s0.z + bf16hi(w.y) * s0.w +
-                   bf16lo(w.z) * s1.x + bf16hi(w.z) * s1.y + bf16lo(w.w) * s1.z + bf16hi(w.w) * s1.w;
-    }
-    __syncthreads();
-    if (tid < 32 * HG) {                                  // fixed summation order
-        const int hq = tid >> 5, row = tid & 31;
-        float acc_b = bias_pre;
-        for (int j = 0; j < 2 * nks; ++j) acc_b += sPart[(hq * 2 * nks + j) * 32 + row];
-        sBp[tid] = acc_b;
-    }
-    __syncthreads();
-    RLDM_ASTAMP();                                        // 2: W', b' in LDS
-
-    // ---- projection of this wave's pixel tiles: q stays in registers, k / v go to the head's LDS image ----------------------
-    bf16_t* sKh = sK + (size_t)hl * Lp * 8;
-    bf16_t* sVh = sVt + (size_t)hl * 10 * vst;
-    const bf16_t* sWh = sW + (size_t)hl * nks * 512;
-    float binit[12];
-#pragma unroll
-    for (int r = 0; r < 12; ++r) binit[r] = sBp[hl * 32 + 8 * (r >> 2) + 4 * hh + (r & 3)];
-    uint4 qB[TPW];                                        // B operand of S^T: lanes 0..31 q[0..7] of the query, lanes 32..63 {-m, 0...}
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int T = T0 + ti * wph;
-        qB[ti] = make_uint4(0u, 0u, 0u, 0u);
-        if (T >= ntiles) continue;
-        const int px = min(T * 32 + l31, L - 1);          // keys / queries past L: a clamped row, masked later
-        const bf16_t* xrow = p.x + ((size_t)b * L + px) * C + 8 * hh;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = r < 12 ? binit[r] : 0.f;
-        for (int k0 = 0; k0 < nks; k0 += KB) {
-            bf16x8 xv[KB];
-#pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                if (k0 == 0) xv[j] = xpre[ti][j];
-                else if (k0 + j < nks) xv[j] = *reinterpret_cast<const bf16x8*>(xrow + (k0 + j) * 16);
-            }
-            if (k0 + KB <= nks) {                         // a full batch: all W' fragments requested, then the MFMAs back to back
-                bf16x8 wf[KB];
-#pragma unroll
-                for (int j = 0; j < KB; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sWh + ((size_t)(k0 + j) * 64 + lane) * 8);
-#pragma unroll
-                for (int j = 0; j < KB; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xv[j], acc, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < KB; ++j) {
-                    if (k0 + j >= nks) break;
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sWh + ((size_t)(k0 + j) * 64 + lane) * 8);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xv[j], acc, 0, 0, 0);
-                }
-            }
-        }
-        uint2 qp, kp, vp;
-        qp.x = pack_bf16x2(acc[0], acc[1]); qp.y = pack_bf16x2(acc[2], acc[3]);
-        kp.x = pack_bf16x2(acc[4], acc[5]); kp.y = pack_bf16x2(acc[6], acc[7]);
-        vp.x = pack_bf16x2(acc[8], acc[9]); vp.y = pack_bf16x2(acc[10], acc[11]);
-        // lanes 0..31 gather q[4..7] of their query from the partner half-wave
-        const uint32_t px_ = __shfl(qp.x, lane | 32), py_ = __shfl(qp.y, lane | 32);
-        if (hh == 0) qB[ti] = make_uint4(qp.x, qp.y, px_, py_);
-        const int key = T * 32 + l31;
-        *reinterpret_cast<uint2*>(sKh + (size_t)key * 8 + 4 * hh) = kp;
-        const int j16 = key & 15;
-        const int pos = (key & ~15) + 8 * ((j16 >> 2) & 1) + (j16 & 3) + 4 * (j16 >> 3);
-        bf16_t* vcol = sVh + pos;
-        vcol[(4 * hh + 0) * vst] = (bf16_t)(vp.x & 0xffffu);
-        vcol[(4 * hh + 1) * vst] = (bf16_t)(vp.x >> 16);
-        vcol[(4 * hh + 2) * vst] = (bf16_t)(vp.y & 0xffffu);
-        vcol[(4 * hh + 3) * vst] = (bf16_t)(vp.y >> 16);
-        if (hh == 0) {
-            vcol[8 * vst] = (bf16_t)0x3f80;               // 1.0: the PV MFMA's row 8 accumulates the softmax denominator
-            vcol[9 * vst] = (bf16_t)0;
-        }
-    }
-    RLDM_ASTAMP();                                        // 3: this wave's tiles projected
-    __syncthreads();
-    RLDM_ASTAMP();                                        // 4: everyone's
-
-    // ---- key loop -------------------------------------------------------------------------------------------------------------
-    const int q0a = T0 * 32, q0b = (T0 + wph) * 32;
-    if (q0a >= L) return;                                 // (no barriers below)
-    const bool haveB = PAIR && q0b < L;
-    // A operand of S^T: lanes 0..31 the 16-byte K row of their key, lanes 32..63 the constant row {1, 0, ...} (stride 0)
-    const bf16_t* kptr = hh == 0 ? sKh + l31 * 8 : sC;
-    const int kstep = hh == 0 ? 32 * 8 : 0;
-    const bf16_t* vptr = sVh + min(l31, 9) * vst + 8 * hh;
-    const bool ragged = (L & 31) != 0;
-    f32x16 zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-
-    // stabiliser: m = exact maximum over the first key tile (raw scores: the -m slot is still zero), rounded to bf16
-    uint4 kf = *reinterpret_cast<const uint4*>(kptr);
-    kptr += kstep;
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        f32x16 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[ti]), zero, 0, 0, 0);
-        if (ragged && 32 > L) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * hh >= L) s0[r] = -1e30f;
-        }
-        float tmax = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s0[r]), s0[r + 1]);
-        tmax = fmaxf(tmax, s0[15]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        if (hh == 1) qB[ti].x = pack_bf16x2(-tmax, 0.f);
-    }
-    RLDM_ASTAMP();                                        // 5: stabilisers
-
-    // rotated loop: on entry of iteration k0, sA / sB hold S(k0) and v0 / v1 the V^T fragments of tile k0; kf holds K(k0 + 32)
-    // (the reads past the last tile land in the LDS regions behind sK / sVt and are never used)
-    f32x16 oA, oB, sA, sB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oA[r] = 0.f; oB[r] = 0.f; }
-    sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[0]), zero, 0, 0, 0);
-    if (PAIR) sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[TPW - 1]), zero, 0, 0, 0);
-    kf = *reinterpret_cast<const uint4*>(kptr);
-    kptr += kstep;
-    uint4 v0 = *reinterpret_cast<const uint4*>(vptr);
-    uint4 v1 = *reinterpret_cast<const uint4*>(vptr + 16);
-    for (int k0 = 0; k0 < Lp; k0 += 32) {
-        if (ragged && k0 + 32 > L) {                      // last tile: keys >= L get -inf scores
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) { sA[r] = -1e30f; if (PAIR) sB[r] = -1e30f; }
-        }
-        uint32_t pk[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(__builtin_amdgcn_exp2f(sA[r]), __builtin_amdgcn_exp2f(sA[r + 1]));
-        __builtin_amdgcn_sched_barrier(0);
-        oA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0),
-                                                     __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])), oA, 0, 0, 0);
-        oA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1),
-                                                     __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7])), oA, 0, 0, 0);
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[0]), zero, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PAIR) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(__builtin_amdgcn_exp2f(sB[r]), __builtin_amdgcn_exp2f(sB[r + 1]));
-            __builtin_amdgcn_sched_barrier(0);
-            oB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0),
-                                                         __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])), oB, 0, 0, 0);
-            oB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1),
-                                                         __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7])), oB, 0, 0, 0);
-            sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[TPW - 1]), zero, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // next iteration's fragments (consumed a whole chain of exponentials from now)
-        kf = *reinterpret_cast<const uint4*>(kptr);
-        kptr += kstep;
-        v0 = *reinterpret_cast<const uint4*>(vptr + k0 + 32);
-        v1 = *reinterpret_cast<const uint4*>(vptr + k0 + 48);
-    }
-    RLDM_ASTAMP();                                        // 6: key loop done
-#ifdef RLDM_ABLATE
-    if (p.ts && p.L == p.ts_L && lane == 0) {
-        if (blockIdx.x == 0 && wave < 16)
-            for (int i = 0; i < 8; ++i) p.ts[wave * 8 + i] = i < tsn ? tsv[i] : 0ull;
-        if (blockIdx.x < 2048 && wave == 0) {
-            p.ts[256 + 2 * blockIdx.x] = t_real0;
-            p.ts[257 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-#endif
-#undef RLDM_ASTAMP
-    // o rows: reg r of half hh <-> row (r&3) + 8*(r>>2) + 4*hh.  d = 4*hh + r for r < 4; denominator = row 8 = reg 4 of hh 0
-    bf16_t* out_bh = p.out + ((size_t)b * L) * C + h * 8;
-    const float dA = __shfl(oA[4], l31);
-    const float dB = PAIR ? __shfl(oB[4], l31) : 1.f;
-    // a denominator that is not a finite number below 2^120: some score beat the first tile's maximum by ~100 log2 units ->
-    // this wave redoes its tiles with the running-maximum loop (rare; exercised by tests/test_hip_kernels.py)
-    const bool bad = !(dA < 1.3e36f) || (haveB && !(dB < 1.3e36f));
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
-#pragma unroll
-        for (int ti = 0; ti < TPW; ++ti) {
-            if (ti == 1 && !haveB) break;
-            // attention_tile's B operand: lane (query l31, half hh) holds q[4hh .. 4hh+3]
-            const uint32_t zz = __shfl(qB[ti].z, l31), ww = __shfl(qB[ti].w, l31);   // (all lanes: not under the hh select)
-            uint2 qq;
-            qq.x = hh ? zz : qB[ti].x;
-            qq.y = hh ? ww : qB[ti].y;
-            attention_tile(sKh, sVh, vst, L, Lp, C, ti ? q0b : q0a, __builtin_bit_cast(s16x4, qq), out_bh, l31, hh);
-        }
-        return;
-    }
-    {
-        const float inv = 1.0f / dA;
-        uint2 ov;
-        ov.x = pack_bf16x2(oA[0] * inv, oA[1] * inv);
-        ov.y = pack_bf16x2(oA[2] * inv, oA[3] * inv);
-        if (q0a + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0a + l31) * C + 4 * hh) = ov;
-    }
-    if (haveB) {
-        const float inv = 1.0f / dB;
-        uint2 ov;
-        ov.x = pack_bf16x2(oB[0] * inv, oB[1] * inv);
-        ov.y = pack_bf16x2(oB[2] * inv, oB[3] * inv);
-        if (q0b + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0b + l31) * C + 4 * hh) = ov;
-    }
+    const TrunkSeam none = {};
+    attention_qkv2_body<PAIR, false>(p, waves, Lp, HG, bid / hgroups, bid % hgroups, none);
 }
 
 static int g_attn_old = getenv("RLDM_ATTN_OLD") ? atoi(getenv("RLDM_ATTN_OLD")) : 0;

@@ -5,64 +5,13 @@
 //                phase ends by publishing (arrive on the cluster's counter) instead of by a kernel boundary.
 #pragma once
 #include "kernels.h"
+#include "trunk_seam.h"
 
 namespace rldm {
 
 __device__ __forceinline__ void lds_barrier_s() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-}
-
-// ---- cluster seam of the persistent trunk (tools/ubench/xcd_cluster.hip: 1.4 us for 16 workgroups of one XCD) --------------------
-// The workgroups of one image sit on ONE XCD (block -> XCD round-robin; checked by the host once per plan), so a plain store that
-// has been acknowledged (s_waitcnt vmcnt(0)) is in the L2 they share, and a load that bypasses the reader's L1 sees it.
-constexpr int kTrunkPrefetch = 12;            // weight fragments per wave requested one phase ahead (registers carried across phases)
-struct TrunkSeam {
-    unsigned* counter;              // arrivals of this image's cluster (monotonic over the launch; zeroed by the launch before)
-    unsigned wait_for;              // arrivals that must have happened before this phase reads activations
-    int has_wait;                   // (0: the launch's first phase -- its inputs crossed a kernel boundary)
-    unsigned next_rec;              // lane l: word l of the next phase's record (kernels.h TrunkWord), or 0 behind the last phase
-    int next_rank_kg;               // this wave's weight stream of a layer = (channel tile * k-groups + k-group)
-    int* error;                     // device flag: a bounded poll gave up (the host refuses the plan's results)
-    unsigned long long* ts;         // ABLATE builds: 16 stamp slots of this phase (workgroup 0) or null
-    // the phase's time-embedding row (the launch's arguments, not the phase record: the table belongs to the caller of the plan)
-    const float* temb;              // table + this layer's channel offset, or null
-    const int* step_ptr;
-    int temb_rows_per_step, temb_per_sample, temb_ld;
-};
-__device__ __forceinline__ void trunk_wait(const TrunkSeam& s, int tid) {
-    if (tid == 0 && s.has_wait) {
-        int polls = 0;
-        while ((int)(__hip_atomic_load(s.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - s.wait_for) < 0) {   // (wrap-safe)
-            __builtin_amdgcn_s_sleep(1);
-            if (++polls > (1 << 22)) { *s.error = 1; break; }      // bounded: a protocol error must not hang the device
-        }
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void trunk_arrive(const TrunkSeam& s, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this thread's stores are in the cluster's L2
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(s.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// activation loads: past the L1 inside the trunk (another CU of the cluster wrote the line during this launch)
-template <bool BYPASS> __device__ __forceinline__ uint4 ld_act16(const void* p) {
-    if constexpr (BYPASS) {
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    } else {
-        return *reinterpret_cast<const uint4*>(p);
-    }
-}
-template <bool BYPASS> __device__ __forceinline__ float2 ld_act8(const float2* p) {
-    if constexpr (BYPASS) {
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p));
-        return make_float2(v.x, v.y);
-    } else {
-        return *p;
-    }
 }
 
 // BM = 32 * MI pixels (64: the 64x4 / 32x2 levels and the pointwise convs; 128: the 128x8 level; 32: 32x1 images -- the lowest nuScenes level), BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.

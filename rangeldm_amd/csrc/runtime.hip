@@ -741,6 +741,46 @@ struct Builder {
         return rc;
     }
 
+    // attention core as a trunk phase: x arrives normalised, C / 8 heads split over N / 32 = C / 32 workgroups of 8 waves
+    static size_t trunk_attention_lds(int L, int C, int HG) {
+        const size_t Lp = (size_t)(L + 31) / 32 * 32;
+        return HG * Lp * 16 + (size_t)HG * 10 * (Lp + 8) * 2 + 16 + (size_t)C * 8 +
+               std::max((size_t)2 * C * 8, (size_t)HG * (C / 16) * 64 * 4) + (size_t)HG * C * 64 + (size_t)HG * 128 + 128;
+    }
+    bool trunk_attention_ok(const Tensor& x, bool pre) const {
+        const int L = x.W * x.H, ranks = x.C / 32;
+        if (!trunk_enabled() || !pre || x.C % 32 != 0 || ranks < 2 || ranks > 16) return false;
+        const int HG = (x.C / 8) / ranks, wph = (L + 31) / 32;
+        if (HG * wph != 8 || L > 64) return false;                // 8 waves: one query tile per wave
+        if (8 * ranks * ((x.B + 7) / 8) > 256) return false;
+        return trunk_attention_lds(L, x.C, HG) <= 160 * 1024;
+    }
+    void trunk_begin(int B, int ranks) {
+        if (trunk_open && (pend.ranks != ranks || pend.B != B)) flush_trunk();
+        if (!trunk_open) {
+            ++launches;
+            trunk_open = true;
+            pend.B = B;
+            pend.ranks = ranks;
+        }
+    }
+    void trunk_push_attention(const AttnQkvParams& ap, double fl, double by) {
+        TrunkPhase ph;
+        memset(&ph, 0, sizeof(ph));
+        auto put64 = [&](int at, const void* ptr) {
+            const unsigned long long u = (unsigned long long)(uintptr_t)ptr;
+            ph.w[at] = (unsigned)u;
+            ph.w[at + 1] = (unsigned)(u >> 32);
+        };
+        put64(TW_X0, ap.x); put64(TW_WPK, ap.wfrag); put64(TW_BIAS, ap.bias); put64(TW_Y, ap.out);
+        ph.w[TW_WIN] = ap.L; ph.w[TW_N] = ap.C;
+        ph.w[TW_KIND] = 3; ph.w[TW_G] = 0; ph.w[TW_NMINE] = 0; ph.w[TW_TEMBOFF] = (unsigned)-1;
+        pend.phases.push_back(ph);
+        pend.lds = std::max(pend.lds, trunk_attention_lds(ap.L, ap.C, (ap.C / 8) / pend.ranks));
+        pend.flops += fl;
+        pend.bytes += by;
+    }
+
     template <class T> T* ptr(size_t off) const { return reinterpret_cast<T*>(base + off); }
     bf16_t* tptr(const Tensor& t) const { return t.valid() ? ptr<bf16_t>(t.off) : nullptr; }
     const float2* sptr(const Tensor& t) const { return (t.valid() && t.P) ? ptr<float2>(t.st_off) : nullptr; }
@@ -1449,7 +1489,9 @@ struct NetCommon {
             Tensor o = b.make(x.B, x.W, x.H, x.C);
             const double fl = 4.0 * (double)x.B * (x.C / 8) * (double)Lt * Lt * 8 + 2.0 * (double)x.B * Lt * 3.0 * x.C * x.C;
             b.plan->flops += fl;
-            b.note_launch();
+            const bool in_trunk = b.trunk_attention_ok(x, pre);     // a phase of the persistent trunk launch (trunk.hip)
+            if (in_trunk) b.trunk_begin(x.B, x.C / 32);
+            else b.note_launch();
             if (!b.dry) {
                 AttnFused* f = nullptr;
                 if (get_attn_fused(p, x.C, &f)) return 1;
@@ -1471,8 +1513,10 @@ struct NetCommon {
                 ap.B = x.B; ap.L = Lt; ap.C = x.C;
                 ap.ts = getenv("RLDM_TS_TRUNK") ? nullptr : g_ts_buf;
                 ap.ts_L = getenv("RLDM_TS_ATTN_L") ? atoi(getenv("RLDM_TS_ATTN_L")) : 0;
-                b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl,
-                                       (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0});
+                const double by = (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0;
+                if (in_trunk) b.trunk_push_attention(ap, fl, by);
+                else
+                b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl, by});
             }
             if (pre) b.release(xn);
             ConvArgs co;

@@ -15,6 +15,7 @@
 // DIFFERENT images: they drift apart freely (so activations of a segment are never recycled inside it: runtime.hip defers the
 // arena releases to the segment's end).
 #include "conv_small_body.h"
+#include "attention_body.h"
 
 namespace rldm {
 
@@ -114,7 +115,26 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
         switch (kind) {
             case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
             case 1: conv_small_body<1, 4, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
-            default: conv_small_body<1, 2, 1, 2, true>(cp, rank, 0, b, wpf, seam); break;
+            case 2: conv_small_body<1, 2, 1, 2, true>(cp, rank, 0, b, wpf, seam); break;
+            default: {
+                // attention core of the block (GroupNorm already applied by the producer of x): this workgroup's heads / ranks
+                // heads of image b, one query tile per wave; its output projection is the next phase (a 1x1 conv)
+                AttnQkvParams ap;
+                ap.x = cp.x0; ap.st = nullptr; ap.P = 0; ap.gamma = nullptr; ap.beta = nullptr; ap.eps = 0.f; ap.groups = 1;
+                ap.inv_n = 0.f; ap.magic_cpg = 0;
+                ap.wfrag = cp.wpk; ap.bias = cp.bias; ap.out = cp.y;
+                ap.B = tp.B; ap.L = cp.Win; ap.C = cp.N; ap.ts = nullptr; ap.ts_L = 0;
+                const int Lp = (ap.L + 31) & ~31;
+                attention_qkv2_body<0, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
+                // the next phase's first weight fragments (what a conv phase requests behind its K loop)
+                const int next_g = (int)rl(nrec, TW_G);
+                if (next_g > 0) {
+                    const unsigned char* nw = wave_stream(nrec);
+#pragma unroll
+                    for (int j = 0; j < kTrunkPrefetch; ++j)
+                        if (j < next_g) wpf[j] = *reinterpret_cast<const bf16x8*>(nw + (unsigned)(j * 1024 + lane * 16));
+                }
+            } break;
         }
         if (i == 1 && rank != 0 && tid == 0) {  // (rank 0's first arrive has been waited for: its XCC id is there)
             const unsigned x0 = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
