@@ -122,6 +122,7 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     int tsn = 0;
     const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #define RLDM_ASTAMP() if (tsn < 8) tsv[tsn++] = __builtin_amdgcn_s_memtime()
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #else
 #define RLDM_ASTAMP()
 #endif
@@ -160,7 +161,7 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     if (own_ch && !prenorm) { g_pre = p.gamma[tid]; b_pre = p.beta[tid]; }
     const bf16_t* wf_ptr = p.wfrag + (size_t)(hg * HG) * nks * 512;
     const int npieces = HG * nks * 64;
-    constexpr int NPW = 2;                                // weight pieces held per thread up front (more: loaded in the loop)
+    constexpr int NPW = TRUNK ? 4 : 2;                    // weight pieces held per thread up front (more: loaded in the loop)
     uint4 wpre[NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j)
@@ -181,9 +182,22 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
 
     // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic; one fold per workgroup) ----------------------------------
     if (prenorm) {
-        for (int t = tid; t < C; t += NT) { sGa[t] = 1.f; sGs[t] = 0.f; }
+        // x arrives normalised: W' = W and b' = b exactly (what the fold below computes with a = 1, s = 0), so the head's weight
+        // fragments are copied to LDS as they are -- no affine, no per-row bias sums, one barrier instead of three
         if (tid < 8) sC[tid] = tid == 0 ? (bf16_t)0x3f80 : (bf16_t)0;
+        for (int q = tid, j = 0; q < npieces; q += NT, ++j) {
+            uint4 w;
+            bool have = false;
+#pragma unroll
+            for (int k = 0; k < NPW; ++k)
+                if (j == k) { w = wpre[k]; have = true; }
+            if (!have) w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);
+            *reinterpret_cast<uint4*>(sW + (size_t)q * 8) = w;
+        }
+        if (tid < 32 * HG) sBp[tid] = bias_pre;
         __syncthreads();
+        RLDM_ASTAMP();                                    // 1
+        RLDM_ASTAMP();                                    // 2: W, b in LDS
     } else {
         const int cpg = C / p.groups;
         for (int t = tid; t < C; t += NT) {
@@ -223,7 +237,6 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
             sGs[t] = bt - (float)mean * a;
         }
         __syncthreads();
-    }
     RLDM_ASTAMP();                                        // 1: GroupNorm affine in LDS
 
     // ---- W' = W_h * diag(a) (bf16, A-fragment order), b' = b_h + W_h * s for the HG heads of this workgroup -----------------
@@ -233,7 +246,7 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
         uint4 w;
         if (j == 0) w = wpre[0];
         else if (j == 1) w = wpre[1];
-        else w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);
+        else w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);     // (NPW > 2: trunk phases, which never fold)
         const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
         const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
         uint4 n;
@@ -254,6 +267,7 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     }
     __syncthreads();
     RLDM_ASTAMP();                                        // 2: W', b' in LDS
+    }
 
     // ---- projection of this wave's pixel tiles: q stays in registers, k / v go to the head's LDS image ----------------------
     bf16_t* sKh = sK + (size_t)hl * Lp * 8;
@@ -445,7 +459,16 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
         if (q0b + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0b + l31) * C + 4 * hh) = ov;
     }
     } while (false);
-    if constexpr (TRUNK) trunk_arrive(seam, tid);
+    if constexpr (TRUNK) {
+        trunk_arrive(seam, tid);
+#ifdef RLDM_ABLATE
+        if (seam.ts && tid == 0) {
+            seam.ts[0] = t_entry;
+            for (int i = 0; i < 8; ++i) seam.ts[1 + i] = i < tsn ? tsv[i] : 0ull;
+            seam.ts[9] = __builtin_amdgcn_s_memtime();
+        }
+#endif
+    }
 }
 
 }  // namespace rldm
