@@ -954,9 +954,11 @@ struct Builder {
         // a phase of the persistent trunk launch (trunk.hip) instead of a launch of its own: the tile owns the image, the input
         // arrives pre-activated (or needs no norm), one of the three instances the trunk kernel carries
         const int cpt_t = Cin_t / 128;
-        const int trunk_kind = (taps == 9 && Cin_t == 256) ? 0 : ((taps == 9 && Cin_t == 512) ? 1 : ((taps == 1 && Cin_t == 256) ? 2 : -1));
+        const int px_t = p.TW * p.TH;
+        const int kind_l = (taps == 9 && Cin_t == 256) ? 0 : ((taps == 9 && Cin_t == 512) ? 1 : ((taps == 1 && Cin_t == 256) ? 2 : -1));
+        const int trunk_kind = kind_l < 0 ? -1 : kind_l + (px_t == 32 ? 4 : 0);      // (+4: the 32-pixel instances)
         const int ranks_t = N / 32;
-        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && p.TW * p.TH == 64 && !gn_fused && !preact &&
+        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && (px_t == 64 || px_t == 32) && !gn_fused && !preact &&
                         trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && 8 * ranks_t * ((x0.B + 7) / 8) <= 256 &&
                         2 * p.TH * (Cin_t / 8) <= 512 && vts.size() <= 2;
         if (in_trunk && trunk_open && (pend.ranks != ranks_t || pend.B != x0.B)) flush_trunk();
@@ -1025,7 +1027,7 @@ struct Builder {
                 ph.w[TW_HOUT] = p.Hout; ph.w[TW_TW] = p.TW; ph.w[TW_TH] = p.TH; ph.w[TW_COLB] = p.colb; ph.w[TW_THSHIFT] = p.th_shift;
                 ph.w[TW_N] = p.N; ph.w[TW_YLD] = p.y_ld; ph.w[TW_NVIEWS] = p.nviews;
                 const int cpt = Cin_t / 128, KG = 8;
-                const int G = trunk_kind == 0 ? 18 : (trunk_kind == 1 ? 12 : cpt);
+                const int G = (trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt);
                 ph.w[TW_KIND] = trunk_kind;
                 ph.w[TW_G] = std::min(G, 12);       // == kTrunkPrefetch (conv_small_body.h)
                 ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;

@@ -116,6 +116,10 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
             case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
             case 1: conv_small_body<1, 4, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
             case 2: conv_small_body<1, 2, 1, 2, true>(cp, rank, 0, b, wpf, seam); break;
+            // 32-pixel images (the 32x1 level of the nuScenes network): the same three layers on one 32-pixel tile
+            case 4: conv_small_body<1, 2, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
+            case 5: conv_small_body<1, 4, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
+            case 6: conv_small_body<1, 2, 1, 1, true>(cp, rank, 0, b, wpf, seam); break;
             default: {
                 // attention core of the block (GroupNorm already applied by the producer of x): this workgroup's heads / ranks
                 // heads of image b, one query tile per wave; its output projection is the next phase (a 1x1 conv)
