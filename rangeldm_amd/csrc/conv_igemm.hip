@@ -265,8 +265,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
             float f4 = bf16lo(v.z) * ga1.x + gs1.x, f5 = bf16hi(v.z) * ga1.y + gs1.y;
             float f6 = bf16lo(v.w) * ga1.z + gs1.z, f7 = bf16hi(v.w) * ga1.w + gs1.w;
             if (p.silu) {
-                f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
-                f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+                silu_x8(f0, f1, f2, f3, f4, f5, f6, f7);
             }
             v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
             v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);

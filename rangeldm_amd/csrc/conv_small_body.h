@@ -297,8 +297,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
                         float f4 = bf16lo(o.z) * ga[4] + gs[4], f5 = bf16hi(o.z) * ga[5] + gs[5];
                         float f6 = bf16lo(o.w) * ga[6] + gs[6], f7 = bf16hi(o.w) * ga[7] + gs[7];
                         if (p.silu) {
-                            f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
-                            f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+                            silu_x8(f0, f1, f2, f3, f4, f5, f6, f7);
                         }
                         o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
                         o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);

@@ -221,8 +221,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
             float f4 = bf16lo(v[j].z) * a1.x + s1.x, f5 = bf16hi(v[j].z) * a1.y + s1.y;
             float f6 = bf16lo(v[j].w) * a1.z + s1.z, f7 = bf16hi(v[j].w) * a1.w + s1.w;
             if (p.silu) {
-                f0 = silu_f(f0); f1 = silu_f(f1); f2 = silu_f(f2); f3 = silu_f(f3);
-                f4 = silu_f(f4); f5 = silu_f(f5); f6 = silu_f(f6); f7 = silu_f(f7);
+                silu_x8(f0, f1, f2, f3, f4, f5, f6, f7);
             }
             uint4 o;
             o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
