@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--preset", default="RangeLDM")
     ap.add_argument("--seed", type=int, default=20240310)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary three-requests-in-flight measurement")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 5 instead of the headline: the data-parallel training step (tools/bench_train.py, same "
                          "--gpus / --steps / --warmup contract, metric training samples/sec)")
@@ -264,6 +265,24 @@ def main():
             res["unet_launches_per_step"] = unet.num_launches(B)
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(p, usd, vsd, B, S)
+            if world == 1 and not args.no_pipelined and args.preset == "RangeLDM" and B == 16 and zs is None and conds is None:
+                # NOT `value`: the same kernels with THREE batch-16 requests in flight (three chains of 16 on separate HIP streams,
+                # one pipeline call of 48 samples) -- what a throughput driver that does not wait for batch i before it starts
+                # batch i + 1 gets out of the chip.  `value` above stays the one-request-at-a-time figure (ldm/inference.py:159-183).
+                nreq = 3
+                xp = [torch.cat([xs[(i * nreq + j) % n_iter] for j in range(nreq)]) for i in range(3)]
+                runp = lambda i: pipe(batch_size=nreq * B, num_inference_steps=S, latents=xp[i], output_type="torch")
+                runp(0)
+                torch.cuda.synchronize()
+                tp0 = time.perf_counter()
+                for i in (1, 2):
+                    outp = runp(i)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - tp0
+                res["pipelined"] = {"requests_in_flight": nreq, "request_batch": B, "value": round(2 * nreq * B / dtp, 2),
+                                    "unit": "range-images/sec", "ms_per_request": round(dtp / (2 * nreq) * 1e3, 3),
+                                    "note": "secondary figure; `value` is one request at a time"}
+                assert torch.isfinite(outp).all()
         print(json.dumps(res), flush=True)
     D.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():

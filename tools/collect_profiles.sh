@@ -7,7 +7,7 @@ TAG=${1:-vX}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined"
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/${TAG}_gpu_tests.txt
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python tools/bench_train.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_train.json 2>> $OUT/${TAG}_bench.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # VGPR / spill / scratch of every kernel in one .hip file: tools/kernel_regs.sh rangeldm_amd/csrc/conv_small.hip
 f=$1
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -Wno-array-bounds --cuda-device-only -S "$f" -o /tmp/_regs.s -I$(dirname $f) 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -Wno-array-bounds $EXTRA --cuda-device-only -S "$f" -o /tmp/_regs.s -I$(dirname $f) 2>/dev/null
 python3 - <<'PY'
 import re
 txt=open('/tmp/_regs.s').read()
