@@ -127,7 +127,9 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
 #define RLDM_ASTAMP()
 #endif
     RLDM_ASTAMP();
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    if constexpr (TRUNK) asm volatile("" : "+v"(tid_));     // (opaque per phase: see conv_small_body.h)
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = waves * 64;
     const int heads = p.C >> 3;
@@ -207,12 +209,12 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
             for (; q + 8 <= p.P; q += 8) {
                 float2 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(q + j) * C];
+                for (int j = 0; j < 8; ++j) v[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * C);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
             }
             for (; q < p.P; ++q) {
-                const float2 v = src[(size_t)q * C];
+                const float2 v = ld_act8<TRUNK>(src + (size_t)q * C);
                 S += (double)v.x;
                 SS += (double)v.y;
             }

@@ -17,7 +17,7 @@ __device__ __forceinline__ void lds_barrier_s() {
 // BM = 32 * MI pixels (64: the 64x4 / 32x2 levels and the pointwise convs; 128: the 128x8 level; 32: 32x1 images -- the lowest nuScenes level), BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
 // TAPS == 9: 3x3 over a pre-activated input.  TAPS == 1: pointwise (attention q/k/v and output projections); there the
 // GroupNorm affine (no separate launch: one FMA per element while the tile is on its way to LDS) is folded in.
-template <int NWN, int CPT, int TAPS, int MI, bool TRUNK>
+template <int NWN, int CPT, int TAPS, int MI, bool TRUNK, int PF = kTrunkPrefetch>
 __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int nt, const int mt, const int b, bf16x8 (&wpf)[kTrunkPrefetch],
                                                 const TrunkSeam& seam) {
     constexpr int NT = 512, KG = 8 / NWN, BM = 32 * MI, BN = 32 * NWN;
@@ -42,7 +42,11 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     constexpr int NCW = MI >= 4 ? 3 : 5, KB = MI >= 4 ? (10 + SPI - 1) / SPI : 4;
     static_assert(C8 <= 64 && G % PFX == 0 && TAPS % TPG == 0 && PFX <= G, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    // (a phase of the persistent launch: the thread index is made opaque per phase, or every lane-dependent constant of every
+    //  instance is hoisted out of the phase loop and lives in registers across all of them)
+    if constexpr (TRUNK) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % NWN, kg = wave / NWN;
     const int kh = lane >> 5, l31 = lane & 31;
@@ -109,7 +113,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
 
     // ---- TAPS == 1: the GroupNorm inputs of channel `tid` (statistics partials of the producer, gamma, beta), requested now
     // (3x3: single-input convs only; concatenated inputs come pre-activated.  Trunk phases: pre-activated inputs only)
-    const bool gn = TRUNK ? false : p.st0 != nullptr;
+    const bool gn = (TRUNK && NWN == 1) ? false : p.st0 != nullptr;       // (image-owning trunk phases: pre-activated inputs only)
     double gS = 0.0, gSS = 0.0;
     float g_gamma = 0.f, g_beta = 0.f;
     if (gn && tid < CIN) {
@@ -149,8 +153,10 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     if constexpr (TRUNK) {                      // requested by the previous phase, behind its K loop
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            if (j < kTrunkPrefetch) wr[j] = wpf[j];
-            else wr[j] = w_load(wbase, j);      // (the rest of a long ring: in flight during the seam and the gather)
+            if (j < PF) wr[j] = wpf[j];
+            else wr[j] = w_load(wbase, j);      // (the rest of a long ring: in flight during the seam and the gather; PF == 0 --
+                                                //  multi-tile clusters, whose instances leave no registers to carry a ring across
+                                                //  phases: the whole ring, requested here like a stand-alone launch's)
         }
     } else {
 #pragma unroll
@@ -168,7 +174,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     // instruction moves SPI rows x C8 16-byte pieces of a column, so a lane's row, channel and both offsets never change.
     // TAPS == 1 with statistics: the GroupNorm affine of the image is derived while the first loads are in flight and
     // applied on the way into LDS ----
-    const bool whole_image = TRUNK || (tiles_img == 1 && p.up == 1 && !gn && p.TW == p.Win && p.TH == p.Hin && 2 * p.TH * C8 <= NT);
+    const bool whole_image = (TRUNK && NWN == 1) || (!TRUNK && tiles_img == 1 && p.up == 1 && !gn && p.TW == p.Win && p.TH == p.Hin && 2 * p.TH * C8 <= NT);
     if (whole_image) {
         // the tile IS the image and arrives ready (pre-activated, or no norm): [npx][CIN] is one contiguous block -- a linear copy
         // (thread-constant piece index -> pixel / channel by constant divisions, no per-piece predicates), the two wrap-around halo
@@ -208,7 +214,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
             const int row = hrem / C8, c8 = hrem - row * C8;
             *reinterpret_cast<uint4*>(sA + (hside ? TWv - 1 : 0) * colb + (row + 1) * RSM + c8 * 16) = hv[0];
         }
-    } else if constexpr (!TRUNK) {
+    } else if constexpr (!TRUNK || NWN > 1) {
         const int c8 = lane & (LPS - 1), rsub = lane / LPS;
         const bool laneok = c8 < C8;
         const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x0);
@@ -608,7 +614,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     }
     RLDM_STAMP();
     if constexpr (TRUNK) trunk_arrive(seam, tid);
-    if constexpr (TRUNK) {                      // the next phase's first fragments: requested behind the arrive (its vmcnt(0) must not
+    if constexpr (TRUNK && PF > 0) {            // the next phase's first fragments: requested behind the arrive (its vmcnt(0) must not
                                                 // wait for them), in flight during the seam and the next gather
         const unsigned nr = seam.next_rec;
         const int next_g = __builtin_amdgcn_readlane((int)nr, TW_G);
@@ -617,7 +623,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         const unsigned char* next_w = reinterpret_cast<const unsigned char*>(wp) +
                                       ((size_t)seam.next_rank_kg * (unsigned)__builtin_amdgcn_readlane((int)nr, TW_NMINE)) * 1024;
 #pragma unroll
-        for (int j = 0; j < kTrunkPrefetch; ++j)
+        for (int j = 0; j < PF; ++j)
             if (j < next_g) wpf[j] = *reinterpret_cast<const bf16x8*>(next_w + (unsigned)(j * 1024 + lane * 16));
     }
 #ifdef RLDM_ABLATE

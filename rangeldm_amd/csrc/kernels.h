@@ -144,15 +144,26 @@ enum TrunkWord {
     TW_KIND, TW_G, TW_NMINE, TW_TEMBOFF,
     TW_NV0 = 34,            // 2 views x 11 words: y (2), gamma (2), beta (2), ld, cpg_shift, inv_n, eps, silu
     TW_NVSTRIDE = 11,
+    // phases of a MULTI-TILE cluster (kind >= 8: an image is several 64-pixel tiles x 64-channel tiles; no views) keep the
+    // consumer-side GroupNorm of their input in the words the views would occupy
+    TW_ST0 = 34, TW_GAMMA = 36, TW_BETA = 38,                   // 64-bit pointers
+    TW_P0 = 40, TW_GROUPS, TW_MAGIC_CPG, TW_INVN, TW_EPS, TW_SILU, TW_TILES_H, TW_TILES_IMG,
     TW_WORDS = 64
 };
+// phase kinds: 0..2 / 4..6 image-owning conv_small tiles (64 / 32 pixels), 3 attention over a pre-normalised x,
+// 9..11 3x3 conv over 256 / 384 / 512 channels on 64-pixel x 64-channel tiles of a multi-tile image (8: 128 channels, not instantiated), 12 its 1x1 over 256,
+// 13 attention with the GroupNorm fold inside (two query tiles per wave)
+// 14 GroupNorm (+ SiLU) of a concatenated input as a phase of its own (norm.hip's gn_apply_kernel; record: x0 / x1 in TW_X0 / TW_R0,
+// their channels in TW_R0C / TW_R1C, statistics in TW_ST0 / TW_RES with TW_P0 / TW_TILES_H partials, pixels per image in TW_WIN)
+enum TrunkKind { TK_ATTN = 3, TK_CL_3x3_128 = 8, TK_CL_3x3_256, TK_CL_3x3_384, TK_CL_3x3_512, TK_CL_1x1_256, TK_ATTN_FOLD, TK_GN_APPLY };
 struct TrunkPhase {
     unsigned w[TW_WORDS];
 };
 struct TrunkParams {
     const TrunkPhase* phases;   // device
     int nphases;
-    int B, ranks;               // images; channel tiles per image (N / 32)
+    int B, ranks;               // images; workgroups per image (its cluster): channel tiles x pixel tiles
+    int ntile_n, nwn;           // channel tiles per image and 32-channel tiles per workgroup (N / 32 and 1 for image-owning tiles)
     unsigned* counters;         // device [B][32] zero-initialised: [0] arrivals (monotonic), [1] rank 0's XCC id + 1, [3] launches so far
     int* error;                 // device flag: 1 a bounded wait gave up, 2 a cluster is spread over several XCDs
     const float* temb;          // the plan's time-embedding table (PlanIO), set per launch

@@ -505,6 +505,8 @@ static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: devic
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
 
+static thread_local int g_concurrent_plans = 1;   // plans being built will share the device with this many of their kind (sampler chains)
+
 struct TileChoice {
     ConvTile tile;
     int TW = 1, TH = 1, ksplit = 1;
@@ -686,6 +688,7 @@ struct Builder {
         std::vector<TrunkPhase> phases;
         size_t lds = 0;
         int B = 0, ranks = 0;
+        int ntile_n = 0, nwn = 1;      // channel tiles per image, 32-channel tiles per workgroup (multi-tile clusters: nwn == 2)
         double flops = 0, bytes = 0;
     } pend;
     bool trunk_open = false;
@@ -718,6 +721,8 @@ struct Builder {
             tp.nphases = (int)pend.phases.size();
             tp.B = pend.B;
             tp.ranks = pend.ranks;
+            tp.ntile_n = pend.nwn == 1 ? pend.ranks : pend.ntile_n;
+            tp.nwn = pend.nwn;
             tp.counters = ctrs->as<unsigned>();
             tp.error = plan->trunk_error.as<int>();
             tp.temb_ld = temb_ld;
@@ -755,14 +760,38 @@ struct Builder {
         if (8 * ranks * ((x.B + 7) / 8) > 256) return false;
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024;
     }
-    void trunk_begin(int B, int ranks) {
-        if (trunk_open && (pend.ranks != ranks || pend.B != B)) flush_trunk();
+    // ... of a multi-tile cluster: raw x + statistics (the fold runs inside the phase), two query tiles per wave; 0: not eligible
+    int cluster_attention_ranks(const Tensor& x, bool pre) const {
+        const int L = x.W * x.H, ranks = cluster_ranks(x.B, x.C, L);
+        if (!cluster_enabled() || pre || ranks == 0 || x.P <= 0 || (x.C / 8) % ranks != 0 || L % 32 != 0) return 0;
+        const int HG = (x.C / 8) / ranks, wph = L / 32;
+        if (HG * wph != 16 || x.C > 512) return 0;                // 8 waves x two query tiles
+        return trunk_attention_lds(L, x.C, HG) <= 160 * 1024 ? ranks : 0;
+    }
+    void trunk_begin(int B, int ranks, int ntile_n = 0, int nwn = 1) {
+        if (nwn == 1) ntile_n = ranks;
+        if (trunk_open && (pend.ranks != ranks || pend.B != B || pend.nwn != nwn || pend.ntile_n != ntile_n)) flush_trunk();
         if (!trunk_open) {
             ++launches;
             trunk_open = true;
             pend.B = B;
             pend.ranks = ranks;
+            pend.ntile_n = ntile_n;
+            pend.nwn = nwn;
         }
+    }
+    // multi-tile clusters (trunk.hip, kinds 8..13): an image = (N / 64) channel tiles x (pixels / 64) pixel tiles of conv_small's
+    // 64 x 64 instance, all of them resident at once and on one XCD (8 * ranks * ceil(B / 8) workgroups <= the chip's CUs).
+    // rldm_debug_set_flags(1 << 26) keeps these levels as separate launches (A/B runs)
+    // (and only for plans that run ALONE on the device: a 256-workgroup launch of one sampler chain and one of another could each
+    //  hold part of the chip and wait for the rest -- sampler_build_plans sets g_concurrent_plans to its number of chains)
+    static bool cluster_enabled() { return trunk_enabled() && !(g_dbg_flags & (1 << 26)) && g_concurrent_plans <= 1; }
+    static int cluster_ranks(int B, int C, int npix) {
+        if (C % 64 != 0 || npix % 64 != 0) return 0;
+        const int r = (C / 64) * (npix / 64);
+        static int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
+        const int limit = std::min(256, cus > 0 ? cus : 256);
+        return (r >= 2 && r <= 16 && npix > 64 && 8 * r * ((B + 7) / 8) <= limit) ? r : 0;
     }
     void trunk_push_attention(const AttnQkvParams& ap, double fl, double by) {
         TrunkPhase ph;
@@ -774,7 +803,12 @@ struct Builder {
         };
         put64(TW_X0, ap.x); put64(TW_WPK, ap.wfrag); put64(TW_BIAS, ap.bias); put64(TW_Y, ap.out);
         ph.w[TW_WIN] = ap.L; ph.w[TW_N] = ap.C;
-        ph.w[TW_KIND] = 3; ph.w[TW_G] = 0; ph.w[TW_NMINE] = 0; ph.w[TW_TEMBOFF] = (unsigned)-1;
+        ph.w[TW_KIND] = ap.st ? TK_ATTN_FOLD : TK_ATTN; ph.w[TW_G] = 0; ph.w[TW_NMINE] = 0; ph.w[TW_TEMBOFF] = (unsigned)-1;
+        if (ap.st) {                    // the consumer-side GroupNorm of x (multi-tile clusters)
+            put64(TW_ST0, ap.st); put64(TW_GAMMA, ap.gamma); put64(TW_BETA, ap.beta);
+            ph.w[TW_P0] = ap.P; ph.w[TW_GROUPS] = ap.groups; ph.w[TW_MAGIC_CPG] = ap.magic_cpg;
+            memcpy(&ph.w[TW_INVN], &ap.inv_n, 4); memcpy(&ph.w[TW_EPS], &ap.eps, 4);
+        }
         pend.phases.push_back(ph);
         pend.lds = std::max(pend.lds, trunk_attention_lds(ap.L, ap.C, (ap.C / 8) / pend.ranks));
         pend.flops += fl;
@@ -905,27 +939,8 @@ struct Builder {
             RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
             RLDM_REQUIRE(a.x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
         }
-        // GroupNorm + SiLU once, ahead of the conv: every channel tile of the conv would otherwise redo it (4-8x at these levels)
         Tensor act;
-        if (preact) {
-            act = make(a.x0.B, a.x0.W, a.x0.H, Cin_t);
-            note_launch();
-            if (!dry) {
-                GnApplyParams g;
-                memset(&g, 0, sizeof(g));
-                g.x0 = tptr(a.x0); g.x1 = tptr(a.x1);
-                g.C0 = a.x0.C; g.C1 = a.x1.valid() ? a.x1.C : 0;
-                g.st0 = sptr(a.x0); g.st1 = sptr(a.x1);
-                g.P0 = a.x0.P; g.P1 = a.x1.valid() ? a.x1.P : 0;
-                g.B = a.x0.B; g.npix = a.x0.W * a.x0.H;
-                g.groups = a.groups;
-                g.gamma = a.gn->gamma.as<float>(); g.beta = a.gn->beta.as<float>();
-                g.eps = a.eps; g.silu = a.silu;
-                g.y = tptr(act);
-                const double by = (double)g.B * g.npix * Cin_t * 4.0;
-                plan->ops.push_back({[g](hipStream_t s) { return launch_gn_apply(g, s); }, "gn_apply_kernel", 0.0, by});
-            }
-        }
+        if (preact) act = make(a.x0.B, a.x0.W, a.x0.H, Cin_t);
         const Tensor& x0 = preact ? act : a.x0;
         ConvParams p;
         bool epi_res = false;
@@ -961,17 +976,62 @@ struct Builder {
         bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && (px_t == 64 || px_t == 32) && !gn_fused && !preact &&
                         trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && 8 * ranks_t * ((x0.B + 7) / 8) <= 256 &&
                         2 * p.TH * (Cin_t / 8) <= 512 && vts.size() <= 2;
-        if (in_trunk && trunk_open && (pend.ranks != ranks_t || pend.B != x0.B)) flush_trunk();
-        if (in_trunk) {
-            if (!trunk_open) {
-                ++launches;
-                trunk_open = true;
-                pend.B = x0.B;
-                pend.ranks = ranks_t;
+        // ... or a phase of a MULTI-TILE cluster (the 64x4 level at batch <= 16): conv_small's default 64-pixel x 64-channel tiles, the
+        // consumer-side GroupNorm fold stays inside the phase
+        // (3x3 over 128 channels -- the all-taps-ring instance, 211 registers on its own -- does not fit beside the phase loop's state)
+        const int kind_c = (taps == 9 && Cin_t == 256) ? TK_CL_3x3_256 :
+                           (taps == 9 && Cin_t == 384) ? TK_CL_3x3_384 : (taps == 9 && Cin_t == 512) ? TK_CL_3x3_512 :
+                           (taps == 1 && Cin_t == 256) ? TK_CL_1x1_256 : -1;
+        const int ranks_c = cluster_ranks(x0.B, N, Wout * Hout);
+        const bool in_cluster = !in_trunk && cluster_enabled() && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 && p.up == 1 &&
+                                vts.empty() && ranks_c == (N / 64) * p.tiles_img && p.Win == Wout && p.Hin == Hout;
+        // GroupNorm + SiLU once, ahead of the conv: every channel tile of the conv would otherwise redo it (4-8x at these levels) --
+        // as a launch (norm.hip) or, in front of a multi-tile cluster phase, as a phase of the same persistent launch
+        if (preact) {
+            const bool gn_phase = in_cluster && Cin_t <= 512 && (Wout * Hout) % ranks_c == 0 && a.x0.C % 8 == 0 &&
+                                  (!a.x1.valid() || a.x1.C % 8 == 0) && !(g_dbg_flags & (1 << 27));
+            if (gn_phase) trunk_begin(x0.B, ranks_c, N / 64, 2);
+            else note_launch();
+            if (!dry) {
+                GnApplyParams g;
+                memset(&g, 0, sizeof(g));
+                g.x0 = tptr(a.x0); g.x1 = tptr(a.x1);
+                g.C0 = a.x0.C; g.C1 = a.x1.valid() ? a.x1.C : 0;
+                g.st0 = sptr(a.x0); g.st1 = sptr(a.x1);
+                g.P0 = a.x0.P; g.P1 = a.x1.valid() ? a.x1.P : 0;
+                g.B = a.x0.B; g.npix = a.x0.W * a.x0.H;
+                g.groups = a.groups;
+                g.gamma = a.gn->gamma.as<float>(); g.beta = a.gn->beta.as<float>();
+                g.eps = a.eps; g.silu = a.silu;
+                g.y = tptr(act);
+                const double by = (double)g.B * g.npix * Cin_t * 4.0;
+                if (gn_phase) {
+                    TrunkPhase ph;
+                    memset(&ph, 0, sizeof(ph));
+                    auto put64 = [&](int at, const void* ptr) {
+                        const unsigned long long u = (unsigned long long)(uintptr_t)ptr;
+                        ph.w[at] = (unsigned)u;
+                        ph.w[at + 1] = (unsigned)(u >> 32);
+                    };
+                    put64(TW_X0, g.x0); put64(TW_R0, g.x1); put64(TW_ST0, g.st0); put64(TW_RES, g.st1);
+                    put64(TW_GAMMA, g.gamma); put64(TW_BETA, g.beta); put64(TW_Y, g.y);
+                    ph.w[TW_R0C] = g.C0; ph.w[TW_R1C] = g.C1; ph.w[TW_P0] = g.P0; ph.w[TW_TILES_H] = g.P1; ph.w[TW_WIN] = g.npix;
+                    ph.w[TW_GROUPS] = g.groups; ph.w[TW_SILU] = g.silu;
+                    const float inv_n = (float)(1.0 / ((double)g.npix * (Cin_t / g.groups)));
+                    memcpy(&ph.w[TW_INVN], &inv_n, 4); memcpy(&ph.w[TW_EPS], &g.eps, 4);
+                    ph.w[TW_KIND] = TK_GN_APPLY; ph.w[TW_TEMBOFF] = (unsigned)-1;
+                    pend.phases.push_back(ph);
+                    pend.lds = std::max(pend.lds, (size_t)(2 * 512 * 8 + 2 * 512 * 4));
+                    pend.bytes += by;
+                } else {
+                    plan->ops.push_back({[g](hipStream_t s) { return launch_gn_apply(g, s); }, "gn_apply_kernel", 0.0, by});
+                }
             }
-        } else {
-            note_launch();
         }
+        if (in_trunk) trunk_begin(x0.B, ranks_t);
+        else if (in_cluster) trunk_begin(x0.B, ranks_c, N / 64, 2);
+        else note_launch();
+        in_trunk = in_trunk || in_cluster;
         (void)cpt_t;
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
@@ -1026,11 +1086,24 @@ struct Builder {
                 ph.w[TW_R0C] = p.R0; ph.w[TW_R1C] = p.R1; ph.w[TW_WIN] = p.Win; ph.w[TW_HIN] = p.Hin; ph.w[TW_WOUT] = p.Wout;
                 ph.w[TW_HOUT] = p.Hout; ph.w[TW_TW] = p.TW; ph.w[TW_TH] = p.TH; ph.w[TW_COLB] = p.colb; ph.w[TW_THSHIFT] = p.th_shift;
                 ph.w[TW_N] = p.N; ph.w[TW_YLD] = p.y_ld; ph.w[TW_NVIEWS] = p.nviews;
+                if (in_cluster) {
+                    const int KG = 4, cpt = Cin_t / (16 * KG);
+                    const int TPG = taps == 1 ? 1 : (cpt <= 2 ? 9 : (cpt <= 4 ? 3 : 1));      // conv_small_body.h, MI == 2
+                    ph.w[TW_KIND] = kind_c;
+                    ph.w[TW_G] = std::min(TPG * cpt, 12);
+                    ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
+                    RLDM_REQUIRE(p.nviews == 0, "conv " + L->name + ": a multi-tile cluster phase writes no views");
+                    put64(TW_ST0, p.st0); put64(TW_GAMMA, p.gn_gamma); put64(TW_BETA, p.gn_beta);
+                    ph.w[TW_P0] = p.P0; ph.w[TW_GROUPS] = p.gn_groups; ph.w[TW_MAGIC_CPG] = p.magic_cpg;
+                    putf(TW_INVN, p.gn_inv_n); putf(TW_EPS, p.gn_eps);
+                    ph.w[TW_SILU] = p.silu; ph.w[TW_TILES_H] = p.tiles_h; ph.w[TW_TILES_IMG] = p.tiles_img;
+                } else {
                 const int cpt = Cin_t / 128, KG = 8;
                 const int G = (trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt);
                 ph.w[TW_KIND] = trunk_kind;
                 ph.w[TW_G] = std::min(G, 12);       // == kTrunkPrefetch (conv_small_body.h)
                 ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
+                }
                 ph.w[TW_TEMBOFF] = (unsigned)temb_off;
                 for (int v = 0; v < p.nviews; ++v) {
                     const int at = TW_NV0 + v * TW_NVSTRIDE;
@@ -1491,9 +1564,12 @@ struct NetCommon {
             Tensor o = b.make(x.B, x.W, x.H, x.C);
             const double fl = 4.0 * (double)x.B * (x.C / 8) * (double)Lt * Lt * 8 + 2.0 * (double)x.B * Lt * 3.0 * x.C * x.C;
             b.plan->flops += fl;
-            const bool in_trunk = b.trunk_attention_ok(x, pre);     // a phase of the persistent trunk launch (trunk.hip)
+            bool in_trunk = b.trunk_attention_ok(x, pre);           // a phase of the persistent trunk launch (trunk.hip)
+            const int cl_ranks = in_trunk ? 0 : b.cluster_attention_ranks(x, pre);
             if (in_trunk) b.trunk_begin(x.B, x.C / 32);
+            else if (cl_ranks) b.trunk_begin(x.B, cl_ranks, x.C / 64, 2);
             else b.note_launch();
+            in_trunk = in_trunk || cl_ranks != 0;
             if (!b.dry) {
                 AttnFused* f = nullptr;
                 if (get_attn_fused(p, x.C, &f)) return 1;
@@ -2177,7 +2253,10 @@ static int sampler_build_plans(rldm_sampler* s) {
         ln->captured_noise = nullptr;
         ln->uplan.reset();
         ln->dplan.reset();
-        if (unet_make_plan(unet, ln->nb, &ln->uplan)) return 1;
+        g_concurrent_plans = (int)s->lanes.size();
+        const int prc = unet_make_plan(unet, ln->nb, &ln->uplan);
+        g_concurrent_plans = 1;
+        if (prc) return 1;
         PlanIO& io = ln->uplan->io;
         io.sample = ln->x.as<float>();
         io.sample_channels = uc.out_channels;

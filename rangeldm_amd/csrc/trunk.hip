@@ -57,7 +57,134 @@ __device__ __forceinline__ void unpack_phase(ConvParams& q, unsigned rec) {
     q.x1 = nullptr; q.C0 = 0; q.C1 = 0; q.st0 = nullptr; q.st1 = nullptr; q.P0 = 0; q.P1 = 0; q.temb = nullptr; q.step_ptr = nullptr;
     q.ts = nullptr; q.up = 1; q.stride = 1; q.tiles_h = 1; q.tiles_img = 1; q.dbg = 0; q.silu = 0; q.B = 0;
 }
+// a phase of a multi-tile cluster (kind >= 8): no views; the words they would occupy carry the consumer-side GroupNorm of the input
+__device__ __forceinline__ void unpack_cluster_phase(ConvParams& q, unsigned rec) {
+    unpack_phase(q, rec);
+    q.nviews = 0;
+    q.st0 = rl_ptr<const float2>(rec, TW_ST0);
+    q.gn_gamma = rl_ptr<const float>(rec, TW_GAMMA);
+    q.gn_beta = rl_ptr<const float>(rec, TW_BETA);
+    q.P0 = (int)rl(rec, TW_P0);
+    q.gn_groups = (int)rl(rec, TW_GROUPS);
+    q.magic_cpg = (int)rl(rec, TW_MAGIC_CPG);
+    q.gn_inv_n = __uint_as_float(rl(rec, TW_INVN));
+    q.gn_eps = __uint_as_float(rl(rec, TW_EPS));
+    q.silu = (int)rl(rec, TW_SILU);
+    q.tiles_h = (int)rl(rec, TW_TILES_H);
+    q.tiles_img = (int)rl(rec, TW_TILES_IMG);
+}
 
+// GroupNorm (+ SiLU) of cat[x0, x1] as a phase (a concatenated conv input is normalised once, not by every channel tile of the conv:
+// norm.hip's gn_apply_kernel, same arithmetic per element): rank r of the image's cluster takes pixels [r, r + 1) * npix / ranks, all
+// channels (<= 512: one thread per channel folds its group).
+__device__ __forceinline__ void gn_apply_phase(const ConvParams& cp, const int rank, const int ranks, const int b, const TrunkSeam& seam) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));              // (opaque per phase: conv_small_body.h)
+    const int tid = tid_;
+    constexpr int NT = 512;
+    const int C0 = cp.R0, C1 = cp.R1, Cin = C0 + C1, npix = cp.Win;
+    const bf16_t* const gx0 = cp.x0;
+    const bf16_t* const gx1 = cp.r0;
+    const float2* const gs0 = cp.st0;
+    const float2* const gs1 = reinterpret_cast<const float2*>(cp.res);
+    const int nP0 = cp.P0, nP1 = cp.tiles_h;
+    double* sD = reinterpret_cast<double*>(smem);               // [2][512]
+    float* sGa = reinterpret_cast<float*>(sD + 2 * 512);        // [512]
+    float* sGs = sGa + 512;
+    float gam = 0.f, bet = 0.f;
+    if (tid < Cin) { gam = cp.gn_gamma[tid]; bet = cp.gn_beta[tid]; }
+    trunk_wait(seam, tid);
+    double S = 0.0, SS = 0.0;
+    if (tid < Cin) {
+        const bool first = tid < C0;
+        const int c = first ? tid : tid - C0;
+        const int C = first ? C0 : C1;
+        const int P = first ? nP0 : nP1;
+        const float2* src = (first ? gs0 : gs1) + (size_t)b * P * C + c;
+        int q = 0;
+        for (; q + 4 <= P; q += 4) {
+            float2 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = ld_act8<true>(src + (size_t)(q + j) * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { S += (double)u[j].x; SS += (double)u[j].y; }
+        }
+        for (; q < P; ++q) {
+            const float2 u = ld_act8<true>(src + (size_t)q * C);
+            S += (double)u.x;
+            SS += (double)u.y;
+        }
+    }
+    const int n8 = Cin >> 3, ppr = npix / ranks, px0 = rank * ppr, total = ppr * n8;
+    constexpr int NB = 4;
+    uint4 v[NB];
+    int cl[NB];
+    size_t dst[NB];
+    auto load_batch = [&](int q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int q = q0 + j * NT;
+            const int pl = q / n8;
+            cl[j] = (q - pl * n8) * 8;
+            const size_t pix = (size_t)b * npix + px0 + pl;
+            dst[j] = pix * Cin + cl[j];
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < total) {
+                const bool first = cl[j] < C0;
+                v[j] = ld_act16<true>(first ? gx0 + pix * C0 + cl[j] : gx1 + pix * C1 + (cl[j] - C0));
+            }
+        }
+    };
+    load_batch(tid);
+    if (tid < Cin) {
+        sD[tid] = S;
+        sD[512 + tid] = SS;
+    }
+    __syncthreads();
+    if (tid < Cin) {                            // every channel's thread folds its own group (no serial phase)
+        const int cpg = Cin / cp.gn_groups;
+        const int gb = (tid / cpg) * cpg;
+        double GS = 0.0, GSS = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+            GS += sD[gb + i];
+            GSS += sD[512 + gb + i];
+        }
+        const double inv_n = (double)cp.gn_inv_n;
+        const double mean = GS * inv_n;
+        double var = GSS * inv_n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float a = gam * __builtin_amdgcn_rsqf((float)var + cp.gn_eps);
+        sGa[tid] = a;
+        sGs[tid] = bet - (float)mean * a;
+    }
+    __syncthreads();
+    for (int q0 = tid; q0 < total; q0 += NT * NB) {
+        if (q0 != tid) load_batch(q0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (q0 + j * NT >= total) continue;
+            const float4 a0 = *reinterpret_cast<const float4*>(sGa + cl[j]), a1 = *reinterpret_cast<const float4*>(sGa + cl[j] + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(sGs + cl[j]), s1 = *reinterpret_cast<const float4*>(sGs + cl[j] + 4);
+            float f0 = bf16lo(v[j].x) * a0.x + s0.x, f1 = bf16hi(v[j].x) * a0.y + s0.y;
+            float f2 = bf16lo(v[j].y) * a0.z + s0.z, f3 = bf16hi(v[j].y) * a0.w + s0.w;
+            float f4 = bf16lo(v[j].z) * a1.x + s1.x, f5 = bf16hi(v[j].z) * a1.y + s1.y;
+            float f6 = bf16lo(v[j].w) * a1.z + s1.z, f7 = bf16hi(v[j].w) * a1.w + s1.w;
+            if (cp.silu) {
+                silu_x8(f0, f1, f2, f3, f4, f5, f6, f7);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
+            o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);
+            *reinterpret_cast<uint4*>(cp.y + dst[j]) = o;
+        }
+    }
+    trunk_arrive(seam, tid);
+}
+
+// CL = false: image-owning tiles (kinds 0..6 + attention over a pre-normalised x); CL = true: multi-tile clusters (kinds 8..13).
+// Two kernels, so that each set of instances gets its own register allocation.
+template <bool CL>
 __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
     // block id -> (image, channel tile): ids with the same (id % 8) share an XCD; an image's `ranks` tiles are 8 apart
     const int wg = blockIdx.x;
@@ -66,7 +193,10 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
     const int rank = t % ranks, b = (t / ranks) * 8 + (wg & 7);
     if (b >= tp.B) return;                      // (batch not a multiple of 8: the surplus workgroups have no cluster)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int kg = __builtin_amdgcn_readfirstlane(tid >> 6);        // NWN == 1: wave = k-group
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a workgroup's place in its image: channel tile nt (NWN 32-channel tiles wide) of pixel tile mt; its waves' weight streams
+    const int nwn = tp.nwn, nt = rank % tp.ntile_n, mt = rank / tp.ntile_n;
+    const int stream_id = (nt * nwn + wave % nwn) * (8 / nwn) + wave / nwn;     // (NWN == 1: rank * 8 + k-group)
     unsigned* const counter = tp.counters + b * 32;
     const unsigned* const recs = reinterpret_cast<const unsigned*>(tp.phases);
 
@@ -83,9 +213,9 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
     bf16x8 wpf[kTrunkPrefetch];
     unsigned rec = recs[lane];                  // phase 0's record
     auto wave_stream = [&](unsigned r) __attribute__((always_inline)) {
-        return reinterpret_cast<const unsigned char*>(rl_ptr<const bf16_t>(r, TW_WPK)) + ((size_t)(rank * 8 + kg) * rl(r, TW_NMINE)) * 1024;
+        return reinterpret_cast<const unsigned char*>(rl_ptr<const bf16_t>(r, TW_WPK)) + ((size_t)stream_id * rl(r, TW_NMINE)) * 1024;
     };
-    {
+    if constexpr (!CL) {
         const unsigned char* w0 = wave_stream(rec);
         const int g0 = (int)rl(rec, TW_G);
 #pragma unroll
@@ -95,7 +225,9 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
     for (int i = 0; i < tp.nphases; ++i) {
         const unsigned nrec = i + 1 < tp.nphases ? recs[(i + 1) * TW_WORDS + lane] : 0u;     // requested a phase ahead
         ConvParams cp;
-        unpack_phase(cp, rec);
+        const int kind = (int)rl(rec, TW_KIND);
+        if constexpr (CL) unpack_cluster_phase(cp, rec);
+        else unpack_phase(cp, rec);
         TrunkSeam seam;
         seam.counter = counter;
         seam.wait_for = base + (unsigned)(i * ranks);
@@ -108,19 +240,34 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
         seam.temb_rows_per_step = tp.temb_rows_per_step;
         seam.temb_per_sample = tp.temb_per_sample;
         seam.temb_ld = tp.temb_ld;
-        const int kind = (int)rl(rec, TW_KIND);
         // (the next record has long arrived when the K loop ends: its weight stream is resolved inside the body, behind the K loop)
         seam.next_rec = nrec;
-        seam.next_rank_kg = rank * 8 + kg;
-        switch (kind) {
-            case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
-            case 1: conv_small_body<1, 4, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
-            case 2: conv_small_body<1, 2, 1, 2, true>(cp, rank, 0, b, wpf, seam); break;
-            // 32-pixel images (the 32x1 level of the nuScenes network): the same three layers on one 32-pixel tile
-            case 4: conv_small_body<1, 2, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
-            case 5: conv_small_body<1, 4, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
-            case 6: conv_small_body<1, 2, 1, 1, true>(cp, rank, 0, b, wpf, seam); break;
-            default: {
+        seam.next_rank_kg = stream_id;
+        bool conv_done = true;
+        if constexpr (!CL) {
+            switch (kind) {
+                case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
+                case 1: conv_small_body<1, 4, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
+                case 2: conv_small_body<1, 2, 1, 2, true>(cp, rank, 0, b, wpf, seam); break;
+                // 32-pixel images (the 32x1 level of the nuScenes network): the same three layers on one 32-pixel tile
+                case 4: conv_small_body<1, 2, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
+                case 5: conv_small_body<1, 4, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
+                case 6: conv_small_body<1, 2, 1, 1, true>(cp, rank, 0, b, wpf, seam); break;
+                default: conv_done = false; break;
+            }
+        } else {
+            // multi-tile clusters (the 64x4 level: 4 pixel tiles x 4 channel tiles of 64 per image): GroupNorm + SiLU of the input
+            // folded into the staging as in the stand-alone launch, from the statistics the previous phase published
+            switch (kind) {
+                case TK_CL_3x3_256: conv_small_body<2, 4, 9, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
+                case TK_CL_3x3_384: conv_small_body<2, 6, 9, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
+                case TK_CL_3x3_512: conv_small_body<2, 8, 9, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
+                case TK_CL_1x1_256: conv_small_body<2, 4, 1, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
+                case TK_GN_APPLY: gn_apply_phase(cp, rank, ranks, b, seam); break;
+                default: conv_done = false; break;
+            }
+        }
+        if (!conv_done) {
                 // attention core of the block (GroupNorm already applied by the producer of x): this workgroup's heads / ranks
                 // heads of image b, one query tile per wave; its output projection is the next phase (a 1x1 conv)
                 AttnQkvParams ap;
@@ -129,16 +276,21 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
                 ap.wfrag = cp.wpk; ap.bias = cp.bias; ap.out = cp.y;
                 ap.B = tp.B; ap.L = cp.Win; ap.C = cp.N; ap.ts = nullptr; ap.ts_L = 0;
                 const int Lp = (ap.L + 31) & ~31;
-                attention_qkv2_body<0, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
+                if (CL && kind == TK_ATTN_FOLD) {   // raw x + the producer's statistics (cluster words), two query tiles per wave
+                    ap.st = cp.st0; ap.P = cp.P0; ap.gamma = cp.gn_gamma; ap.beta = cp.gn_beta; ap.eps = cp.gn_eps;
+                    ap.groups = cp.gn_groups; ap.inv_n = cp.gn_inv_n; ap.magic_cpg = cp.magic_cpg;
+                    if constexpr (CL) attention_qkv2_body<1, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
+                } else if constexpr (!CL) {
+                    attention_qkv2_body<0, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
+                }
                 // the next phase's first weight fragments (what a conv phase requests behind its K loop)
-                const int next_g = (int)rl(nrec, TW_G);
+                const int next_g = CL ? 0 : (int)rl(nrec, TW_G);       // (multi-tile clusters carry no ring across phases)
                 if (next_g > 0) {
                     const unsigned char* nw = wave_stream(nrec);
 #pragma unroll
                     for (int j = 0; j < kTrunkPrefetch; ++j)
                         if (j < next_g) wpf[j] = *reinterpret_cast<const bf16x8*>(nw + (unsigned)(j * 1024 + lane * 16));
                 }
-            } break;
         }
         if (i == 1 && rank != 0 && tid == 0) {  // (rank 0's first arrive has been waited for: its XCC id is there)
             const unsigned x0 = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,14 +302,17 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
 }
 
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
-    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 && tp.B >= 1, "trunk: bad parameters");
+    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 && tp.B >= 1 && (tp.nwn == 1 || tp.nwn == 2) && tp.ntile_n >= 1 &&
+                     tp.ranks % tp.ntile_n == 0, "trunk: bad parameters");
     RLDM_REQUIRE(lds <= 160 * 1024, "trunk: LDS tile too large");
     const int groups = (tp.B + 7) / 8;
     const int grid = 8 * tp.ranks * groups;
     RLDM_REQUIRE(grid <= 256, "trunk: the grid must be co-resident (one workgroup per CU)");
-    static DynLdsLimit lds_limit;                // per device, thread safe
-    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(trunk_kernel), lds));
-    hipLaunchKernelGGL(trunk_kernel, dim3(grid), dim3(512), lds, stream, tp);
+    static DynLdsLimit lds_limit[2];             // per instantiation and device, thread safe
+    const int cl = tp.nwn == 2 ? 1 : 0;
+    auto kern = cl ? trunk_kernel<true> : trunk_kernel<false>;
+    RLDM_HIP_CHECK(lds_limit[cl].ensure(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, tp);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -122,10 +122,11 @@ def test_producer_side_groupnorm_matches_consumer_side(size):
         assert outs[0][1] < outs[1][1]                     # the separate gn_apply launches in front of the up-block convs are gone
 
 
-@pytest.mark.parametrize("B,size", [(2, (256, 16)), (16, (256, 16)), (5, (256, 16)), (4, (256, 8)), (9, (256, 8))])
+@pytest.mark.parametrize("B,size", [(2, (256, 16)), (16, (256, 16)), (13, (256, 16)), (5, (256, 16)), (4, (256, 8)), (9, (256, 8))])
 def test_persistent_trunk_matches_separate_launches(B, size):
     """The persistent trunk launch (trunk.hip: the convs of the 32x2 level and the mid block as phases of one launch, the channel
-    tiles of an image handing over through their XCD's L2) against the same plan as separate launches
+    tiles of an image handing over through their XCD's L2; from 13 images on also the 64x4 level as multi-tile clusters -- 4 pixel
+    tiles x 4 channel tiles per image, GroupNorm folds and gn_apply as phases) against the same plan as separate launches
     (rldm_debug_set_flags(1 << 24)): the SAME kernels' code on the SAME operands in the same order, so the outputs are identical,
     and repeated forwards (the cluster counters re-arm themselves) stay identical."""
     from rangeldm_amd import _lib
