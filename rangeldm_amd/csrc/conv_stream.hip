@@ -20,65 +20,19 @@
 // Second instance for the 128x8 level (too few 256-pixel tiles to fill the chip): 128 pixels x 64 channels per workgroup,
 // 8 waves = 2 channel tiles x 4 k-groups (k-group kg owns the kg-th 16-channel group of every tap of a chunk: one k-step
 // per tap, ring = the 9 steps of a chunk); the k-groups' fp32 partial tiles meet in LDS for the epilogue (conv_small.hip's).
-#include "kernels.h"
+#include "conv_stream_body.h"
 
 namespace rldm {
-
-#ifdef RLDM_ABLATE
-#define RLDM_TDBG(p, bit) (((p).dbg & (bit)) != 0)
-#else
-#define RLDM_TDBG(p, bit) false
-#endif
-
-namespace {
-__device__ __forceinline__ void lds_barrier_b() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-}  // namespace
 
 // WM pixel parts (128 pixels each) x WN 32-channel tiles x KG k-groups = 8 waves
 template <int WM, int WN>
 __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p) {
-    constexpr int NT = 512, CK = 64, MI = 4, KG = 8 / (WM * WN);
-    constexpr int BM = 128 * WM, BN = 32 * WN;
-    constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
-    constexpr int C8 = CK / 8;
-    constexpr int ACH = ((BM / 8 + 2) * 10 * C8 + NT - 1) / NT;    // 16-byte halo pieces per thread and chunk (6 | 3)
-    constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
-    constexpr int ROW = 3 * SPT;               // ... per row of taps
-    constexpr int CST = 9 * SPT;               // ... per chunk
-    constexpr int G = KG == 1 ? ROW : CST;     // weight fragments in flight per wave (ring): a row of taps | a chunk
-    constexpr int PFX = KG == 1 ? 2 : 3;       // pixel fragments read ahead; divides CST
-    constexpr int ERS = BN * 2 + 16, NC8 = BN / 8;
-    static_assert(WM * WN * KG == 8 && (KG == 1 || WM == 1) && CST % PFX == 0 && G <= 16, "wave grid");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave / (WM * WN);
-    const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
-    const int grp = wave >> 2;                 // the two waves of a SIMD are in different halves of the workgroup
-    const int kh = lane >> 5, l31 = lane & 31;
-#ifdef RLDM_ABLATE
-    unsigned long long tsv[12];
-    int tsn = 0;
-#define RLDM_STAMP() if (tsn < 12) tsv[tsn++] = __builtin_amdgcn_s_memtime()
-#else
-#define RLDM_STAMP()
-#endif
-    RLDM_STAMP();
-#ifdef RLDM_ABLATE
-    const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-    // ---- which tile: grid = (channel tiles, pixel tiles of an image, images) -------------------------------------------
-    const int tiles_h = p.tiles_h, tiles_img = p.tiles_img;       // tiles_h is a power of two
     // Workgroups are dispatched x-fastest and land on XCD (linear id % 8).  Re-number them so that every XCD owns a contiguous
     // run of (image, pixel tile, channel tile) ids: the tiles of an image then share ONE L2, and the halo rows two neighbouring
     // tiles both read (34 x 10 positions for 32 x 8 pixels: 1.33x the tile) are fetched from HBM / Infinity Cache once.
     int nt, mt, b;
     {
-        const int gx = p.ntile_n, gy = tiles_img;      // (== gridDim.x / .y: from the arguments, not a dependent read of the dispatch packet)
+        const int gx = p.ntile_n, gy = p.tiles_img;    // (== gridDim.x / .y: from the arguments, not a dependent read of the dispatch packet)
         const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const int rid = (p.dbg & (1 << 21)) ? lin : xcd_remap(lin, gx * gy * p.B);
         const int q = rid / gx;
@@ -86,435 +40,8 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
         b = q / gy;
         mt = q - b * gy;
     }
-    const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
-    const int w0 = tw * p.TW, h0 = th * p.TH;
-
-    // the sampler's step index selects the time-embedding row: requested first, used after everything else is in flight
-    const int temb_step = (p.temb && p.step_ptr && tid < BN) ? load_step_vector(p.step_ptr) : 0;
-
-    const int Cin = p.C0 + p.C1;
-    const int NCC = Cin / CK;                  // main-phase chunks: 9 taps x 4 k-steps
-    const int NCB = (p.R0 + p.R1) / CK;        // residual-phase chunks: centre tap, 4 k-steps, raw input
-    const int NCT = NCC + NCB;
-    const int THv = p.TH + 2, TWv = p.TW + 2;
-    const int colb = p.colb;
-    const int abytes = TWv * colb;
-    const int Wv = p.Win * p.up, Hv = p.Hin * p.up;
-    const int upshift = p.up - 1;
-
-    unsigned char* sA = smem;                                  // 2 * abytes
-    float* sGa = reinterpret_cast<float*>(sA + 2 * abytes);    // Cin
-    float* sGs = sGa + Cin;
-    float* sBias = sGs + Cin;                                  // BN
-
-    // ---- this wave's weight stream (channel tile WN*nt + wn, k-group kg): [NCC][9 taps][SPT k-steps] then [NCB][SPT], 1 KiB each
-    const int nsteps = NCC * CST + NCB * SPT;
-    const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk) +
-                                (size_t)((nt * WN + wn) * KG + kg) * nsteps * 1024;
-    const unsigned woff = lane * 16 + 4096;     // lane offset: immediates of +-4 KiB around it reach 8 fragments
-    auto w_load = [&](const unsigned char* base, int idx) __attribute__((always_inline)) {      // fragment idx in [0, 16)
-        return *reinterpret_cast<const bf16x8*>(base + (idx / 8) * 8192 + woff + ((idx % 8) * 1024 - 4096));
-    };
-    RLDM_STAMP();
-    // ---- halo staging: thread-constant source pixel of each of its ACH 16-byte pieces ---------------------------------
-    const int atotal = TWv * THv * C8;
-    int apix[ACH];
-    const int my_c8 = (tid % C8) * 8;
-    uint4 areg[ACH];
-    const bool gn = p.st0 != nullptr;
-    const bf16_t* const gx0 = p.x0;             // (locals: selecting between fields of `p` by address would copy it to scratch)
-    const bf16_t* const gx1 = p.x1;
-    const bf16_t* const gr0 = p.r0;
-    const bf16_t* const gr1 = p.r1;
-    const int nC0 = p.C0, nC1 = p.C1, nR0 = p.R0, nR1 = p.R1;
-    auto load_a = [&](int cs) __attribute__((always_inline)) {                  // chunk cs of the sequence main, residual
-        const bool main_phase = cs < NCC;
-        const int c = (main_phase ? cs : cs - NCC) * CK + my_c8;
-        const int split = main_phase ? nC0 : nR0;
-        const bool first = c < split;
-        const bf16_t* t0 = main_phase ? gx0 : gr0;
-        const bf16_t* t1 = main_phase ? gx1 : gr1;
-        const bf16_t* base = first ? t0 + c : t1 + (c - split);
-        const int ld = first ? split : (main_phase ? nC1 : nR1);
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int pix = apix[i] < 0 ? 0 : apix[i];
-            areg[i] = *reinterpret_cast<const uint4*>(base + (size_t)pix * ld);
-        }
-    };
-    auto store_a = [&](int cs) __attribute__((always_inline)) {                 // GroupNorm + SiLU (main phase) -> LDS
-        unsigned char* dstbuf = sA + (cs & 1) * abytes;
-        const bool anorm = gn && cs < NCC;
-        float4 ga0, ga1, gs0, gs1;
-        if (anorm) {
-            const int c = cs * CK + my_c8;
-            ga0 = *reinterpret_cast<const float4*>(sGa + c);
-            ga1 = *reinterpret_cast<const float4*>(sGa + c + 4);
-            gs0 = *reinterpret_cast<const float4*>(sGs + c);
-            gs1 = *reinterpret_cast<const float4*>(sGs + c + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            uint4 v = areg[i];
-            if (apix[i] < 0) {
-                v = make_uint4(0u, 0u, 0u, 0u);
-            } else if (anorm) {
-                float f0 = bf16lo(v.x) * ga0.x + gs0.x, f1 = bf16hi(v.x) * ga0.y + gs0.y;
-                float f2 = bf16lo(v.y) * ga0.z + gs0.z, f3 = bf16hi(v.y) * ga0.w + gs0.w;
-                float f4 = bf16lo(v.z) * ga1.x + gs1.x, f5 = bf16hi(v.z) * ga1.y + gs1.y;
-                float f6 = bf16lo(v.w) * ga1.z + gs1.z, f7 = bf16hi(v.w) * ga1.w + gs1.w;
-                if (p.silu) {
-                    silu_x8(f0, f1, f2, f3, f4, f5, f6, f7);
-                }
-                v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
-                v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);
-            }
-            const int q = tid + i * NT;
-            const int slot = q / C8, c8 = q - slot * C8;
-            const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
-            if (q < atotal) *reinterpret_cast<uint4*>(dstbuf + vwl * colb + vhl * RS + c8 * 16) = v;
-        }
-    };
-    RLDM_STAMP();
-    // ---- GroupNorm: the statistics partials of channel `tid`, gamma and beta are requested first, then the first halo
-    // chunk; the fold runs while they are all in flight.  Every channel's thread folds its own group (no serial phase).
-    double gS = 0.0, gSS = 0.0;
-    float g_gamma = 0.f, g_beta = 0.f;
-    if (gn && tid < Cin) {
-        const float2* const gs0p = p.st0;
-        const float2* const gs1p = p.st1;
-        const int nP0 = p.P0, nP1 = p.P1;
-        const bool first = tid < nC0;
-        const int c = first ? tid : tid - nC0;
-        const int C = first ? nC0 : nC1;
-        const int P = first ? nP0 : nP1;
-        const float2* src = (first ? gs0p : gs1p) + (size_t)b * P * C + c;
-        g_gamma = p.gn_gamma[tid];
-        g_beta = p.gn_beta[tid];
-        int q = 0;
-        for (; q + 16 <= P; q += 16) {          // 16 partials per round trip (P = pixel tiles per image of the producer)
-            float2 v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(q + j) * C];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { gS += (double)v[j].x; gSS += (double)v[j].y; }
-        }
-        for (; q + 4 <= P; q += 4) {
-            float2 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = src[(size_t)(q + j) * C];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { gS += (double)v[j].x; gSS += (double)v[j].y; }
-        }
-        for (; q < P; ++q) {
-            const float2 v = src[(size_t)q * C];
-            gS += (double)v.x;
-            gSS += (double)v.y;
-        }
-    }
-    float bias_v = 0.f;
-    if (tid < BN) bias_v = p.bias[nt * BN + tid];
-    // the weight ring is requested BEHIND the statistics partials: s_waitcnt vmcnt counts in order, so the fold below would otherwise
-    // wait for the ring's 12 KB per wave (96 KB per CU through a 64 B/clk L1) before it sees its few hundred bytes
-    bf16x8 wr[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        wr[j] = w_load(wptr, j);
-        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the counted waits below rely on it
-    }
-    wptr += G * 1024;                           // -> the fragments the first row of taps refills
-
-    RLDM_STAMP();
-    // (address arithmetic of the halo pieces: integer multiplies, done while the requests above are in flight)
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-        const int q = tid + i * NT;
-        const int slot = q / C8;
-        const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
-        const int vh = h0 - 1 + vhl;
-        int vw = w0 - 1 + vwl;
-        vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
-        const bool ok = q < atotal && vh >= 0 && vh < Hv;
-        apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
-    }
-    if (NCT > 0) load_a(0);
-    if (p.temb && tid < BN)
-        bias_v += p.temb[(size_t)(temb_step * p.temb_rows_per_step + (p.temb_per_sample ? b : 0)) * p.temb_ld + nt * BN + tid];
-    if (gn) {
-        double* sD = reinterpret_cast<double*>(sA);             // scratch: [2][Cin] doubles (the halo is not written yet)
-        const int cpg = Cin / p.gn_groups;
-        if (tid < Cin) {
-            sD[tid] = gS;
-            sD[Cin + tid] = gSS;
-        }
-        __syncthreads();
-        float ga = 0.f, gs = 0.f;               // Cin <= NT
-        if (tid < Cin) {
-            const int g0 = ((tid * p.magic_cpg) >> 20) * cpg;
-            double S = 0.0, SS = 0.0;
-            for (int i = 0; i < cpg; ++i) {
-                S += sD[g0 + i];
-                SS += sD[Cin + g0 + i];
-            }
-            const double inv_n = (double)p.gn_inv_n;
-            const double mean = S * inv_n;
-            double var = SS * inv_n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            ga = g_gamma * __builtin_amdgcn_rsqf((float)var + p.gn_eps);
-            gs = g_beta - (float)mean * ga;
-            sGa[tid] = ga;                      // (sGa / sGs sit behind both halo buffers: disjoint from the scratch)
-            sGs[tid] = gs;
-        }
-        __syncthreads();                        // affine visible; sD fully consumed before the halo is written
-    }
-    RLDM_STAMP();
-    if (tid < BN) sBias[tid] = bias_v;
-    if (NCT > 0) store_a(0);
-    RLDM_STAMP();
-
-    // ---- per-lane LDS offsets of the pixel fragments; accumulators start at bias + temb ---------------------------------
-    int xoff[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int pidx = wm * (MI * 32) + mi * 32 + l31;
-        const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        xoff[mi] = pw * colb + ph * RS + kh * 16 + kg * (SPT * 32);
-    }
-    lds_barrier_b();                            // sBias and halo chunk 0 are written
-    f32x16 acc[MI];
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        float4 bv = *reinterpret_cast<const float4*>(sBias + wn * 32 + 8 * r4 + 4 * kh);
-        if (kg != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            acc[mi][r4 * 4 + 0] = bv.x; acc[mi][r4 * 4 + 1] = bv.y;
-            acc[mi][r4 * 4 + 2] = bv.z; acc[mi][r4 * 4 + 3] = bv.w;
-        }
-    }
-
-    // ---- K loop ----------------------------------------------------------------------------------------------------------
-    // chunk step c = ROW * ti + SPT * tj + ks; its fragment sits in ring slot c % G and is refilled with the fragment G
-    // steps ahead (next row / next chunk / residual phase: the stream is linear) right after its MFMAs
-    bf16x8 xr[PFX][MI];
-    // cur / nxt: per-lane LDS addresses of the pixel at tap (ti, 0) / (ti + 1, 0); r = step within the row (may run into the next)
-    auto x_read = [&](const int (&cur)[MI], const int (&nxt)[MI], int r, bf16x8 (&dst)[MI]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-            dst[mi] = *reinterpret_cast<const bf16x8*>(smem + (r < ROW ? cur[mi] : nxt[mi]) + ((r % ROW) / SPT) * RS + (r % SPT) * 32);
-    };
-    auto tap_row = [&](const int (&cur)[MI], const int (&nxt)[MI], int ti) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < ROW; ++j) {
-            const int c = ti * ROW + j, slot = c % G;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xr[c % PFX][mi], acc[mi], 0, 0, 0);
-            wr[slot] = w_load(wptr, slot);
-            if (c + PFX < CST) x_read(cur, nxt, j + PFX, xr[c % PFX]);   // (no read-ahead across the chunk's barrier)
-            __builtin_amdgcn_sched_barrier(0);  // steps stay in program order: every wait then leaves G - 1 loads in flight
-        }
-        if ((ti * ROW + ROW) % G == 0) wptr += G * 1024;
-    };
-    static_assert(PFX <= ROW, "the read-ahead reaches at most into the next row of taps");
-    RLDM_STAMP();
-    for (int cs = 0; cs < NCC; ++cs) {
-        if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_a(cs + 1);       // next chunk (main or first residual): requested now, written below
-        int cur[MI], nxt[MI];
-        const int boff = (cs & 1) * abytes;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) { cur[mi] = xoff[mi] + boff; nxt[mi] = cur[mi] + colb; }
-#pragma unroll
-        for (int j = 0; j < PFX; ++j) {
-            x_read(cur, nxt, j, xr[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tap_row(cur, nxt, 0);
-        if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) { cur[mi] = nxt[mi]; nxt[mi] += colb; }
-        tap_row(cur, nxt, 1);
-        if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) cur[mi] = nxt[mi];
-        tap_row(cur, nxt, 2);
-        lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
-    }
-    // residual phase: centre tap of the raw block input, SPT k-steps per chunk; ring slots continue (CST % G == 0)
-    constexpr int RCR = G / SPT;                // residual chunks per ring revolution
-    for (int rc0 = 0; rc0 < NCB; rc0 += RCR) {
-#pragma unroll
-        for (int r = 0; r < RCR; ++r) {
-            const int rc = rc0 + r;
-            if (rc < NCB) {
-                const int cs = NCC + rc;
-                if (cs + 1 < NCT) load_a(cs + 1);
-                int xc[MI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) xc[mi] = xoff[mi] + (cs & 1) * abytes + colb + RS;
-#pragma unroll
-                for (int ks = 0; ks < SPT; ++ks) {
-                    bf16x8 xf[MI];
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(smem + xc[mi] + ks * 32);
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[r * SPT + ks], xf[mi], acc[mi], 0, 0, 0);
-                    wr[r * SPT + ks] = w_load(wptr, r * SPT + ks);
-                }
-                if (cs + 1 < NCT) store_a(cs + 1);
-                lds_barrier_b();
-            }
-        }
-        wptr += G * 1024;
-    }
-    RLDM_STAMP();
-
-    if constexpr (KG > 1) {
-    // ---- epilogue of the k-group instance (conv_small.hip's), 64 pixels at a time: fp32 partials [k-group][pixel][channel] in
-    // LDS -> all threads sum the k-groups of one (pixel, 8 channels) item each, round, store 16 bytes, statistics ----------
-    constexpr int HB = 64, NHALF = BM / HB, FRS = BN * 4 + 16, TRS = BN * 2 + 16;
-    constexpr int NPASS = (HB * NC8 + NT - 1) / NT;
-    unsigned char* sE = smem;
-    unsigned char* sT = sE + KG * HB * FRS;
-    const int c8 = tid % NC8;
-    const int chg = nt * BN + c8 * 8;
-    constexpr int NCP = BN / 2, NG = NT / NCP, PPG = HB / NG;
-    const int cp = tid % NCP, pg = tid / NCP;
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-    for (int hp = 0; hp < NHALF; ++hp) {
-        if (hp > 0) lds_barrier_b();            // the previous half-tile has been consumed
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
-            const int mi = hp * 2 + m2, pl = m2 * 32 + l31;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int chl = wn * 32 + 8 * r4 + 4 * kh;
-                *reinterpret_cast<float4*>(sE + (kg * HB + pl) * FRS + chl * 4) =
-                    make_float4(acc[mi][r4 * 4 + 0], acc[mi][r4 * 4 + 1], acc[mi][r4 * 4 + 2], acc[mi][r4 * 4 + 3]);
-            }
-        }
-        lds_barrier_b();
-#pragma unroll
-        for (int q = 0; q < NPASS; ++q) {
-            const int pl = tid / NC8 + q * (NT / NC8), pidx = hp * HB + pl;
-            if (pl >= HB) break;
-            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < KG; ++g) {
-                const float4 v0 = *reinterpret_cast<const float4*>(sE + (g * HB + pl) * FRS + c8 * 32);
-                const float4 v1 = *reinterpret_cast<const float4*>(sE + (g * HB + pl) * FRS + c8 * 32 + 16);
-                f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
-                f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
-            }
-            uint4 v;
-            v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
-            v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
-            const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-            const size_t pix = ((size_t)b * p.Wout + (w0 + pw)) * p.Hout + (h0 + ph);
-            *reinterpret_cast<uint4*>(p.y + pix * p.y_ld + chg) = v;
-            *reinterpret_cast<uint4*>(sT + pl * TRS + c8 * 16) = v;
-        }
-        if (p.y_stats) {
-            lds_barrier_b();
-#pragma unroll
-            for (int j = 0; j < PPG; ++j) {
-                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sT + (pg * PPG + j) * TRS + cp * 4);
-                const float a0 = bf16lo(w2), a1 = bf16hi(w2);
-                s0 += a0; s1 += a1;
-                q0 += a0 * a0; q1 += a1 * a1;
-            }
-        }
-    }
-    if (p.y_stats) {
-        float* sS = reinterpret_cast<float*>(sT + HB * TRS);                // [8 waves][2][BN]
-#pragma unroll
-        for (int d = NCP; d < 64; d <<= 1) {
-            s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d);
-            q0 += __shfl_xor(q0, d); q1 += __shfl_xor(q1, d);
-        }
-        if (lane < NCP) {
-            *reinterpret_cast<float2*>(sS + (wave * 2 + 0) * BN + cp * 2) = make_float2(s0, s1);
-            *reinterpret_cast<float2*>(sS + (wave * 2 + 1) * BN + cp * 2) = make_float2(q0, q1);
-        }
-        lds_barrier_b();
-        if (tid < 2 * BN) {
-            const int kind = tid / BN, c = tid - kind * BN;
-            float S = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
-            reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
-        }
-    }
-    } else {
-    // ---- epilogue (conv_igemm.hip's): bf16 -> LDS [pixel][channel] -> 16-byte coalesced stores + statistics -----------------
-    unsigned char* sE = smem;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int pidx = wm * (MI * 32) + mi * 32 + l31;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int chl = wn * 32 + 8 * r4 + 4 * kh;
-            uint2 o;
-            o.x = pack_bf16x2(acc[mi][r4 * 4 + 0], acc[mi][r4 * 4 + 1]);
-            o.y = pack_bf16x2(acc[mi][r4 * 4 + 2], acc[mi][r4 * 4 + 3]);
-            *reinterpret_cast<uint2*>(sE + pidx * ERS + chl * 2) = o;
-        }
-    }
-    lds_barrier_b();
-    RLDM_STAMP();
-    // thread (g = tid / 16, c8 = tid % 16) stores 16 bytes of pixels g, g + 32, ... (4 halo columns apart: a constant
-    // address step), then the statistics of the ROUNDED tile: lane = channel pair, 8 pixel groups, LDS fold over the waves
-    const int c8 = tid % NC8;
-    const int chg = nt * BN + c8 * 8;
-    {
-        const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7)
-        bf16_t* yp = p.y + (((size_t)b * p.Wout + w0 + (g >> 3)) * p.Hout + h0 + (g & 7)) * p.y_ld + chg;
-        const size_t ystep = (size_t)4 * p.Hout * p.y_ld;
-#pragma unroll
-        for (int i = 0; i < BM / (NT / NC8); ++i) {
-            *reinterpret_cast<uint4*>(yp) = *reinterpret_cast<const uint4*>(sE + (g + i * (NT / NC8)) * ERS + c8 * 16);
-            yp += ystep;
-        }
-    }
-    if (p.y_stats) {
-        constexpr int NCP = BN / 2, NG = NT / NCP, PPG = BM / NG;          // 64 channel pairs x 8 pixel groups of 32
-        const int cp = tid % NCP, pg = tid / NCP;
-        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < PPG; ++j) {
-            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sE + (pg * PPG + j) * ERS + cp * 4);
-            const float a0 = bf16lo(w2), a1 = bf16hi(w2);
-            s0 += a0; s1 += a1;
-            q0 += a0 * a0; q1 += a1 * a1;
-        }
-        float* sS = reinterpret_cast<float*>(sE + BM * ERS);                // [8 waves][2][BN]
-        *reinterpret_cast<float2*>(sS + (wave * 2 + 0) * BN + cp * 2) = make_float2(s0, s1);
-        *reinterpret_cast<float2*>(sS + (wave * 2 + 1) * BN + cp * 2) = make_float2(q0, q1);
-        lds_barrier_b();
-        if (tid < 2 * BN) {
-            const int kind = tid / BN, c = tid - kind * BN;
-            float S = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
-            reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
-        }
-    }
-    }
-    RLDM_STAMP();
-#ifdef RLDM_ABLATE
-    if (p.ts && blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z == 0 && tid == 0)
-        for (int i = 0; i < 12; ++i) p.ts[blockIdx.y * 64 + i] = i < tsn ? tsv[i] : 0ull;
-    {
-        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (p.ts && tid == 0 && lin < 2048) {
-            p.ts[256 + 2 * lin] = t_real0;
-            p.ts[257 + 2 * lin] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-#endif
-#undef RLDM_STAMP
+    const TrunkSeam none = {};
+    conv_stream_body<WM, WN, false>(p, nt, mt, b, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

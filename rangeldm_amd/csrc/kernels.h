@@ -148,6 +148,9 @@ enum TrunkWord {
     // consumer-side GroupNorm of their input in the words the views would occupy
     TW_ST0 = 34, TW_GAMMA = 36, TW_BETA = 38,                   // 64-bit pointers
     TW_P0 = 40, TW_GROUPS, TW_MAGIC_CPG, TW_INVN, TW_EPS, TW_SILU, TW_TILES_H, TW_TILES_IMG,
+    // conv_stream phases (kind 15: the full-resolution levels as clusters of 16 pixel tiles / 8 pixel tiles x 2 channel tiles)
+    TW_X1 = 48, TW_ST1 = 50,                                    // 64-bit pointers
+    TW_C0 = 52, TW_C1, TW_P1, TW_MAGIC_THV, TW_UP,
     TW_WORDS = 64
 };
 // phase kinds: 0..2 / 4..6 image-owning conv_small tiles (64 / 32 pixels), 3 attention over a pre-normalised x,
@@ -155,7 +158,7 @@ enum TrunkWord {
 // 13 attention with the GroupNorm fold inside (two query tiles per wave)
 // 14 GroupNorm (+ SiLU) of a concatenated input as a phase of its own (norm.hip's gn_apply_kernel; record: x0 / x1 in TW_X0 / TW_R0,
 // their channels in TW_R0C / TW_R1C, statistics in TW_ST0 / TW_RES with TW_P0 / TW_TILES_H partials, pixels per image in TW_WIN)
-enum TrunkKind { TK_ATTN = 3, TK_CL_3x3_128 = 8, TK_CL_3x3_256, TK_CL_3x3_384, TK_CL_3x3_512, TK_CL_1x1_256, TK_ATTN_FOLD, TK_GN_APPLY };
+enum TrunkKind { TK_ATTN = 3, TK_CL_3x3_128 = 8, TK_CL_3x3_256, TK_CL_3x3_384, TK_CL_3x3_512, TK_CL_1x1_256, TK_ATTN_FOLD, TK_GN_APPLY, TK_STREAM };
 struct TrunkPhase {
     unsigned w[TW_WORDS];
 };
@@ -164,6 +167,8 @@ struct TrunkParams {
     int nphases;
     int B, ranks;               // images; workgroups per image (its cluster): channel tiles x pixel tiles
     int ntile_n, nwn;           // channel tiles per image and 32-channel tiles per workgroup (N / 32 and 1 for image-owning tiles)
+    int variant;                // kernel: 0 image-owning conv_small tiles, 1 multi-tile conv_small clusters, 2 conv_stream<256 px, 128 ch>,
+                                // 3 conv_stream<128 px, 64 ch> (each set of instances has its own register allocation)
     unsigned* counters;         // device [B][32] zero-initialised: [0] arrivals (monotonic), [1] rank 0's XCC id + 1, [3] launches so far
     int* error;                 // device flag: 1 a bounded wait gave up, 2 a cluster is spread over several XCDs
     const float* temb;          // the plan's time-embedding table (PlanIO), set per launch

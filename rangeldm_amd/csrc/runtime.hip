@@ -689,6 +689,7 @@ struct Builder {
         size_t lds = 0;
         int B = 0, ranks = 0;
         int ntile_n = 0, nwn = 1;      // channel tiles per image, 32-channel tiles per workgroup (multi-tile clusters: nwn == 2)
+        int variant = 0;               // TrunkParams::variant
         double flops = 0, bytes = 0;
     } pend;
     bool trunk_open = false;
@@ -723,6 +724,7 @@ struct Builder {
             tp.ranks = pend.ranks;
             tp.ntile_n = pend.nwn == 1 ? pend.ranks : pend.ntile_n;
             tp.nwn = pend.nwn;
+            tp.variant = pend.variant;
             tp.counters = ctrs->as<unsigned>();
             tp.error = plan->trunk_error.as<int>();
             tp.temb_ld = temb_ld;
@@ -737,7 +739,9 @@ struct Builder {
                 tp.temb_per_sample = pl->io.temb_per_sample;
                 tp.ts = (getenv("RLDM_TS_TRUNK") && tp.nphases == atoi(getenv("RLDM_TS_TRUNK"))) ? g_ts_buf : nullptr;
                 return launch_trunk(tp, lds, st);
-            }, "trunk_kernel<" + std::to_string(pend.phases.size()) + " phases>", pend.flops, pend.bytes});
+            }, std::string("trunk_kernel<") + (pend.variant == 0 ? "conv_small image tiles" : pend.variant == 1 ? "conv_small 64x64 clusters" :
+                                               pend.variant == 2 ? "conv_stream 256x128" : "conv_stream 128x64") +
+                   ", " + std::to_string(pend.phases.size()) + " phases>", pend.flops, pend.bytes});
         }
         pend = PendingTrunk();
         std::vector<Tensor> d;
@@ -768,9 +772,11 @@ struct Builder {
         if (HG * wph != 16 || x.C > 512) return 0;                // 8 waves x two query tiles
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024 ? ranks : 0;
     }
-    void trunk_begin(int B, int ranks, int ntile_n = 0, int nwn = 1) {
+    void trunk_begin(int B, int ranks, int ntile_n = 0, int nwn = 1, int variant = -1) {
         if (nwn == 1) ntile_n = ranks;
-        if (trunk_open && (pend.ranks != ranks || pend.B != B || pend.nwn != nwn || pend.ntile_n != ntile_n)) flush_trunk();
+        if (variant < 0) variant = nwn == 1 ? 0 : 1;
+        if (trunk_open && (pend.ranks != ranks || pend.B != B || pend.nwn != nwn || pend.ntile_n != ntile_n || pend.variant != variant))
+            flush_trunk();
         if (!trunk_open) {
             ++launches;
             trunk_open = true;
@@ -778,7 +784,12 @@ struct Builder {
             pend.ranks = ranks;
             pend.ntile_n = ntile_n;
             pend.nwn = nwn;
+            pend.variant = variant;
         }
+    }
+    static int device_cus() {
+        static int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
+        return std::min(256, cus > 0 ? cus : 256);
     }
     // multi-tile clusters (trunk.hip, kinds 8..13): an image = (N / 64) channel tiles x (pixels / 64) pixel tiles of conv_small's
     // 64 x 64 instance, all of them resident at once and on one XCD (8 * ranks * ceil(B / 8) workgroups <= the chip's CUs).
@@ -1193,7 +1204,14 @@ struct Builder {
         if (a.want_stats) add_stats(y, p.tiles_img);
         const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
         plan->flops += fl;
-        note_launch();
+        // a phase of the persistent launch (trunk.hip, variants 2 / 3): the image's tiles_img x ntile_n workgroups (16 at both
+        // full-resolution levels) form a cluster on one XCD; consecutive convs of a level hand over through its L2 -- no end-of-kernel
+        // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
+        const int ranks_s = p.tiles_img * p.ntile_n;
+        const bool in_stream_cluster = cluster_enabled() && !(g_dbg_flags & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
+                                       8 * ranks_s * ((x0.B + 7) / 8) <= device_cus() && y.P <= kFoldAboveP;
+        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW == 32 ? 4 : 2, p.TW == 32 ? 2 : 3);
+        else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
             if (L->get_streampacked(Cin_t, conv_stream_kgroups(p), &pk)) return 1;
@@ -1219,6 +1237,31 @@ struct Builder {
             const int temb_off = a.temb_off;
             const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * 9 + L->R) * 2.0 +
                               (double)x0.B * Wout * Hout * N * 2.0 + (double)x0.B * Wout * Hout * R_t * 2.0;
+            if (in_stream_cluster) {
+                TrunkPhase ph;
+                memset(&ph, 0, sizeof(ph));
+                auto put64 = [&](int at, const void* ptr) {
+                    const unsigned long long u = (unsigned long long)(uintptr_t)ptr;
+                    ph.w[at] = (unsigned)u;
+                    ph.w[at + 1] = (unsigned)(u >> 32);
+                };
+                auto putf = [&](int at, float f) { memcpy(&ph.w[at], &f, 4); };
+                put64(TW_X0, p.x0); put64(TW_X1, p.x1); put64(TW_R0, p.r0); put64(TW_R1, p.r1); put64(TW_WPK, p.wpk); put64(TW_BIAS, p.bias);
+                put64(TW_Y, p.y); put64(TW_YSTATS, p.y_stats); put64(TW_ST0, p.st0); put64(TW_ST1, p.st1);
+                put64(TW_GAMMA, p.gn_gamma); put64(TW_BETA, p.gn_beta);
+                ph.w[TW_C0] = p.C0; ph.w[TW_C1] = p.C1; ph.w[TW_R0C] = p.R0; ph.w[TW_R1C] = p.R1; ph.w[TW_P0] = p.P0; ph.w[TW_P1] = p.P1;
+                ph.w[TW_WIN] = p.Win; ph.w[TW_HIN] = p.Hin; ph.w[TW_WOUT] = p.Wout; ph.w[TW_HOUT] = p.Hout; ph.w[TW_UP] = p.up;
+                ph.w[TW_TW] = p.TW; ph.w[TW_TH] = p.TH; ph.w[TW_COLB] = p.colb; ph.w[TW_THSHIFT] = p.th_shift;
+                ph.w[TW_TILES_H] = p.tiles_h; ph.w[TW_TILES_IMG] = p.tiles_img; ph.w[TW_MAGIC_THV] = p.magic_thv;
+                ph.w[TW_MAGIC_CPG] = p.magic_cpg; ph.w[TW_GROUPS] = p.gn_groups; ph.w[TW_SILU] = p.silu;
+                putf(TW_INVN, p.gn_inv_n); putf(TW_EPS, p.gn_eps);
+                ph.w[TW_N] = p.N; ph.w[TW_YLD] = p.y_ld;
+                ph.w[TW_KIND] = TK_STREAM; ph.w[TW_TEMBOFF] = (unsigned)temb_off;
+                pend.phases.push_back(ph);
+                pend.lds = std::max(pend.lds, conv_stream_lds_bytes(p));
+                pend.flops += fl;
+                pend.bytes += by;
+            } else
             plan->ops.push_back({[p, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;

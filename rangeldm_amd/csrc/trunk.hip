@@ -15,6 +15,7 @@
 // DIFFERENT images: they drift apart freely (so activations of a segment are never recycled inside it: runtime.hip defers the
 // arena releases to the segment's end).
 #include "conv_small_body.h"
+#include "conv_stream_body.h"
 #include "attention_body.h"
 
 namespace rldm {
@@ -72,6 +73,16 @@ __device__ __forceinline__ void unpack_cluster_phase(ConvParams& q, unsigned rec
     q.silu = (int)rl(rec, TW_SILU);
     q.tiles_h = (int)rl(rec, TW_TILES_H);
     q.tiles_img = (int)rl(rec, TW_TILES_IMG);
+}
+
+// a conv_stream phase (kind TK_STREAM): the cluster words + the second input tensor of a concatenation, nearest-x2, halo divisor
+__device__ __forceinline__ void unpack_stream_phase(ConvParams& q, unsigned rec) {
+    unpack_cluster_phase(q, rec);
+    q.x1 = rl_ptr<const bf16_t>(rec, TW_X1);
+    q.st1 = rl_ptr<const float2>(rec, TW_ST1);
+    q.C0 = (int)rl(rec, TW_C0); q.C1 = (int)rl(rec, TW_C1); q.P1 = (int)rl(rec, TW_P1);
+    q.magic_thv = (int)rl(rec, TW_MAGIC_THV);
+    q.up = (int)rl(rec, TW_UP);
 }
 
 // GroupNorm (+ SiLU) of cat[x0, x1] as a phase (a concatenated conv input is normalised once, not by every channel tile of the conv:
@@ -184,8 +195,9 @@ __device__ __forceinline__ void gn_apply_phase(const ConvParams& cp, const int r
 
 // CL = false: image-owning tiles (kinds 0..6 + attention over a pre-normalised x); CL = true: multi-tile clusters (kinds 8..13).
 // Two kernels, so that each set of instances gets its own register allocation.
-template <bool CL>
+template <int V>
 __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
+    constexpr bool CL = V == 1, ST = V >= 2;
     // block id -> (image, channel tile): ids with the same (id % 8) share an XCD; an image's `ranks` tiles are 8 apart
     const int wg = blockIdx.x;
     const int ranks = tp.ranks;
@@ -215,7 +227,7 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
     auto wave_stream = [&](unsigned r) __attribute__((always_inline)) {
         return reinterpret_cast<const unsigned char*>(rl_ptr<const bf16_t>(r, TW_WPK)) + ((size_t)stream_id * rl(r, TW_NMINE)) * 1024;
     };
-    if constexpr (!CL) {
+    if constexpr (V == 0) {
         const unsigned char* w0 = wave_stream(rec);
         const int g0 = (int)rl(rec, TW_G);
 #pragma unroll
@@ -226,7 +238,8 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
         const unsigned nrec = i + 1 < tp.nphases ? recs[(i + 1) * TW_WORDS + lane] : 0u;     // requested a phase ahead
         ConvParams cp;
         const int kind = (int)rl(rec, TW_KIND);
-        if constexpr (CL) unpack_cluster_phase(cp, rec);
+        if constexpr (ST) unpack_stream_phase(cp, rec);
+        else if constexpr (CL) unpack_cluster_phase(cp, rec);
         else unpack_phase(cp, rec);
         TrunkSeam seam;
         seam.counter = counter;
@@ -244,7 +257,11 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
         seam.next_rec = nrec;
         seam.next_rank_kg = stream_id;
         bool conv_done = true;
-        if constexpr (!CL) {
+        if constexpr (V == 2) {
+            conv_stream_body<2, 4, true>(cp, nt, mt, b, seam);      // full-resolution level: 16 tiles of 256 pixels x 128 channels per image
+        } else if constexpr (V == 3) {
+            conv_stream_body<1, 2, true>(cp, nt, mt, b, seam);      // 128x8 level: 8 tiles of 128 pixels x 2 channel tiles of 64
+        } else if constexpr (!CL) {
             switch (kind) {
                 case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
                 case 1: conv_small_body<1, 4, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
@@ -267,7 +284,7 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
                 default: conv_done = false; break;
             }
         }
-        if (!conv_done) {
+        if (!ST && !conv_done) {
                 // attention core of the block (GroupNorm already applied by the producer of x): this workgroup's heads / ranks
                 // heads of image b, one query tile per wave; its output projection is the next phase (a 1x1 conv)
                 AttnQkvParams ap;
@@ -280,11 +297,11 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
                     ap.st = cp.st0; ap.P = cp.P0; ap.gamma = cp.gn_gamma; ap.beta = cp.gn_beta; ap.eps = cp.gn_eps;
                     ap.groups = cp.gn_groups; ap.inv_n = cp.gn_inv_n; ap.magic_cpg = cp.magic_cpg;
                     if constexpr (CL) attention_qkv2_body<1, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
-                } else if constexpr (!CL) {
+                } else if constexpr (V == 0) {
                     attention_qkv2_body<0, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
                 }
                 // the next phase's first weight fragments (what a conv phase requests behind its K loop)
-                const int next_g = CL ? 0 : (int)rl(nrec, TW_G);       // (multi-tile clusters carry no ring across phases)
+                const int next_g = V != 0 ? 0 : (int)rl(nrec, TW_G);   // (multi-tile clusters carry no ring across phases)
                 if (next_g > 0) {
                     const unsigned char* nw = wave_stream(nrec);
 #pragma unroll
@@ -302,15 +319,16 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
 }
 
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
-    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 && tp.B >= 1 && (tp.nwn == 1 || tp.nwn == 2) && tp.ntile_n >= 1 &&
+    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 && tp.B >= 1 && (tp.nwn == 1 || tp.nwn == 2 || tp.nwn == 4) && tp.ntile_n >= 1 &&
                      tp.ranks % tp.ntile_n == 0, "trunk: bad parameters");
     RLDM_REQUIRE(lds <= 160 * 1024, "trunk: LDS tile too large");
     const int groups = (tp.B + 7) / 8;
     const int grid = 8 * tp.ranks * groups;
     RLDM_REQUIRE(grid <= 256, "trunk: the grid must be co-resident (one workgroup per CU)");
-    static DynLdsLimit lds_limit[2];             // per instantiation and device, thread safe
-    const int cl = tp.nwn == 2 ? 1 : 0;
-    auto kern = cl ? trunk_kernel<true> : trunk_kernel<false>;
+    static DynLdsLimit lds_limit[4];             // per instantiation and device, thread safe
+    RLDM_REQUIRE(tp.variant >= 0 && tp.variant <= 3, "trunk: bad kernel variant");
+    const int cl = tp.variant;
+    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : trunk_kernel<3>));
     RLDM_HIP_CHECK(lds_limit[cl].ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, tp);
     RLDM_HIP_CHECK(hipGetLastError());

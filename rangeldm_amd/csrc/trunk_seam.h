@@ -29,7 +29,9 @@ __device__ __forceinline__ void trunk_wait(const TrunkSeam& s, int tid) {
             if (++polls > (1 << 22)) { *s.error = 1; break; }      // bounded: a protocol error must not hang the device
         }
     }
-    __syncthreads();
+    // (a barrier that waits for LDS only: global requests of the phase issued ahead of the wait -- the weight ring of a conv_stream
+    //  phase -- stay in flight across it; the "memory" clobber keeps the phase's loads behind it)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ void trunk_arrive(const TrunkSeam& s, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this thread's stores are in the cluster's L2
