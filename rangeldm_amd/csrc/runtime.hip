@@ -984,9 +984,13 @@ struct Builder {
         const int kind_l = (taps == 9 && Cin_t == 256) ? 0 : ((taps == 9 && Cin_t == 512) ? 1 : ((taps == 1 && Cin_t == 256) ? 2 : -1));
         const int trunk_kind = kind_l < 0 ? -1 : kind_l + (px_t == 32 ? 4 : 0);      // (+4: the 32-pixel instances)
         const int ranks_t = N / 32;
-        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && (px_t == 64 || px_t == 32) && !gn_fused && !preact &&
+        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && (px_t == 64 || px_t == 32) && !gn_fused &&
                         trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && 8 * ranks_t * ((x0.B + 7) / 8) <= 256 &&
                         2 * p.TH * (Cin_t / 8) <= 512 && vts.size() <= 2;
+        // (a concatenated input is normalised by a gn_apply phase in front of the conv's -- or the conv stays a launch of its own)
+        const bool gn_phase_t = in_trunk && preact && Cin_t <= 512 && (Wout * Hout) % ranks_t == 0 && a.x0.C % 8 == 0 &&
+                                (!a.x1.valid() || a.x1.C % 8 == 0) && !(g_dbg_flags & (1 << 27));
+        in_trunk = in_trunk && (!preact || gn_phase_t);
         // ... or a phase of a MULTI-TILE cluster (the 64x4 level at batch <= 16): conv_small's default 64-pixel x 64-channel tiles, the
         // consumer-side GroupNorm fold stays inside the phase
         // (3x3 over 128 channels -- the all-taps-ring instance, 211 registers on its own -- does not fit beside the phase loop's state)
@@ -994,14 +998,16 @@ struct Builder {
                            (taps == 9 && Cin_t == 384) ? TK_CL_3x3_384 : (taps == 9 && Cin_t == 512) ? TK_CL_3x3_512 :
                            (taps == 1 && Cin_t == 256) ? TK_CL_1x1_256 : -1;
         const int ranks_c = cluster_ranks(x0.B, N, Wout * Hout);
-        const bool in_cluster = !in_trunk && cluster_enabled() && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 && p.up == 1 &&
-                                vts.empty() && ranks_c == (N / 64) * p.tiles_img && p.Win == Wout && p.Hin == Hout;
+        const bool in_cluster = !in_trunk && cluster_enabled() && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 &&
+                                (p.up == 1 || p.up == 2) && vts.empty() && ranks_c == (N / 64) * p.tiles_img &&
+                                p.Win * p.up == Wout && p.Hin * p.up == Hout;
         // GroupNorm + SiLU once, ahead of the conv: every channel tile of the conv would otherwise redo it (4-8x at these levels) --
         // as a launch (norm.hip) or, in front of a multi-tile cluster phase, as a phase of the same persistent launch
         if (preact) {
-            const bool gn_phase = in_cluster && Cin_t <= 512 && (Wout * Hout) % ranks_c == 0 && a.x0.C % 8 == 0 &&
-                                  (!a.x1.valid() || a.x1.C % 8 == 0) && !(g_dbg_flags & (1 << 27));
-            if (gn_phase) trunk_begin(x0.B, ranks_c, N / 64, 2);
+            const bool gn_phase = gn_phase_t || (in_cluster && Cin_t <= 512 && (Wout * Hout) % ranks_c == 0 && a.x0.C % 8 == 0 &&
+                                                 (!a.x1.valid() || a.x1.C % 8 == 0) && !(g_dbg_flags & (1 << 27)));
+            if (gn_phase_t) trunk_begin(x0.B, ranks_t);
+            else if (gn_phase) trunk_begin(x0.B, ranks_c, N / 64, 2);
             else note_launch();
             if (!dry) {
                 GnApplyParams g;
@@ -1108,6 +1114,7 @@ struct Builder {
                     ph.w[TW_P0] = p.P0; ph.w[TW_GROUPS] = p.gn_groups; ph.w[TW_MAGIC_CPG] = p.magic_cpg;
                     putf(TW_INVN, p.gn_inv_n); putf(TW_EPS, p.gn_eps);
                     ph.w[TW_SILU] = p.silu; ph.w[TW_TILES_H] = p.tiles_h; ph.w[TW_TILES_IMG] = p.tiles_img;
+                    ph.w[TW_UP] = p.up;
                 } else {
                 const int cpt = Cin_t / 128, KG = 8;
                 const int G = (trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt);

@@ -73,6 +73,7 @@ __device__ __forceinline__ void unpack_cluster_phase(ConvParams& q, unsigned rec
     q.silu = (int)rl(rec, TW_SILU);
     q.tiles_h = (int)rl(rec, TW_TILES_H);
     q.tiles_img = (int)rl(rec, TW_TILES_IMG);
+    q.up = max((int)rl(rec, TW_UP), 1);         // (nearest x2 folded into the staging of an up-sampler's conv)
 }
 
 // a conv_stream phase (kind TK_STREAM): the cluster words + the second input tensor of a concatenation, nearest-x2, halo divisor
@@ -82,7 +83,6 @@ __device__ __forceinline__ void unpack_stream_phase(ConvParams& q, unsigned rec)
     q.st1 = rl_ptr<const float2>(rec, TW_ST1);
     q.C0 = (int)rl(rec, TW_C0); q.C1 = (int)rl(rec, TW_C1); q.P1 = (int)rl(rec, TW_P1);
     q.magic_thv = (int)rl(rec, TW_MAGIC_THV);
-    q.up = (int)rl(rec, TW_UP);
 }
 
 // GroupNorm (+ SiLU) of cat[x0, x1] as a phase (a concatenated conv input is normalised once, not by every channel tile of the conv:
@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
         const int kind = (int)rl(rec, TW_KIND);
         if constexpr (ST) unpack_stream_phase(cp, rec);
         else if constexpr (CL) unpack_cluster_phase(cp, rec);
+        else if (kind == TK_GN_APPLY) unpack_cluster_phase(cp, rec);
         else unpack_phase(cp, rec);
         TrunkSeam seam;
         seam.counter = counter;
@@ -270,6 +271,16 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
                 case 4: conv_small_body<1, 2, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
                 case 5: conv_small_body<1, 4, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
                 case 6: conv_small_body<1, 2, 1, 1, true>(cp, rank, 0, b, wpf, seam); break;
+                case TK_GN_APPLY: {             // (a phase without weights: the next conv's first fragments are requested here)
+                    gn_apply_phase(cp, rank, ranks, b, seam);
+                    const int next_g = (int)rl(nrec, TW_G);
+                    if (next_g > 0) {
+                        const unsigned char* nw = wave_stream(nrec);
+#pragma unroll
+                        for (int j = 0; j < kTrunkPrefetch; ++j)
+                            if (j < next_g) wpf[j] = *reinterpret_cast<const bf16x8*>(nw + (unsigned)(j * 1024 + lane * 16));
+                    }
+                } break;
                 default: conv_done = false; break;
             }
         } else {
