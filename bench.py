@@ -119,8 +119,18 @@ def roofline(pipe, sampler_handle, x_T, steps):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
-            except (OSError, ValueError):
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom)
+                if traffic is None and dom.startswith("trunk_kernel<"):
+                    # persistent launches: the counters know the kernel VARIANT only ("trunk_kernel<conv_stream 256x128>": bytes per
+                    # launch averaged over its launches of 4 and 7 phases); this launch's share = its phases / the variant's mean
+                    variant = dom.split(",")[0] + ">"
+                    phases = lambda k: int(k.split(",")[1].split()[0])
+                    same = {k: v for k, v in tot.items() if k.startswith(dom.split(",")[0] + ",")}
+                    mean_ph = sum(phases(k) * v["launches"] for k, v in same.items()) / max(1, sum(v["launches"] for v in same.values()))
+                    if tj.get(variant) is not None and mean_ph > 0:
+                        traffic = int(tj[variant] * phases(dom) / mean_ph)
+            except (OSError, ValueError, IndexError):
                 traffic = None
             if traffic is not None:
                 break

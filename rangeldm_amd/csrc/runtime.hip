@@ -686,6 +686,8 @@ struct Builder {
     // ---- persistent trunk (trunk.hip): consecutive image-owning conv_small launches collected into one launch ----------------
     struct PendingTrunk {
         std::vector<TrunkPhase> phases;
+        std::vector<Op> standalone;   // the same layers as launches of their own (a one-phase segment runs as that: a phase costs its
+                                      // record fetch, the padded grid and the arrive for nothing)
         size_t lds = 0;
         int B = 0, ranks = 0;
         int ntile_n = 0, nwn = 1;      // channel tiles per image, 32-channel tiles per workgroup (multi-tile clusters: nwn == 2)
@@ -706,7 +708,9 @@ struct Builder {
         if (!trunk_open) return 0;
         trunk_open = false;
         int rc = 0;
-        if (!dry && !pend.phases.empty()) {
+        if (!dry && pend.phases.size() == 1 && pend.standalone.size() == 1 && !(g_dbg_flags & (1 << 29))) {
+            plan->ops.push_back(pend.standalone[0]);
+        } else if (!dry && !pend.phases.empty()) {
             auto recs = std::make_unique<DevBuf>();
             auto ctrs = std::make_unique<DevBuf>();
             if (upload(*recs, pend.phases.data(), pend.phases.size() * sizeof(TrunkPhase))) return 1;
@@ -1040,6 +1044,7 @@ struct Builder {
                     pend.phases.push_back(ph);
                     pend.lds = std::max(pend.lds, (size_t)(2 * 512 * 8 + 2 * 512 * 4));
                     pend.bytes += by;
+                    pend.standalone.push_back({[g](hipStream_t s) { return launch_gn_apply(g, s); }, "gn_apply_kernel", 0.0, by});
                 } else {
                     plan->ops.push_back({[g](hipStream_t s) { return launch_gn_apply(g, s); }, "gn_apply_kernel", 0.0, by});
                 }
@@ -1134,8 +1139,8 @@ struct Builder {
                 pend.lds = std::max(pend.lds, conv_small_lds_bytes(p, taps, BN));
                 pend.flops += fl;
                 pend.bytes += by;
-            } else
-            plan->ops.push_back({[p, BN, taps, pl, temb_off](hipStream_t s) mutable {
+            }
+            Op standalone{[p, BN, taps, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;
                     p.step_ptr = pl->io.step_ptr;
@@ -1143,7 +1148,9 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_small(p, taps, BN, s);
-            }, kname, fl, by});
+            }, kname, fl, by};
+            if (in_trunk) pend.standalone.push_back(standalone);
+            else plan->ops.push_back(standalone);
         }
         if (preact) release(act);
         *out = y;
@@ -1268,8 +1275,8 @@ struct Builder {
                 pend.lds = std::max(pend.lds, conv_stream_lds_bytes(p));
                 pend.flops += fl;
                 pend.bytes += by;
-            } else
-            plan->ops.push_back({[p, pl, temb_off](hipStream_t s) mutable {
+            }
+            Op standalone{[p, pl, temb_off](hipStream_t s) mutable {
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;
                     p.step_ptr = pl->io.step_ptr;
@@ -1277,7 +1284,9 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_stream(p, s);
-            }, p.TW == 32 ? "conv_stream_kernel<256,128,CK64,taps9>" : "conv_stream_kernel<128,64,CK64,taps9>", fl, by});
+            }, p.TW == 32 ? "conv_stream_kernel<256,128,CK64,taps9>" : "conv_stream_kernel<128,64,CK64,taps9>", fl, by};
+            if (in_stream_cluster) pend.standalone.push_back(standalone);
+            else plan->ops.push_back(standalone);
         }
         *out = y;
         return 0;
@@ -1642,9 +1651,13 @@ struct NetCommon {
                 ap.ts = getenv("RLDM_TS_TRUNK") ? nullptr : g_ts_buf;
                 ap.ts_L = getenv("RLDM_TS_ATTN_L") ? atoi(getenv("RLDM_TS_ATTN_L")) : 0;
                 const double by = (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0;
-                if (in_trunk) b.trunk_push_attention(ap, fl, by);
-                else
-                b.plan->ops.push_back({[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl, by});
+                Op standalone{[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl, by};
+                if (in_trunk) {
+                    b.trunk_push_attention(ap, fl, by);
+                    b.pend.standalone.push_back(standalone);
+                } else {
+                    b.plan->ops.push_back(standalone);
+                }
             }
             if (pre) b.release(xn);
             ConvArgs co;

@@ -9,8 +9,6 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined"
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/${TAG}_gpu_tests.txt
-python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python tools/bench_train.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_train.json 2>> $OUT/${TAG}_bench.err
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/kt -o kt -- $BENCH > /tmp/prof_$TAG/kt.log 2>&1
 DB=$(find /tmp/prof_$TAG/kt -name '*.db' | head -1)
@@ -19,7 +17,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$TAG/$c -o pmc -- $BENCH > /tmp/prof_$TAG/$c.log 2>&1
   python tools/pmc_summary.py /tmp/prof_$TAG/$c > $OUT/${TAG}_pmc_$(echo $c | tr A-Z a-z).txt
 done
-python tools/traffic_json.py /tmp/prof_$TAG/FETCH_SIZE /tmp/prof_$TAG/WRITE_SIZE > $OUT/${TAG}_traffic.json
+python tools/traffic_json.py /tmp/prof_$TAG/FETCH_SIZE /tmp/prof_$TAG/WRITE_SIZE > $OUT/${TAG}_traffic.json; cp $OUT/${TAG}_traffic.json profiles/round2_traffic.json 2>/dev/null
+# (bench.py after the traffic passes: its roofline.traffic reads profiles/round2_traffic.json)
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python tools/bench_train.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_train.json 2>> $OUT/${TAG}_bench.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_$TAG/mfma -o pmc -- $BENCH > /tmp/prof_$TAG/mfma.log 2>&1
 python tools/pmc_summary.py /tmp/prof_$TAG/mfma > $OUT/${TAG}_pmc_mfma.txt
 python tools/mfma_util.py $OUT/${TAG}_pmc_mfma.txt > $OUT/${TAG}_mfma_util.txt

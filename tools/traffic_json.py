@@ -29,6 +29,9 @@ def op_name(k):
     if m:
         wm, wn = map(int, m.groups())
         return f"conv_stream_kernel<{128 * wm},{32 * wn},CK64,taps9>"
+    m = re.match(r"trunk_kernel<(\d+)>", k)
+    if m:       # persistent launches: one entry per kernel variant (bench.py scales it by a launch's share of the variant's phases)
+        return "trunk_kernel<" + ("conv_small image tiles", "conv_small 64x64 clusters", "conv_stream 256x128", "conv_stream 128x64")[int(m.group(1))] + ">"
     return re.sub(r"\(.*$", "", k)
 
 
@@ -52,7 +55,7 @@ def main():
                     "uncorrected. Raw per-kernel values under _raw_kib."}
     raw = {}
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
-        if not (k.startswith("conv_") or k.startswith("attention") or k.startswith("gn_")):
+        if not (k.startswith("conv_") or k.startswith("attention") or k.startswith("gn_") or k.startswith("trunk_")):
             continue
         f, nf = fetch[k]
         w = write.get(k, (0.0, 0))[0]
