@@ -776,6 +776,10 @@ struct Builder {
         if (HG * wph != 16 || x.C > 512) return 0;                // 8 waves x two query tiles
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024 ? ranks : 0;
     }
+    static int device_cus() {
+        static int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
+        return std::min(256, cus > 0 ? cus : 256);
+    }
     void trunk_begin(int B, int ranks, int ntile_n = 0, int nwn = 1, int variant = -1) {
         if (nwn == 1) ntile_n = ranks;
         if (variant < 0) variant = nwn == 1 ? 0 : 1;
@@ -791,10 +795,6 @@ struct Builder {
             pend.variant = variant;
         }
     }
-    static int device_cus() {
-        static int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
-        return std::min(256, cus > 0 ? cus : 256);
-    }
     // multi-tile clusters (trunk.hip, kinds 8..13): an image = (N / 64) channel tiles x (pixels / 64) pixel tiles of conv_small's
     // 64 x 64 instance, all of them resident at once and on one XCD (8 * ranks * ceil(B / 8) workgroups <= the chip's CUs).
     // rldm_debug_set_flags(1 << 26) keeps these levels as separate launches (A/B runs)
@@ -804,9 +804,7 @@ struct Builder {
     static int cluster_ranks(int B, int C, int npix) {
         if (C % 64 != 0 || npix % 64 != 0) return 0;
         const int r = (C / 64) * (npix / 64);
-        static int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
-        const int limit = std::min(256, cus > 0 ? cus : 256);
-        return (r >= 2 && r <= 16 && npix > 64 && 8 * r * ((B + 7) / 8) <= limit) ? r : 0;
+        return (r >= 2 && r <= 16 && npix > 64 && 8 * r * ((B + 7) / 8) <= device_cus()) ? r : 0;
     }
     void trunk_push_attention(const AttnQkvParams& ap, double fl, double by) {
         TrunkPhase ph;
