@@ -1221,7 +1221,9 @@ struct Builder {
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
         const int ranks_s = p.tiles_img * p.ntile_n;
         const bool in_stream_cluster = cluster_enabled() && !(g_dbg_flags & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
-                                       8 * ranks_s * ((x0.B + 7) / 8) <= device_cus() && y.P <= kFoldAboveP;
+                                       8 * ranks_s * ((x0.B + 7) / 8) <= device_cus() && y.P <= kFoldAboveP &&
+                                       (p.TW == 32 || (g_dbg_flags & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
+                                       // 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
         if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW == 32 ? 4 : 2, p.TW == 32 ? 2 : 3);
         else note_launch();
         if (!dry) {
