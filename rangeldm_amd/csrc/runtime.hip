@@ -771,7 +771,7 @@ struct Builder {
     // ... of a multi-tile cluster: raw x + statistics (the fold runs inside the phase), two query tiles per wave; 0: not eligible
     int cluster_attention_ranks(const Tensor& x, bool pre) const {
         const int L = x.W * x.H, ranks = cluster_ranks(x.B, x.C, L);
-        if (!cluster_enabled() || pre || ranks == 0 || x.P <= 0 || (x.C / 8) % ranks != 0 || L % 32 != 0) return 0;
+        if (!cluster_enabled() || (g_dbg_flags & 512) || pre || ranks == 0 || x.P <= 0 || (x.C / 8) % ranks != 0 || L % 32 != 0) return 0;
         const int HG = (x.C / 8) / ranks, wph = L / 32;
         if (HG * wph != 16 || x.C > 512) return 0;                // 8 waves x two query tiles
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024 ? ranks : 0;
@@ -1000,7 +1000,7 @@ struct Builder {
                            (taps == 9 && Cin_t == 384) ? TK_CL_3x3_384 : (taps == 9 && Cin_t == 512) ? TK_CL_3x3_512 :
                            (taps == 1 && Cin_t == 256) ? TK_CL_1x1_256 : -1;
         const int ranks_c = cluster_ranks(x0.B, N, Wout * Hout);
-        const bool in_cluster = !in_trunk && cluster_enabled() && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 &&
+        const bool in_cluster = !in_trunk && cluster_enabled() && !(g_dbg_flags & 512) && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 &&
                                 (p.up == 1 || p.up == 2) && vts.empty() && ranks_c == (N / 64) * p.tiles_img &&
                                 p.Win * p.up == Wout && p.Hin * p.up == Hout;
         // GroupNorm + SiLU once, ahead of the conv: every channel tile of the conv would otherwise redo it (4-8x at these levels) --
