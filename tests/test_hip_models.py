@@ -309,6 +309,40 @@ def test_full_config_sampler_properties():
     assert rel_l2(solo[0], a[1]) < 2e-2                                 # GroupNorm / attention never mix samples
 
 
+@pytest.mark.parametrize("sched_name", ["ddim", "ddpm"])
+def test_batch16_sampler_clusters_match_launch_per_layer(sched_name):
+    """BASELINE config 2 at its real batch (16 images: every level of the UNet runs as clusters of 16 workgroups per image inside
+    persistent launches, trunk.hip) through the CAPTURED sampler -- step graphs, fused scheduler tail, VAE decode -- against the same
+    sampler with the clusters off (rldm_debug_set_flags(1 << 26): one launch per layer above the 32x2 level).  Same kernels' code on
+    the same operands: identical images; the launch count drops."""
+    from rangeldm_amd import _lib
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
+    cfg = UNetConfig()
+    x_T = T(normal(21, "xT", (16, 4, 256, 16)))
+    zs = T(normal(22, "zs", (3, 16, 4, 256, 16)))
+    outs, launches = [], []
+    for flags in (0, 1 << 26):
+        _lib.lib().rldm_debug_set_flags(flags)
+        try:
+            unet, _ = hip_unet(cfg, "")
+            vae, _, _ = hip_vae()
+            sched = DDIMSchedulerHIP() if sched_name == "ddim" else DDPMSchedulerHIP()
+            pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=sched, pos_encoding=True)
+            kw = dict(batch_size=16, num_inference_steps=3, latents=x_T, output_type="torch")
+            if sched_name == "ddpm":
+                kw["step_noise"] = zs
+            a = pipe(**kw).cpu()
+            b = pipe(**kw).cpu()                          # replayed graphs: the cluster counters re-arm themselves
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+            outs.append(a)
+            launches.append(unet.num_launches(16))
+        finally:
+            _lib.lib().rldm_debug_set_flags(0)
+    assert launches[0] < launches[1]
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_concurrent_chains_match_single_chain(monkeypatch):
     """The sampler splits a batch >= 32 into chains of >= 16 samples on separate streams (sampler_num_lanes, runtime.hip);
     RLDM_LANES forces the split at a small batch here.  Samples never interact, so the chains must reproduce the
