@@ -2238,7 +2238,10 @@ struct SamplerLane {
     bool fused_tail = true;                         // scheduler step in conv_out's epilogue, step index advanced by pack_input
     const float* captured_noise = nullptr;
     long long n_latent = 0, n_image = 0, n_cond = 0;
+    int* check_host = nullptr;                      // pinned: the persistent launches' self-check word of the PREVIOUS call (copied behind
+    bool check_pending = false;                     // its last launch, read at the start of the next call: no synchronisation of its own)
     ~SamplerLane() {
+        if (check_host) (void)hipHostFree(check_host);
         if (step_graph) (void)hipGraphExecDestroy(step_graph);
         if (decode_graph) (void)hipGraphExecDestroy(decode_graph);
         if (ev_out) (void)hipEventDestroy(ev_out);
@@ -2695,6 +2698,17 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
         (s->vae && !s->vae->params.finalized)) {
         if (sampler_build_plans(s)) return 1;       // the models were reloaded since the graphs were captured
     }
+    // the previous call's self-check of the persistent launches (a cluster wait that gave up: e.g. another stream held part of the chip
+    // -- INTEGRATION.md section 5): its images were wrong, and this call says so
+    for (auto& lnp : s->lanes) {
+        SamplerLane* ln = lnp.get();
+        if (ln->check_pending && hipEventQuery(ln->ev_out) == hipSuccess) {
+            ln->check_pending = false;
+            RLDM_REQUIRE(*ln->check_host == 0, "a persistent launch of the PREVIOUS rldm_sample call failed its self-check (code " +
+                                                   std::to_string(*ln->check_host) + "): its images are invalid; set RLDM_DBG_FLAGS=67108864 "
+                                                   "(or 16777216) if this GPU is shared with other streams");
+        }
+    }
     RLDM_HIP_CHECK(hipEventRecord(s->ev_in, caller));
     // per lane: inputs, (first call) eager warm step + graph capture
     for (auto& lnp : s->lanes) {
@@ -2758,6 +2772,14 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             } else {
                 RLDM_HIP_CHECK(hipMemcpyAsync(images + lat_off, ln->x.p, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
             }
+        }
+        if (ln->uplan->trunk_error.p) {
+            if (!ln->check_host) {
+                RLDM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln->check_host), 64, hipHostMallocDefault));
+                *ln->check_host = 0;
+            }
+            RLDM_HIP_CHECK(hipMemcpyAsync(ln->check_host, ln->uplan->trunk_error.p, 4, hipMemcpyDeviceToHost, st));
+            ln->check_pending = true;
         }
         RLDM_HIP_CHECK(hipEventRecord(ln->ev_out, st));
         RLDM_HIP_CHECK(hipStreamWaitEvent(caller, ln->ev_out, 0));
