@@ -14,6 +14,13 @@
 // A phase = conv_small_body<..., TRUNK = true> on a ConvParams record in device memory.  Nothing here orders workgroups of
 // DIFFERENT images: they drift apart freely (so activations of a segment are never recycled inside it: runtime.hip defers the
 // arena releases to the segment's end).
+//
+// Second generation: the same seam for images of SEVERAL tiles.  At 13..16 images an image is 16 workgroups at every level --
+// 16 pixel tiles of conv_stream's 256 x 128 instance at 256x16, 4 x 4 tiles of conv_small's 64 x 64 instance at 64x4 -- so
+// 16 images x 16 = 256 workgroups fill the chip once, two images per XCD, and halos, channel slices and GroupNorm statistics
+// partials (folded by the CONSUMER phase, as in the stand-alone kernels) still never leave the image.  Four kernels (template V),
+// one per set of phase bodies, so that each set has its own register allocation; the bodies are the stand-alone kernels' code
+// (conv_small_body.h / conv_stream_body.h / attention_body.h, TRUNK = true) plus gn_apply_phase below.  DESIGN.md section 3.7.
 #include "conv_small_body.h"
 #include "conv_stream_body.h"
 #include "attention_body.h"
