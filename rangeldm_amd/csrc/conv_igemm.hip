@@ -104,6 +104,9 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
     const int wmn = wave - kg * (WM * WN);
     const int wm = wmn % WM, wn = wmn / WM;
     const int kh = lane >> 5, l31 = lane & 31;
+    // the sampler's step index: advanced by the first launch of a step (conv_in: nothing in it reads the index; every later launch of
+    // the step sees the new value across the kernel boundary)
+    if (p.step_inc && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) *p.step_inc += 1;
     int ts_n = 0;
     // in-kernel timeline (ABLATE builds): s_memtime stamps go to the last 512 bytes of the LDS allocation (no VMEM
     // traffic that would perturb the counted waits) and are copied out at the very end by `flush_stamps`
@@ -703,6 +706,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_igemm_kernel(const ConvParams
                             float prev = (p.sch.mode == 0) ? c2 * x0 + c3 * e : c2 * x0 + c3 * x;
                             if (nz) prev += c4 * nz[i];
                             p.sch.x_prev[i] = prev;
+                            if (p.sch.pack) p.sch.pack[(((size_t)b * p.Wout + ow) * p.Hout + oh) * p.sch.pack_ld + ch] = f32_to_bf16(prev);
                         }
                     }
                 }

@@ -37,6 +37,10 @@ struct SchedFuse {
     long long noise_step_stride;
     float* x_prev;
     int mode;                 // 0 ddim, 1 ddpm
+    // the NEXT step's conv_in input (pack_input's bf16 [B][W][H][pack_ld] tensor): the thread that holds x_prev[i] stores its bf16 image
+    // too, so a step's first launch is conv_in instead of a pack launch (the pos-encoding / condition channels never change); or null
+    bf16_t* pack;
+    int pack_ld;
 };
 
 struct ConvParams {
@@ -95,6 +99,7 @@ struct ConvParams {
     unsigned long long* ts;  // tuning: s_memtime stamps of blocks 0..3, wave 0 ([4][64]) or null
     int dbg;                // tuning ablations (rldm_debug_set_flags): 1 skip stores, 2 skip main loop, 4 skip GN finalize
     SchedFuse sch;          // conv_igemm.hip, y_nchw outputs: the sampler's scheduler step in the epilogue
+    int* step_inc;          // conv_igemm.hip: the sampler's device step index, advanced by the step's FIRST launch (conv_in, which does not read it) or null
     int nviews;             // conv_small.hip, image-owning tiles: normalised copies of the output for up to 3 consumers
     NormView nv[3];
 };

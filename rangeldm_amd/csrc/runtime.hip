@@ -318,6 +318,11 @@ struct PlanIO {
     // sampler only: the step index advanced by the step's first launch, the scheduler step in conv_out's epilogue
     int* step_inc = nullptr;
     SchedFuse sch = {};
+    // sampler only: conv_out's epilogue also writes the next step's conv_in input (sch.pack = xin), so the plan's pack_input launch is
+    // skipped and conv_in advances the step index; the sampler packs x_T itself once per call
+    bool pack_fused = false;
+    bf16_t* xin = nullptr;         // the plan's conv_in input tensor [B][W][H][xin_ld] (never recycled inside the plan)
+    int xin_ld = 0;
 };
 
 struct Op {
@@ -460,6 +465,7 @@ struct ConvArgs {
     bool want_stats = false;       // emit per-channel statistics of the output (a GroupNorm will read it)
     bool out_f32_nchw = false;     // conv_out: write plan->io.out
     bool own_image = false;        // conv_small route with ONE tile per image (the producer normalises for its consumers)
+    bool first_of_step = false;    // conv_in: advances the sampler's step index when the plan's pack_input launch is fused away
 };
 
 // Producer-side GroupNorm: which convs write a normalised (+ activated) copy of their output for which
@@ -1368,8 +1374,9 @@ struct Builder {
         RLDM_REQUIRE(Wv % a.stride == 0 && Hv % a.stride == 0, "conv " + L->name + ": odd size under stride 2");
         RLDM_REQUIRE(R_t == 0 || (a.r0.W == Wout && a.r0.H == Hout), "conv " + L->name + ": residual resolution mismatch");
         const int N = L->Cout;
-        if (small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, taps, Wout, Hout, out);
-        {
+        // (conv_in stays on the generic kernel: it is the launch that advances the sampler's step index)
+        if (!a.first_of_step && small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, taps, Wout, Hout, out);
+        if (!a.first_of_step) {
             ConvParams q;
             if (stream_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_stream(a, Cin_t, R_t, Wout, Hout, out);
         }
@@ -1462,13 +1469,15 @@ struct Builder {
             p.temb_ld = temb_ld;
             const int temb_off = a.temb_off;
             const bool f32out = a.out_f32_nchw;
+            const bool first_of_step = a.first_of_step;
             const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * taps + (L->sc_identity ? 0.0 : (double)L->R));
             const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * (L->Cin * taps + L->R) * 2.0 +
                               (double)x0.B * Wout * Hout * N * (a.out_f32_nchw ? 4.0 : 2.0) +
                               (double)x0.B * Wout * Hout * R_t * 2.0;
             const std::string kname = "conv_igemm_kernel<" + std::to_string(tile.BM) + "," + std::to_string(tile.BN) +
                                       ",CK" + std::to_string(tile.CK) + ",taps" + std::to_string(tile.taps) + ">";
-            plan->ops.push_back({[p, tile, pl, temb_off, f32out](hipStream_t s) mutable {
+            plan->ops.push_back({[p, tile, pl, temb_off, f32out, first_of_step](hipStream_t s) mutable {
+                p.step_inc = (first_of_step && pl->io.pack_fused) ? pl->io.step_inc : nullptr;
                 if (temb_off >= 0) {
                     p.temb = pl->io.temb + temb_off;
                     p.step_ptr = pl->io.step_ptr;
@@ -1879,7 +1888,10 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
     b.note_launch();
     if (!b.dry) {
         bf16_t* dst = b.tptr(xin);
+        plan->io.xin = dst;
+        plan->io.xin_ld = Cpad;
         plan->ops.push_back({[plan, dst, B, W, H, Cpad](hipStream_t s) {
+            if (plan->io.pack_fused) return 0;          // (the sampler packed x_T; afterwards conv_out's epilogue writes this tensor)
             PackInputParams p{};
             p.x = plan->io.sample; p.cx = plan->io.sample_channels; p.scale = plan->io.sample_scale;
             p.pos_encoding = plan->io.pos_encoding;
@@ -1896,8 +1908,9 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
         a.layer = net.layers.get_conv("conv_in");
         a.x0 = xin;
         a.want_stats = true;
+        a.first_of_step = true;
         if (b.conv(a, &h)) return 1;
-        b.release(xin);
+        // (xin is never released: with the pack launch fused away it must survive from conv_out's epilogue to the next step's conv_in)
     }
     std::vector<Tensor> skips;
     b.retain(h);
@@ -2270,6 +2283,21 @@ static Plan* g_trace_plan = nullptr;
 // (rldm_debug_set_flags(1 << 23) at sampler creation keeps the scheduler step and the step counter as launches of their own)
 static bool sampler_fused_tail() { return !(g_dbg_flags & (1 << 23)); }
 
+// x_T (just copied into the lane's x) as conv_in's input: once per call when the steps' pack_input launch is fused into conv_out
+static int sampler_pack_x(rldm_sampler* s, SamplerLane* ln, hipStream_t st) {
+    const PlanIO& io = ln->uplan->io;
+    if (!io.pack_fused) return 0;
+    const auto& uc = s->unet->cfg;
+    PackInputParams p{};
+    p.x = io.sample; p.cx = io.sample_channels; p.scale = io.sample_scale;
+    p.pos_encoding = io.pos_encoding;
+    p.cond = io.cond; p.cc = io.cond_channels;
+    p.B = ln->nb; p.W = uc.sample_w; p.H = uc.sample_h; p.Cpad = io.xin_ld;
+    p.out = io.xin;
+    p.step_inc = nullptr;
+    return launch_pack_input(p, st);
+}
+
 static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* noise, hipStream_t st) {
     const bool fused = ln->fused_tail;
     if (fused) ln->uplan->io.sch.noise = noise;        // (the rest of io.sch / io.step_inc: sampler_build_plans)
@@ -2346,6 +2374,12 @@ static int sampler_build_plans(rldm_sampler* s) {
             f.x_prev = ln->x.as<float>();
             f.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
             io.step_inc = ln->step.as<int>();
+            // ... and the next step's conv_in input: no pack_input launch inside the steps (rldm_debug_set_flags(64) keeps it)
+            if (!(g_dbg_flags & 64) && io.xin && io.sample_scale == 1.f) {
+                io.pack_fused = true;
+                f.pack = io.xin;
+                f.pack_ld = io.xin_ld;
+            }
         }
         if (vae) {
             if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan)) return 1;
@@ -2720,6 +2754,7 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
         if (cond)
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->cond.p, cond + (size_t)ln->b0 * (ln->n_cond / ln->nb), ln->n_cond * 4,
                                           hipMemcpyDeviceToDevice, st));
+        if (sampler_pack_x(s, ln, st)) return 1;
         if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
         const float* noise = s->cfg.mode == RLDM_SAMPLER_DDPM ? step_noise + lat_off : nullptr;
         if (!ln->step_graph || ln->captured_noise != noise) {
@@ -2733,6 +2768,7 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
                                             "): set RLDM_DBG_FLAGS=16777216 to run the levels as separate launches");
             }
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+            if (sampler_pack_x(s, ln, st)) return 1;
             if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
             // the graph holds `gs` consecutive steps (the step index lives on the device, so the steps are identical launches):
             // fewer, longer graphs keep the queue fed across step boundaries
@@ -2753,6 +2789,7 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             RLDM_HIP_CHECK(hipStreamSynchronize(st));
             if (capture(st, [&]() { return ln->dplan->run(st); }, &ln->decode_graph)) return 1;
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T + lat_off, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+            if (sampler_pack_x(s, ln, st)) return 1;
         }
     }
     // the chains: step-major so every stream always has work queued
@@ -2794,6 +2831,7 @@ int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size
     SamplerLane* ln = s->lanes[0].get();
     hipStream_t st = ln->stream;
     RLDM_HIP_CHECK(hipMemcpyAsync(ln->x.p, x_T, ln->n_latent * 4, hipMemcpyDeviceToDevice, st));
+    if (sampler_pack_x(s, ln, st)) return 1;
     if (launch_step_counter(ln->step.as<int>(), ln->fused_tail ? -1 : 0, 0, st)) return 1;
     if (ln->uplan->run(st)) return 1;                      // warm
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
