@@ -134,12 +134,13 @@ def roofline(pipe, sampler_handle, x_T, steps):
                 traffic = None
             if traffic is not None:
                 break
+    step_launches = sum(v["launches"] for v in prof.get("unet_step", {}).values())      # what the captured step really launches
     rl = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
           "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
           "alg_flops_per_launch": d["flops"] / d["launches"], "alg_bytes_per_launch": d["bytes"] / d["launches"],
           "launches_per_batch": d["launches"], "eager_kernel_ms_per_batch": round(all_ms, 3),
-          "concurrent_chains": lanes, "chain_batch": prof.get("lane_batch")}
+          "concurrent_chains": lanes, "chain_batch": prof.get("lane_batch"), "step_launches": step_launches}
     return rl, kernels
 
 
@@ -272,7 +273,7 @@ def main():
             res["gflop_per_image"] = round(gflop_per_image, 1)
             res["end_to_end_tflops"] = round(res["value"] * gflop_per_image / 1e3, 1)
             res["end_to_end_frac_of_mfma_peak"] = round(res["value"] / world * gflop_per_image / 1e3 / PEAK_BF16_TFLOPS, 4)
-            res["unet_launches_per_step"] = unet.num_launches(B)
+            res["unet_launches_per_step"] = rl.pop("step_launches") or unet.num_launches(B)
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(p, usd, vsd, B, S)
             if world == 1 and not args.no_pipelined and args.preset == "RangeLDM" and B == 16 and zs is None and conds is None:

@@ -330,6 +330,7 @@ struct Op {
     std::string name;       // kernel (template instance) the op launches
     double flops = 0;       // algorithmic FLOPs (2*MACs) of this launch
     double bytes = 0;       // algorithmic HBM bytes: every input / weight / output touched once
+    std::function<bool()> active;   // optional: false -> the op launches nothing this run (the sampler's fused pack_input) and is skipped
 };
 
 struct KernelStat {
@@ -348,16 +349,19 @@ struct Plan {
     double flops = 0;
     int run(hipStream_t s) {
         for (auto& o : ops)
-            if (o.fn(s)) return 1;
+            if ((!o.active || o.active()) && o.fn(s)) return 1;
         return 0;
     }
     // same, with a timestamp launch around every op (rldm_debug_graph_trace: the timeline of the ops as they run
     // back to back inside the captured graph, which a host-side profiler cannot see without spacing them out)
     int run_stamped(hipStream_t s, unsigned long long* slots, int cap) {
         if (launch_stamp(slots, s)) return 1;
+        int n = 0;                              // (ops that launch nothing this run leave no stamp)
         for (size_t i = 0; i < ops.size(); ++i) {
+            if (ops[i].active && !ops[i].active()) continue;
             if (ops[i].fn(s)) return 1;
-            if ((int)i + 1 < cap && launch_stamp(slots + i + 1, s)) return 1;
+            ++n;
+            if (n < cap && launch_stamp(slots + n, s)) return 1;
         }
         return 0;
     }
@@ -366,12 +370,15 @@ struct Plan {
         std::vector<hipEvent_t> ev(ops.size() + 1);
         for (auto& e : ev) RLDM_HIP_CHECK(hipEventCreate(&e));
         RLDM_HIP_CHECK(hipEventRecord(ev[0], s));
+        std::vector<char> ran(ops.size(), 1);
         for (size_t i = 0; i < ops.size(); ++i) {
-            if (ops[i].fn(s)) return 1;
+            ran[i] = !ops[i].active || ops[i].active();
+            if (ran[i] && ops[i].fn(s)) return 1;
             RLDM_HIP_CHECK(hipEventRecord(ev[i + 1], s));
         }
         RLDM_HIP_CHECK(hipStreamSynchronize(s));
         for (size_t i = 0; i < ops.size(); ++i) {
+            if (!ran[i]) continue;
             float ms = 0.f;
             RLDM_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             KernelStat& k = stats[ops[i].name];
@@ -1900,7 +1907,7 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
             p.out = dst;
             p.step_inc = plan->io.step_inc;
             return launch_pack_input(p, s);
-        }, "pack_input_kernel", 0.0, (double)B * W * H * (Cpad * 2.0 + 4.0 * 5)});
+        }, "pack_input_kernel", 0.0, (double)B * W * H * (Cpad * 2.0 + 4.0 * 5), [plan]() { return !plan->io.pack_fused; }});
     }
     Tensor h;
     {
@@ -3015,12 +3022,14 @@ int rldm_debug_block_times(unsigned long long* host_out, int nblocks) {
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap) {
     if (!g_trace.p || !g_trace_plan) return 0;
     (void)hipDeviceSynchronize();
-    const int n = (int)g_trace_plan->ops.size();
+    int n = 0;                                  // (the ops that launched: run_stamped leaves no stamp for the others)
+    for (auto& o : g_trace_plan->ops) n += (!o.active || o.active()) ? 1 : 0;
     const int m = std::min(cap, n + 1);
     if (stamps && m > 0 && hipMemcpy(stamps, g_trace.p, (size_t)m * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (names && names_cap) {
         std::string all;
-        for (auto& o : g_trace_plan->ops) all += o.name + "\n";
+        for (auto& o : g_trace_plan->ops)
+            if (!o.active || o.active()) all += o.name + "\n";
         strncpy(names, all.c_str(), names_cap - 1);
         names[names_cap - 1] = 0;
     }
