@@ -343,6 +343,31 @@ def test_batch16_sampler_clusters_match_launch_per_layer(sched_name):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_sampler_falls_back_when_the_cluster_self_check_fails(monkeypatch):
+    """The persistent launches check their one assumption (an image's workgroups on one XCD, all resident) at the sampler's eager
+    warm-up step; if the check word is set, the process falls back to one launch per layer -- same kernels, same images.  The failure
+    is injected (RLDM_TEST_TRUNK_FAIL)."""
+    from rangeldm_amd import _lib
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    cfg = UNetConfig()
+    x_T = T(normal(23, "xT", (16, 4, 256, 16)))
+    outs = []
+    try:
+        for fail in (False, True):
+            if fail:
+                monkeypatch.setenv("RLDM_TEST_TRUNK_FAIL", "1")
+            unet, _ = hip_unet(cfg, "")
+            vae, _, _ = hip_vae()
+            pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=True)
+            outs.append(pipe(batch_size=16, num_inference_steps=2, latents=x_T, output_type="torch").cpu())
+            assert torch.isfinite(outs[-1]).all()
+    finally:
+        monkeypatch.delenv("RLDM_TEST_TRUNK_FAIL", raising=False)
+        _lib.lib().rldm_debug_set_flags(0)              # (the fall-back sets 1 << 24 for the process)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_concurrent_chains_match_single_chain(monkeypatch):
     """The sampler splits a batch >= 32 into chains of >= 16 samples on separate streams (sampler_num_lanes, runtime.hip);
     RLDM_LANES forces the split at a small batch here.  Samples never interact, so the chains must reproduce the
