@@ -6,7 +6,9 @@ namespace rldm {
 
 // ---- cluster seam of the persistent trunk (tools/ubench/xcd_cluster.hip: 1.4 us for 16 workgroups of one XCD) --------------------
 // The workgroups of one image sit on ONE XCD (block -> XCD round-robin; checked by the host once per plan), so a plain store that
-// has been acknowledged (s_waitcnt vmcnt(0)) is in the L2 they share, and a load that bypasses the reader's L1 sees it.
+// has been acknowledged (s_waitcnt vmcnt(0)) is in the L2 they share, and a load that does not hit a stale line of the reader's L1
+// sees it: the consumer invalidates its CU's vector L1 once, behind the wait (buffer_inv sc0: the L1 only -- sc1 would also walk the
+// L2 and made the whole step 30 % slower), and then uses ordinary cached loads.
 constexpr int kTrunkPrefetch = 12;            // weight fragments per wave requested one phase ahead (registers carried across phases)
 struct TrunkSeam {
     unsigned* counter;              // arrivals of this image's cluster (monotonic over the launch; zeroed by the launch before)
@@ -21,6 +23,12 @@ struct TrunkSeam {
     const int* step_ptr;
     int temb_rows_per_step, temb_per_sample, temb_ld;
 };
+#ifndef RLDM_TRUNK_PLAIN_LOADS
+#define RLDM_TRUNK_PLAIN_LOADS 1   // (0: L1-bypassing nontemporal loads instead of one L1 invalidate per phase -- measured 0.7 % slower)
+#endif
+#ifndef RLDM_TRUNK_INV
+#define RLDM_TRUNK_INV "buffer_inv sc0"
+#endif
 __device__ __forceinline__ void trunk_wait(const TrunkSeam& s, int tid) {
     if (tid == 0 && s.has_wait) {
         int polls = 0;
@@ -32,6 +40,11 @@ __device__ __forceinline__ void trunk_wait(const TrunkSeam& s, int tid) {
     // (a barrier that waits for LDS only: global requests of the phase issued ahead of the wait -- the weight ring of a conv_stream
     //  phase -- stay in flight across it; the "memory" clobber keeps the phase's loads behind it)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if RLDM_TRUNK_PLAIN_LOADS
+    // the CU's vector L1 is invalidated ONCE per phase, behind the wait: the phase's activation loads are then ordinary cached loads
+    // (first touch from the XCD's L2, re-reads of a halo line from the L1) instead of L1-bypassing ones
+    asm volatile(RLDM_TRUNK_INV ::: "memory");
+#endif
 }
 __device__ __forceinline__ void trunk_arrive(const TrunkSeam& s, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this thread's stores are in the cluster's L2
@@ -40,7 +53,7 @@ __device__ __forceinline__ void trunk_arrive(const TrunkSeam& s, int tid) {
 }
 // activation loads: past the L1 inside the trunk (another CU of the cluster wrote the line during this launch)
 template <bool BYPASS> __device__ __forceinline__ uint4 ld_act16(const void* p) {
-    if constexpr (BYPASS) {
+    if constexpr (BYPASS && !RLDM_TRUNK_PLAIN_LOADS) {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
         return make_uint4(v.x, v.y, v.z, v.w);
@@ -49,7 +62,7 @@ template <bool BYPASS> __device__ __forceinline__ uint4 ld_act16(const void* p) 
     }
 }
 template <bool BYPASS> __device__ __forceinline__ float2 ld_act8(const float2* p) {
-    if constexpr (BYPASS) {
+    if constexpr (BYPASS && !RLDM_TRUNK_PLAIN_LOADS) {
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
         const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p));
         return make_float2(v.x, v.y);
@@ -60,7 +73,7 @@ template <bool BYPASS> __device__ __forceinline__ float2 ld_act8(const float2* p
 
 // 16 bytes of bf16 activations as an MFMA operand
 template <bool BYPASS> __device__ __forceinline__ bf16x8 ld_act_frag(const bf16_t* p) {
-    if constexpr (BYPASS) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+    if constexpr (BYPASS && !RLDM_TRUNK_PLAIN_LOADS) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
     else return *reinterpret_cast<const bf16x8*>(p);
 }
 
