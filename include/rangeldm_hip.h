@@ -367,6 +367,12 @@ int rldm_debug_force_tile(int BM, int BN, int ksplit);
 int rldm_unet_trunk_status(rldm_unet* m, int B);
 int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
 int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLATE builds: [start, end] (100 MHz) of every workgroup of the last conv_stream launch */
+/* routing / ablation switches, read when a plan is built (RLDM_DBG_FLAGS seeds them).  The ones a maintainer may need
+ * (INTEGRATION.md section 5): 1 << 24 every layer a launch of its own with the persistent launches' tiles (identical results),
+ * 1 << 25 ... with the default tiles, 1 << 26 no multi-tile clusters (the 64x4 / 256x16 levels as launches: required when the GPU
+ * is shared with other streams), 512 / 1 << 28 only the conv_small / conv_stream clusters off, 1 << 27 gn_apply stays a launch,
+ * 1 << 30 the 128x8 conv pairs as 2-phase launches, 64 keeps the sampler's pack_input launch, 1 << 23 keeps the scheduler step
+ * a launch, 1 << 20 every GroupNorm on the consumer side.  0 restores the defaults. */
 int rldm_debug_set_flags(int flags);
 /* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */
