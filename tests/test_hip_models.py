@@ -481,6 +481,78 @@ def test_50_step_full_width_sampler_matches_reference_loop(golden, sched):
         assert rel_l2(unet(x.cuda(), ts[i]).sample.cpu(), ou(x, ts[i]).sample) < TOL_FWD, i
 
 
+def test_batch16_forward_matches_reference_model(golden):
+    """The HEADLINE batch against reference code, directly: 16 x (5, 256, 16) through the plan every level of which runs as clusters
+    of 16 workgroups per image inside persistent launches (trunk.hip variants 0 / 1 / 2 exist only from 13 images on), against eps of
+    the reference-composed full-width Model at two timesteps (tests/golden/b16.npz, oracle/validate_batch16_against_reference.py)."""
+    g = golden("b16")
+    m = hip_ref_unet(UNetConfig(**SGM_SINUSOID), "ref/full.")
+    x = T(normal(61, "b16/x", (16, 5, 256, 16))).cuda()
+    n_clustered = m.num_launches(16)
+    for t in (480, 37):
+        out = m(x, t).sample.cpu()
+        ref = T(g[f"b16_eps_t{t}_f16"]).float()
+        e = rel_l2(out, ref)
+        worst = max(float(rel_l2(out[j], ref[j])) for j in range(16))
+        print(f"B=16 forward t={t}: rel-L2 {float(e):.3e}, worst sample {worst:.3e}, {n_clustered} launches")
+        assert e < TOL_FWD and worst < 1.5 * TOL_FWD
+    assert m.trunk_status(16) == 0
+    assert n_clustered <= 40                               # (the cluster plan, not the launch-per-layer one: 90+)
+
+
+def test_batch16_sampler_matches_reference_loop(golden):
+    """... and the captured batch-16 sampler (step graphs, fused scheduler tail, clusters ON): x_0 after 3 DDIM steps against the
+    reference's own LDMPipelineRange loop (ldm/pipelines.py:353-362) at batch 16, at the latent tolerance of the 50-step test."""
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    g = golden("b16")
+    unet = hip_ref_unet(UNetConfig(**SGM_SINUSOID), "ref/full.")
+    vae, _, _ = hip_vae()
+    pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=True)
+    x_T = T(normal(62, "b16/x_T", (16, 4, 256, 16)))
+    h = pipe._fused.get(unet, vae, pipe.scheduler, 16, 3, 0, True, 0)
+    img = torch.empty((16, 2, 1024, 64), device="cuda")
+    lat = torch.empty((16, 4, 256, 16), device="cuda")
+    pipe._fused.run(h, x_T.cuda().contiguous(), None, None, img, latents_out=lat)
+    ref = T(g["b16_ddim3_latent_f16"]).float()
+    e = rel_l2(lat.cpu(), ref)
+    worst = max(float(rel_l2(lat[j].cpu(), ref[j])) for j in range(16))
+    print(f"B=16 3-step DDIM: final latent rel-L2 {float(e):.3e}, worst sample {worst:.3e}")
+    assert e < TOL_X0 and worst < 2 * TOL_X0
+    assert torch.isfinite(img).all()
+    assert unet.num_launches(16) <= 40
+
+
+def test_upscale_full_width_pipeline_matches_reference_loop(golden):
+    """BASELINE config 4 end to end at full width: LDMUpscalePipelineRange.__call__ (ldm/pipelines.py:414-519) for 10 strided-DDPM
+    steps at batch 2 on the 12-channel UNet (30.1 M parameters) with SparseRangeImageEncoder2, against the reference's loop driving
+    the reference-composed Model and the sgm Decoder (tests/golden/upfull.npz)."""
+    from rangeldm_amd.pipelines import LDMUpscalePipelineRange
+    from rangeldm_amd.schedulers import DDPMSchedulerHIP
+    from rangeldm_amd.encoders import SparseRangeImageEncoder2
+    g = golden("upfull")
+    unet = hip_ref_unet(UNetConfig(in_channels=12, **SGM_SINUSOID), "ref/up.")
+    vae, _, _ = hip_vae()
+    pipe = LDMUpscalePipelineRange(vae=vae, unet=unet, scheduler=DDPMSchedulerHIP())
+    cond_img = T(normal(63, "upfull/cond", (2, 2, 1024, 16)))
+    x_T = T(normal(64, "upfull/x_T", (2, 4, 256, 16)))
+    zs = torch.stack([T(normal(65, f"upfull/z/{i}", (2, 4, 256, 16))) for i in range(10)])
+    img = pipe(image=cond_img.cuda(), condition_encoder=SparseRangeImageEncoder2(), batch_size=2, num_inference_steps=10,
+               latents=x_T, step_noise=zs, output_type="torch").cpu()
+    e_img = rel_l2(img, T(g["upfull_image_f16"]).float())
+    print(f"full-width upscale pipeline, 10 steps: decoded image rel-L2 {float(e_img):.3e}")
+    assert img.shape == (2, 2, 1024, 64) and e_img < TOL_TRAJ
+    # the latent itself (the discriminating quantity: the decoder's GroupNorms renormalise it)
+    cond = SparseRangeImageEncoder2()(cond_img.cuda()).contiguous()
+    h = pipe._fused.get(unet, vae, pipe.scheduler, 2, 10, 1, False, 8)
+    lat = torch.empty((2, 4, 256, 16), device="cuda")
+    out = torch.empty((2, 2, 1024, 64), device="cuda")
+    pipe._fused.run(h, x_T.cuda().contiguous(), zs.cuda().contiguous(), cond, out, latents_out=lat)
+    e_lat = rel_l2(lat.cpu(), T(g["upfull_latent"]))
+    print(f"full-width upscale pipeline, 10 steps: final latent rel-L2 {float(e_lat):.3e}")
+    assert e_lat < TOL_X0
+
+
 def test_inpainting_mask_path_matches_reference(golden):
     """LDMUpscalePipelineRange with a mask: encode_masked_image (ldm/pipelines.py:406-412) + the conditional loop."""
     from rangeldm_amd.pipelines import LDMUpscalePipelineRange

@@ -299,3 +299,44 @@ def test_50_step_full_width_sampler_matches_reference_loop(golden, sched):
     img = vae.decode(lat / vcfg.scaling_factor).sample
     r = T(g[f"traj_{sched}_image_ref_f16"]).float()
     assert float((img - r).norm() / r.norm()) < 2e-3
+
+
+def test_batch16_goldens_pin_the_oracle(golden):
+    """tests/golden/b16.npz (oracle/validate_batch16_against_reference.py): the reference-composed full-width Model at the headline
+    batch (16 x (5, 256, 16), two timesteps) and 3 DDIM steps of the reference's LDMPipelineRange loop.  Samples never interact,
+    so the oracle is re-checked on the first two of the 16 (the CPU suite's time budget); the GPU suite runs all 16."""
+    from rangeldm_amd.synth import normal
+    g = golden("b16")
+    cfg = UNetConfig(**SGM_SINUSOID)
+    sd = {k: T(v) for k, v in ref_unet_sd(cfg, "ref/full.").items()}
+    x = T(normal(61, "b16/x", (16, 5, 256, 16)))[:2]
+    for t in (480, 37):
+        ref = T(g[f"b16_eps_t{t}_f16"]).float()[:2]
+        eps = o_unet.unet_forward(sd, cfg, x, t)
+        assert float((eps - ref).norm() / ref.norm()) < 1e-3              # (the golden is stored as fp16)
+    unet = o_unet.OracleUNet(cfg, ref_unet_sd(cfg, "ref/full."))
+    x_T = T(normal(62, "b16/x_T", (16, 4, 256, 16)))[:2]
+    lat = o_pipe.ldm_pipeline(None, unet, o_sched.OracleDDIMScheduler(), x_T, 3, pos_encoding=True, decode=False)
+    ref = T(g["b16_ddim3_latent_f16"]).float()[:2]
+    assert float((lat - ref).norm() / ref.norm()) < 1e-3
+
+
+def test_upscale_full_width_golden_pins_the_oracle(golden):
+    """tests/golden/upfull.npz: 10 strided-DDPM steps of the reference's LDMUpscalePipelineRange.__call__ (ldm/pipelines.py:414-519)
+    at batch 2 on the full-width 12-channel UNet with SparseRangeImageEncoder2 and the sgm Decoder (BASELINE config 4)."""
+    from rangeldm_amd.synth import normal
+    g = golden("upfull")
+    cfg = UNetConfig(in_channels=12, **SGM_SINUSOID)
+    unet = o_unet.OracleUNet(cfg, ref_unet_sd(cfg, "ref/up."))
+    vcfg = VAEConfig()
+    vae = o_vae.OracleVAE(vcfg, synth_state_dict(vae_param_shapes(vcfg), prefix="vae."))
+    cond = o_pipe.sparse_range_image_encoder2(T(normal(63, "upfull/cond", (2, 2, 1024, 16))))
+    x_T = T(normal(64, "upfull/x_T", (2, 4, 256, 16)))
+    zs = [T(normal(65, f"upfull/z/{i}", (2, 4, 256, 16))) for i in range(9)] + [None]
+    lat = o_pipe.ldm_pipeline(vae, unet, o_sched.OracleDDPMScheduler(), x_T, 10, pos_encoding=False, step_noise=zs, cond=cond,
+                              decode=False)
+    ref = T(g["upfull_latent"])
+    assert float((lat - ref).norm() / ref.norm()) < 1e-4
+    img = vae.decode(lat / vcfg.scaling_factor).sample
+    r = T(g["upfull_image_f16"]).float()
+    assert float((img - r).norm() / r.norm()) < 2e-3
