@@ -226,7 +226,9 @@ def main():
                  for i in range(n_iter)]
 
     def one_step(i):
-        kw = dict(batch_size=B, num_inference_steps=S, latents=xs[i], output_type="torch")
+        # check=False: the timed loop stays asynchronous; the (sticky) self-check word of the persistent launches is read once,
+        # behind the loop's final synchronisation (pipe._fused.status_all() below)
+        kw = dict(batch_size=B, num_inference_steps=S, latents=xs[i], output_type="torch", check=False)
         if zs is not None:
             kw["step_noise"] = zs
         if conds is not None:
@@ -247,7 +249,25 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
+    pipe._fused.status_all()                             # raises if any call of the loop tripped the persistent launches' self-check
     assert torch.isfinite(out).all()
+    # the exchange step on its own (it is inside the timed region too): one all-gather of a finished batch, HIP events on the
+    # stream it is issued on; and the proof that `world` ranks met -- every rank's id through the same collective path
+    comm = D.comm_info(dev)
+    gather_ms = 0.0
+    if world > 1:
+        img_l = out[rank * B:(rank + 1) * B].contiguous()
+        D.all_gather_images(img_l)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        D.barrier()
+        e0.record()
+        for _ in range(5):
+            D.all_gather_images(img_l)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_ms = D.max_over_ranks(e0.elapsed_time(e1) / 5, dev)
+    assert sorted(comm["ranks_seen"]) == list(range(world)), comm
 
     if rank == 0:
         total_images = world * B * args.steps
@@ -263,6 +283,8 @@ def main():
                                    ", synthetic weights, x_T resident in HBM",
                        "global_batch": B * world, "batch_per_gpu": B, "inference_steps": S, "sampler": args.sampler,
                        "parallelism": f"sample-sharded x{world}, RCCL all-gather of finished images"},
+            # N ranks really met: world / ranks_seen from a collective over the images' own path, the RCCL communicator's view
+            "comm": dict(comm, allgather_ms=round(gather_ms, 4), allgather_bytes_per_rank=int(B * out[0].numel() * 4)),
         }
         if True:                                        # (per-GPU figures, measured on rank 0's GPU for every N)
             h = pipe._fused.get(unet, vae, sched, B, S, 0 if args.sampler == "ddim" else 1, p["pos_encoding"], p["cond_channels"])
@@ -296,6 +318,7 @@ def main():
                 assert torch.isfinite(outp).all()
         print(json.dumps(res), flush=True)
     D.barrier()
+    D.close()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -132,6 +132,9 @@ typedef struct rldm_sampler_config {
     const float* coef;
     /* timesteps, HOST int64 [num_steps] (scheduler.timesteps)                                                 */
     const int64_t* timesteps;
+    /* routing options of THIS sampler's plans: the bits of rldm_debug_set_flags, scoped to the sampler (0: defaults).
+     * 1 << 24 = every layer a launch of its own -- what a host sets for a sampler it knows will share the GPU.         */
+    int32_t plan_flags;
 } rldm_sampler_config;
 
 /* replaces Pipeline.__init__ + the per-call setup of ldm/pipelines.py:329-349; vae may be NULL (pixel-space RangeDM) */
@@ -143,6 +146,14 @@ void rldm_sampler_destroy(rldm_sampler* s);
  * the sampler has no VAE); latents_out: optional device fp32 [B, out_ch, W, H] receiving the final latent. */
 int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, const float* cond, float* images,
                 float* latents_out, void* stream);
+/* The reference's contract is "a correct tensor or an exception" (ldm/pipelines.py:218-222,463-464).  rldm_sample is asynchronous,
+ * so the exception half is this call: it waits for the last rldm_sample of `s` and returns 0 when its outputs are valid.  Non-zero
+ * = the self-check of the call's persistent launches tripped (1: a wait inside a workgroup cluster gave up, i.e. the GPU was shared
+ * with other work; 2: a cluster was spread over several XCDs); the outputs of that call were NaN-marked ON THE DEVICE by the call's
+ * last launch (so an unchecked consumer cannot mistake them for images), rldm_last_error() explains, and the sampler has already
+ * rebuilt its plans as one launch per layer: calling rldm_sample again gives valid images.  The Python shim calls it in every
+ * pipeline __call__ and raises RuntimeError. */
+int rldm_sampler_status(rldm_sampler* s);
 
 /* ---- multi-GPU exchange steps: RCCL over xGMI on the caller's stream (rangeldm_amd/csrc/collective.hip) --
  * One process per GPU.  Rank 0 makes the id and hands its RLDM_UNIQUE_ID_BYTES bytes to the other ranks by any side channel
@@ -365,6 +376,10 @@ int rldm_debug_force_tile(int BM, int BN, int ksplit);
 /* self-check word of the persistent trunk launches (trunk.hip) of the batch-B plan of a UNet: 0 fine or no trunk, 1 a bounded
  * wait gave up, 2 a cluster of workgroups was spread over several XCDs; synchronises the device */
 int rldm_unet_trunk_status(rldm_unet* m, int B);
+/* routing options of the rldm_unet_forward plans of ONE model (the bits of rldm_debug_set_flags, scoped; drops its cached plans) */
+int rldm_unet_set_plan_flags(rldm_unet* m, int flags);
+/* tests: the next rldm_sample of `s` behaves as if a cluster wait had given up in the middle of the run (code 1 or 2) */
+int rldm_debug_inject_trunk_error(rldm_sampler* s, int code);
 int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
 int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLATE builds: [start, end] (100 MHz) of every workgroup of the last conv_stream launch */
 /* routing / ablation switches, read when a plan is built (RLDM_DBG_FLAGS seeds them).  The ones a maintainer may need

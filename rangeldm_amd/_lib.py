@@ -27,7 +27,8 @@ class VAEConfigC(C.Structure):
 
 class SamplerConfigC(C.Structure):
     _fields_ = [("batch", C.c_int32), ("num_steps", C.c_int32), ("mode", C.c_int32), ("pos_encoding", C.c_int32),
-                ("cond_channels", C.c_int32), ("coef", C.POINTER(C.c_float)), ("timesteps", C.POINTER(C.c_int64))]
+                ("cond_channels", C.c_int32), ("coef", C.POINTER(C.c_float)), ("timesteps", C.POINTER(C.c_int64)),
+                ("plan_flags", C.c_int32)]
 
 
 class ConvDescC(C.Structure):
@@ -85,6 +86,9 @@ PROTOTYPES = {
     "rldm_sampler_create": (C.c_int, [_P, _P, C.POINTER(SamplerConfigC), C.POINTER(_P)]),
     "rldm_sampler_destroy": (None, [_P]),
     "rldm_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rldm_sampler_status": (C.c_int, [_P]),
+    "rldm_unet_set_plan_flags": (C.c_int, [_P, C.c_int]),
+    "rldm_debug_inject_trunk_error": (C.c_int, [_P, C.c_int]),
     "rldm_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
     "rldm_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "rldm_comm_destroy": (None, [_P]),

@@ -59,7 +59,11 @@ int bind_rccl() {
         h = dlopen(paths[i], RTLD_NOW | RTLD_GLOBAL);
         if (h) origin = paths[i];
     }
-    RLDM_REQUIRE(h != nullptr, std::string("RCCL not found (librccl.so; set RLDM_RCCL_LIB): ") + (dlerror() ? dlerror() : ""));
+    if (!h) {                                              // (dlerror() returns the message ONCE and clears it)
+        const char* e = dlerror();
+        const std::string why = e ? e : "";
+        RLDM_REQUIRE(false, "RCCL not found (librccl.so; set RLDM_RCCL_LIB): " + why);
+    }
     Rccl r;
     r.handle = h;
     r.origin = origin;

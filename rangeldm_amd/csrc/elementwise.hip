@@ -235,6 +235,22 @@ int launch_stamp(unsigned long long* slot, hipStream_t stream) {
     return 0;
 }
 
+// Same-call failure signal of the persistent launches (trunk.hip): behind a sampler call's last copy, ONE workgroup reads the plan's
+// self-check word and, if a cluster wait gave up during the call, overwrites the head of the call's outputs with NaN -- a host that
+// consumes the images without asking rldm_sampler_status never sees plausible-looking wrong pixels (ldm/pipelines.py:218-222, 463-464:
+// the reference's contract is a correct tensor or an exception).
+__global__ void __launch_bounds__(256) trunk_check_kernel(const int* err, float* a, long long na, float* b, long long nb) {
+    if (*err == 0) return;
+    const float nan = __int_as_float(0x7fc00000);
+    for (long long i = threadIdx.x; i < na && i < 4096; i += 256) a[i] = nan;
+    for (long long i = threadIdx.x; i < nb && i < 4096; i += 256) b[i] = nan;
+}
+int launch_trunk_check(const int* err, float* a, long long na, float* b, long long nb, hipStream_t stream) {
+    hipLaunchKernelGGL(trunk_check_kernel, dim3(1), dim3(256), 0, stream, err, a, a ? na : 0, b, b ? nb : 0);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_step_counter(int* step_ptr, int set_to, int increment, hipStream_t stream) {
     hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, step_ptr, set_to, increment);
     RLDM_HIP_CHECK(hipGetLastError());

@@ -14,6 +14,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -340,6 +341,7 @@ struct KernelStat {
 
 struct Plan {
     int B = 0, W = 0, H = 0;
+    int flags = 0;                 // routing options of THIS plan (the bits of rldm_debug_set_flags), in force while it is built
     DevBuf arena;
     DevBuf tickets;                // split-K arrival counters of every conv in the plan
     std::vector<std::unique_ptr<DevBuf>> trunk_bufs;   // phase records / cluster counters of the persistent trunk launches
@@ -514,6 +516,10 @@ struct ViewPlan {
 
 // routing / ablation switches (rldm_debug_set_flags); RLDM_DBG_FLAGS seeds them for A/B runs of unmodified drivers
 static int g_dbg_flags = getenv("RLDM_DBG_FLAGS") ? atoi(getenv("RLDM_DBG_FLAGS")) : 0;
+// ... and the options of the plan being built (Plan::flags: rldm_sampler_config::plan_flags, rldm_unet_set_plan_flags, the fall-back
+// of a sampler whose persistent launches failed their self-check) -- scoped to that plan, unlike the process-wide word above
+static thread_local int t_plan_flags = 0;
+static inline int dbg() { return g_dbg_flags | t_plan_flags; }
 static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
@@ -711,8 +717,8 @@ struct Builder {
     std::vector<Tensor> deferred;  // releases held back while a segment is open (clusters of different images drift apart)
     // rldm_debug_set_flags: 1 << 24 keeps every phase a launch of its own with the tiles unchanged (tests: identical results);
     // 1 << 25 also gives the convs back their default tiles (A/B runs of the whole feature)
-    static bool trunk_enabled() { return !(g_dbg_flags & ((1 << 24) | (1 << 25))); }
-    static bool trunk_tiles() { return !(g_dbg_flags & (1 << 25)); }
+    static bool trunk_enabled() { return !(dbg() & ((1 << 24) | (1 << 25))); }
+    static bool trunk_tiles() { return !(dbg() & (1 << 25)); }
     void note_launch() {           // every launch that is not a trunk phase closes the open segment
         flush_trunk();
         ++launches;
@@ -721,7 +727,7 @@ struct Builder {
         if (!trunk_open) return 0;
         trunk_open = false;
         int rc = 0;
-        if (!dry && pend.phases.size() == 1 && pend.standalone.size() == 1 && !(g_dbg_flags & (1 << 29))) {
+        if (!dry && pend.phases.size() == 1 && pend.standalone.size() == 1 && !(dbg() & (1 << 29))) {
             plan->ops.push_back(pend.standalone[0]);
         } else if (!dry && !pend.phases.empty()) {
             auto recs = std::make_unique<DevBuf>();
@@ -778,13 +784,13 @@ struct Builder {
         if (!trunk_enabled() || !pre || x.C % 32 != 0 || ranks < 2 || ranks > 16) return false;
         const int HG = (x.C / 8) / ranks, wph = (L + 31) / 32;
         if (HG * wph != 8 || L > 64) return false;                // 8 waves: one query tile per wave
-        if (8 * ranks * ((x.B + 7) / 8) > 256) return false;
+        if (!trunk_grid_fits(ranks, x.B)) return false;
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024;
     }
     // ... of a multi-tile cluster: raw x + statistics (the fold runs inside the phase), two query tiles per wave; 0: not eligible
     int cluster_attention_ranks(const Tensor& x, bool pre) const {
         const int L = x.W * x.H, ranks = cluster_ranks(x.B, x.C, L);
-        if (!cluster_enabled() || (g_dbg_flags & 512) || pre || ranks == 0 || x.P <= 0 || (x.C / 8) % ranks != 0 || L % 32 != 0) return 0;
+        if (!cluster_enabled() || (dbg() & 512) || pre || ranks == 0 || x.P <= 0 || (x.C / 8) % ranks != 0 || L % 32 != 0) return 0;
         const int HG = (x.C / 8) / ranks, wph = L / 32;
         if (HG * wph != 16 || x.C > 512) return 0;                // 8 waves x two query tiles
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024 ? ranks : 0;
@@ -793,6 +799,10 @@ struct Builder {
         static int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
         return std::min(256, cus > 0 ? cus : 256);
     }
+    // a persistent launch spin-waits on its own workgroups: ALL of them must be resident at once, whatever else the plan's owner runs
+    // beside it -- a sampler's other chains (g_concurrent_plans: two 256-workgroup launches could each hold part of the chip and wait
+    // for the rest) and the device's real CU count (partitions / smaller parts)
+    static bool trunk_grid_fits(int ranks, int B) { return 8 * ranks * ((B + 7) / 8) * std::max(1, g_concurrent_plans) <= device_cus(); }
     void trunk_begin(int B, int ranks, int ntile_n = 0, int nwn = 1, int variant = -1) {
         if (nwn == 1) ntile_n = ranks;
         if (variant < 0) variant = nwn == 1 ? 0 : 1;
@@ -813,11 +823,11 @@ struct Builder {
     // rldm_debug_set_flags(1 << 26) keeps these levels as separate launches (A/B runs)
     // (and only for plans that run ALONE on the device: a 256-workgroup launch of one sampler chain and one of another could each
     //  hold part of the chip and wait for the rest -- sampler_build_plans sets g_concurrent_plans to its number of chains)
-    static bool cluster_enabled() { return trunk_enabled() && !(g_dbg_flags & (1 << 26)) && g_concurrent_plans <= 1; }
+    static bool cluster_enabled() { return trunk_enabled() && !(dbg() & (1 << 26)) && g_concurrent_plans <= 1; }
     static int cluster_ranks(int B, int C, int npix) {
         if (C % 64 != 0 || npix % 64 != 0) return 0;
         const int r = (C / 64) * (npix / 64);
-        return (r >= 2 && r <= 16 && npix > 64 && 8 * r * ((B + 7) / 8) <= device_cus()) ? r : 0;
+        return (r >= 2 && r <= 16 && npix > 64 && trunk_grid_fits(r, B)) ? r : 0;
     }
     void trunk_push_attention(const AttnQkvParams& ap, double fl, double by) {
         TrunkPhase ph;
@@ -875,20 +885,20 @@ struct Builder {
     }
     // geometry + channel counts of the route; `epi_res`: the identity residual is added in the epilogue instead of the K loop
     static bool small_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q, bool* epi_res) {
-        if (g_dbg_flags & 256) return false;
+        if (dbg() & 256) return false;
         if ((taps != 9 && taps != 1) || a.stride != 1 || (a.up != 1 && !(a.up == 2 && taps == 9 && !a.gn && R_t == 0)) || a.out_f32_nchw)
             return false;
         // (128-pixel tiles for the 128x8 level are built and tested but lose to the generic kernel there: the separate
         //  GroupNorm pass over a 12 MB tensor costs more than the faster K loop wins; rldm_debug_set_flags(1024) routes them)
         // small images (C2: the 64x4 / 32x2 levels at batch 16), or few pixels in the whole batch (C1 / C3: 128x8 at batch 1,
         // 128x4 at batch 4): the same 64-pixel tiles, more of them per image
-        const bool few_px = (long long)a.x0.B * Wout * Hout <= 4096 && !(g_dbg_flags & 65536);
-        if (taps == 9 && (a.pad_mode != 0 || (Wout * Hout > ((g_dbg_flags & 1024) ? 1024 : 256) && !few_px))) return false;
+        const bool few_px = (long long)a.x0.B * Wout * Hout <= 4096 && !(dbg() & 65536);
+        if (taps == 9 && (a.pad_mode != 0 || (Wout * Hout > ((dbg() & 1024) ? 1024 : 256) && !few_px))) return false;
         // pixel tile: 64; 128 for the 3x3 convs of the 128x8 level (each weight fragment then feeds 4 MFMAs)
         // (32 for 32x1 images: the lowest nuScenes level, which otherwise runs as 8 workgroups of the generic kernel; and for
         //  32x2 images, as two tiles each: twice the workgroups, half the staging / epilogue per workgroup -- level-3 convs
         //  13.4-14.2 -> 13.0 us, +0.5-1 % end to end; rldm_debug_set_flags(524288) keeps the 64-pixel tile: A/B runs, tests)
-        int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : ((Wout * Hout == 32 || (Wout * Hout == 64 && Hout == 2 && !(g_dbg_flags & 524288))) && a.up == 1 ? 32 : 64);
+        int bm = (taps == 9 && Wout * Hout > 256 && !few_px) ? 128 : ((Wout * Hout == 32 || (Wout * Hout == 64 && Hout == 2 && !(dbg() & 524288))) && a.up == 1 ? 32 : 64);
         if (a.own_image) {                      // one tile per image (<= 64 pixels), or not this route
             if (Wout * Hout > 64 || a.up != 1) return false;
             bm = Wout * Hout;
@@ -947,7 +957,7 @@ struct Builder {
     // GroupNorm (+ SiLU) folded into the conv's staging: every 1x1, and the 3x3 convs over ONE input tensor (a concatenated
     // input keeps the separate gn_apply launch; rldm_debug_set_flags(131072) keeps it for every 3x3: A/B runs)
     static bool small_gn_fused(const ConvArgs& a, int taps) {
-        return a.gn != nullptr && (taps == 1 || (!a.x1.valid() && !(g_dbg_flags & 131072)));
+        return a.gn != nullptr && (taps == 1 || (!a.x1.valid() && !(dbg() & 131072)));
     }
     bool small_route(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout) const {
         ConvParams q;
@@ -971,7 +981,7 @@ struct Builder {
         ConvParams p;
         bool epi_res = false;
         RLDM_REQUIRE(small_params(a, Cin_t, R_t, taps, Wout, Hout, &p, &epi_res), "conv " + L->name + ": conv_small route lost");
-        p.dbg = g_dbg_flags;
+        p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         const int BN = small_bn(p, taps, gn_fused, a.own_image);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
@@ -1000,11 +1010,11 @@ struct Builder {
         const int trunk_kind = kind_l < 0 ? -1 : kind_l + (px_t == 32 ? 4 : 0);      // (+4: the 32-pixel instances)
         const int ranks_t = N / 32;
         bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && (px_t == 64 || px_t == 32) && !gn_fused &&
-                        trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && 8 * ranks_t * ((x0.B + 7) / 8) <= 256 &&
+                        trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && trunk_grid_fits(ranks_t, x0.B) &&
                         2 * p.TH * (Cin_t / 8) <= 512 && vts.size() <= 2;
         // (a concatenated input is normalised by a gn_apply phase in front of the conv's -- or the conv stays a launch of its own)
         const bool gn_phase_t = in_trunk && preact && Cin_t <= 512 && (Wout * Hout) % ranks_t == 0 && a.x0.C % 8 == 0 &&
-                                (!a.x1.valid() || a.x1.C % 8 == 0) && !(g_dbg_flags & (1 << 27));
+                                (!a.x1.valid() || a.x1.C % 8 == 0) && !(dbg() & (1 << 27));
         in_trunk = in_trunk && (!preact || gn_phase_t);
         // ... or a phase of a MULTI-TILE cluster (the 64x4 level at batch <= 16): conv_small's default 64-pixel x 64-channel tiles, the
         // consumer-side GroupNorm fold stays inside the phase
@@ -1013,14 +1023,14 @@ struct Builder {
                            (taps == 9 && Cin_t == 384) ? TK_CL_3x3_384 : (taps == 9 && Cin_t == 512) ? TK_CL_3x3_512 :
                            (taps == 1 && Cin_t == 256) ? TK_CL_1x1_256 : -1;
         const int ranks_c = cluster_ranks(x0.B, N, Wout * Hout);
-        const bool in_cluster = !in_trunk && cluster_enabled() && !(g_dbg_flags & 512) && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 &&
+        const bool in_cluster = !in_trunk && cluster_enabled() && !(dbg() & 512) && !a.own_image && kind_c >= 0 && BN == 64 && px_t == 64 &&
                                 (p.up == 1 || p.up == 2) && vts.empty() && ranks_c == (N / 64) * p.tiles_img &&
                                 p.Win * p.up == Wout && p.Hin * p.up == Hout;
         // GroupNorm + SiLU once, ahead of the conv: every channel tile of the conv would otherwise redo it (4-8x at these levels) --
         // as a launch (norm.hip) or, in front of a multi-tile cluster phase, as a phase of the same persistent launch
         if (preact) {
             const bool gn_phase = gn_phase_t || (in_cluster && Cin_t <= 512 && (Wout * Hout) % ranks_c == 0 && a.x0.C % 8 == 0 &&
-                                                 (!a.x1.valid() || a.x1.C % 8 == 0) && !(g_dbg_flags & (1 << 27)));
+                                                 (!a.x1.valid() || a.x1.C % 8 == 0) && !(dbg() & (1 << 27)));
             if (gn_phase_t) trunk_begin(x0.B, ranks_t);
             else if (gn_phase) trunk_begin(x0.B, ranks_c, N / 64, 2);
             else note_launch();
@@ -1172,7 +1182,7 @@ struct Builder {
     // (the 128x8 level) of 16 x 8 pixels x 64 channels
     static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, long long min_blocks,
                                  long long max_blocks, ConvParams* q) {
-        if (g_dbg_flags & 2048) return false;
+        if (dbg() & 2048) return false;
         if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
         if (Wout % TW != 0 || Hout % 8 != 0) return false;
         memset(q, 0, sizeof(*q));
@@ -1200,7 +1210,7 @@ struct Builder {
         q->ksplit = 1;
         if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only its presence matters to the shape check)
         const long long blocks = (long long)q->B * q->tiles_img * (q->N / conv_stream_bn(*q));
-        const bool ok = conv_stream_supported(*q, 9) && ((g_dbg_flags & 4096) || (blocks >= min_blocks && blocks <= max_blocks));
+        const bool ok = conv_stream_supported(*q, 9) && ((dbg() & 4096) || (blocks >= min_blocks && blocks <= max_blocks));
         q->st0 = nullptr;
         return ok;
     }
@@ -1208,7 +1218,7 @@ struct Builder {
         // 256-pixel tiles when they fill the chip; else the 4-k-group instance (it re-streams the weights per 128 pixels:
         // only where its grid is about one or two rounds); else 256-pixel tiles on at least half the chip
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
-        if (!(g_dbg_flags & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
+        if (!(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
         return stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 128, 1ll << 40, q);
     }
 
@@ -1222,7 +1232,7 @@ struct Builder {
             RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
             RLDM_REQUIRE(x0.P > 0 && (!a.x1.valid() || a.x1.P > 0), "conv " + L->name + ": GroupNorm input without statistics");
         }
-        p.dbg = g_dbg_flags;
+        p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         p.ntile_n = N / conv_stream_bn(p);
         Tensor y = make(x0.B, Wout, Hout, N);
@@ -1233,9 +1243,9 @@ struct Builder {
         // full-resolution levels) form a cluster on one XCD; consecutive convs of a level hand over through its L2 -- no end-of-kernel
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
         const int ranks_s = p.tiles_img * p.ntile_n;
-        const bool in_stream_cluster = cluster_enabled() && !(g_dbg_flags & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
-                                       8 * ranks_s * ((x0.B + 7) / 8) <= device_cus() && y.P <= kFoldAboveP &&
-                                       (p.TW == 32 || (g_dbg_flags & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
+        const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
+                                       trunk_grid_fits(ranks_s, x0.B) && y.P <= kFoldAboveP &&
+                                       (p.TW == 32 || (dbg() & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
                                        // 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
         if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW == 32 ? 4 : 2, p.TW == 32 ? 2 : 3);
         else note_launch();
@@ -1309,7 +1319,7 @@ struct Builder {
     // workgroup of every consumer (gn_fold_kernel); RLDM_DBG_FLAGS=262144 keeps the raw partials for A/B runs.
     static constexpr int kFoldAboveP = 32;
     int fold_stats(Tensor& y) {
-        if (!y.valid() || y.P <= kFoldAboveP || (g_dbg_flags & 262144)) return 0;
+        if (!y.valid() || y.P <= kFoldAboveP || (dbg() & 262144)) return 0;
         const size_t raw_off = y.st_off, raw_bytes = y.st_bytes();
         const int rawP = y.P;
         add_stats(y, 2);
@@ -1347,7 +1357,7 @@ struct Builder {
             if ((int)vp->can_emit.size() <= ord) vp->can_emit.resize(ord + 1, 0);
             if ((int)vp->out_c.size() <= ord) vp->out_c.resize(ord + 1, 0);
             vp->out_c[ord] = L->Cout;
-            vp->can_emit[ord] = !(g_dbg_flags & 1048576) && !a.out_f32_nchw && small_route(o, Cin_t, R_t, taps, Wout, Hout) &&
+            vp->can_emit[ord] = !(dbg() & 1048576) && !a.out_f32_nchw && small_route(o, Cin_t, R_t, taps, Wout, Hout) &&
                                 (!a.gn || small_route(oc, Cin_t, R_t, taps, Wout, Hout));
         } else if (vp) {
             if (take_view(a.gn, &view)) {
@@ -1420,7 +1430,7 @@ struct Builder {
         p.N = N;
         p.silu = a.silu;
         p.gn_eps = a.eps;
-        p.dbg = g_dbg_flags;
+        p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         p.gn_groups = a.groups;
         p.ksplit = tc.ksplit;
@@ -1506,7 +1516,14 @@ struct Builder {
 
 // Two passes over the same walk: a dry one sizes the activation arena (and the split-K counters), the real one bakes
 // device pointers into the launch list.
+struct PlanFlagScope {            // t_plan_flags = the plan's options for the duration of its construction
+    int saved;
+    explicit PlanFlagScope(int f) : saved(t_plan_flags) { t_plan_flags = f; }
+    ~PlanFlagScope() { t_plan_flags = saved; }
+};
+
 static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)>& walk, int* launches = nullptr) {
+    PlanFlagScope scope(plan->flags);
     // pass 0 records which GroupNorms could be applied by the producers of their inputs (ViewPlan)
     ViewPlan vplan;
     {
@@ -1521,7 +1538,7 @@ static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)
         // tuning aid (tools/bench_conv.py on a single conv): RLDM_FAKE_VIEWS=n makes every conv that could normalise for a
         // consumer write n copies nobody reads (identity affine, SiLU on), so the epilogue's cost can be stamped alone
         const char* fv = getenv("RLDM_FAKE_VIEWS");
-        if (!fv && (g_dbg_flags & (1 << 22))) fv = "2";     // (tests: the own-image tile + epilogue on single-conv plans)
+        if (!fv && (dbg() & (1 << 22))) fv = "2";     // (tests: the own-image tile + epilogue on single-conv plans)
         if (fv) {
             static std::map<int, std::unique_ptr<NormParams>> dummies;
             for (int ord = 0; ord < (int)vplan.can_emit.size(); ++ord) {
@@ -1630,7 +1647,7 @@ struct NetCommon {
 
     int attention(Builder& b, const std::string& p, Tensor x, Tensor* out) {
         const int Lt = x.W * x.H;
-        if (!(g_dbg_flags & 32768) && x.C % 16 == 0 && x.C <= 512 && Lt <= 1024 && x.P > 0 && x.C % groups == 0) {
+        if (!(dbg() & 32768) && x.C % 16 == 0 && x.C <= 512 && Lt <= 1024 && x.P > 0 && x.C % groups == 0) {
             // GroupNorm + q/k/v projection inside the attention launch: no [B][L][3C] tensor, one launch less
             NormParams* gnp = layers.get_norm(p + ".group_norm");
             b.record_consumer(gnp, x, Tensor(), 0, true, groups, eps);
@@ -1768,6 +1785,8 @@ struct rldm_unet {
     DevBuf temb_scratch;                            // hidden layers of the time-embedding MLP (launch_temb)
     uint64_t generation = 0;                        // bumped whenever the device weights are (re)built: samplers re-plan
     int temb_rows_cap = 0;
+    int plan_flags = 0;                             // rldm_unet_set_plan_flags: routing options of the rldm_unet_forward plans
+    std::map<int, bool> trunk_checked;              // batch -> the plan's persistent launches passed their self-check once
     std::vector<std::string> resnet_order;
 
     int levels() const { return cfg.num_levels; }
@@ -1999,9 +2018,10 @@ static int unet_walk(rldm_unet* m, Builder& b, int B) {
     return 0;
 }
 
-static int unet_make_plan(rldm_unet* m, int B, std::unique_ptr<Plan>* out, int* launches = nullptr) {
+static int unet_make_plan(rldm_unet* m, int B, std::unique_ptr<Plan>* out, int* launches = nullptr, int flags = 0) {
     auto plan = std::make_unique<Plan>();
     plan->B = B; plan->W = m->cfg.sample_w; plan->H = m->cfg.sample_h;
+    plan->flags = flags;
     if (build_plan(plan.get(), m->net.temb_ld, [&](Builder& b) { return unet_walk(m, b, B); }, launches)) return 1;
     *out = std::move(plan);
     return 0;
@@ -2219,9 +2239,10 @@ static int vae_walk_encode(rldm_vae* m, Builder& b, int B, int w, int h) {
     return 0;
 }
 
-static int vae_make_plan(rldm_vae* m, int B, int w, int h, bool enc, std::unique_ptr<Plan>* out) {
+static int vae_make_plan(rldm_vae* m, int B, int w, int h, bool enc, std::unique_ptr<Plan>* out, int flags = 0) {
     auto plan = std::make_unique<Plan>();
     plan->B = B; plan->W = w; plan->H = h;
+    plan->flags = flags;
     if (build_plan(plan.get(), 0, [&](Builder& b) { return enc ? vae_walk_encode(m, b, B, w, h) : vae_walk_decode(m, b, B, w, h); }))
         return 1;
     *out = std::move(plan);
@@ -2258,8 +2279,9 @@ struct SamplerLane {
     bool fused_tail = true;                         // scheduler step in conv_out's epilogue, step index advanced by pack_input
     const float* captured_noise = nullptr;
     long long n_latent = 0, n_image = 0, n_cond = 0;
-    int* check_host = nullptr;                      // pinned: the persistent launches' self-check word of the PREVIOUS call (copied behind
-    bool check_pending = false;                     // its last launch, read at the start of the next call: no synchronisation of its own)
+    int* check_host = nullptr;                      // pinned: the persistent launches' self-check word of the last call (copied behind its
+    bool check_pending = false;                     // last launch; read by rldm_sampler_status, the next call or the destructor)
+    bool call_recorded = false;                     // ev_out has been recorded at least once
     ~SamplerLane() {
         if (check_host) (void)hipHostFree(check_host);
         if (step_graph) (void)hipGraphExecDestroy(step_graph);
@@ -2278,17 +2300,47 @@ struct rldm_sampler {
     hipEvent_t ev_in = nullptr;
     long long n_latent = 0, n_image = 0;            // whole batch
     uint64_t unet_gen = 0, vae_gen = 0;             // generations of the weights the lanes' plans and graphs were built on
-    ~rldm_sampler() {
-        lanes.clear();
-        if (ev_in) (void)hipEventDestroy(ev_in);
+    int plan_flags = 0;                             // routing options of this sampler's plans (rldm_sampler_config::plan_flags | fall-backs)
+    int device = 0;
+    hipStream_t last_caller = nullptr;              // stream of the last rldm_sample call (ordering against other samplers' calls)
+    int inject_error = 0;                           // tests: rldm_debug_inject_trunk_error (one shot)
+    bool has_persistent() const {
+        for (auto& ln : lanes)
+            if (ln->uplan && ln->uplan->trunk_error.p) return true;
+        return false;
     }
+    bool in_flight() const {                        // some lane's last call has not finished
+        for (auto& ln : lanes)
+            if (ln->ev_out && ln->call_recorded && hipEventQuery(ln->ev_out) == hipErrorNotReady) return true;
+        return false;
+    }
+    ~rldm_sampler();
 };
+
+// Live samplers of the process: a sampler whose plans hold persistent launches (trunk.hip: 256 co-resident workgroups that wait for
+// each other) must have the device to itself while they run.  rldm_sample looks for another sampler's call still in flight on a
+// DIFFERENT caller stream (same stream: ordered behind it) and, if there is one, runs -- from then on -- one launch per layer.
+static std::mutex g_samplers_mu;
+static std::vector<rldm_sampler*> g_samplers;
+
+rldm_sampler::~rldm_sampler() {
+    {
+        std::lock_guard<std::mutex> lk(g_samplers_mu);
+        g_samplers.erase(std::remove(g_samplers.begin(), g_samplers.end(), this), g_samplers.end());
+    }
+    for (auto& ln : lanes) {                        // the last call of a run is never followed by another: say so here
+        if (ln->check_pending && ln->ev_out && hipEventSynchronize(ln->ev_out) == hipSuccess && ln->check_host && *ln->check_host != 0)
+            fprintf(stderr, "librangeldm_hip: the LAST rldm_sample call of a sampler failed the self-check of its persistent launches "
+                            "(code %d): its images were NaN-marked\n", *ln->check_host);
+    }
+    lanes.clear();
+    if (ev_in) (void)hipEventDestroy(ev_in);
+}
 
 static DevBuf g_trace;                 // rldm_debug_graph_trace: 4096 timestamps
 static Plan* g_trace_plan = nullptr;
 
 // (rldm_debug_set_flags(1 << 23) at sampler creation keeps the scheduler step and the step counter as launches of their own)
-static bool sampler_fused_tail() { return !(g_dbg_flags & (1 << 23)); }
 
 // x_T (just copied into the lane's x) as conv_in's input: once per call when the steps' pack_input launch is fused into conv_out
 static int sampler_pack_x(rldm_sampler* s, SamplerLane* ln, hipStream_t st) {
@@ -2308,7 +2360,7 @@ static int sampler_pack_x(rldm_sampler* s, SamplerLane* ln, hipStream_t st) {
 static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* noise, hipStream_t st) {
     const bool fused = ln->fused_tail;
     if (fused) ln->uplan->io.sch.noise = noise;        // (the rest of io.sch / io.step_inc: sampler_build_plans)
-    if (g_dbg_flags & 8192) {
+    if ((g_dbg_flags | s->plan_flags) & 8192) {
         if (!g_trace.p) {
             if (g_trace.alloc(4096 * 8)) return 1;
             RLDM_HIP_CHECK(hipMemset(g_trace.p, 0, 4096 * 8));
@@ -2355,8 +2407,9 @@ static int sampler_build_plans(rldm_sampler* s) {
         ln->uplan.reset();
         ln->dplan.reset();
         g_concurrent_plans = (int)s->lanes.size();
-        const int prc = unet_make_plan(unet, ln->nb, &ln->uplan);
+        const int prc = unet_make_plan(unet, ln->nb, &ln->uplan, nullptr, s->plan_flags);
         g_concurrent_plans = 1;
+        ln->check_pending = false;
         if (prc) return 1;
         PlanIO& io = ln->uplan->io;
         io.sample = ln->x.as<float>();
@@ -2369,7 +2422,7 @@ static int sampler_build_plans(rldm_sampler* s) {
         io.step_ptr = ln->step.as<int>();
         io.temb_rows_per_step = 1;
         io.temb_per_sample = 0;
-        ln->fused_tail = sampler_fused_tail();
+        ln->fused_tail = !((g_dbg_flags | s->plan_flags) & (1 << 23));
         if (ln->fused_tail) {
             // the scheduler step rides in conv_out's epilogue, the step index is advanced by pack_input: 2 launches per step fewer
             SchedFuse& f = io.sch;
@@ -2382,14 +2435,14 @@ static int sampler_build_plans(rldm_sampler* s) {
             f.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
             io.step_inc = ln->step.as<int>();
             // ... and the next step's conv_in input: no pack_input launch inside the steps (rldm_debug_set_flags(64) keeps it)
-            if (!(g_dbg_flags & 64) && io.xin && io.sample_scale == 1.f) {
+            if (!((g_dbg_flags | s->plan_flags) & 64) && io.xin && io.sample_scale == 1.f) {
                 io.pack_fused = true;
                 f.pack = io.xin;
                 f.pack_ld = io.xin_ld;
             }
         }
         if (vae) {
-            if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan)) return 1;
+            if (vae_make_plan(vae, ln->nb, W, H, false, &ln->dplan, s->plan_flags)) return 1;
             PlanIO& d = ln->dplan->io;
             d.sample = ln->x.as<float>();
             d.sample_channels = vae->cfg.z_channels;
@@ -2489,8 +2542,9 @@ static int unet_get_plan(rldm_unet* m, int B, Plan** out) {
     auto it = m->plans.find(B);
     if (it == m->plans.end()) {
         std::unique_ptr<Plan> p;
-        if (unet_make_plan(m, B, &p)) return 1;
+        if (unet_make_plan(m, B, &p, nullptr, m->plan_flags)) return 1;
         it = m->plans.emplace(B, std::move(p)).first;
+        m->trunk_checked.erase(B);
     }
     *out = it->second.get();
     return 0;
@@ -2520,7 +2574,24 @@ int rldm_unet_forward(rldm_unet* m, const float* sample, const int64_t* timestep
     plan->io.step_ptr = nullptr;
     plan->io.temb_rows_per_step = nt;
     plan->io.temb_per_sample = (nt == B && B > 1) ? 1 : 0;
-    return plan->run(st);
+    if (plan->run(st)) return 1;
+    if (plan->trunk_error.p && !m->trunk_checked[B]) {
+        // first run of a plan with persistent launches: read their self-check word before anybody uses `out` (the sampler does the same
+        // at its warm-up step); if it is set, this model's plans are rebuilt as one launch per layer and the forward runs again
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        int terr = 0;
+        RLDM_HIP_CHECK(hipMemcpy(&terr, plan->trunk_error.p, 4, hipMemcpyDeviceToHost));
+        if (terr != 0) {
+            RLDM_REQUIRE(!((g_dbg_flags | m->plan_flags) & (1 << 24)), "internal: self-check word set without persistent launches");
+            fprintf(stderr, "librangeldm_hip: persistent launches of rldm_unet_forward failed their self-check (code %d); this model runs "
+                            "one launch per layer from here on\n", terr);
+            m->plan_flags |= (1 << 24);
+            m->plans.clear();
+            return rldm_unet_forward(m, sample, timesteps, nt, B, out, stream);
+        }
+        m->trunk_checked[B] = true;
+    }
+    return 0;
 }
 
 double rldm_unet_flops(rldm_unet* m, int B) {
@@ -2541,8 +2612,16 @@ int rldm_unet_trunk_status(rldm_unet* m, int B) {
     return terr;
 }
 
+int rldm_unet_set_plan_flags(rldm_unet* m, int flags) {
+    RLDM_REQUIRE(m, "null argument");
+    if (flags != m->plan_flags) m->plans.clear();
+    m->plan_flags = flags;
+    return 0;
+}
+
 int rldm_unet_num_launches(rldm_unet* m, int B) {
     if (!m || !m->params.finalized) return -1;
+    PlanFlagScope scope(m->plan_flags);
     Plan tmp;
     ViewPlan vplan;                     // same three-pass scheme as build_plan, without the real pass
     {
@@ -2692,6 +2771,8 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
     s->cfg = *cfg;
     s->cfg.coef = nullptr;
     s->cfg.timesteps = nullptr;
+    s->plan_flags = cfg->plan_flags;
+    RLDM_HIP_CHECK(hipGetDevice(&s->device));
     const int B = cfg->batch, W = uc.sample_w, H = uc.sample_h;
     const long long per_latent = (long long)uc.out_channels * W * H;
     const long long per_cond = (long long)cfg->cond_channels * W * H;
@@ -2723,10 +2804,48 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
         s->lanes.push_back(std::move(ln));
     }
     if (sampler_build_plans(s.get())) return 1;
+    {
+        std::lock_guard<std::mutex> lk(g_samplers_mu);
+        g_samplers.push_back(s.get());
+    }
     *out = s.release();
     return 0;
 }
 void rldm_sampler_destroy(rldm_sampler* s) { delete s; }
+
+// this sampler's plans again, every layer a launch of its own (same kernels, same tiles: rldm_debug_set_flags(1 << 24), scoped to it)
+static int sampler_drop_persistent(rldm_sampler* s, const char* why, int code) {
+    fprintf(stderr, "librangeldm_hip: %s (code %d); this sampler runs one launch per layer from here on\n", why, code);
+    s->plan_flags |= (1 << 24);
+    return sampler_build_plans(s);
+}
+
+// Self-check of the LAST rldm_sample call: waits for the call (the lanes' final events), then reads the word its persistent launches
+// left.  0: the call's outputs are valid.  Non-zero (1 a cluster wait gave up, 2 a cluster was spread over several XCDs): the outputs
+// were NaN-marked, rldm_last_error says why, and the sampler has already rebuilt itself without persistent launches -- call again.
+int rldm_sampler_status(rldm_sampler* s) {
+    RLDM_REQUIRE(s, "null argument");
+    int code = 0;
+    for (auto& lnp : s->lanes) {
+        SamplerLane* ln = lnp.get();
+        if (!ln->check_pending) continue;
+        RLDM_HIP_CHECK(hipEventSynchronize(ln->ev_out));
+        ln->check_pending = false;
+        if (*ln->check_host != 0) code = *ln->check_host;
+    }
+    if (code == 0) return 0;
+    if (sampler_drop_persistent(s, "a persistent launch of the last rldm_sample call failed its self-check", code)) return -1;
+    set_error("a persistent launch of this rldm_sample call failed its self-check (code " + std::to_string(code) +
+              ": 1 a cluster wait gave up -- the GPU was shared with other work --, 2 a cluster was spread over several XCDs); the call's "
+              "outputs are invalid and NaN-marked; the sampler now runs one launch per layer: call rldm_sample again");
+    return code;
+}
+
+int rldm_debug_inject_trunk_error(rldm_sampler* s, int code) {
+    RLDM_REQUIRE(s, "null argument");
+    s->inject_error = code;
+    return 0;
+}
 
 int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, const float* cond, float* images,
                 float* latents_out, void* stream) {
@@ -2739,17 +2858,32 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
         (s->vae && !s->vae->params.finalized)) {
         if (sampler_build_plans(s)) return 1;       // the models were reloaded since the graphs were captured
     }
-    // the previous call's self-check of the persistent launches (a cluster wait that gave up: e.g. another stream held part of the chip
-    // -- INTEGRATION.md section 5): its images were wrong, and this call says so
+    // a host that did not ask rldm_sampler_status about the previous call learns here that it failed (its outputs were NaN-marked);
+    // the sampler has rebuilt itself without persistent launches by the time this returns, so the retry is valid
     for (auto& lnp : s->lanes) {
         SamplerLane* ln = lnp.get();
         if (ln->check_pending && hipEventQuery(ln->ev_out) == hipSuccess) {
             ln->check_pending = false;
-            RLDM_REQUIRE(*ln->check_host == 0, "a persistent launch of the PREVIOUS rldm_sample call failed its self-check (code " +
-                                                   std::to_string(*ln->check_host) + "): its images are invalid; set RLDM_DBG_FLAGS=67108864 "
-                                                   "(or 16777216) if this GPU is shared with other streams");
+            const int code = *ln->check_host;
+            if (code != 0) {
+                if (sampler_drop_persistent(s, "a persistent launch of the PREVIOUS rldm_sample call failed its self-check", code)) return 1;
+                RLDM_REQUIRE(false, "a persistent launch of the PREVIOUS rldm_sample call failed its self-check (code " + std::to_string(code) +
+                                        "): its outputs were invalid (NaN-marked); the sampler now runs one launch per layer: call again");
+            }
         }
     }
+    // persistent launches need the device to themselves: another sampler's call still in flight on a different stream ends them here
+    if (s->has_persistent()) {
+        bool shared = false;
+        {
+            std::lock_guard<std::mutex> lk(g_samplers_mu);
+            for (rldm_sampler* o : g_samplers)
+                if (o != s && o->device == s->device && o->last_caller != caller && o->in_flight()) shared = true;
+        }
+        if (shared && sampler_drop_persistent(s, "another sampler is running on this device on a different stream: persistent launches "
+                                                 "need the chip to themselves", 0)) return 1;
+    }
+    s->last_caller = caller;
     RLDM_HIP_CHECK(hipEventRecord(s->ev_in, caller));
     // per lane: inputs, (first call) eager warm step + graph capture
     for (auto& lnp : s->lanes) {
@@ -2771,14 +2905,12 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             if (ln->uplan->trunk_error.p) {         // the persistent trunk's self-check (a wait that gave up / a cluster off its XCD)
                 int terr = 0;
                 RLDM_HIP_CHECK(hipMemcpy(&terr, ln->uplan->trunk_error.p, 4, hipMemcpyDeviceToHost));
-                if (getenv("RLDM_TEST_TRUNK_FAIL") && !(g_dbg_flags & (1 << 24))) terr = 2;      // (tests: the fall-back path below)
-                if (terr != 0 && !(g_dbg_flags & (1 << 24))) {
+                const bool off = ((g_dbg_flags | s->plan_flags) & (1 << 24)) != 0;
+                if (getenv("RLDM_TEST_TRUNK_FAIL") && !off) terr = 2;      // (tests: the fall-back path below)
+                if (terr != 0 && !off) {
                     // the clusters' only assumption (an image's workgroups share an XCD; all of them resident) does not hold on this
-                    // device / driver: this process runs every layer as a launch of its own from here on (same kernels, same tiles)
-                    fprintf(stderr, "librangeldm_hip: persistent launches failed their self-check (code %d); falling back to one launch "
-                                    "per layer (RLDM_DBG_FLAGS=16777216)\n", terr);
-                    g_dbg_flags |= (1 << 24);
-                    if (sampler_build_plans(s)) return 1;
+                    // device / driver / right now: THIS sampler runs every layer as a launch of its own from here on (same kernels, tiles)
+                    if (sampler_drop_persistent(s, "persistent launches failed their self-check at the warm-up step", terr)) return 1;
                     return rldm_sample(s, x_T, step_noise, cond, images, latents_out, stream);
                 }
                 RLDM_REQUIRE(terr == 0, "persistent trunk launch failed its self-check (code " + std::to_string(terr) +
@@ -2809,6 +2941,11 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             if (sampler_pack_x(s, ln, st)) return 1;
         }
     }
+    if (s->inject_error) {                          // tests: a cluster wait that gave up in the middle of a run
+        for (auto& lnp : s->lanes)
+            if (lnp->uplan->trunk_error.p && launch_step_counter(lnp->uplan->trunk_error.as<int>(), s->inject_error, 0, lnp->stream)) return 1;
+        s->inject_error = 0;
+    }
     // the chains: step-major so every stream always has work queued
     for (int i = 0; i < s->cfg.num_steps; i += s->lanes[0]->graph_steps)
         for (auto& lnp : s->lanes) RLDM_HIP_CHECK(hipGraphLaunch(lnp->step_graph, lnp->stream));
@@ -2828,14 +2965,20 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
             }
         }
         if (ln->uplan->trunk_error.p) {
+            // same-call failure signal: the call's outputs are NaN-marked on the device if a persistent launch gave up a wait, and
+            // the word travels to pinned memory for rldm_sampler_status (no host synchronisation here)
             if (!ln->check_host) {
                 RLDM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln->check_host), 64, hipHostMallocDefault));
                 *ln->check_host = 0;
             }
+            float* img_l = images ? images + (s->vae ? (size_t)ln->b0 * (ln->n_image / ln->nb) : lat_off) : nullptr;
+            if (launch_trunk_check(ln->uplan->trunk_error.as<int>(), img_l, s->vae ? ln->n_image : ln->n_latent,
+                                   latents_out ? latents_out + lat_off : nullptr, ln->n_latent, st)) return 1;
             RLDM_HIP_CHECK(hipMemcpyAsync(ln->check_host, ln->uplan->trunk_error.p, 4, hipMemcpyDeviceToHost, st));
             ln->check_pending = true;
         }
         RLDM_HIP_CHECK(hipEventRecord(ln->ev_out, st));
+        ln->call_recorded = true;
         RLDM_HIP_CHECK(hipStreamWaitEvent(caller, ln->ev_out, 0));
     }
     return 0;

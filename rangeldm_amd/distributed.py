@@ -77,12 +77,14 @@ class Communicator:
         return buf.value.decode()
 
     def all_gather_images(self, local_images):
+        """fp32 on the wire (the C ABI moves floats: rldm_allgather_images); other dtypes are cast for the transfer and cast back, so
+        the result has the input's dtype like the torch.distributed path."""
         x = local_images.contiguous().float()
         out = torch.empty((self.world * x.shape[0], *x.shape[1:]), dtype=torch.float32, device=x.device)
         self._lib.check(self._lib.lib().rldm_allgather_images(self._h, self._C.c_void_p(x.data_ptr()),
                                                               self._C.c_void_p(out.data_ptr()), x.numel(),
                                                               self._lib.stream_ptr(x.device)), "rldm_allgather_images")
-        return out
+        return out if local_images.dtype == torch.float32 else out.to(local_images.dtype)
 
     def all_reduce_grads(self, flat, average=True):
         """in place over a contiguous fp32 slice of the flat gradient buffer (one bucket)"""
@@ -92,44 +94,123 @@ class Communicator:
                         "rldm_allreduce_grads")
         return flat
 
+    def info(self):
+        """(rank, world, origin of the RCCL copy) as the communicator itself reports them (rldm_comm_info)."""
+        C = self._C
+        r, w, buf = C.c_int(-1), C.c_int(-1), C.create_string_buffer(256)
+        self._lib.check(self._lib.lib().rldm_comm_info(self._h, C.byref(r), C.byref(w), buf, 256), "rldm_comm_info")
+        return r.value, w.value, buf.value.decode()
+
+    def close(self):
+        """Destroy the communicator NOW (drivers call this before they exit: at interpreter shutdown torch may already have torn
+        down RCCL / HIP under a destructor)."""
+        if getattr(self, "_h", None):
+            self._lib.lib().rldm_comm_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                self._lib.lib().rldm_comm_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 
 
 _COMM = None
+_COMM_FAILED = None
+
+
+def _env_world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def collective_choice():
+    """"cabi" (rldm_allgather_images / rldm_allreduce_grads: RCCL on the CURRENT stream, i.e. stream-ordered behind the sampler's /
+    trainer's launches with no hand-off to a communication stream) or "torch" (torch.distributed).  Default: cabi whenever more
+    than one rank drives real GPUs over RCCL; torch for one rank, CPU tensors and the gloo rehearsals (RCCL refuses two ranks on
+    one device).  RLDM_COLLECTIVE=cabi|torch overrides."""
+    env = os.environ.get("RLDM_COLLECTIVE")
+    if env in ("cabi", "torch"):
+        return env
+    if not torch.cuda.is_available() or _env_world() <= 1:
+        return "torch"
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+        return "torch"
+    return "cabi"
 
 
 def cabi_communicator():
-    """The process-wide Communicator when RLDM_COLLECTIVE=cabi asks for the C-ABI path (default: torch.distributed, whose
-    "nccl" backend is the same RCCL).  Both move the same bytes with the same collective; the C-ABI one is what a non-Python
-    host uses and runs on the sampler's stream without torch's NCCL stream hand-off."""
-    global _COMM
-    if os.environ.get("RLDM_COLLECTIVE", "torch") != "cabi" or not torch.cuda.is_available():
+    """The process-wide Communicator of the C-ABI path, or None when collective_choice() says torch.  Works without a process
+    group too (RANK / WORLD_SIZE / MASTER_* from the environment: the id travels through a TCPStore).  If RCCL cannot be bound or
+    bootstrapped the failure is printed once and the torch.distributed path is used (`comm_info()["collective"]` says which)."""
+    global _COMM, _COMM_FAILED
+    if collective_choice() != "cabi" or not torch.cuda.is_available() or _COMM_FAILED:
         return None
     if _COMM is None:
-        _COMM = Communicator()
+        try:
+            _COMM = Communicator()
+        except Exception as e:                          # (a missing librccl, a bootstrap error: never silently, never fatally)
+            _COMM_FAILED = str(e)
+            import sys
+            print(f"rangeldm_amd.distributed: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            if os.environ.get("RLDM_COLLECTIVE") == "cabi":
+                raise
+            return None
     return _COMM
+
+
+def close():
+    """Tear the C-ABI communicator down explicitly (see Communicator.close)."""
+    global _COMM
+    if _COMM is not None:
+        _COMM.close()
+        _COMM = None
 
 
 def all_gather_images(local_images, world=None):
     """All-gather finished (B_local, C, W, H) tensors along dim 0; every rank gets the full batch in rank order.
     One collective per batch: 8 x 1 MiB for BASELINE config 2/3 -- latency-bound, negligible vs the sampling time."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _env_world() == 1:
         return local_images
     comm = cabi_communicator() if local_images.is_cuda else None
     if comm is not None:
         return comm.all_gather_images(local_images)
+    if not dist.is_available() or not dist.is_initialized():
+        raise RuntimeError("all_gather_images: WORLD_SIZE > 1 but neither a torch.distributed process group nor the C-ABI "
+                           "communicator is available")
     world = dist.get_world_size()
     local_images = local_images.contiguous()
     out = torch.empty((world * local_images.shape[0], *local_images.shape[1:]), dtype=local_images.dtype,
                       device=local_images.device)
     dist.all_gather_into_tensor(out, local_images)
     return out
+
+
+def comm_info(device=None):
+    """What a scaling record needs to prove that N ranks really met: the world the process group reports, the ranks that answered
+    a collective (every rank contributes its id to an all-gather through the SAME path the images take; `ranks_seen` lists them),
+    which path that was, and -- C-ABI path -- rank / world / library origin as the RCCL communicator itself reports them."""
+    world = _env_world()
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else int(os.environ.get("RANK", "0"))
+    info = {"world": world, "rank": rank, "backend": dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None,
+            "collective": "none" if world == 1 else "torch", "ranks_seen": [rank]}
+    if world == 1:
+        return info
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                                             else torch.device("cpu"))
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        dev_t = torch.device("cpu")
+    else:
+        dev_t = dev
+    mine = torch.full((1, 1), float(rank), dtype=torch.float32, device=dev_t)
+    comm = cabi_communicator() if mine.is_cuda else None
+    got = all_gather_images(mine)
+    info["ranks_seen"] = [int(v) for v in got.flatten().tolist()]
+    if comm is not None:
+        r, w, origin = comm.info()
+        info.update(collective="cabi", rccl_rank=r, rccl_world=w, rank0_rccl_origin=origin)
+    elif _COMM_FAILED:
+        info["cabi_unavailable"] = _COMM_FAILED
+    return info
 
 
 def barrier():

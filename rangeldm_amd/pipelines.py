@@ -56,11 +56,26 @@ class _FusedSampler:
         self._cache[key] = (h, unet, vae)
         return h
 
-    def run(self, h, x_T, step_noise, cond, out, latents_out=None):
+    def run(self, h, x_T, step_noise, cond, out, latents_out=None, check=True):
+        """One rldm_sample call.  `check` (default): wait for it and raise RuntimeError if the self-check of its persistent
+        launches tripped -- the reference's contract is a correct tensor or an exception (ldm/pipelines.py:218-222,463-464);
+        the failed call's outputs are NaN-marked on the device either way, and the sampler has then already rebuilt itself as
+        one launch per layer, so calling again works.  check=False keeps the call asynchronous (throughput loops that ask
+        `status(h)` themselves before they use the images)."""
         def p(t):
             return C.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(_lib.lib().rldm_sample(h, p(x_T), p(step_noise), p(cond), p(out), p(latents_out),
                                           _lib.stream_ptr(x_T.device)), "rldm_sample")
+        if check:
+            self.status(h)
+
+    def status(self, h):
+        """rldm_sampler_status: waits for the sampler's last call; raises if its outputs are invalid."""
+        _lib.check(_lib.lib().rldm_sampler_status(h), "rldm_sample (self-check of the persistent launches)")
+
+    def status_all(self):
+        for ent in self._cache.values():
+            self.status(ent[0])
 
     def __del__(self):
         try:
@@ -146,7 +161,7 @@ class DDPMPipelineRange(_PipelineBase):
 
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, num_inference_steps=1000, output_type="torch", return_dict=True,
-                 fused=True, latents=None, step_noise=None):
+                 fused=True, latents=None, step_noise=None, **kwargs):
         """`latents` / `step_noise` (not in the reference signature): x_T and the [steps][B, C, W, H] ancestral noise
         already on the device, instead of drawing them from `generator`."""
         cfg = self.unet.config
@@ -165,7 +180,7 @@ class DDPMPipelineRange(_PipelineBase):
             zs = zs.to(self.device, torch.float32).contiguous()
             h = self._fused.get(self.unet, None, self.scheduler, batch_size, num_inference_steps, 1, False, 0)
             out = torch.empty_like(image)
-            self._fused.run(h, image.contiguous(), zs, None, out)
+            self._fused.run(h, image.contiguous(), zs, None, out, check=kwargs.get("check", True))
             image = out
         else:
             for i, t in enumerate(self.progress_bar(self.scheduler.timesteps)):
@@ -186,7 +201,7 @@ class DDIMPipelineRange(_PipelineBase):
 
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, eta=0.0, num_inference_steps=50, use_clipped_model_output=None,
-                 output_type="torch", return_dict=True, fused=True, latents=None):
+                 output_type="torch", return_dict=True, fused=True, latents=None, **kwargs):
         """`latents` (not in the reference signature): x_T already resident on the device, instead of drawing it."""
         cfg = self.unet.config
         ss = cfg.sample_size if not isinstance(cfg.sample_size, int) else (cfg.sample_size, cfg.sample_size)
@@ -206,7 +221,7 @@ class DDIMPipelineRange(_PipelineBase):
             h = self._fused.get(self.unet, None, self.scheduler, batch_size, num_inference_steps, 0,
                                 self.pos_encoding, 0, eta)
             out = torch.empty_like(image)
-            self._fused.run(h, image.contiguous(), None, None, out)
+            self._fused.run(h, image.contiguous(), None, None, out, check=kwargs.get("check", True))
             image = out
         else:
             if self.pos_encoding:
@@ -256,7 +271,7 @@ class LDMPipelineRange(_PipelineBase):
             f = self.vae._cfg.downscale
             image = torch.empty((batch_size, self.vae._cfg.out_channels, shape[2] * f, shape[3] * f),
                                 device=self.device, dtype=torch.float32)
-            self._fused.run(h, latents.float().contiguous(), zs, None, image)
+            self._fused.run(h, latents.float().contiguous(), zs, None, image, check=kwargs.get("check", True))
             return self._finish(image, output_type, return_dict)
         extra_kwargs = {"eta": eta} if accepts_eta else {}
         if self.pos_encoding:
@@ -339,7 +354,7 @@ class LDMUpscalePipelineRange(_PipelineBase):
             f = self.vae._cfg.downscale
             out = torch.empty((batch_size, self.vae._cfg.out_channels, shape[2] * f, shape[3] * f),
                               device=self.device, dtype=torch.float32)
-            self._fused.run(h, latents.float().contiguous(), zs, image.float().contiguous(), out)
+            self._fused.run(h, latents.float().contiguous(), zs, image.float().contiguous(), out, check=kwargs.get("check", True))
             return self._finish(out, output_type, return_dict)
         extra_kwargs = {"eta": eta} if accepts_eta else {}
         for i, t in enumerate(self.progress_bar(self.scheduler.timesteps)):

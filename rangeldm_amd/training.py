@@ -210,14 +210,18 @@ class UNetTrainer:
     def save_state(self, path):
         """`accelerator.save_state(checkpoint-N)` counterpart (ldm/train_unconditional.py:560-584): everything a resumed run
         needs besides the weights -- AdamW moments, EMA copy, step counter (lr schedule, bias corrections, EMA warm-up)."""
+        # inside an accumulation window the partially summed gradient buffer is part of the state (the next optimizer step divides by
+        # the window length whatever the buffer holds)
         torch.save({"params": self.params.cpu(), "ema": None if self.ema is None else self.ema.cpu(),
                     "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "global_step": self.global_step,
-                    "micro": self._micro, "names": list(self.names), "hp": dict(self.hp)}, path)
+                    "micro": self._micro, "grads": self.grads.cpu() if self._micro else None,
+                    "names": list(self.names), "hp": {k: (v if isinstance(v, (int, float, str, bool, type(None))) else list(v))
+                                                      for k, v in self.hp.items()}}, path)
 
     def load_state(self, path):
         """`accelerator.load_state` (resume_from_checkpoint, ldm/train_unconditional.py:449-463): restores the buffers IN PLACE
         (captured step graphs keep pointing at them) and resynchronises the device-side step counter."""
-        st = torch.load(path, map_location="cpu", weights_only=False)
+        st = torch.load(path, map_location="cpu", weights_only=True)       # tensors, lists, dicts, numbers: nothing to unpickle
         if list(st["names"]) != list(self.names):
             raise RuntimeError("training state was saved for a different parameter layout")
         self.params.copy_(st["params"])
@@ -230,6 +234,11 @@ class UNetTrainer:
         self.global_step = int(st["global_step"])
         self._micro = int(st.get("micro", 0))
         self.grads.zero_()
+        if self._micro:
+            if st.get("grads") is None:                  # (a state written before the gradient buffer was saved: restart the window)
+                self._micro = 0
+            else:
+                self.grads.copy_(st["grads"])
         self._step_dev.fill_(self.global_step)
         self._step_dev_mirror = self.global_step
         self.repack()

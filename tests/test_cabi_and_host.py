@@ -41,6 +41,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.PackDescC) == 48 and _lib.PackDescC.N.offset == 32
     assert ctypes.sizeof(_lib.LidarConfigC) == 4 * (7 + 3 + 6 + 1)
     assert _lib.SamplerConfigC.coef.offset == 24 and _lib.SamplerConfigC.timesteps.offset == 32
+    assert _lib.SamplerConfigC.plan_flags.offset == 40 and ctypes.sizeof(_lib.SamplerConfigC) == 48
 
 
 def test_product_has_no_cpu_fallback():

@@ -43,9 +43,10 @@ def _worker(rank, world, port, q):
     xs = torch.from_numpy(np.stack([latent_noise(7, 100 + j, shape) for j in range(lo, hi)]))
     strong = D.all_gather_images(_fake_sampler(xs))
     t = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    info = D.comm_info(torch.device("cpu"))              # the `comm` block of the bench line: every rank answered a collective
     D.barrier()
     if rank == 0:
-        q.put((full.numpy(), t, strong.numpy()))
+        q.put((full.numpy(), t, strong.numpy(), info))
     dist.destroy_process_group()
 
 
@@ -56,11 +57,12 @@ def test_two_rank_sharding_and_allgather():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, tmax, strong = q.get(timeout=120)
+    full, tmax, strong, info = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert tmax == 2.0
+    assert info["world"] == 2 and info["ranks_seen"] == [0, 1] and info["backend"] == "gloo" and info["collective"] == "torch"
     # every rank holds all images, ordered by GLOBAL sample index (ldm/inference.py:174-183 file-index arithmetic):
     # iteration i, rank r, slot j -> index (r + world*i)*B + j
     B, shape = 3, (4, 8, 2)

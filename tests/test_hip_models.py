@@ -368,6 +368,76 @@ def test_sampler_falls_back_when_the_cluster_self_check_fails(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_mid_run_cluster_failure_is_reported_by_the_same_call():
+    """A cluster wait that gives up in the MIDDLE of a run (not at the warm-up step) used to cost one call's images silently.  Now the
+    call that tripped it raises (rldm_sampler_status, asked by every pipeline __call__), its outputs are NaN-marked on the device by the
+    call's last launch, and the sampler has rebuilt itself as one launch per layer -- same kernels, same tiles, so the retry returns
+    exactly the images of a healthy run.  The failure is injected (rldm_debug_inject_trunk_error: the self-check word is set on the
+    sampler's stream ahead of the step graphs, as a timed-out poll would)."""
+    from rangeldm_amd import _lib
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    cfg = UNetConfig()
+    x_T = T(normal(23, "xT", (16, 4, 256, 16)))
+    unet, _ = hip_unet(cfg, "")
+    vae, _, _ = hip_vae()
+    pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=True)
+    kw = dict(batch_size=16, num_inference_steps=2, latents=x_T, output_type="torch")
+    good = pipe(**kw).cpu()
+    assert torch.isfinite(good).all()
+    h = pipe._fused.get(unet, vae, pipe.scheduler, 16, 2, 0, True, 0)
+    # (1) the synchronous contract: the failing call raises
+    _lib.check(_lib.lib().rldm_debug_inject_trunk_error(h, 1), "inject")
+    with pytest.raises(RuntimeError, match="self-check"):
+        pipe(**kw)
+    again = pipe(**kw).cpu()                               # the sampler fell back by itself: one launch per layer, identical images
+    assert torch.equal(again, good)
+    # (2) an asynchronous caller: the outputs of the failed call are NaN-marked, status() says why
+    unet2, _ = hip_unet(cfg, "")
+    pipe2 = LDMPipelineRange(vae=vae, unet=unet2, scheduler=DDIMSchedulerHIP(), pos_encoding=True)
+    assert torch.equal(pipe2(**kw).cpu(), good)
+    h2 = pipe2._fused.get(unet2, vae, pipe2.scheduler, 16, 2, 0, True, 0)
+    _lib.check(_lib.lib().rldm_debug_inject_trunk_error(h2, 1), "inject")
+    bad = pipe2(check=False, **kw)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad.flatten()[:64]).all()
+    with pytest.raises(RuntimeError, match="self-check"):
+        pipe2._fused.status(h2)
+    assert torch.equal(pipe2(**kw).cpu(), good)
+    # the fall-back is scoped to the sampler that failed: a fresh one still builds its persistent launches
+    unet3, _ = hip_unet(cfg, "")
+    assert unet3.num_launches(16) <= 40
+
+
+def test_two_samplers_on_two_streams_do_not_share_persistent_launches():
+    """Persistent launches need the chip to themselves (256 co-resident workgroups waiting for each other).  A second sampler whose call
+    arrives on ANOTHER stream while the first one's is still in flight drops its persistent launches by itself (no debug flag for the
+    host to know about); both calls return the images of the serial runs."""
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    cfg = UNetConfig()
+    vae, _, _ = hip_vae()
+    xa = T(normal(31, "xTa", (16, 4, 256, 16)))
+    xb = T(normal(32, "xTb", (16, 4, 256, 16)))
+    pipes = []
+    for _ in range(2):
+        unet, _sd = hip_unet(cfg, "")
+        pipes.append(LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=True))
+    kw = dict(batch_size=16, num_inference_steps=4, output_type="torch")
+    ref_a = pipes[0](latents=xa, **kw).cpu()               # serial (each has the device to itself: persistent launches on)
+    ref_b = pipes[1](latents=xb, **kw).cpu()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        a = pipes[0](latents=xa, check=False, **kw)
+    with torch.cuda.stream(s2):
+        b = pipes[1](latents=xb, check=False, **kw)          # sees pipes[0]'s call in flight on s1: one launch per layer from here on
+    torch.cuda.synchronize()
+    for p in pipes:
+        p._fused.status_all()
+    assert torch.equal(a.cpu(), ref_a) and torch.equal(b.cpu(), ref_b)
+
+
 def test_concurrent_chains_match_single_chain(monkeypatch):
     """The sampler splits a batch >= 32 into chains of >= 16 samples on separate streams (sampler_num_lanes, runtime.hip);
     RLDM_LANES forces the split at a small batch here.  Samples never interact, so the chains must reproduce the
