@@ -620,7 +620,9 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         const int next_g = __builtin_amdgcn_readlane((int)nr, TW_G);
         const unsigned long long wp = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)nr, TW_WPK + 1) << 32) |
                                       (unsigned)__builtin_amdgcn_readlane((int)nr, TW_WPK);
-        const unsigned char* next_w = reinterpret_cast<const unsigned char*>(wp) +
+        // (a GLOBAL-address-space pointer: built from the integer alone it would be a flat one, and flat loads also count on lgkmcnt)
+        typedef __attribute__((address_space(1))) const unsigned char* global_bytes_t;
+        const unsigned char* next_w = (const unsigned char*)(global_bytes_t)wp +
                                       ((size_t)seam.next_rank_kg * (unsigned)__builtin_amdgcn_readlane((int)nr, TW_NMINE)) * 1024;
 #pragma unroll
         for (int j = 0; j < PF; ++j)

@@ -251,6 +251,22 @@ int launch_trunk_check(const int* err, float* a, long long na, float* b, long lo
     return 0;
 }
 
+// tuning aid (rldm_bench_conv, RLDM_BENCH_THRASH_MB): sweep a buffer so that the NEXT launch finds its weights and activations
+// out of the L2s (64-128 MB: still in the Infinity Cache; > 256 MB: out of that as well)
+__global__ void __launch_bounds__(256) thrash_kernel(const float4* buf, long long n4, float* sink) {
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = buf[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) *sink = acc;
+}
+int launch_thrash(const void* buf, size_t bytes, float* sink, hipStream_t stream) {
+    hipLaunchKernelGGL(thrash_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<const float4*>(buf), (long long)(bytes / 16), sink);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_step_counter(int* step_ptr, int set_to, int increment, hipStream_t stream) {
     hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, step_ptr, set_to, increment);
     RLDM_HIP_CHECK(hipGetLastError());

@@ -304,6 +304,7 @@ int launch_add_noise(const float* x0, const float* noise, const float* sa, const
 int launch_diag_gaussian(const float* moments, const float* noise, float scale, int B, int z, int spatial, float* out,
                          hipStream_t stream);
 int launch_step_counter(int* step_ptr, int set_to, int increment, hipStream_t stream);
+int launch_thrash(const void* buf, size_t bytes, float* sink, hipStream_t stream);   // tuning aid: sweep a buffer through the caches
 int launch_trunk_check(const int* err, float* a, long long na, float* b, long long nb, hipStream_t stream);   // NaN-poison on a tripped self-check
 int launch_stamp(unsigned long long* slot, hipStream_t stream);   // *slot = wall_clock64() (100 MHz)
 int launch_scale_f32(const float* src, float* dst, float scale, long long n, hipStream_t stream);

@@ -714,6 +714,7 @@ struct Builder {
         double flops = 0, bytes = 0;
     } pend;
     bool trunk_open = false;
+    std::map<int, int> trunk_seen;  // persistent launches built so far, by phase count (RLDM_TS_TRUNK_FIRST)
     std::vector<Tensor> deferred;  // releases held back while a segment is open (clusters of different images drift apart)
     // rldm_debug_set_flags: 1 << 24 keeps every phase a launch of its own with the tiles unchanged (tests: identical results);
     // 1 << 25 also gives the convs back their default tiles (A/B runs of the whole feature)
@@ -755,12 +756,13 @@ struct Builder {
             plan->trunk_bufs.push_back(std::move(ctrs));
             Plan* pl = plan;
             const size_t lds = pend.lds;
-            plan->ops.push_back({[tp, lds, pl](hipStream_t st) mutable {
+            const bool ts_ok = !getenv("RLDM_TS_TRUNK_FIRST") || ++trunk_seen[(int)pend.phases.size()] == 1;   // (timeline of the FIRST such launch)
+            plan->ops.push_back({[tp, lds, pl, ts_ok](hipStream_t st) mutable {
                 tp.temb = pl->io.temb;
                 tp.step_ptr = pl->io.step_ptr;
                 tp.temb_rows_per_step = pl->io.temb_rows_per_step;
                 tp.temb_per_sample = pl->io.temb_per_sample;
-                tp.ts = (getenv("RLDM_TS_TRUNK") && tp.nphases == atoi(getenv("RLDM_TS_TRUNK"))) ? g_ts_buf : nullptr;
+                tp.ts = (ts_ok && getenv("RLDM_TS_TRUNK") && tp.nphases == atoi(getenv("RLDM_TS_TRUNK"))) ? g_ts_buf : nullptr;
                 return launch_trunk(tp, lds, st);
             }, std::string("trunk_kernel<") + (pend.variant == 0 ? "conv_small image tiles" : pend.variant == 1 ? "conv_small 64x64 clusters" :
                                                pend.variant == 2 ? "conv_stream 256x128" : "conv_stream 128x64") +
@@ -983,6 +985,7 @@ struct Builder {
         RLDM_REQUIRE(small_params(a, Cin_t, R_t, taps, Wout, Hout, &p, &epi_res), "conv " + L->name + ": conv_small route lost");
         p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
+        if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;
         const int BN = small_bn(p, taps, gn_fused, a.own_image);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
         p.ntile_n = N / BN;
@@ -1234,6 +1237,7 @@ struct Builder {
         }
         p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
+        if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;   // ONE conv of a network
         p.ntile_n = N / conv_stream_bn(p);
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img);
@@ -1432,6 +1436,7 @@ struct Builder {
         p.gn_eps = a.eps;
         p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
+        if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;
         p.gn_groups = a.groups;
         p.ksplit = tc.ksplit;
         const int tiles_img = (Wout / p.TW) * (Hout / p.TH);
@@ -1681,7 +1686,7 @@ struct NetCommon {
                 ap.bias = f->bias.as<float>();
                 ap.out = b.tptr(o);
                 ap.B = x.B; ap.L = Lt; ap.C = x.C;
-                ap.ts = getenv("RLDM_TS_TRUNK") ? nullptr : g_ts_buf;
+                ap.ts = (getenv("RLDM_TS_TRUNK") || getenv("RLDM_TS_ORD")) ? nullptr : g_ts_buf;
                 ap.ts_L = getenv("RLDM_TS_ATTN_L") ? atoi(getenv("RLDM_TS_ATTN_L")) : 0;
                 const double by = (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0;
                 Op standalone{[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl, by};
@@ -3248,6 +3253,29 @@ int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int wa
     hipEvent_t e0, e1;
     RLDM_HIP_CHECK(hipEventCreate(&e0));
     RLDM_HIP_CHECK(hipEventCreate(&e1));
+    // RLDM_BENCH_THRASH_MB=n: a sweep over n MB in front of every timed launch (not timed itself): the conv then finds its weights
+    // and input out of the L2s (n ~ 96: Infinity-Cache warm; n >= 512: HBM cold) -- the states a layer meets inside a sampler step
+    const size_t thrash = getenv("RLDM_BENCH_THRASH_MB") ? (size_t)atoi(getenv("RLDM_BENCH_THRASH_MB")) << 20 : 0;
+    if (thrash) {
+        DevBuf tb, sink;
+        if (tb.alloc(thrash) || sink.alloc(64)) return 1;
+        RLDM_HIP_CHECK(hipMemsetAsync(tb.p, 0, thrash, st));
+        double tot = 0.0;
+        for (int i = 0; i < iters; ++i) {
+            if (launch_thrash(tb.p, thrash, sink.as<float>(), st)) return 1;
+            RLDM_HIP_CHECK(hipEventRecord(e0, st));
+            if (run_unit()) return 1;
+            RLDM_HIP_CHECK(hipEventRecord(e1, st));
+            RLDM_HIP_CHECK(hipStreamSynchronize(st));
+            float ms = 0.f;
+            RLDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            tot += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_us = (float)(tot * 1000.0 / iters);
+        return 0;
+    }
     RLDM_HIP_CHECK(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
         if (run_unit()) return 1;

@@ -32,8 +32,18 @@ namespace rldm {
 // field by field would be ~60 dependent VECTOR loads per phase: the launch also writes device memory, so the compiler may not use
 // scalar loads for it.)
 __device__ __forceinline__ unsigned rl(unsigned rec, int word) { return (unsigned)__builtin_amdgcn_readlane((int)rec, word); }
+// The pointer is built as a GLOBAL-address-space pointer and only then converted to the generic type the bodies take: the compiler
+// then proves every access through it global and emits global_load / global_store.  Built from an integer alone it is a FLAT pointer:
+// every load and store of every phase became a flat_* instruction, which counts on lgkmcnt as well as vmcnt -- each LDS wait of a K
+// loop then also waited for the whole weight ring in flight, i.e. the ring was no ring (round 3: the "open question" of DESIGN.md 3.7,
+// a 128x8 phase's K loop 16.3 k cycles against 12.8 k in the stand-alone launch; tools/l1_probe.sh).
 template <class T> __device__ __forceinline__ T* rl_ptr(unsigned rec, int word) {
+#ifdef RLDM_TRUNK_FLAT          // (A/B builds: the round-2 behaviour)
     return reinterpret_cast<T*>(((unsigned long long)rl(rec, word + 1) << 32) | rl(rec, word));
+#else
+    typedef __attribute__((address_space(1))) T* global_ptr_t;
+    return (T*)(global_ptr_t)(((unsigned long long)rl(rec, word + 1) << 32) | rl(rec, word));
+#endif
 }
 __device__ __forceinline__ void unpack_phase(ConvParams& q, unsigned rec) {
     q.x0 = rl_ptr<const bf16_t>(rec, TW_X0);
