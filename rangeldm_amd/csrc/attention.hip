@@ -277,9 +277,10 @@ int launch_attention_qkv2(const AttnQkvParams& p, hipStream_t stream) {
     while (HG * 2 * wph <= 16 && heads % (HG * 2) == 0 && (long long)p.B * (heads / (HG * 2)) >= 256) HG *= 2;
     if (g_attn_hg > 0 && g_attn_hg * wph <= 16 && heads % g_attn_hg == 0) HG = g_attn_hg;
     int waves = HG * wph;
-    if (waves > 16 || p.L > 1024) return -1;              // (caller falls back to the first-generation kernel)
-    const size_t lds = (size_t)HG * Lp * 16 + (size_t)HG * 10 * (Lp + 8) * 2 + 16 + (size_t)p.C * 8 +
-                       std::max((size_t)2 * p.C * 8, (size_t)HG * (p.C / 16) * 64 * 4) + (size_t)HG * p.C * 64 + (size_t)HG * 128 + 128;
+    if (waves > 16 || p.L > 1024 || p.C % 64 != 0) return -1;      // (caller falls back to the first-generation kernel; C % 64: the
+                                                                    //  projection stages x in groups of 64 channels)
+    const size_t lds = attention_qkv2_lds_bytes(p.L, p.C, HG, waves);
+    if (lds > 160 * 1024) return -1;
     auto kern = pair ? attention_qkv2_d8_kernel<1> : attention_qkv2_d8_kernel<0>;
     static DynLdsLimit lds_limit[2];             // per instantiation, per device
     RLDM_HIP_CHECK(lds_limit[pair].ensure(reinterpret_cast<const void*>(kern), lds));

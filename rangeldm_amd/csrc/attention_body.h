@@ -152,6 +152,9 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     const int scratch = max(2 * C * 8, HG * nks * 64 * 4);              // bytes of sD / sPart (the partial sums of b' need more for HG > 1)
     bf16_t* sW = reinterpret_cast<bf16_t*>(reinterpret_cast<unsigned char*>(sD) + scratch);    // [HG][C/16][64 lanes][8]
     float* sBp = reinterpret_cast<float*>(sW + (size_t)HG * nks * 512); // [HG][32]
+    // x staging tile of this wave: [32 rows][128 bytes + 16 pad] -- 64 channels of a query tile at a time (see the projection)
+    constexpr int XRS = kAttnXRowBytes;
+    unsigned char* sXw = reinterpret_cast<unsigned char*>(sBp + HG * 32) + (size_t)wave * kAttnXStageBytes;
 
     // ---- every global read of the prologue, requested up front (one memory round trip instead of five) ----------------------
     constexpr int TPW = PAIR ? 2 : 1;
@@ -163,7 +166,8 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     if (own_ch && !prenorm) { g_pre = p.gamma[tid]; b_pre = p.beta[tid]; }
     const bf16_t* wf_ptr = p.wfrag + (size_t)(hg * HG) * nks * 512;
     const int npieces = HG * nks * 64;
-    constexpr int NPW = TRUNK ? 4 : 2;                    // weight pieces held per thread up front (more: loaded in the loop)
+    constexpr int NPW = TRUNK ? 8 : 2;                    // weight pieces held per thread up front (more: loaded in the loop -- one
+                                                          // dependent L2 round trip each: a trunk phase holds all 8 of a 4-head group)
     uint4 wpre[NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j)
@@ -172,14 +176,24 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     if (tid < 32 * HG && (tid & 31) < 24) bias_pre = p.bias[(hg * HG + (tid >> 5)) * 32 + (tid & 31)];
     // (persistent trunk: the weights above do not depend on the previous phase; x does)
     if constexpr (TRUNK) trunk_wait(seam, tid);
+    // x rows of this wave's query tiles.  The projection's B operand wants lane = (pixel, 16 bytes): read like that, a wave
+    // instruction touches 32 different 128-byte lines for 32 bytes each, every line is visited by four instructions, and the
+    // CU's L1 (one line per ~2 clocks) made the prologue of an L = 1024 launch ~24 k cycles for 256 KB of x per workgroup.
+    // With C % 64 == 0 the rows are therefore requested COALESCED -- group g = channels [64 g, 64 g + 64) of the 32 rows of a
+    // tile = 4 instructions of 8 whole 128-byte segments each -- and transposed to the fragment layout through a 4.5 KB LDS
+    // tile of the wave's own (conflict-free both ways; no barrier: a wave's LDS instructions execute in order).
+    // (C % 64 != 0 -- toy configurations -- runs on the first-generation kernel: launch_attention_qkv2 declines)
+    const int xr8 = lane >> 3, xc8 = lane & 7;           // coalesced piece (i, lane): row 8 i + xr8 of the tile, 16-byte chunk xc8
     bf16x8 xpre[TPW][KB];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-        const int px = min((T0 + ti * wph) * 32 + l31, L - 1);
-        const bf16_t* xrow = p.x + ((size_t)b * L + px) * C + 8 * hh;
+        const bf16_t* xt = p.x + ((size_t)b * L) * C + xc8 * 8;
 #pragma unroll
         for (int j = 0; j < KB; ++j)
-            if (j < nks) xpre[ti][j] = ld_act_frag<TRUNK>(xrow + j * 16);
+            if ((j & ~3) < nks) {
+                const int row = min((T0 + ti * wph) * 32 + (j & 3) * 8 + xr8, L - 1);
+                xpre[ti][j] = ld_act_frag<TRUNK>(xt + (size_t)row * C + (j >> 2) * 64);
+            }
     }
 
     // ---- GroupNorm affine of image b (conv_igemm.hip's arithmetic; one fold per workgroup) ----------------------------------
@@ -246,9 +260,11 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     for (int q = tid, j = 0; q < npieces; q += NT, ++j) { // piece q = (head, k-step, lane): row q & 31, channels 16*ks + 8*(lane >> 5) ..
         const int c0 = ((q >> 6) % nks) * 16 + ((q >> 5) & 1) * 8;
         uint4 w;
-        if (j == 0) w = wpre[0];
-        else if (j == 1) w = wpre[1];
-        else w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);     // (NPW > 2: trunk phases, which never fold)
+        bool have = false;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k)
+            if (j == k) { w = wpre[k]; have = true; }
+        if (!have) w = *reinterpret_cast<const uint4*>(wf_ptr + (size_t)q * 8);
         const float4 a0 = *reinterpret_cast<const float4*>(sGa + c0), a1 = *reinterpret_cast<const float4*>(sGa + c0 + 4);
         const float4 s0 = *reinterpret_cast<const float4*>(sGs + c0), s1 = *reinterpret_cast<const float4*>(sGs + c0 + 4);
         uint4 n;
@@ -284,31 +300,34 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
         const int T = T0 + ti * wph;
         qB[ti] = make_uint4(0u, 0u, 0u, 0u);
         if (T >= ntiles) continue;
-        const int px = min(T * 32 + l31, L - 1);          // keys / queries past L: a clamped row, masked later
-        const bf16_t* xrow = p.x + ((size_t)b * L + px) * C + 8 * hh;
-        f32x16 acc;
+        f32x16 acc;                                       // (keys / queries past L: a clamped row, masked later)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = r < 12 ? binit[r] : 0.f;
         for (int k0 = 0; k0 < nks; k0 += KB) {
             bf16x8 xv[KB];
+            const bf16_t* xt = p.x + ((size_t)b * L) * C + xc8 * 8;
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 if (k0 == 0) xv[j] = xpre[ti][j];
-                else if (k0 + j < nks) xv[j] = ld_act_frag<TRUNK>(xrow + (k0 + j) * 16);
+                else if (k0 + (j & ~3) < nks)
+                    xv[j] = ld_act_frag<TRUNK>(xt + (size_t)min(T * 32 + (j & 3) * 8 + xr8, L - 1) * C + ((k0 + j) >> 2) * 64);
             }
-            if (k0 + KB <= nks) {                         // a full batch: all W' fragments requested, then the MFMAs back to back
-                bf16x8 wf[KB];
 #pragma unroll
-                for (int j = 0; j < KB; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sWh + ((size_t)(k0 + j) * 64 + lane) * 8);
+            for (int g = 0; g < KB / 4; ++g) {
+                if (k0 + 4 * g >= nks) break;
+                asm volatile("" ::: "memory");            // (the tile is re-used: keep the writes behind the previous group's reads)
 #pragma unroll
-                for (int j = 0; j < KB; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xv[j], acc, 0, 0, 0);
-            } else {
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<bf16x8*>(sXw + (i * 8 + xr8) * XRS + xc8 * 16) = xv[4 * g + i];
+                asm volatile("" ::: "memory");            // same wave, in-order LDS: the reads below see the rows the other lanes wrote
+                bf16x8 xf[4], wf[4];
 #pragma unroll
-                for (int j = 0; j < KB; ++j) {
-                    if (k0 + j >= nks) break;
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sWh + ((size_t)(k0 + j) * 64 + lane) * 8);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xv[j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    xf[j] = *reinterpret_cast<const bf16x8*>(sXw + l31 * XRS + (2 * j + hh) * 16);
+                    wf[j] = *reinterpret_cast<const bf16x8*>(sWh + ((size_t)(k0 + 4 * g + j) * 64 + lane) * 8);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[j], acc, 0, 0, 0);
             }
         }
         uint2 qp, kp, vp;

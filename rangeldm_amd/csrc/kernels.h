@@ -256,6 +256,15 @@ struct AttnQkvParams {
     int ts_L;
 };
 int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream);
+// LDS of the second-generation fused attention body (attention_body.h) for HG heads per workgroup on `waves` waves: K rows, V^T,
+// the GroupNorm affine + scratch, the heads' W' fragments and biases, and one 32-row x 144-byte x staging tile per wave
+constexpr int kAttnXRowBytes = 128 + 16, kAttnXStageBytes = 32 * kAttnXRowBytes;
+inline size_t attention_qkv2_lds_bytes(int L, int C, int HG, int waves) {
+    const size_t Lp = (size_t)(L + 31) / 32 * 32;
+    const size_t a = (size_t)2 * C * 8, b2 = (size_t)HG * (C / 16) * 64 * 4;
+    return HG * Lp * 16 + (size_t)HG * 10 * (Lp + 8) * 2 + 16 + (size_t)C * 8 + (a > b2 ? a : b2) + (size_t)HG * C * 64 +
+           (size_t)HG * 128 + (size_t)waves * kAttnXStageBytes + 128;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small kernels (elementwise.hip)

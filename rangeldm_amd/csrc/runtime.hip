@@ -776,11 +776,7 @@ struct Builder {
     }
 
     // attention core as a trunk phase: x arrives normalised, C / 8 heads split over N / 32 = C / 32 workgroups of 8 waves
-    static size_t trunk_attention_lds(int L, int C, int HG) {
-        const size_t Lp = (size_t)(L + 31) / 32 * 32;
-        return HG * Lp * 16 + (size_t)HG * 10 * (Lp + 8) * 2 + 16 + (size_t)C * 8 +
-               std::max((size_t)2 * C * 8, (size_t)HG * (C / 16) * 64 * 4) + (size_t)HG * C * 64 + (size_t)HG * 128 + 128;
-    }
+    static size_t trunk_attention_lds(int L, int C, int HG) { return attention_qkv2_lds_bytes(L, C, HG, 8); }
     bool trunk_attention_ok(const Tensor& x, bool pre) const {
         const int L = x.W * x.H, ranks = x.C / 32;
         if (!trunk_enabled() || !pre || x.C % 32 != 0 || ranks < 2 || ranks > 16) return false;
