@@ -265,26 +265,67 @@ __global__ void __launch_bounds__(1024) attention_qkv2_d8_kernel(const AttnQkvPa
 static int g_attn_old = getenv("RLDM_ATTN_OLD") ? atoi(getenv("RLDM_ATTN_OLD")) : 0;
 static int g_attn_hg = getenv("RLDM_ATTN_HG") ? atoi(getenv("RLDM_ATTN_HG")) : 0;      // force heads per workgroup (A/B runs)
 
-int launch_attention_qkv2(const AttnQkvParams& p, hipStream_t stream) {
-    const int Lp = (p.L + 31) / 32 * 32;
+int attention_qkv2_geometry(int B, int L, int C, int* HG_out, int* waves_out) {
+    const int Lp = (L + 31) / 32 * 32;
     const int ntiles = Lp / 32;
-    const int heads = p.C / 8;
+    const int heads = C / 8;
     // a head's query tiles go two to a wave when it has >= 32 of them (L = 1024: 16 waves x 2 tiles), else one to a wave; heads
     // with few tiles share a workgroup (HG heads) as long as the grid still covers the chip once
     const int pair = ntiles >= 32 ? 1 : 0;
     const int wph = pair ? (ntiles + 1) / 2 : ntiles;     // waves per head
     int HG = 1;
-    while (HG * 2 * wph <= 16 && heads % (HG * 2) == 0 && (long long)p.B * (heads / (HG * 2)) >= 256) HG *= 2;
+    while (HG * 2 * wph <= 16 && heads % (HG * 2) == 0 && (long long)B * (heads / (HG * 2)) >= 256) HG *= 2;
     if (g_attn_hg > 0 && g_attn_hg * wph <= 16 && heads % g_attn_hg == 0) HG = g_attn_hg;
-    int waves = HG * wph;
-    if (waves > 16 || p.L > 1024 || p.C % 64 != 0) return -1;      // (caller falls back to the first-generation kernel; C % 64: the
+    const int waves = HG * wph;
+    if (waves > 16 || L > 1024 || C % 64 != 0) return -1;          // (caller falls back to the first-generation kernel; C % 64: the
                                                                     //  projection stages x in groups of 64 channels)
+    if (attention_qkv2_lds_bytes(L, C, HG, waves) > 160 * 1024) return -1;
+    *HG_out = HG;
+    *waves_out = waves;
+    return 0;
+}
+
+// The output projection rides in the attention launch when: the geometry above holds; an image's R = heads / HG workgroups each
+// take one 64-pixel block of it (L == 64 R); C <= 128 (the tail keeps a wave's 8 weight fragments in registers; 2 x C/32 output
+// sub-tiles <= waves); the XCD-contiguous id ranges (xcd_remap) never cut an image: grid % 8 == 0 and (grid / 8) % R == 0; and every
+// workgroup is resident at once (1024 threads, > 80 KB of LDS: one per CU).
+bool attention_proj_fusable(int B, int L, int C, int cus) {     // (cus < 0: the shape only -- the tail as a launch of its own)
+    int HG = 0, waves = 0;
+    if (g_attn_old || attention_qkv2_geometry(B, L, C, &HG, &waves)) return false;
+    const int R = (C / 8) / HG, grid = B * R;
+    if (cus < 0) cus = grid;
+    const int ng = waves * 128 / C;                       // pixel groups of the tail's statistics pass (threads / channel pairs)
+    return L == 64 * R && C <= 128 && 2 * (C / 32) <= waves && (waves * 128) % C == 0 && ng <= 64 && 64 % ng == 0 &&
+           grid % 8 == 0 && (grid / 8) % R == 0 && grid <= cus;
+}
+
+// the output projection as a launch of its own (attention_proj_tail<false>): one workgroup per 64-pixel block of an image
+__global__ void __launch_bounds__(1024) attention_proj_kernel(const AttnQkvParams p, const int R) {
+    attention_proj_tail<false>(p, blockIdx.x / R, blockIdx.x % R, R, blockDim.x);
+}
+
+int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream) {
+    int HG = 0, waves = 0;
+    RLDM_REQUIRE(p.proj_w && attention_qkv2_geometry(p.B, p.L, p.C, &HG, &waves) == 0, "attention_proj: unsupported shape");
+    const int R = (p.C / 8) / HG;
+    const size_t lds = (size_t)64 * (p.C * 2 + 16) + (size_t)64 * (p.C * 4 + 16) + (size_t)(waves * 128 / p.C) * 2 * p.C * 4;
+    static DynLdsLimit lds_limit;
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(attention_proj_kernel), lds));
+    hipLaunchKernelGGL(attention_proj_kernel, dim3(p.B * R), dim3(64 * waves), lds, stream, p, R);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_attention_qkv2(const AttnQkvParams& p, hipStream_t stream) {
+    const int Lp = (p.L + 31) / 32 * 32;
+    const int pair = Lp / 32 >= 32 ? 1 : 0;
+    int HG = 0, waves = 0;
+    if (attention_qkv2_geometry(p.B, p.L, p.C, &HG, &waves)) return -1;
     const size_t lds = attention_qkv2_lds_bytes(p.L, p.C, HG, waves);
-    if (lds > 160 * 1024) return -1;
     auto kern = pair ? attention_qkv2_d8_kernel<1> : attention_qkv2_d8_kernel<0>;
     static DynLdsLimit lds_limit[2];             // per instantiation, per device
     RLDM_HIP_CHECK(lds_limit[pair].ensure(reinterpret_cast<const void*>(kern), lds));
-    hipLaunchKernelGGL(kern, dim3(p.B * (heads / HG)), dim3(64 * waves), lds, stream, p, waves, Lp, HG);
+    hipLaunchKernelGGL(kern, dim3(p.B * ((p.C / 8) / HG)), dim3(64 * waves), lds, stream, p, waves, Lp, HG);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -296,6 +337,7 @@ int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream) {
         const int rc = launch_attention_qkv2(p, stream);
         if (rc >= 0) return rc;
     }
+    RLDM_REQUIRE(p.proj_w == nullptr, "attention_qkv: the fused output projection needs the second-generation launch");
     const int Lp = (p.L + 31) / 32 * 32;
     const int ntiles = Lp / 32;
     // up to 16 waves per (image, head): with 1024 tokens that is 4 waves per SIMD on one workgroup per CU

@@ -88,6 +88,114 @@ __device__ __forceinline__ void attention_tile(const bf16_t* sK, const bf16_t* s
     if (q0 + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0 + l31) * C + 4 * hh) = ov;
 }
 
+// ---- output projection inside the attention launch (round 3) --------------------------------------------------------------------
+// y = to_out(o) + bias + x for the 64-pixel block `slot` of image b, by the workgroup that just finished head group `slot`:
+// once ALL R head groups of the image have published their 8-channel column slices of o (arrive / wait on the image's counter --
+// trunk_seam.h's protocol; the image's workgroups share an XCD, checked), the block's rows of o are complete in the XCD's L2.
+// Waves 0 .. 2 C/32 - 1 each own one 32 x 32 output sub-tile (K = C: <= 8 k-steps, weight fragments requested BEFORE the seam);
+// the fp32 tile meets the residual in LDS, is rounded, stored with 16-byte rows, and its per-channel (sum, sumsq) become row
+// `slot` of y's statistics partials -- conv_small.hip's pointwise epilogue, so the consumers read y like any conv output.
+// Replaces a launch of its own (12.4 us in the sampler's graph at 1024 tokens: argument fetch, tile + weight round trips,
+// k-group exchange) by one seam and ~4 us of tail.
+// SEAM = false: the same tail as a launch of its own behind the attention launch (what the per-layer fall-back of a sampler and
+// the A/B switches run: the same code on the same operands in the same order, so the results are identical bit for bit).
+template <bool SEAM>
+__device__ __forceinline__ void attention_proj_tail(const AttnQkvParams& p, const int b, const int slot, const int R, const int NT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PB = 64;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, L = p.L;
+    const int nks = C >> 4, nct = C >> 5, c8n = C >> 3;
+    const int pt = wave & 1, nt = wave >> 1;
+    const bool gemm_wave = nt < nct;
+    unsigned* const counter = SEAM ? p.proj_counter + b * 32 : nullptr;
+    const unsigned epoch = SEAM ? counter[3] : 0u;        // launches so far (advanced by slot 0 at the very end)
+    bf16x8 wf[8];
+    f32x16 acc;
+    if (gemm_wave) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < nks) wf[ks] = *reinterpret_cast<const bf16x8*>(p.proj_w + ((size_t)(nt * nks + ks) * 64 + lane) * 8);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.proj_bias + 32 * nt + 8 * r4 + 4 * hh);
+            acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
+        }
+    }
+    if constexpr (SEAM) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        if (slot == 0 && tid == 0) __hip_atomic_store(counter + 1, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TrunkSeam seam = {};
+        seam.counter = counter;
+        seam.wait_for = (epoch + 1u) * (unsigned)R;
+        seam.has_wait = 1;
+        seam.error = p.proj_error;
+        trunk_arrive(seam, tid);                          // this head group's rows of o are in the XCD's L2
+        trunk_wait(seam, tid);                            // ... and everybody else's
+        if (slot != 0 && tid == 0) {
+            const unsigned x0 = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x0 != xcc + 1u) *p.proj_error = 2;        // not on slot 0's XCD: the rows read below may be stale
+        }
+    }
+    const int ORS = C * 2 + 16, FRS = C * 4 + 16;
+    unsigned char* sO = smem;                             // [64][C] bf16: the block's rows of o, later the rounded output tile
+    unsigned char* sF = sO + PB * ORS;                    // [64][C] fp32: projection + bias
+    float* sS = reinterpret_cast<float*>(sF + PB * FRS);  // [pixel groups][2][C]
+    const size_t row0 = (size_t)b * L + (size_t)slot * PB;
+    for (int q = tid; q < PB * c8n; q += NT) {
+        const int px = q / c8n, c8 = q - px * c8n;
+        *reinterpret_cast<uint4*>(sO + px * ORS + c8 * 16) = *reinterpret_cast<const uint4*>(p.out + (row0 + px) * C + c8 * 8);
+    }
+    __syncthreads();
+    if (gemm_wave) {
+        const unsigned char* xrow = sO + (pt * 32 + l31) * ORS + hh * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < nks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8*>(xrow + ks * 32), acc, 0, 0, 0);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            *reinterpret_cast<float4*>(sF + (pt * 32 + l31) * FRS + (32 * nt + 8 * r4 + 4 * hh) * 4) =
+                make_float4(acc[r4 * 4 + 0], acc[r4 * 4 + 1], acc[r4 * 4 + 2], acc[r4 * 4 + 3]);
+    }
+    __syncthreads();
+    for (int q = tid; q < PB * c8n; q += NT) {
+        const int px = q / c8n, c8 = q - px * c8n;
+        const uint4 rq = *reinterpret_cast<const uint4*>(p.proj_res + (row0 + px) * C + c8 * 8);
+        const float4 v0 = *reinterpret_cast<const float4*>(sF + px * FRS + c8 * 32);
+        const float4 v1 = *reinterpret_cast<const float4*>(sF + px * FRS + c8 * 32 + 16);
+        uint4 o;
+        o.x = pack_bf16x2(bf16lo(rq.x) + v0.x, bf16hi(rq.x) + v0.y); o.y = pack_bf16x2(bf16lo(rq.y) + v0.z, bf16hi(rq.y) + v0.w);
+        o.z = pack_bf16x2(bf16lo(rq.z) + v1.x, bf16hi(rq.z) + v1.y); o.w = pack_bf16x2(bf16lo(rq.w) + v1.z, bf16hi(rq.w) + v1.w);
+        *reinterpret_cast<uint4*>(p.proj_y + (row0 + px) * C + c8 * 8) = o;
+        *reinterpret_cast<uint4*>(sO + px * ORS + c8 * 16) = o;
+    }
+    __syncthreads();
+    // statistics of the ROUNDED tile: thread = (channel pair, pixel group); fixed summation order
+    const int NCP = C >> 1, NG = NT / NCP, PPG = PB / NG;
+    if (PPG >= 1 && tid < NG * NCP) {
+        const int cp = tid % NCP, pg = tid / NCP;
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        for (int j = 0; j < PPG; ++j) {
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sO + (pg * PPG + j) * ORS + cp * 4);
+            const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+            s0 += a0; s1 += a1;
+            q0 += a0 * a0; q1 += a1 * a1;
+        }
+        *reinterpret_cast<float2*>(sS + (pg * 2 + 0) * C + cp * 2) = make_float2(s0, s1);
+        *reinterpret_cast<float2*>(sS + (pg * 2 + 1) * C + cp * 2) = make_float2(q0, q1);
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int kind = tid / C, c = tid - kind * C;
+        float S = 0.f;
+        for (int g = 0; g < NG; ++g) S += sS[(g * 2 + kind) * C + c];
+        reinterpret_cast<float*>(p.proj_stats + ((size_t)b * R + slot) * C + c)[kind] = S;
+    }
+    if (SEAM && slot == 0 && tid == 0) counter[3] = epoch + 1u;
+}
+
 // =====================================================================================================================
 // Second generation of the fused launch (round 2).  Same contract as attention_qkv_d8_kernel; what changed and why
 // (per-wave s_memtime stamps of both generations: tools/attn_timeline2.py, profiles/round2_attn_timeline.txt):
@@ -480,6 +588,9 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
         if (q0b + l31 < L) *reinterpret_cast<uint2*>(out_bh + (size_t)(q0b + l31) * C + 4 * hh) = ov;
     }
     } while (false);
+    if constexpr (!TRUNK) {
+        if (p.proj_w && p.proj_counter) attention_proj_tail<true>(p, b, hg, (C >> 3) / HG, NT);
+    }
     if constexpr (TRUNK) {
         trunk_arrive(seam, tid);
 #ifdef RLDM_ABLATE

@@ -221,6 +221,10 @@ struct GnApplyParams {
     int silu;
     bf16_t* y;
     float inv_n;            // 1 / (npix * channels per group) (set by launch_gn_apply)
+    // two outputs instead of one (ysplit > 0, a multiple of 8): channels [0, ysplit) -> y [B][npix][ysplit], the rest -> y1
+    // [B][npix][Cin - ysplit] -- a concatenation wider than a conv kernel takes is convolved half by half (runtime.hip)
+    bf16_t* y1;
+    int ysplit;
 };
 int launch_gn_apply(const GnApplyParams& p, hipStream_t stream);
 
@@ -254,8 +258,23 @@ struct AttnQkvParams {
     int B, L, C;
     unsigned long long* ts;     // ABLATE builds: phase stamps of workgroup 0 + [start, end] of every workgroup, launches with L == ts_L
     int ts_L;
+    // fused output projection (round 3; null proj_w: off): y = to_out(attention) + bias + res and y's GroupNorm statistics, computed
+    // by the SAME launch once all heads of the image have published their rows (a cluster seam like trunk.hip's: the image's
+    // workgroups share an XCD).  proj_w: MFMA A fragments [C/32][C/16][64 lanes][8 bf16]; proj_stats: [B][L/64][C] partials.
+    const bf16_t* proj_w;
+    const float* proj_bias;
+    const bf16_t* proj_res;
+    bf16_t* proj_y;
+    float2* proj_stats;
+    unsigned* proj_counter;     // [B][32] arrival counters (monotonic; [3] = launches so far), zeroed at allocation
+    int* proj_error;            // the plan's self-check word (1: a wait gave up, 2: an image's workgroups on several XCDs)
 };
 int launch_attention_qkv(const AttnQkvParams& p, hipStream_t stream);
+// the second-generation launch's geometry for (B, L, C): heads per workgroup and waves; non-zero: it declines this shape
+int attention_qkv2_geometry(int B, int L, int C, int* HG, int* waves);
+// ... and whether that launch can carry the output projection (workgroups of an image = 64-pixel blocks, all co-resident)
+bool attention_proj_fusable(int B, int L, int C, int cus);
+int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream);    // the same tail as a launch of its own (proj_counter unused)
 // LDS of the second-generation fused attention body (attention_body.h) for HG heads per workgroup on `waves` waves: K rows, V^T,
 // the GroupNorm affine + scratch, the heads' W' fragments and biases, and one 32-row x 144-byte x staging tile per wave
 constexpr int kAttnXRowBytes = 128 + 16, kAttnXStageBytes = 32 * kAttnXRowBytes;

@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
     constexpr int NB = 4;
     uint4 v[NB];
     int cl[NB];
-    size_t dst[NB];
+    bf16_t* dst[NB];
+    bf16_t* const gy0 = p.y;
+    bf16_t* const gy1 = p.y1;
+    const int ysplit = p.ysplit;
     auto load_batch = [&](int q0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -156,7 +159,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
             cl[j] = (q - pl * n8) * 8;
             const int c = c0 + cl[j];
             const size_t pix = (size_t)b * p.npix + px0 + pl;
-            dst[j] = pix * Cin + c;
+            dst[j] = ysplit == 0 ? gy0 + pix * Cin + c
+                                 : (c < ysplit ? gy0 + pix * ysplit + c : gy1 + pix * (Cin - ysplit) + (c - ysplit));
             v[j] = make_uint4(0u, 0u, 0u, 0u);
             if (q < total) {
                 const bool first = c < nC0;
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
             uint4 o;
             o.x = pack_bf16x2(f0, f1); o.y = pack_bf16x2(f2, f3);
             o.z = pack_bf16x2(f4, f5); o.w = pack_bf16x2(f6, f7);
-            *reinterpret_cast<uint4*>(p.y + dst[j]) = o;
+            *reinterpret_cast<uint4*>(dst[j]) = o;
         }
     }
 }
@@ -234,6 +238,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const GnApplyParams p, in
 int launch_gn_apply(const GnApplyParams& p, hipStream_t stream) {
     const int Cin = p.C0 + p.C1;
     RLDM_REQUIRE(Cin % p.groups == 0 && p.C0 % 8 == 0 && p.C1 % 8 == 0, "gn_apply: unsupported channels");
+    RLDM_REQUIRE(p.ysplit == 0 || (p.ysplit % 8 == 0 && p.ysplit < Cin && p.y1 != nullptr), "gn_apply: bad output split");
     const int cpg = Cin / p.groups;
     // groups per block: ~1/8 of them, widened until the slice is whole 16-byte pieces (<= 128 channels)
     int gsl = (p.groups + 7) / 8;

@@ -332,6 +332,7 @@ struct Op {
     double flops = 0;       // algorithmic FLOPs (2*MACs) of this launch
     double bytes = 0;       // algorithmic HBM bytes: every input / weight / output touched once
     std::function<bool()> active;   // optional: false -> the op launches nothing this run (the sampler's fused pack_input) and is skipped
+    std::string tag;                // layer name(s), for RLDM_PRINT_PLAN
 };
 
 struct KernelStat {
@@ -1369,7 +1370,12 @@ struct Builder {
             a.own_image = cur_emit != nullptr ||
                           (trunk_tiles() && !a.gn && ord < (int)vp->can_emit.size() && vp->can_emit[ord] && !a.x1.valid());
         }
+        const size_t ops_before = plan->ops.size(), ph_before = pend.standalone.size();
         if (conv_route(a, out)) return 1;
+        if (!dry) {
+            for (size_t i = ops_before; i < plan->ops.size(); ++i) plan->ops[i].tag += L->name + " ";
+            for (size_t i = ph_before; i < pend.standalone.size(); ++i) pend.standalone[i].tag += L->name + " ";
+        }
         cur_emit = nullptr;
         if (view.valid()) release(view);
         out->prod = ord;
@@ -1580,7 +1586,14 @@ static int build_plan(Plan* plan, int temb_ld, const std::function<int(Builder&)
     real.temb_ld = temb_ld;
     real.vp = &vplan;
     if (walk(real)) return 1;
-    return real.flush_trunk();
+    if (real.flush_trunk()) return 1;
+    if (getenv("RLDM_PRINT_PLAN")) {                 // tuning aid: the launch list of every plan built
+        fprintf(stderr, "plan B=%d %dx%d: %zu launches\n", plan->B, plan->W, plan->H, plan->ops.size());
+        for (size_t i = 0; i < plan->ops.size(); ++i)
+            fprintf(stderr, "  %3zu %-64s %8.3f GFLOP %8.2f MB  %s\n", i, plan->ops[i].name.c_str(), plan->ops[i].flops * 1e-9,
+                    plan->ops[i].bytes * 1e-6, plan->ops[i].tag.c_str());
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1593,9 +1606,172 @@ struct NetCommon {
     int temb_ld = 0;                                 // total projected channels (0: no time embedding)
     std::map<std::string, int> temb_off;             // resnet prefix -> channel offset in the temb row
 
+    // ---- a concatenation wider than the low-resolution conv kernel takes (RangeDM's 512-channel levels: 512 + 512 and 512 + 256
+    // input channels, ldm/configs/RangeDM.yaml:19-21) -----------------------------------------------------------------------
+    // conv_small.hip copies ALL input channels of its pixel tile to LDS (<= 512); past that the generic kernel walked K = 9216 on a
+    // handful of workgroups (54-63 us per conv, 36 % of a RangeDM step at 0.9 % of the MFMA peak).  The convolution is linear in
+    // its input channels, so the block runs as
+    //     (a0, a1) = silu(GN1(cat[x, skip]))            one gn_apply launch, two output tensors (x.C | skip.C channels)
+    //     t  = conv1[:, :x.C](a0)                       no bias
+    //     h1 = conv1[:, x.C:](a1) + b1 + temb + t       t enters as the epilogue's identity residual
+    //     u  = conv2(silu(GN2(h1))) + shortcut[:, :x.C](x) + b2 + b_sc       (the K-phase residual over x alone)
+    //     y  = shortcut[:, x.C:](skip) + u              a 1x1 conv with u as its identity residual
+    // -- four launches of the fast kernel for two of the slow one; t and u are rounded to bf16 on the way (one more rounding of a
+    // partial sum: inside the network tolerance, tests/test_hip_models.py::test_other_presets_full_size_match_reference).
+    // rldm_debug_set_flags(1 << 21) keeps the two generic launches (A/B runs).
+    bool wide_concat(const Builder& b, const Tensor& x, const Tensor& skip) const {
+        if (dbg() & (1 << 21)) return false;
+        if (!skip.valid() || x.C + skip.C <= 512 || x.C > 512 || skip.C > 512 || x.C % 64 != 0 || skip.C % 64 != 0) return false;
+        const long long px = (long long)x.W * x.H;
+        (void)b;
+        return (px <= 256 || (long long)x.B * px <= 4096) && x.H >= 2;      // where conv_small.hip would run the halves
+    }
+    ConvLayer* derived_conv(const std::string& name, const ConvLayer* src, int c_lo, int c_hi, bool keep_bias) {
+        if (ConvLayer* L = layers.get_conv(name)) return L;
+        auto L = std::make_unique<ConvLayer>();
+        const int taps = src->ksize * src->ksize, Ci = c_hi - c_lo;
+        L->name = name;
+        L->Cout = src->Cout; L->Cin = Ci; L->ksize = src->ksize;
+        L->w.resize((size_t)src->Cout * Ci * taps);
+        for (int n = 0; n < src->Cout; ++n)
+            for (int c = 0; c < Ci; ++c)
+                for (int t = 0; t < taps; ++t)
+                    L->w[((size_t)n * Ci + c) * taps + t] = src->w[((size_t)n * src->Cin + c_lo + c) * taps + t];
+        L->b = keep_bias ? src->b : std::vector<float>(src->Cout, 0.f);
+        ConvLayer* raw = L.get();
+        layers.conv[name] = std::move(L);
+        return raw;
+    }
+    int resnet_wide(Builder& b, const std::string& p, Tensor x, Tensor skip, Tensor* out) {
+        ConvLayer* c1 = layers.get_conv(p + ".conv1");
+        ConvLayer* c2 = layers.get_conv(p + ".conv2");
+        NormParams* n1 = layers.get_norm(p + ".norm1");
+        const int Ctot = x.C + skip.C;
+        RLDM_REQUIRE(c1 && c2 && n1 && c1->Cin == Ctot && c2->R == Ctot && !c2->sc_identity, "resnet " + p + ": not a wide concatenation");
+        // -- GroupNorm + SiLU of the concatenation, once, into the two halves
+        Tensor a0 = b.make(x.B, x.W, x.H, x.C), a1 = b.make(x.B, x.W, x.H, skip.C);
+        RLDM_REQUIRE(x.P > 0 && skip.P > 0 && Ctot % groups == 0, "resnet " + p + ": GroupNorm input without statistics");
+        b.note_launch();
+        if (!b.dry) {
+            GnApplyParams g;
+            memset(&g, 0, sizeof(g));
+            g.x0 = b.tptr(x); g.x1 = b.tptr(skip);
+            g.C0 = x.C; g.C1 = skip.C;
+            g.st0 = b.sptr(x); g.st1 = b.sptr(skip);
+            g.P0 = x.P; g.P1 = skip.P;
+            g.B = x.B; g.npix = x.W * x.H;
+            g.groups = groups;
+            g.gamma = n1->gamma.as<float>(); g.beta = n1->beta.as<float>();
+            g.eps = eps; g.silu = 1;
+            g.y = b.tptr(a0); g.y1 = b.tptr(a1); g.ysplit = x.C;
+            b.plan->ops.push_back({[g](hipStream_t s) { return launch_gn_apply(g, s); }, "gn_apply_kernel", 0.0,
+                                   (double)g.B * g.npix * Ctot * 4.0});
+        }
+        // -- conv1 in two halves
+        ConvLayer* c1a = derived_conv(p + ".conv1@lo", c1, 0, x.C, false);
+        ConvLayer* c1b = derived_conv(p + ".conv1@hi", c1, x.C, Ctot, true);
+        c1b->R = c1b->Cout;
+        c1b->sc_identity = true;
+        ConvArgs A;
+        A.layer = c1a; A.x0 = a0;
+        Tensor t;
+        if (b.conv(A, &t)) return 1;
+        b.release(a0);
+        ConvArgs B_;
+        B_.layer = c1b; B_.x0 = a1; B_.r0 = t;
+        auto it = temb_off.find(p);
+        B_.temb_off = it == temb_off.end() ? -1 : it->second;
+        B_.want_stats = true;
+        Tensor h1;
+        if (b.conv(B_, &h1)) return 1;
+        b.release(a1);
+        b.release(t);
+        // -- conv2 with the shortcut over x in its K loop, then the shortcut over skip as a pointwise conv on top
+        ConvLayer* c2a = layers.get_conv(p + ".conv2@lo");
+        if (!c2a) {
+            auto L = std::make_unique<ConvLayer>();         // (own host weights; the packed images are built per layer)
+            L->name = p + ".conv2@lo";
+            L->Cout = c2->Cout; L->Cin = c2->Cin; L->ksize = c2->ksize;
+            L->w = c2->w;
+            L->b = c2->b;
+            L->R = x.C;
+            L->sc_w.resize((size_t)c2->Cout * x.C);
+            for (int n = 0; n < c2->Cout; ++n)
+                for (int c = 0; c < x.C; ++c) L->sc_w[(size_t)n * x.C + c] = c2->sc_w[(size_t)n * Ctot + c];
+            c2a = L.get();
+            layers.conv[L->name] = std::move(L);
+        }
+        ConvLayer* c2b = layers.get_conv(p + ".conv2@hi");
+        if (!c2b) {
+            auto L = std::make_unique<ConvLayer>();
+            L->name = p + ".conv2@hi";
+            L->Cout = c2->Cout; L->Cin = skip.C; L->ksize = 1;
+            L->w.resize((size_t)c2->Cout * skip.C);
+            for (int n = 0; n < c2->Cout; ++n)
+                for (int c = 0; c < skip.C; ++c) L->w[(size_t)n * skip.C + c] = c2->sc_w[(size_t)n * Ctot + x.C + c];
+            L->b.assign(c2->Cout, 0.f);
+            L->R = c2->Cout;
+            L->sc_identity = true;
+            c2b = L.get();
+            layers.conv[L->name] = std::move(L);
+        }
+        ConvArgs C2;
+        C2.layer = c2a; C2.x0 = h1;
+        C2.gn = layers.get_norm(p + ".norm2");
+        C2.eps = eps; C2.groups = groups; C2.silu = 1;
+        C2.r0 = x;
+        Tensor u;
+        if (!b.small_route(C2, h1.C, x.C, 9, h1.W, h1.H)) {
+            // the 3x3 tile and the shortcut's input tile do not fit the LDS together (64x4 images: 112 + 67 KB): the shortcut over x
+            // becomes a pointwise conv of its own as well --  u0 = conv2(..) + b;  u = shortcut[:, :x.C](x) + u0
+            ConvLayer* c2m = layers.get_conv(p + ".conv2@main");
+            if (!c2m) {
+                auto L = std::make_unique<ConvLayer>();
+                L->name = p + ".conv2@main";
+                L->Cout = c2->Cout; L->Cin = c2->Cin; L->ksize = c2->ksize;
+                L->w = c2->w;
+                L->b = c2->b;
+                c2m = L.get();
+                layers.conv[L->name] = std::move(L);
+            }
+            ConvLayer* c2x = layers.get_conv(p + ".conv2@x");
+            if (!c2x) {
+                auto L = std::make_unique<ConvLayer>();
+                L->name = p + ".conv2@x";
+                L->Cout = c2->Cout; L->Cin = x.C; L->ksize = 1;
+                L->w = c2a->sc_w;
+                L->b.assign(c2->Cout, 0.f);
+                L->R = c2->Cout;
+                L->sc_identity = true;
+                c2x = L.get();
+                layers.conv[L->name] = std::move(L);
+            }
+            C2.layer = c2m;
+            C2.r0 = Tensor();
+            Tensor u0;
+            if (b.conv(C2, &u0)) return 1;
+            ConvArgs X;
+            X.layer = c2x; X.x0 = x; X.r0 = u0;
+            if (b.conv(X, &u)) return 1;
+            b.release(u0);
+        } else if (b.conv(C2, &u)) {
+            return 1;
+        }
+        b.release(h1);
+        ConvArgs D;
+        D.layer = c2b; D.x0 = skip; D.r0 = u;
+        D.want_stats = true;
+        if (b.conv(D, out)) return 1;
+        b.release(u);
+        b.release(x);
+        b.release(skip);
+        return 0;
+    }
+
     // ResnetBlock2D / sgm ResnetBlock (model.py:342-362) in two launches: conv1 = GN1+SiLU+conv+temb, conv2 =
     // GN2+SiLU+conv with the shortcut (1x1 conv or identity) as the residual K-phase.  Releases one reference of x and skip.
     int resnet(Builder& b, const std::string& p, Tensor x, Tensor skip, Tensor* out) {
+        if (wide_concat(b, x, skip)) return resnet_wide(b, p, x, skip, out);
         ConvArgs c1;
         c1.layer = layers.get_conv(p + ".conv1");
         c1.x0 = x; c1.x1 = skip;
@@ -1663,6 +1839,20 @@ struct NetCommon {
             else if (cl_ranks) b.trunk_begin(x.B, cl_ranks, x.C / 64, 2);
             else b.note_launch();
             in_trunk = in_trunk || cl_ranks != 0;
+            // the stand-alone launch also carries the block's output projection (+ x, + statistics) when an image's workgroups are
+            // 64-pixel blocks of it on one XCD, all resident: the 128x8 level at batch 8 / 16 (attention_body.h, attention_proj_tail);
+            // rldm_debug_set_flags(128) keeps the projection a launch of its own
+            // (without clusters -- a sampler's per-layer fall-back, several chains, the A/B switches -- the SAME tail runs as a launch of
+            //  its own behind the attention launch: identical results)
+            const bool proj_tail = !in_trunk && !(dbg() & 128) && attention_proj_fusable(x.B, Lt, x.C, -1);
+            const bool proj_seam = proj_tail && Builder::cluster_enabled() &&
+                                   attention_proj_fusable(x.B, Lt, x.C, Builder::device_cus() / std::max(1, g_concurrent_plans));
+            const bool fuse_proj = proj_tail;
+            Tensor yfused;
+            if (fuse_proj) {
+                yfused = b.make(x.B, x.W, x.H, x.C);
+                b.add_stats(yfused, Lt / 64);
+            }
             if (!b.dry) {
                 AttnFused* f = nullptr;
                 if (get_attn_fused(p, x.C, &f)) return 1;
@@ -1684,16 +1874,58 @@ struct NetCommon {
                 ap.B = x.B; ap.L = Lt; ap.C = x.C;
                 ap.ts = (getenv("RLDM_TS_TRUNK") || getenv("RLDM_TS_ORD")) ? nullptr : g_ts_buf;
                 ap.ts_L = getenv("RLDM_TS_ATTN_L") ? atoi(getenv("RLDM_TS_ATTN_L")) : 0;
-                const double by = (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0;
-                Op standalone{[ap](hipStream_t s) { return launch_attention_qkv(ap, s); }, "attention_qkv_d8_kernel", fl, by};
+                double by = (double)x.B * Lt * x.C * 2.0 * 2.0 + 3.0 * x.C * x.C * 2.0;
+                double flp = fl;
+                if (fuse_proj) {
+                    ConvLayer* Lo = layers.get_conv(p + ".to_out.0");
+                    ConvLayer::Packed* pk = nullptr;
+                    RLDM_REQUIRE(Lo && Lo->Cin == x.C && Lo->Cout == x.C && Lo->sc_identity, "attention " + p + ": unexpected to_out");
+                    if (Lo->get_fragpacked(x.C, 1, true, &pk)) return 1;
+                    ap.proj_w = pk->w.as<bf16_t>();
+                    ap.proj_bias = pk->bias.as<float>();
+                    ap.proj_res = b.tptr(x);
+                    ap.proj_y = b.tptr(yfused);
+                    ap.proj_stats = b.ptr<float2>(yfused.st_off);
+                    if (proj_seam) {
+                        auto ctrs = std::make_unique<DevBuf>();
+                        if (ctrs->alloc((size_t)x.B * 32 * 4)) return 1;
+                        RLDM_HIP_CHECK(hipMemset(ctrs->p, 0, ctrs->bytes));
+                        if (!b.plan->trunk_error.p) {
+                            if (b.plan->trunk_error.alloc(64)) return 1;
+                            RLDM_HIP_CHECK(hipMemset(b.plan->trunk_error.p, 0, 64));
+                        }
+                        ap.proj_counter = ctrs->as<unsigned>();
+                        ap.proj_error = b.plan->trunk_error.as<int>();
+                        b.plan->trunk_bufs.push_back(std::move(ctrs));
+                        flp += 2.0 * (double)x.B * Lt * x.C * x.C;
+                        by += (double)x.B * Lt * x.C * 2.0 * 3.0 + (double)x.C * x.C * 2.0;
+                    }
+                }
+                Op standalone{[ap](hipStream_t s) { return launch_attention_qkv(ap, s); },
+                              proj_seam ? "attention_qkv_d8_kernel + to_out" : "attention_qkv_d8_kernel", flp, by};
+                standalone.tag = p;
                 if (in_trunk) {
                     b.trunk_push_attention(ap, fl, by);
                     b.pend.standalone.push_back(standalone);
                 } else {
                     b.plan->ops.push_back(standalone);
                 }
+                if (fuse_proj && !proj_seam) {          // the tail as its own launch (no seam: the kernel boundary orders it)
+                    Op tail{[ap](hipStream_t s) { return launch_attention_proj(ap, s); }, "attention_proj_kernel",
+                            2.0 * (double)x.B * Lt * x.C * x.C, (double)x.B * Lt * x.C * 2.0 * 3.0 + (double)x.C * x.C * 2.0};
+                    tail.tag = p + ".to_out.0";
+                    b.plan->ops.push_back(tail);
+                }
             }
+            if (fuse_proj && !proj_seam) b.note_launch();
             if (pre) b.release(xn);
+            if (fuse_proj) {
+                b.plan->flops += 2.0 * (double)x.B * Lt * x.C * x.C;
+                b.release(o);
+                b.release(x);
+                *out = yfused;
+                return 0;
+            }
             ConvArgs co;
             co.layer = layers.get_conv(p + ".to_out.0");
             co.x0 = o;
