@@ -782,7 +782,9 @@ struct Builder {
         const int L = x.W * x.H, ranks = x.C / 32;
         if (!trunk_enabled() || !pre || x.C % 32 != 0 || ranks < 2 || ranks > 16) return false;
         const int HG = (x.C / 8) / ranks, wph = (L + 31) / 32;
-        if (HG * wph != 8 || L > 64) return false;                // 8 waves: one query tile per wave
+        // 8 waves: one query tile per wave of a head (32-token images -- the lowest nuScenes level -- leave every second wave idle:
+        // without the phase that level was five persistent launches with an attention launch between each pair)
+        if (HG * wph > 8 || 8 % HG != 0 || (8 / HG) < wph || L > 64) return false;
         if (!trunk_grid_fits(ranks, x.B)) return false;
         return trunk_attention_lds(L, x.C, HG) <= 160 * 1024;
     }
@@ -946,6 +948,9 @@ struct Builder {
         if (taps == 9) {
             const bool ok64 = conv_small_supported(t, 9, 64), ok32 = conv_small_supported(t, 9, 32);
             if (ok64 && (tiles * (q.N / 64) >= 200 || !ok32)) return 64;
+            // (measured, round 3: giving a level that COULD run as multi-tile clusters the cluster's 64 x 64 tile at small batches --
+            //  nuScenes 64x2 at 4 images: 66 -> 42 launches per step -- is slower, 84.3 against 86.9 img/s, and neutral for the KITTI
+            //  network at 4 / 8 images: a phase costs what a launch costs; the 32-channel tiles' extra workgroups win)
             return ok32 ? 32 : 0;
         }
         const int cand[3] = {32, 64, 128};
