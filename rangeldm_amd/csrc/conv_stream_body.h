@@ -192,20 +192,10 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     }
     float bias_v = 0.f;
     if (tid < BN) bias_v = p.bias[nt * BN + tid];
-    // the weight ring is requested BEHIND the statistics partials: s_waitcnt vmcnt counts in order, so the fold below would otherwise
-    // wait for the ring's 12 KB per wave (96 KB per CU through a 64 B/clk L1) before it sees its few hundred bytes
-    // (a phase of the persistent launch could request it ahead of its cluster wait -- the weights do not depend on the previous
-    //  phase: measured +-0.1 %, the seam is not where the ring's latency shows)
-    bf16x8 wr[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        wr[j] = w_load(wptr, j);
-        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the counted waits below rely on it
-    }
-    wptr += G * 1024;                           // -> the fragments the first row of taps refills
-
-    RLDM_STAMP();
-    // (address arithmetic of the halo pieces: integer multiplies, done while the requests above are in flight)
+    // Request order = the order the data is needed in (s_waitcnt vmcnt counts in order): statistics partials (the fold), the first
+    // halo chunk (GroupNorm + SiLU of chunk 0), the weight ring (the K loop).  The address arithmetic of the halo pieces (integer
+    // multiplies) runs while the partials are in flight.  Round 3: the halo chunk used to be requested BEHIND the ring -- its wait then
+    // also covered the ring's 12 KB per wave (96 KB per CU through a 64 B/clk L1), ~2 k cycles of every launch / phase.
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
         const int q = tid + i * NT;
@@ -218,6 +208,14 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
     }
     if (NCT > 0) load_a(0);
+    RLDM_STAMP();
+    bf16x8 wr[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        wr[j] = w_load(wptr, j);
+        __builtin_amdgcn_sched_barrier(0);      // issued here and in this order: the counted waits below rely on it
+    }
+    wptr += G * 1024;                           // -> the fragments the first row of taps refills
     if (temb_tab && tid < BN)
         bias_v += temb_tab[(size_t)(temb_step * temb_rps + (temb_ps ? b : 0)) * temb_ld + nt * BN + tid];
     if (gn) {
