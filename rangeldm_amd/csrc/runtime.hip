@@ -1323,7 +1323,7 @@ struct Builder {
 
     // Statistics of a tensor with many pixel tiles per image are folded once, by one small launch, instead of by every
     // workgroup of every consumer (gn_fold_kernel); RLDM_DBG_FLAGS=262144 keeps the raw partials for A/B runs.
-    static constexpr int kFoldAboveP = 32;
+    static inline const int kFoldAboveP = getenv("RLDM_FOLD_ABOVE") ? atoi(getenv("RLDM_FOLD_ABOVE")) : 32;   // (env: tuning runs)
     int fold_stats(Tensor& y) {
         if (!y.valid() || y.P <= kFoldAboveP || (dbg() & 262144)) return 0;
         const size_t raw_off = y.st_off, raw_bytes = y.st_bytes();

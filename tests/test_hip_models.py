@@ -74,6 +74,58 @@ def test_unet_forward_small(kw, B):
     assert rel_l2(m(x.cuda(), ts).sample.cpu(), ref_ps) < TOL_FWD
 
 
+@pytest.mark.parametrize("size,B", [((32, 4), 2), ((64, 8), 1)])
+def test_wide_concatenation_runs_half_by_half(size, B):
+    """RangeDM's 512-channel levels concatenate to 1024 input channels (ldm/configs/RangeDM.yaml:19-21), more than conv_small.hip's LDS
+    tile takes: the resnet runs as gn_apply (two outputs) + conv1 in two halves + conv2 (+ the shortcut as one or two pointwise convs),
+    NetCommon::resnet_wide.  A two-level 512-channel UNet exercises both forms -- (64, 8): the 64-pixel tiles of the 512-pixel level, where
+    the 3x3 tile and the shortcut's tile do not fit the LDS together -- against the oracle, and against the same network on the generic
+    kernel (rldm_debug_set_flags(1 << 21))."""
+    from rangeldm_amd import _lib
+    cfg = UNetConfig(sample_size=size, block_out_channels=(512, 512), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+                     up_block_types=("AttnUpBlock2D", "UpBlock2D"))
+    x = T(normal(17, "x", (B, cfg.in_channels, *cfg.sample_size)))
+    outs, launches = [], []
+    for flags in (0, 1 << 21):
+        _lib.lib().rldm_debug_set_flags(flags)
+        try:
+            m, sd = hip_unet(cfg, "wide.")
+            outs.append(m(x.cuda(), 321).sample.cpu())
+            launches.append(m.num_launches(B))
+        finally:
+            _lib.lib().rldm_debug_set_flags(0)
+    ref = o_unet.OracleUNet(cfg, sd)(x, 321).sample
+    print(f"wide concat {size}: split {float(rel_l2(outs[0], ref)):.3e} generic {float(rel_l2(outs[1], ref)):.3e}, launches {launches}")
+    assert launches[0] > launches[1]                          # (the split is in force: more, cheaper launches)
+    assert rel_l2(outs[0], ref) < TOL_FWD and rel_l2(outs[1], ref) < TOL_FWD
+    assert rel_l2(outs[0], outs[1]) < TOL_FWD / 2
+
+
+@pytest.mark.parametrize("B", [8, 16])
+def test_fused_attention_projection_matches_separate_launch(B):
+    """The 1024-token attention launch carries the block's output projection (+ x, + GroupNorm statistics) behind a cluster seam
+    (attention_proj_tail); rldm_debug_set_flags(128) keeps the projection a conv_small launch, 1 << 24 runs the SAME tail as a launch of
+    its own (identical bits).  All three against the oracle."""
+    from rangeldm_amd import _lib
+    cfg = UNetConfig()
+    x = T(normal(19, "x", (B, cfg.in_channels, *cfg.sample_size)))
+    outs, launches = {}, {}
+    for flags in (0, 128, 1 << 24):
+        _lib.lib().rldm_debug_set_flags(flags)
+        try:
+            m, sd = hip_unet(cfg, "fp.")
+            outs[flags] = m(x.cuda(), 450).sample.cpu()
+            launches[flags] = m.num_launches(B)
+            assert m.trunk_status(B) == 0
+        finally:
+            _lib.lib().rldm_debug_set_flags(0)
+    ref = o_unet.OracleUNet(cfg, sd)(x[:2], 450).sample
+    assert launches[0] == launches[128] - 5                    # five attention blocks at 1024 tokens
+    assert torch.equal(outs[0], outs[1 << 24])
+    assert rel_l2(outs[0][:2], ref) < TOL_FWD and rel_l2(outs[128][:2], ref) < TOL_FWD
+    assert rel_l2(outs[0], outs[128]) < TOL_FWD / 2
+
+
 def test_unet_forward_nuscenes_config():
     """BASELINE config 3 (ldm/configs/nuscenes.yaml: 256 x 8 latents, full channel widths): its lowest level has 32 x 1 images,
     which run on conv_small.hip's 32-pixel tiles (3x3 over 256 / 512 channels and the attention output projection)."""
