@@ -275,6 +275,10 @@ int attention_qkv2_geometry(int B, int L, int C, int* HG, int* waves);
 // ... and whether that launch can carry the output projection (workgroups of an image = 64-pixel blocks, all co-resident)
 bool attention_proj_fusable(int B, int L, int C, int cus);
 int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream);    // the same tail as a launch of its own (proj_counter unused)
+// weight fragments per wave a phase of the persistent launch requests for the NEXT phase (trunk_seam.h; the plan builder's TW_G)
+#ifndef RLDM_TRUNK_PREFETCH
+#define RLDM_TRUNK_PREFETCH 18     /* (round 3: 12 -> 18 = the whole ring of a 3x3 / 256-channel phase: +0.5 %, trunk<0> 201 -> 225 VGPRs) */
+#endif
 // LDS of the second-generation fused attention body (attention_body.h) for HG heads per workgroup on `waves` waves: K rows, V^T,
 // the GroupNorm affine + scratch, the heads' W' fragments and biases, and one 32-row x 144-byte x staging tile per wave
 constexpr int kAttnXRowBytes = 128 + 16, kAttnXStageBytes = 32 * kAttnXRowBytes;

@@ -1138,7 +1138,7 @@ struct Builder {
                     const int KG = 4, cpt = Cin_t / (16 * KG);
                     const int TPG = taps == 1 ? 1 : (cpt <= 2 ? 9 : (cpt <= 4 ? 3 : 1));      // conv_small_body.h, MI == 2
                     ph.w[TW_KIND] = kind_c;
-                    ph.w[TW_G] = std::min(TPG * cpt, 12);
+                    ph.w[TW_G] = std::min(TPG * cpt, RLDM_TRUNK_PREFETCH);
                     ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
                     RLDM_REQUIRE(p.nviews == 0, "conv " + L->name + ": a multi-tile cluster phase writes no views");
                     put64(TW_ST0, p.st0); put64(TW_GAMMA, p.gn_gamma); put64(TW_BETA, p.gn_beta);
@@ -1150,7 +1150,7 @@ struct Builder {
                 const int cpt = Cin_t / 128, KG = 8;
                 const int G = (trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt);
                 ph.w[TW_KIND] = trunk_kind;
-                ph.w[TW_G] = std::min(G, 12);       // == kTrunkPrefetch (conv_small_body.h)
+                ph.w[TW_G] = std::min(G, RLDM_TRUNK_PREFETCH);       // == kTrunkPrefetch (conv_small_body.h)
                 ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
                 }
                 ph.w[TW_TEMBOFF] = (unsigned)temb_off;
