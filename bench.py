@@ -121,7 +121,7 @@ def roofline(pipe, sampler_handle, x_T, steps):
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
                    "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
-    traffic = None
+    traffic, traffic_src = None, None
     for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):   # HBM bytes per launch from the rocprofv3 --pmc passes
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
@@ -140,10 +140,12 @@ def roofline(pipe, sampler_handle, x_T, steps):
             except (OSError, ValueError, IndexError):
                 traffic = None
             if traffic is not None:
+                traffic_src = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/collect_profiles.sh), " \
+                              f"not re-measured in this run"
                 break
     step_launches = sum(v["launches"] for v in prof.get("unet_step", {}).values())      # what the captured step really launches
     rl = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
           "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
           "alg_flops_per_launch": d["flops"] / d["launches"], "alg_bytes_per_launch": d["bytes"] / d["launches"],
           "launches_per_batch": d["launches"], "eager_kernel_ms_per_batch": round(all_ms, 3),
