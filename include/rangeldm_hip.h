@@ -382,7 +382,9 @@ int rldm_unet_set_plan_flags(rldm_unet* m, int flags);
 int rldm_debug_inject_trunk_error(rldm_sampler* s, int code);
 int rldm_debug_timestamps(unsigned long long* host_out);   /* NULL: enable; else read back [4][64] s_memtime stamps */
 int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLATE builds: [start, end] (100 MHz) of every workgroup of the last conv_stream launch */
-/* routing / ablation switches, read when a plan is built (RLDM_DBG_FLAGS seeds them).  The ones a maintainer may need
+/* routing / ablation switches, PROCESS-WIDE, read when a plan is built (RLDM_DBG_FLAGS seeds them): for tuning runs and tests.  A host
+ * that wants one sampler / model routed differently uses rldm_sampler_config::plan_flags / rldm_unet_set_plan_flags (same bits, scoped),
+ * and the library's own fall-backs are scoped the same way.  The ones a maintainer may need
  * (INTEGRATION.md section 5): 1 << 24 every layer a launch of its own with the persistent launches' tiles (identical results),
  * 1 << 25 ... with the default tiles, 1 << 26 no multi-tile clusters (the 64x4 / 256x16 levels as launches: required when the GPU
  * is shared with other streams), 512 / 1 << 28 only the conv_small / conv_stream clusters off, 1 << 27 gn_apply stays a launch,
