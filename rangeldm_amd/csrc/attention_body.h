@@ -335,6 +335,13 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
             }
+            for (; q + 4 <= p.P; q += 4) {                // (P = 4 at the 64x4 level: one round trip, not four dependent ones)
+                float2 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * C);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
+            }
             for (; q < p.P; ++q) {
                 const float2 v = ld_act8<TRUNK>(src + (size_t)q * C);
                 S += (double)v.x;

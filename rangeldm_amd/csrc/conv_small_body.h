@@ -120,6 +120,13 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         const float2* src = p.st0 + (size_t)b * p.P0 * CIN + tid;
         const int P = p.P0;
         int q = 0;
+        for (; q + 8 <= P; q += 8) {            // (8 pixel tiles per image -- 128x4 / 128x8 inputs: one round trip instead of two)
+            float2 u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * CIN);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gS += (double)u[j].x; gSS += (double)u[j].y; }
+        }
         for (; q + 4 <= P; q += 4) {
             float2 u[4];
 #pragma unroll
