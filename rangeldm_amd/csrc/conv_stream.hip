@@ -48,11 +48,13 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 // the instance is chosen by the pixel tile: 32 x 8 -> 256 px x 128 ch (one k-group), 16 x 8 -> 128 px x 64 ch (4 k-groups)
-int conv_stream_bn(const ConvParams& p) { return p.TW == 32 ? 128 : 64; }
-int conv_stream_kgroups(const ConvParams& p) { return p.TW == 32 ? 1 : 4; }
+// the instance is chosen by the pixel tile: 256 pixels (32 x 8) -> <2, 4> (128 channels, no k-groups); 128 pixels (16 x 8, or 32 x 4 for
+// images of 4 beams) -> <1, 2> (64 channels x 4 k-groups)
+int conv_stream_bn(const ConvParams& p) { return p.TW * p.TH == 256 ? 128 : 64; }
+int conv_stream_kgroups(const ConvParams& p) { return p.TW * p.TH == 256 ? 1 : 4; }
 
 size_t conv_stream_lds_bytes(const ConvParams& p) {
-    const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * 8;
+    const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * p.TH;
     const size_t a = (size_t)(p.TW + 2) * p.colb;
     const size_t main_bytes = 2 * a + (size_t)(p.C0 + p.C1) * 8 + BN * 4;
     const size_t gscratch = p.st0 ? (size_t)2 * (p.C0 + p.C1) * 8 : 0;
@@ -66,7 +68,7 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     if (taps != 9 || p.stride != 1 || p.pad_lo != 1 || (p.up != 1 && p.up != 2) || p.y_nchw || p.ksplit > 1) return false;
     if (Cin % 64 != 0 || (p.C1 != 0 && p.C0 % 64 != 0) || R % 64 != 0 || (p.R1 != 0 && p.R0 % 64 != 0)) return false;
     if (R != 0 && p.up != 1) return false;
-    if ((p.TW != 32 && p.TW != 16) || p.TH != 8 || p.Win * p.up < 2) return false;
+    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4)) || p.Win * p.up < 2) return false;
     if (p.N % conv_stream_bn(p) != 0 || Cin > 512) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
@@ -86,7 +88,7 @@ static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t strea
 int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(conv_stream_supported(p, 9), "conv_stream: unsupported shape");
     const size_t lds = conv_stream_lds_bytes(p);
-    return p.TW == 32 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<1, 2>(p, lds, stream);
+    return p.TW * p.TH == 256 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<1, 2>(p, lds, stream);
 }
 
 }  // namespace rldm

@@ -27,7 +27,10 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     constexpr int BM = 128 * WM, BN = 32 * WN;
     constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
     constexpr int C8 = CK / 8;
-    constexpr int ACH = ((BM / 8 + 2) * 10 * C8 + NT - 1) / NT;    // 16-byte halo pieces per thread and chunk (6 | 3)
+    // 16-byte halo pieces per thread and chunk: 34 x 10 pixels (6); the 128-pixel instance 18 x 10 = 16 x 8 tiles, or 34 x 6 = 32 x 4
+    // tiles for images of 4 beams (nuScenes' 128 x 4 level) (4)
+    constexpr int HALO_PX = WM == 1 ? (32 + 2) * (4 + 2) : (BM / 8 + 2) * 10;
+    constexpr int ACH = (HALO_PX * C8 + NT - 1) / NT;
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
     constexpr int ROW = 3 * SPT;               // ... per row of taps
     constexpr int CST = 9 * SPT;               // ... per chunk

@@ -1186,10 +1186,10 @@ struct Builder {
     // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels, or
     // (the 128x8 level) of 16 x 8 pixels x 64 channels
     static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, long long min_blocks,
-                                 long long max_blocks, ConvParams* q) {
+                                 long long max_blocks, ConvParams* q, int TH = 8) {
         if (dbg() & 2048) return false;
         if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
-        if (Wout % TW != 0 || Hout % 8 != 0) return false;
+        if (Wout % TW != 0 || Hout % TH != 0) return false;
         memset(q, 0, sizeof(*q));
         q->C0 = a.x0.C;
         q->C1 = Cin_t - a.x0.C;
@@ -1198,13 +1198,13 @@ struct Builder {
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
         q->up = a.up; q->stride = 1; q->pad_lo = 1;
         q->Wout = Wout; q->Hout = Hout;
-        q->TW = TW; q->TH = 8; q->th_shift = 3;
+        q->TW = TW; q->TH = TH; q->th_shift = TH == 8 ? 3 : 2;
         ConvTile t;
         t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
-        q->colb = conv_halo_col_bytes(t, 8, 1);
-        q->tiles_h = Hout / 8;
+        q->colb = conv_halo_col_bytes(t, TH, 1);
+        q->tiles_h = Hout / TH;
         q->tiles_img = (Wout / TW) * q->tiles_h;
-        q->magic_thv = ((1 << 20) + 10 - 1) / 10;
+        q->magic_thv = ((1 << 20) + (TH + 2) - 1) / (TH + 2);
         const int cpg = std::max(1, Cin_t / a.groups);
         q->magic_cpg = ((1 << 20) + cpg - 1) / cpg;
         q->gn_inv_n = (float)(1.0 / ((double)a.x0.W * a.x0.H * cpg));
@@ -1224,6 +1224,9 @@ struct Builder {
         // only where its grid is about one or two rounds); else 256-pixel tiles on at least half the chip
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
         if (!(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
+        // images of 4 beams (nuScenes' 128 x 4 level at batch 32): the same 128-pixel instance on 32 x 4 tiles (round 3; it ran on the
+        // generic kernel at 27.8 us / 257 TFLOP/s per conv: 16 % of that configuration's step)
+        if (Hout % 8 != 0 && !(dbg() & 16384) && !(dbg() & 16) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 128, 512, q, 4)) return true;
         return stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 128, 1ll << 40, q);
     }
 
@@ -1251,9 +1254,9 @@ struct Builder {
         const int ranks_s = p.tiles_img * p.ntile_n;
         const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
                                        trunk_grid_fits(ranks_s, x0.B) && y.P <= kFoldAboveP &&
-                                       (p.TW == 32 || (dbg() & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
+                                       (p.TW * p.TH == 256 || (dbg() & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
                                        // 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
-        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW == 32 ? 4 : 2, p.TW == 32 ? 2 : 3);
+        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW * p.TH == 256 ? 4 : 2, p.TW * p.TH == 256 ? 2 : 3);
         else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
@@ -1313,7 +1316,7 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_stream(p, s);
-            }, p.TW == 32 ? "conv_stream_kernel<256,128,CK64,taps9>" : "conv_stream_kernel<128,64,CK64,taps9>", fl, by};
+            }, p.TW * p.TH == 256 ? "conv_stream_kernel<256,128,CK64,taps9>" : "conv_stream_kernel<128,64,CK64,taps9>", fl, by};
             if (in_stream_cluster) pend.standalone.push_back(standalone);
             else plan->ops.push_back(standalone);
         }

@@ -55,6 +55,8 @@ CONV_CASES = [
     (1, 256, 256, 64, 16, 3, 1, 0, False),     # conv_stream.hip (flag): 4 chunks, two channel tiles
     (1, 64, 128, 32, 8, 3, 1, 0, False),       # conv_stream.hip (flag): a single chunk, a single tile
     (1, 128, 128, 32, 16, 3, 1, 0, True),      # conv_stream.hip (flag): nearest x2 folded (64x32 output)
+    (32, 128, 128, 128, 4, 3, 1, 0, False),    # conv_stream.hip: images of 4 beams (nuScenes 128x4 level at batch 32): 32 x 4 pixel tiles
+    (2, 256, 128, 1024, 4, 3, 1, 0, False),    # ... wide image, 4 chunks
 ]
 
 
@@ -97,7 +99,8 @@ def test_conv_wrap_seam_exact():
 
 GN_CASES = [(256, 256, 256, 32, 1), (128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
             (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8),
-            (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16)]
+            (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16),
+            (128, 128, 128, 1024, 4)]       # (conv_stream.hip on 32 x 4 tiles: concat, GroupNorm, time embedding, residual)
 
 
 @pytest.fixture(params=[0, 1024, 4096, 256 + 2048, 524288, 1 << 22],
