@@ -7,6 +7,8 @@ Writes tests/golden/b16.npz and tests/golden/upfull.npz:
                             after the reference's surgery, see validate_unet_against_reference.py) on a (16, 5, 256, 16) batch
   * b16_ddim3_latent_f16    x_0 (before the /0.18215) of a 3-step DDIM run of the reference's own `LDMPipelineRange.__call__`
                             loop (ldm/pipelines.py:353-362) at batch 16 with pos-encoding, driving that `Model`
+  * b16_up_eps_t700_f16, b16_nusc4_eps_t250   the 12-channel (config 4) Model at batch 16 and the nuScenes-shape (256 x 8) Model at the 4
+                            images per GPU config 3 runs at, one forward each
   * upfull_latent, upfull_image_f16   10 strided-DDPM steps (injected noise) of `LDMUpscalePipelineRange.__call__`
                             (ldm/pipelines.py:414-519, loop :466-507) at batch 2 on the full-width 12-channel UNet with the
                             reference's `SparseRangeImageEncoder2` (ldm/encoders.py:90-95) and the sgm Decoder
@@ -41,6 +43,8 @@ B16_XT = (62, "b16/x_T", (16, 4, 256, 16))
 UP_COND = (63, "upfull/cond", (2, 2, 1024, 16))
 UP_XT = (64, "upfull/x_T", (2, 4, 256, 16))
 UP_STEPS = 10
+UP16_X = (66, "b16/up_x", (16, 12, 256, 16))
+NUSC4_X = (67, "b16/nusc_x", (4, 5, 256, 8))
 
 
 def up_step_noise(i):
@@ -141,6 +145,25 @@ def main():
     check("LDMUpscalePipelineRange full width, 10 steps, image", mine, ref_img, 2e-3 * float(ref_img.abs().max()))
     gold["upfull_latent"] = lat_ref.numpy()
     gold["upfull_image_f16"] = ref_img.numpy().astype(np.float16)
+
+    print("== the other configurations at the batch they run at: config 4 (12-channel UNet) at 16, config 3 (nuScenes 256x8) at 4 per GPU")
+    xu = T(normal(*UP16_X))
+    with torch.no_grad():
+        ref = um(xu, torch.full((16,), 700))
+    mine = o_unet.unet_forward({k: T(v) for k, v in usd.items()}, ucfg, xu, 700)
+    check("Model(upsample full width, 12 ch) B=16", mine, ref, 2e-5 * float(ref.abs().max()))
+    gold["b16_up_eps_t700_f16"] = ref.numpy().astype(np.float16)
+    del um
+    ncfg = VU.sgm_sinusoid(dict(sample_size=(256, 8)))
+    nsd = VU.synth_unet_sd(ncfg, "ref/nusc.")
+    nm = VU.build_reference_unet(sgm, lu, att, ncfg)
+    VU.load_ref_unet(nm, nsd, 4)
+    xn = T(normal(*NUSC4_X))
+    with torch.no_grad():
+        ref = nm(xn, torch.full((4,), 250))
+    mine = o_unet.unet_forward({k: T(v) for k, v in nsd.items()}, ncfg, xn, 250)
+    check("Model(nuScenes 256x8 full width) B=4", mine, ref, 2e-5 * float(ref.abs().max()))
+    gold["b16_nusc4_eps_t250"] = ref.numpy()
 
     bad = [c for c in V.CHECKS if not c[3]]
     print(f"\n{len(V.CHECKS) - len(bad)}/{len(V.CHECKS)} checks passed")

@@ -622,6 +622,27 @@ def test_batch16_forward_matches_reference_model(golden):
     assert n_clustered <= 40                               # (the cluster plan, not the launch-per-layer one: 90+)
 
 
+def test_other_configs_at_their_batch_match_reference_model(golden):
+    """BASELINE config 4 (12-channel upsample UNet) at its batch 16 -- the same cluster plan as the headline -- and config 3's per-GPU
+    share (nuScenes 256 x 8 latents, 4 images: the 32 x 1 level as one persistent launch with its 32-token attention phases), one
+    forward each against the reference-composed Model (tests/golden/b16.npz)."""
+    g = golden("b16")
+    m = hip_ref_unet(UNetConfig(in_channels=12, **SGM_SINUSOID), "ref/up.")
+    x = T(normal(66, "b16/up_x", (16, 12, 256, 16))).cuda()
+    ref = T(g["b16_up_eps_t700_f16"]).float()
+    out = m(x, 700).sample.cpu()
+    worst = max(float(rel_l2(out[j], ref[j])) for j in range(16))
+    print(f"upsample B=16: rel-L2 {float(rel_l2(out, ref)):.3e}, worst sample {worst:.3e}")
+    assert rel_l2(out, ref) < TOL_FWD and worst < 1.5 * TOL_FWD and m.trunk_status(16) == 0
+    del m
+    m = hip_ref_unet(UNetConfig(sample_size=(256, 8), **SGM_SINUSOID), "ref/nusc.")
+    x = T(normal(67, "b16/nusc_x", (4, 5, 256, 8))).cuda()
+    ref = T(g["b16_nusc4_eps_t250"])
+    out = m(x, 250).sample.cpu()
+    print(f"nuScenes B=4: rel-L2 {float(rel_l2(out, ref)):.3e}")
+    assert rel_l2(out, ref) < TOL_FWD and m.trunk_status(4) == 0
+
+
 def test_batch16_sampler_matches_reference_loop(golden):
     """... and the captured batch-16 sampler (step graphs, fused scheduler tail, clusters ON): x_0 after 3 DDIM steps against the
     reference's own LDMPipelineRange loop (ldm/pipelines.py:353-362) at batch 16, at the latent tolerance of the 50-step test."""

@@ -314,6 +314,11 @@ def test_batch16_goldens_pin_the_oracle(golden):
         ref = T(g[f"b16_eps_t{t}_f16"]).float()[:2]
         eps = o_unet.unet_forward(sd, cfg, x, t)
         assert float((eps - ref).norm() / ref.norm()) < 1e-3              # (the golden is stored as fp16)
+    ncfg = UNetConfig(sample_size=(256, 8), **SGM_SINUSOID)          # config 3's per-GPU share: nuScenes latents, 4 images (first 2 here)
+    nsd = {k: T(v) for k, v in ref_unet_sd(ncfg, "ref/nusc.").items()}
+    ref = T(g["b16_nusc4_eps_t250"])[:2]
+    eps = o_unet.unet_forward(nsd, ncfg, T(normal(67, "b16/nusc_x", (4, 5, 256, 8)))[:2], 250)
+    assert float((eps - ref).norm() / ref.norm()) < 1e-4
     unet = o_unet.OracleUNet(cfg, ref_unet_sd(cfg, "ref/full."))
     x_T = T(normal(62, "b16/x_T", (16, 4, 256, 16)))[:2]
     lat = o_pipe.ldm_pipeline(None, unet, o_sched.OracleDDIMScheduler(), x_T, 3, pos_encoding=True, decode=False)
