@@ -155,6 +155,34 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             if (q < atotal) *reinterpret_cast<uint4*>(dstbuf + vwl * colb + vhl * RS + c8 * 16) = v;
         }
     };
+    // A RESIDUAL chunk (the raw block input under the centre tap: identity, or the 1x1 shortcut) is read at the tile's own pixels only:
+    // a thread-linear mapping of the BM x 8 pieces (4 | 2 per thread instead of the halo's 6 | 4, a quarter fewer bytes), addresses
+    // recomputed per chunk (shifts and adds), the pieces parked in the halo registers.  Round 3: the residual phase of the
+    // full-resolution convs is a burst of loads with 16 MFMAs per wave between two of them -- removing it altogether measured +4.0 %
+    // end to end (an upper bound), the halo-shaped fetch with its unused ring was the most avoidable part of it.
+    constexpr int RCH = (BM * C8 + NT - 1) / NT;
+    static_assert(RCH <= ACH && (BM * C8) % NT == 0, "residual pieces fit the halo registers");
+    constexpr int RSTEP = NT / C8;                                        // tile pixels between a thread's pieces (a whole number of columns)
+    auto load_r = [&](int cs, uint4* rr) __attribute__((always_inline)) {
+        const int cb = (cs - NCC) * CK;                                   // (uniform: the chunk lies in ONE of the two tensors)
+        const bool first = cb < nR0;
+        const bf16_t* base = (first ? gr0 + cb : gr1 + (cb - nR0)) + my_c8;
+        const int ld = first ? nR0 : nR1;
+        const int pidx = tid / C8, pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+        const bf16_t* src = base + (size_t)((b * p.Wout + w0 + pw) * p.Hout + h0 + ph) * ld;
+        const size_t step = (size_t)((RSTEP >> p.th_shift) * p.Hout) * ld;
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) rr[i] = ld_act16<TRUNK>(src + i * step);
+    };
+    auto store_r = [&](int cs, const uint4* rr) __attribute__((always_inline)) {
+        const int pidx = tid / C8, pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+        unsigned char* dst = sA + (cs & 1) * abytes + (pw + 1) * colb + (ph + 1) * RS + (tid % C8) * 16;
+        const int step = (RSTEP >> p.th_shift) * colb;
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) *reinterpret_cast<uint4*>(dst + i * step) = rr[i];
+    };
+    auto load_next = [&](int cs) __attribute__((always_inline)) { if (cs < NCC) load_a(cs); else load_r(cs, areg); };
+    auto store_next = [&](int cs) __attribute__((always_inline)) { if (cs < NCC) store_a(cs); else store_r(cs, areg); };
     RLDM_STAMP();
     if constexpr (TRUNK) trunk_wait(seam, tid);     // (everything above is independent of the previous phase)
     // ---- GroupNorm: the statistics partials of channel `tid`, gamma and beta are requested first, then the first halo
@@ -300,7 +328,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     static_assert(PFX <= ROW, "the read-ahead reaches at most into the next row of taps");
     RLDM_STAMP();
     for (int cs = 0; cs < NCC; ++cs) {
-        if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_a(cs + 1);       // next chunk (main or first residual): requested now, written below
+        if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_next(cs + 1);    // next chunk (main or first residual): requested now, written below
         int cur[MI], nxt[MI];
         const int boff = (cs & 1) * abytes;
 #pragma unroll
@@ -311,25 +339,32 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             __builtin_amdgcn_sched_barrier(0);
         }
         tap_row(cur, nxt, 0);
-        if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
+        if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) { cur[mi] = nxt[mi]; nxt[mi] += colb; }
         tap_row(cur, nxt, 1);
-        if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_a(cs + 1);
+        if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) cur[mi] = nxt[mi];
         tap_row(cur, nxt, 2);
         lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
     }
-    // residual phase: centre tap of the raw block input, SPT k-steps per chunk; ring slots continue (CST % G == 0)
+    // residual phase: centre tap of the raw block input, SPT k-steps per chunk; ring slots continue (CST % G == 0).  A chunk is 16
+    // MFMAs per wave -- far less than a round trip to the L2 -- so RD chunks are kept in flight in registers (the main loop's
+    // read-ahead registers are dead here): chunk k lands in set k % RD, requested RD iterations before it is written to LDS.
     constexpr int RCR = G / SPT;                // residual chunks per ring revolution
-    for (int rc0 = 0; rc0 < NCB; rc0 += RCR) {
+    constexpr int RD = RLDM_RES_DEPTH, RUN = RCR * RD;
+    uint4 rreg[RD][RCH];
 #pragma unroll
-        for (int r = 0; r < RCR; ++r) {
+    for (int k = 1; k < RD; ++k)
+        if (k < NCB) load_r(NCC + k, rreg[k % RD]);             // (chunk 0 came through the halo registers during the last main chunk)
+    for (int rc0 = 0; rc0 < NCB; rc0 += RUN) {
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
             const int rc = rc0 + r;
             if (rc < NCB) {
                 const int cs = NCC + rc;
-                if (cs + 1 < NCT) load_a(cs + 1);
+                if (rc + RD < NCB) load_r(cs + RD, rreg[r % RD]);
                 int xc[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) xc[mi] = xoff[mi] + (cs & 1) * abytes + colb + RS;
@@ -340,14 +375,14 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
                     for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(smem + xc[mi] + ks * 32);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[r * SPT + ks], xf[mi], acc[mi], 0, 0, 0);
-                    wr[r * SPT + ks] = w_load(wptr, r * SPT + ks);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[(r % RCR) * SPT + ks], xf[mi], acc[mi], 0, 0, 0);
+                    wr[(r % RCR) * SPT + ks] = w_load(wptr, (r % RCR) * SPT + ks);
                 }
-                if (cs + 1 < NCT) store_a(cs + 1);
+                if (rc + 1 < NCB) store_r(cs + 1, rreg[(r + 1) % RD]);
                 lds_barrier_b();
             }
+            if (r % RCR == RCR - 1) wptr += G * 1024;
         }
-        wptr += G * 1024;
     }
     RLDM_STAMP();
 

@@ -279,6 +279,9 @@ int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream);    // the
 #ifndef RLDM_TRUNK_PREFETCH
 #define RLDM_TRUNK_PREFETCH 18     /* (round 3: 12 -> 18 = the whole ring of a 3x3 / 256-channel phase: +0.5 %, trunk<0> 201 -> 225 VGPRs) */
 #endif
+#ifndef RLDM_RES_DEPTH
+#define RLDM_RES_DEPTH 1           /* residual chunks of a conv_stream tile in flight in registers (conv_stream_body.h); 2 and 3 measured the same */
+#endif
 // LDS of the second-generation fused attention body (attention_body.h) for HG heads per workgroup on `waves` waves: K rows, V^T,
 // the GroupNorm affine + scratch, the heads' W' fragments and biases, and one 32-row x 144-byte x staging tile per wave
 constexpr int kAttnXRowBytes = 128 + 16, kAttnXStageBytes = 32 * kAttnXRowBytes;
