@@ -50,8 +50,10 @@ __global__ void __launch_bounds__(512, 1) conv_stream_kernel(const ConvParams p)
 // the instance is chosen by the pixel tile: 32 x 8 -> 256 px x 128 ch (one k-group), 16 x 8 -> 128 px x 64 ch (4 k-groups)
 // the instance is chosen by the pixel tile: 256 pixels (32 x 8) -> <2, 4> (128 channels, no k-groups); 128 pixels (16 x 8, or 32 x 4 for
 // images of 4 beams) -> <1, 2> (64 channels x 4 k-groups)
-int conv_stream_bn(const ConvParams& p) { return p.TW * p.TH == 256 ? 128 : 64; }
-int conv_stream_kgroups(const ConvParams& p) { return p.TW * p.TH == 256 ? 1 : 4; }
+// (round 3) <2, 2>: 256 pixels x 64 channels x 2 k-groups for layers of 64 (192, ...) output channels -- the VAE decoder's
+// full-resolution level, which ran on the generic kernel at 278 us per conv
+int conv_stream_bn(const ConvParams& p) { return p.TW * p.TH == 256 && p.N % 128 == 0 ? 128 : 64; }
+int conv_stream_kgroups(const ConvParams& p) { return p.TW * p.TH == 256 ? (p.N % 128 == 0 ? 1 : 2) : 4; }
 
 size_t conv_stream_lds_bytes(const ConvParams& p) {
     const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * p.TH;
@@ -88,7 +90,8 @@ static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t strea
 int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(conv_stream_supported(p, 9), "conv_stream: unsupported shape");
     const size_t lds = conv_stream_lds_bytes(p);
-    return p.TW * p.TH == 256 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<1, 2>(p, lds, stream);
+    if (p.TW * p.TH == 256) return p.N % 128 == 0 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<2, 2>(p, lds, stream);
+    return launch_stream_inst<1, 2>(p, lds, stream);
 }
 
 }  // namespace rldm

@@ -34,10 +34,10 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
     constexpr int ROW = 3 * SPT;               // ... per row of taps
     constexpr int CST = 9 * SPT;               // ... per chunk
-    constexpr int G = KG == 1 ? ROW : CST;     // weight fragments in flight per wave (ring): a row of taps | a chunk
+    constexpr int G = KG == 4 ? CST : ROW;     // weight fragments in flight per wave (ring): a chunk (9) | a row of taps (12 | 6)
     constexpr int PFX = KG == 1 ? 2 : 3;       // pixel fragments read ahead; divides CST
     constexpr int ERS = BN * 2 + 16, NC8 = BN / 8;
-    static_assert(WM * WN * KG == 8 && (KG == 1 || WM == 1) && CST % PFX == 0 && G <= 16, "wave grid");
+    static_assert(WM * WN * KG == 8 && CST % PFX == 0 && G <= 16, "wave grid");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tid_ = threadIdx.x;
     if constexpr (TRUNK) asm volatile("" : "+v"(tid_));          // (opaque per phase: conv_small_body.h)
@@ -403,7 +403,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         if (hp > 0) lds_barrier_b();            // the previous half-tile has been consumed
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
-            const int mi = hp * 2 + m2, pl = m2 * 32 + l31;
+            const int mi = (hp % 2) * 2 + m2, pl = m2 * 32 + l31;       // (the waves of pixel part hp / 2 hold this pass's pixels)
+            if (WM > 1 && wm != hp / 2) continue;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int chl = wn * 32 + 8 * r4 + 4 * kh;

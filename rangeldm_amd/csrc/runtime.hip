@@ -1253,7 +1253,7 @@ struct Builder {
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
         const int ranks_s = p.tiles_img * p.ntile_n;
         const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
-                                       trunk_grid_fits(ranks_s, x0.B) && y.P <= kFoldAboveP &&
+                                       trunk_grid_fits(ranks_s, x0.B) && y.P <= kFoldAboveP && N % 128 == 0 &&
                                        (p.TW * p.TH == 256 || (dbg() & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
                                        // 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
         if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW * p.TH == 256 ? 4 : 2, p.TW * p.TH == 256 ? 2 : 3);
@@ -1316,7 +1316,7 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_stream(p, s);
-            }, p.TW * p.TH == 256 ? "conv_stream_kernel<256,128,CK64,taps9>" : "conv_stream_kernel<128,64,CK64,taps9>", fl, by};
+            }, "conv_stream_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(conv_stream_bn(p)) + ",CK64,taps9>", fl, by};
             if (in_stream_cluster) pend.standalone.push_back(standalone);
             else plan->ops.push_back(standalone);
         }

@@ -57,6 +57,9 @@ CONV_CASES = [
     (1, 128, 128, 32, 16, 3, 1, 0, True),      # conv_stream.hip (flag): nearest x2 folded (64x32 output)
     (32, 128, 128, 128, 4, 3, 1, 0, False),    # conv_stream.hip: images of 4 beams (nuScenes 128x4 level at batch 32): 32 x 4 pixel tiles
     (2, 256, 128, 1024, 4, 3, 1, 0, False),    # ... wide image, 4 chunks
+    (2, 128, 64, 1024, 64, 3, 1, 0, False),    # conv_stream.hip <2, 2>: 64 output channels on 256-pixel tiles, 2 k-groups (VAE decoder, 128 -> 64)
+    (1, 128, 64, 512, 32, 3, 1, 0, True),      # ... behind the folded nearest x2 (the decoder's last upsample is 128 -> 128; this is the shape check)
+    (2, 64, 192, 64, 16, 3, 1, 0, False),      # ... (flag) three 64-channel tiles
 ]
 
 
@@ -100,7 +103,8 @@ def test_conv_wrap_seam_exact():
 GN_CASES = [(256, 256, 256, 32, 1), (128, 128, 128, 32, 16), (256, 128, 256, 16, 8), (256, 256, 256, 32, 2), (64, 32, 64, 16, 8),
             (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8),
             (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16),
-            (128, 128, 128, 1024, 4)]       # (conv_stream.hip on 32 x 4 tiles: concat, GroupNorm, time embedding, residual)
+            (128, 128, 128, 1024, 4),       # (conv_stream.hip on 32 x 4 tiles: concat, GroupNorm, time embedding, residual)
+            (32, 32, 64, 1024, 64), (64, 64, 64, 256, 16)]   # (conv_stream.hip <2, 2>: 64 output channels, identity residual of 64)
 
 
 @pytest.fixture(params=[0, 1024, 4096, 256 + 2048, 524288, 1 << 22],
@@ -143,7 +147,7 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H, conv_flags):
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
                                                 (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3),
                                                 (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1), (2, 128, 128, 128, 8, 3),
-                                                (4, 256, 256, 32, 1, 3), (2, 256, 256, 32, 1, 1)])
+                                                (4, 256, 256, 32, 1, 3), (2, 256, 256, 32, 1, 1), (1, 64, 64, 1024, 64, 3)])
 def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
     the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
