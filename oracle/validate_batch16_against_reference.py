@@ -15,7 +15,8 @@ Writes tests/golden/b16.npz and tests/golden/upfull.npz:
 Inputs are regenerated from rangeldm_amd.synth on both sides (seeds below) and are not stored.  The oracle is checked against
 the same outputs here, so the CPU suite can re-check it from the vectors alone.
 
-    python -m oracle.validate_batch16_against_reference [--check]        (~3 min on 8 cores)
+    python -m oracle.validate_batch16_against_reference [--check] [--long]        (~3 min on 8 cores; --long: + ~25 min)
+  * b16long_ddim50_latent_f16 (--long; tests/golden/b16long.npz)   x_0 of the HEADLINE workload: the same loop for all 50 DDIM steps at batch 16
 """
 import argparse
 import os
@@ -54,6 +55,7 @@ def up_step_noise(i):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--long", action="store_true", help="also the 50-step batch-16 run (tests/golden/b16long.npz, ~25 min)")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -108,6 +110,19 @@ def main():
     check("LDMPipelineRange 3 DDIM steps B=16, final latent", mine, lat_ref, 2e-4 * float(lat_ref.abs().max()))
     assert float(lat_ref.abs().max()) < 6e4
     gold["b16_ddim3_latent_f16"] = lat_ref.numpy().astype(np.float16)
+    if args.long:
+        # the headline workload itself: 50 DDIM steps at batch 16 through the reference's loop (~12 min of reference + ~12 min of oracle)
+        print("== batch 16, the full 50 DDIM steps of the reference's LDMPipelineRange loop (latent only)")
+        t0 = time.time()
+        pipe(batch_size=16, generator=None, num_inference_steps=50, output_type="torch")
+        lat50 = zrec[-1] * VAEConfig().scaling_factor
+        print(f"  (reference loop {time.time() - t0:.0f} s, |x_0| max {float(lat50.abs().max()):.1f})")
+        t0 = time.time()
+        mine = o_pipe.ldm_pipeline(None, ofull, o_sched.OracleDDIMScheduler(), x_T, 50, pos_encoding=True, decode=False)
+        check(f"LDMPipelineRange 50 DDIM steps B=16, final latent ({time.time() - t0:.0f} s)", mine, lat50,
+              2e-4 * float(lat50.abs().max()))
+        assert float(lat50.abs().max()) < 6e4
+        gold["b16long_ddim50_latent_f16"] = lat50.numpy().astype(np.float16)
     del fm, pipe
 
     print("== config 4 at full width: LDMUpscalePipelineRange, 10 strided-DDPM steps, batch 2, 12-channel UNet")

@@ -666,6 +666,30 @@ def test_batch16_sampler_matches_reference_loop(golden):
     assert unet.num_launches(16) <= 40
 
 
+def test_batch16_headline_run_matches_reference_loop(golden):
+    """The headline workload itself (BASELINE config 2): all 50 DDIM steps at batch 16, captured step graphs + persistent launches, against
+    x_0 of the reference's own LDMPipelineRange loop (ldm/pipelines.py:353-362) driving the reference-composed Model
+    (tests/golden/b16long.npz, written by `python -m oracle.validate_batch16_against_reference --long`, which also checks the oracle's
+    50-step run against it)."""
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    g = golden("b16long")
+    unet = hip_ref_unet(UNetConfig(**SGM_SINUSOID), "ref/full.")
+    vae, _, _ = hip_vae()
+    pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=True)
+    x_T = T(normal(62, "b16/x_T", (16, 4, 256, 16)))
+    h = pipe._fused.get(unet, vae, pipe.scheduler, 16, 50, 0, True, 0)
+    img = torch.empty((16, 2, 1024, 64), device="cuda")
+    lat = torch.empty((16, 4, 256, 16), device="cuda")
+    pipe._fused.run(h, x_T.cuda().contiguous(), None, None, img, latents_out=lat)
+    ref = T(g["b16long_ddim50_latent_f16"]).float()
+    e = rel_l2(lat.cpu(), ref)
+    worst = max(float(rel_l2(lat[j].cpu(), ref[j])) for j in range(16))
+    print(f"B=16 50-step DDIM: final latent rel-L2 {float(e):.3e}, worst sample {worst:.3e}")
+    assert e < TOL_X0 and worst < 2 * TOL_X0
+    assert torch.isfinite(img).all()
+
+
 def test_upscale_full_width_pipeline_matches_reference_loop(golden):
     """BASELINE config 4 end to end at full width: LDMUpscalePipelineRange.__call__ (ldm/pipelines.py:414-519) for 10 strided-DDPM
     steps at batch 2 on the 12-channel UNet (30.1 M parameters) with SparseRangeImageEncoder2, against the reference's loop driving

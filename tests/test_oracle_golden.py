@@ -326,6 +326,20 @@ def test_batch16_goldens_pin_the_oracle(golden):
     assert float((lat - ref).norm() / ref.norm()) < 1e-3
 
 
+def test_batch16_headline_golden_pins_the_oracle(golden):
+    """tests/golden/b16long.npz: x_0 of the headline workload -- all 50 DDIM steps of the reference's LDMPipelineRange loop at batch 16
+    (`python -m oracle.validate_batch16_against_reference --long` checked the oracle on all 16 samples; the CPU suite re-runs the
+    first one: samples never interact)."""
+    from rangeldm_amd.synth import normal
+    g = golden("b16long")
+    cfg = UNetConfig(**SGM_SINUSOID)
+    unet = o_unet.OracleUNet(cfg, ref_unet_sd(cfg, "ref/full."))
+    x_T = T(normal(62, "b16/x_T", (16, 4, 256, 16)))[:1]
+    lat = o_pipe.ldm_pipeline(None, unet, o_sched.OracleDDIMScheduler(), x_T, 50, pos_encoding=True, decode=False)
+    ref = T(g["b16long_ddim50_latent_f16"]).float()[:1]
+    assert float((lat - ref).norm() / ref.norm()) < 1e-3
+
+
 def test_upscale_full_width_golden_pins_the_oracle(golden):
     """tests/golden/upfull.npz: 10 strided-DDPM steps of the reference's LDMUpscalePipelineRange.__call__ (ldm/pipelines.py:414-519)
     at batch 2 on the full-width 12-channel UNet with SparseRangeImageEncoder2 and the sgm Decoder (BASELINE config 4)."""
