@@ -7,8 +7,8 @@ Writes tests/golden/b16.npz and tests/golden/upfull.npz:
                             after the reference's surgery, see validate_unet_against_reference.py) on a (16, 5, 256, 16) batch
   * b16_ddim3_latent_f16    x_0 (before the /0.18215) of a 3-step DDIM run of the reference's own `LDMPipelineRange.__call__`
                             loop (ldm/pipelines.py:353-362) at batch 16 with pos-encoding, driving that `Model`
-  * b16_up_eps_t700_f16, b16_nusc4_eps_t250   the 12-channel (config 4) Model at batch 16 and the nuScenes-shape (256 x 8) Model at the 4
-                            images per GPU config 3 runs at, one forward each
+  * b16_up_eps_t700_f16, b16_nusc4_eps_t250, b16_nusc32_eps_t610_f16   the 12-channel (config 4) Model at batch 16 and the nuScenes-shape
+                            (256 x 8) Model at the 4 images per GPU config 3 runs at on 8 GPUs and at its whole batch of 32, one forward each
   * upfull_latent, upfull_image_f16   10 strided-DDPM steps (injected noise) of `LDMUpscalePipelineRange.__call__`
                             (ldm/pipelines.py:414-519, loop :466-507) at batch 2 on the full-width 12-channel UNet with the
                             reference's `SparseRangeImageEncoder2` (ldm/encoders.py:90-95) and the sgm Decoder
@@ -46,6 +46,7 @@ UP_XT = (64, "upfull/x_T", (2, 4, 256, 16))
 UP_STEPS = 10
 UP16_X = (66, "b16/up_x", (16, 12, 256, 16))
 NUSC4_X = (67, "b16/nusc_x", (4, 5, 256, 8))
+NUSC32_X = (68, "b16/nusc32_x", (32, 5, 256, 8))
 
 
 def up_step_noise(i):
@@ -179,6 +180,14 @@ def main():
     mine = o_unet.unet_forward({k: T(v) for k, v in nsd.items()}, ncfg, xn, 250)
     check("Model(nuScenes 256x8 full width) B=4", mine, ref, 2e-5 * float(ref.abs().max()))
     gold["b16_nusc4_eps_t250"] = ref.numpy()
+    # ... and config 3 as ONE GPU runs it (`eval_batch_size: 32`): the batch at which the nuScenes network gets its persistent launches
+    xn32 = T(normal(*NUSC32_X))
+    with torch.no_grad():
+        ref = nm(xn32, torch.full((32,), 610))
+    mine = o_unet.unet_forward({k: T(v) for k, v in nsd.items()}, ncfg, xn32, 610)
+    check("Model(nuScenes 256x8 full width) B=32", mine, ref, 2e-5 * float(ref.abs().max()))
+    assert float(ref.abs().max()) < 6e4
+    gold["b16_nusc32_eps_t610_f16"] = ref.numpy().astype(np.float16)
 
     bad = [c for c in V.CHECKS if not c[3]]
     print(f"\n{len(V.CHECKS) - len(bad)}/{len(V.CHECKS)} checks passed")

@@ -641,6 +641,13 @@ def test_other_configs_at_their_batch_match_reference_model(golden):
     out = m(x, 250).sample.cpu()
     print(f"nuScenes B=4: rel-L2 {float(rel_l2(out, ref)):.3e}")
     assert rel_l2(out, ref) < TOL_FWD and m.trunk_status(4) == 0
+    # ... and config 3's whole batch on one GPU (`eval_batch_size: 32`): clusters at every level, conv_stream on 32 x 4 tiles
+    x = T(normal(68, "b16/nusc32_x", (32, 5, 256, 8))).cuda()
+    ref = T(g["b16_nusc32_eps_t610_f16"]).float()
+    out = m(x, 610).sample.cpu()
+    worst = max(float(rel_l2(out[j], ref[j])) for j in range(32))
+    print(f"nuScenes B=32: rel-L2 {float(rel_l2(out, ref)):.3e}, worst sample {worst:.3e}, {m.num_launches(32)} launches")
+    assert rel_l2(out, ref) < TOL_FWD and worst < 1.5 * TOL_FWD and m.trunk_status(32) == 0
 
 
 def test_batch16_sampler_matches_reference_loop(golden):

@@ -319,6 +319,9 @@ def test_batch16_goldens_pin_the_oracle(golden):
     ref = T(g["b16_nusc4_eps_t250"])[:2]
     eps = o_unet.unet_forward(nsd, ncfg, T(normal(67, "b16/nusc_x", (4, 5, 256, 8)))[:2], 250)
     assert float((eps - ref).norm() / ref.norm()) < 1e-4
+    ref = T(g["b16_nusc32_eps_t610_f16"]).float()[:2]                # ... and of its whole batch of 32 (first 2)
+    eps = o_unet.unet_forward(nsd, ncfg, T(normal(68, "b16/nusc32_x", (32, 5, 256, 8)))[:2], 610)
+    assert float((eps - ref).norm() / ref.norm()) < 1e-3
     unet = o_unet.OracleUNet(cfg, ref_unet_sd(cfg, "ref/full."))
     x_T = T(normal(62, "b16/x_T", (16, 4, 256, 16)))[:2]
     lat = o_pipe.ldm_pipeline(None, unet, o_sched.OracleDDIMScheduler(), x_T, 3, pos_encoding=True, decode=False)
