@@ -74,7 +74,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
 
     const int Cin = p.C0 + p.C1;
     const int NCC = Cin / CK;                  // main-phase chunks: 9 taps x 4 k-steps
-    const int NCB = (p.R0 + p.R1) / CK;        // residual-phase chunks: centre tap, 4 k-steps, raw input
+    const int NCBw = (p.R0 + p.R1) / CK;       // residual-phase chunks: centre tap, 4 k-steps, raw input
+    const int NCB = RLDM_EXP_NORES ? 0 : NCBw;
     const int NCT = NCC + NCB;
     const int THv = p.TH + 2, TWv = p.TW + 2;
     const int colb = p.colb;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     float* sBias = sGs + Cin;                                  // BN
 
     // ---- this wave's weight stream (channel tile WN*nt + wn, k-group kg): [NCC][9 taps][SPT k-steps] then [NCB][SPT], 1 KiB each
-    const int nsteps = NCC * CST + NCB * SPT;
+    const int nsteps = NCC * CST + NCBw * SPT;
     const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk) +
                                 (size_t)((nt * WN + wn) * KG + kg) * nsteps * 1024;
     const unsigned woff = lane * 16 + 4096;     // lane offset: immediates of +-4 KiB around it reach 8 fragments
@@ -124,7 +125,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     };
     auto store_a = [&](int cs) __attribute__((always_inline)) {                 // GroupNorm + SiLU (main phase) -> LDS
         unsigned char* dstbuf = sA + (cs & 1) * abytes;
-        const bool anorm = gn && cs < NCC;
+        const bool anorm = gn && cs < NCC && !RLDM_EXP_NONORM;
         float4 ga0, ga1, gs0, gs1;
         if (anorm) {
             const int c = cs * CK + my_c8;
@@ -196,7 +197,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         const bool first = tid < nC0;
         const int c = first ? tid : tid - nC0;
         const int C = first ? nC0 : nC1;
-        const int P = first ? nP0 : nP1;
+        const int P = RLDM_EXP_NOSTATS ? 0 : (first ? nP0 : nP1);
+        if (RLDM_EXP_NOSTATS) gSS = (double)(1.0f / p.gn_inv_n) / (Cin / p.gn_groups);       // (mean 0, variance 1: finite garbage)
         const float2* src = (first ? gs0p : gs1p) + (size_t)b * P * C + c;
         g_gamma = p.gn_gamma[tid];
         g_beta = p.gn_beta[tid];

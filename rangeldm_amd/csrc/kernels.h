@@ -279,6 +279,22 @@ int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream);    // the
 #ifndef RLDM_TRUNK_PREFETCH
 #define RLDM_TRUNK_PREFETCH 18     /* (round 3: 12 -> 18 = the whole ring of a 3x3 / 256-channel phase: +0.5 %, trunk<0> 201 -> 225 VGPRs) */
 #endif
+// Timing-only ablations of the round-3 headroom study: `make TAG=x EXTRA=-DRLDM_EXP_NORES=1` etc. build a library
+// whose RESULTS ARE WRONG and whose speed bounds what the removed piece can be worth (tools/ab_libs.sh, tools/fwd_time.py).  All 0 in
+// every shipped build.  NORES: conv_stream skips its residual phase; NONORM: ... the GroupNorm + SiLU arithmetic of its staging (raw
+// copy); NOSTATS: ... the statistics partial loads in front of its fold (mean 0 / variance 1 instead); NOWAIT: the persistent launches' cluster waits do not poll.
+#ifndef RLDM_EXP_NORES
+#define RLDM_EXP_NORES 0
+#endif
+#ifndef RLDM_EXP_NONORM
+#define RLDM_EXP_NONORM 0
+#endif
+#ifndef RLDM_EXP_NOSTATS
+#define RLDM_EXP_NOSTATS 0
+#endif
+#ifndef RLDM_EXP_NOWAIT
+#define RLDM_EXP_NOWAIT 0
+#endif
 #ifndef RLDM_RES_DEPTH
 #define RLDM_RES_DEPTH 1           /* residual chunks of a conv_stream tile in flight in registers (conv_stream_body.h); 2 and 3 measured the same */
 #endif

@@ -30,7 +30,7 @@ struct TrunkSeam {
 #define RLDM_TRUNK_INV "buffer_inv sc0"
 #endif
 __device__ __forceinline__ void trunk_wait(const TrunkSeam& s, int tid) {
-    if (tid == 0 && s.has_wait) {
+    if (tid == 0 && s.has_wait && !RLDM_EXP_NOWAIT) {
         int polls = 0;
         while ((int)(__hip_atomic_load(s.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - s.wait_for) < 0) {   // (wrap-safe)
             __builtin_amdgcn_s_sleep(1);
