@@ -153,6 +153,94 @@ def roofline(pipe, sampler_handle, x_T, steps):
     return rl, kernels
 
 
+def other_configs(seed, dev):
+    """The BASELINE configs the headline line does not cover, each as a short leg on ONE GPU AFTER (outside) the headline's timed
+    region: (3) nuScenes at its whole batch of 32 and at its per-GPU share on 8 GPUs (4 images), (4) conditional up-sampling at
+    batch 16, (1) pixel-space RangeDM at batch 1 / 10 steps, (5) the training step at 8 samples.  Same pipelines, synthetic weights,
+    inputs resident in HBM; every leg: build + one warm call (graph capture), then `iters` timed calls between synchronisations.
+    frac_of_peak = algorithmic FLOPs / time / the dense bf16 MFMA peak."""
+    from rangeldm_amd.pipelines import LDMPipelineRange, DDIMPipelineRange, LDMUpscalePipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    from rangeldm_amd.synth import latent_noise, sparse_range_condition
+    legs = []
+
+    def sample_leg(name, preset, B, S, iters):
+        t_leg = time.perf_counter()
+        p, unet, vae, _, _ = build_models(preset, seed)
+        sched = DDIMSchedulerHIP()
+        cond_enc, conds = None, None
+        lat_shape = (p["unet"].out_channels, *p["unet"].sample_size)
+        if p["cond_channels"] == 8:
+            from rangeldm_amd.encoders import SparseRangeImageEncoder2
+            pipe = LDMUpscalePipelineRange(vae=vae, unet=unet, scheduler=sched)
+            cond_enc = SparseRangeImageEncoder2()
+            W4, H4 = p["unet"].sample_size
+            conds = torch.from_numpy(np.stack([sparse_range_condition(seed, j, (2, 4 * W4, H4)) for j in range(B)])).to(dev)
+        elif vae is not None:
+            pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
+        else:
+            pipe = DDIMPipelineRange(unet=unet, scheduler=sched, pos_encoding=p["pos_encoding"])
+        x = torch.from_numpy(np.stack([latent_noise(seed, j, lat_shape) for j in range(B)])).to(dev)
+        kw = dict(batch_size=B, num_inference_steps=S, latents=x, output_type="torch", check=False)
+        if conds is not None:
+            kw.update(image=conds, condition_encoder=cond_enc)
+        out = pipe(**kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = pipe(**kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        pipe._fused.status_all()
+        assert torch.isfinite(out).all()
+        gflop = (S * unet.flops(B) + (vae.decode_flops(B, *lat_shape[1:]) if vae else 0.0)) / B / 1e9
+        legs.append({"workload": name, "value": round(B / dt, 2), "unit": "range-images/sec", "ms": round(dt * 1e3, 3),
+                     "frac_of_peak": round(B / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, 4), "leg_seconds": round(time.perf_counter() - t_leg, 2)})
+        del pipe, unet, vae
+
+    def train_leg(iters):
+        from rangeldm_amd.config import PRESETS
+        from rangeldm_amd.params import unet_param_shapes, vae_param_shapes
+        from rangeldm_amd.schedulers import DDPMSchedulerHIP
+        from rangeldm_amd.synth import synth_state_dict, normal
+        from rangeldm_amd.training import UNetTrainer, training_step
+        from rangeldm_amd.vae import AutoencoderKLHIP
+        t_leg = time.perf_counter()
+        p = PRESETS["RangeLDM"]
+        tr = UNetTrainer(p["unet"], synth_state_dict(unet_param_shapes(p["unet"]), seed=seed), device=dev)
+        vae = AutoencoderKLHIP(p["vae"])
+        vae.load_state_dict(synth_state_dict(vae_param_shapes(p["vae"]), seed=seed, prefix="vae."))
+        sched = DDPMSchedulerHIP()
+        B = 8
+        gen = torch.Generator().manual_seed(seed)
+        imgs = [torch.from_numpy(normal(seed, f"train/0/{i}", (B, 2, 1024, 64))).mul_(0.5).to(dev) for i in range(2 + iters)]
+        for i in range(2):                               # (step 1 runs eagerly and sizes the scratch, step 2 captures the graphs)
+            training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True, graphed=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2, 2 + iters):
+            loss = training_step(tr, vae, sched, imgs[i], generator=gen, pos_encoding=True, graphed=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        gflop = 3 * 34.071 + 75.73
+        assert np.isfinite(float(loss))
+        legs.append({"workload": "config 5 per-GPU share: train_unconditional step (VAE encode + UNet fwd + bwd + AdamW + EMA), batch 8",
+                     "value": round(B / dt, 1), "unit": "samples/sec", "ms": round(dt * 1e3, 3),
+                     "frac_of_peak": round(B / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, 4), "leg_seconds": round(time.perf_counter() - t_leg, 2)})
+
+    for fn, a in ((sample_leg, ("config 3 on one GPU: nuScenes 32x1024, 50-step DDIM, batch 32", "nuscenes", 32, 50, 5)),
+                  (sample_leg, ("config 3 per-GPU share at 8 GPUs: nuScenes, 50-step DDIM, batch 4", "nuscenes", 4, 50, 8)),
+                  (sample_leg, ("config 4: conditional up-sampling 16 -> 64 beams, 50-step DDIM, batch 16", "upsample", 16, 50, 5)),
+                  (sample_leg, ("config 1: RangeDM 64x1024 pixel space, 10-step DDIM, batch 1", "RangeDM", 1, 10, 10)),
+                  (train_leg, (10,))):
+        try:
+            fn(*a)
+        except Exception as e:                           # a leg that fails is reported, not hidden; the headline line still prints
+            legs.append({"workload": str(a[0]), "error": repr(e)[:300]})
+        torch.cuda.empty_cache()
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +256,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20240310)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary three-requests-in-flight measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` block (BASELINE configs 1, 3, 4, 5 as short legs after the headline measurement)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 5 instead of the headline: the data-parallel training step (tools/bench_train.py, same "
                          "--gpus / --steps / --warmup contract, metric training samples/sec)")
@@ -188,6 +278,11 @@ def main():
 
     rank, world, local = D.init_from_env("nccl")
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world > 1 and "RLDM_COLLECTIVE" not in os.environ:
+        # a scaling record must not be a silently re-routed one: with N > 1 ranks on RCCL the exchange goes through the C-ABI
+        # communicator or the run FAILS (every rank together: distributed.Communicator's agreement rounds); RLDM_COLLECTIVE=torch asks
+        # for torch.distributed's collective explicitly, and the line's `comm.collective` says which one carried the images
+        os.environ["RLDM_REQUIRE_CABI"] = "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -325,6 +420,13 @@ def main():
                                     "unit": "range-images/sec", "ms_per_request": round(dtp / (2 * nreq) * 1e3, 3),
                                     "note": "secondary figure; `value` is one request at a time"}
                 assert torch.isfinite(outp).all()
+            if (world == 1 and not args.no_other_configs and args.preset == "RangeLDM" and B == 16 and zs is None and conds is None
+                    and not strong):
+                del pipe
+                torch.cuda.empty_cache()
+                t_oc = time.perf_counter()
+                res["other_configs"] = other_configs(args.seed, dev)
+                res["other_configs_seconds"] = round(time.perf_counter() - t_oc, 1)
         print(json.dumps(res), flush=True)
     D.barrier()
     D.close()

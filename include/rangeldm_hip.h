@@ -391,6 +391,9 @@ int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLA
  * 1 << 30 the 128x8 conv pairs as 2-phase launches, 64 keeps the sampler's pack_input launch, 1 << 23 keeps the scheduler step
  * a launch, 1 << 20 every GroupNorm on the consumer side.  0 restores the defaults. */
 int rldm_debug_set_flags(int flags);
+/* second word of the same kind (RLDM_DBG_FLAGS2 seeds it), round 4: 1 / 2 / 4 keep the 8-wave conv_stream workgroups at the
+ * full-resolution levels / the 128x8 level / the VAE's 64-channel level (default: 4-wave workgroups, two resident per CU). */
+int rldm_debug_set_flags2(int flags);
 /* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */
 /* statistics side-output of the conv epilogue (feeds the next GroupNorm): stats device fp32 [B][Cout][2] = per-image

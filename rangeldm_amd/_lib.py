@@ -146,6 +146,7 @@ PROTOTYPES = {
     "rldm_debug_force_tile": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "rldm_test_conv_stats": (C.c_int, [C.POINTER(ConvDescC), _P, _P, _P, _P, _P]),
     "rldm_debug_set_flags": (C.c_int, [C.c_int]),
+    "rldm_debug_set_flags2": (C.c_int, [C.c_int]),
     "rldm_debug_graph_trace": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t]),
     "rldm_debug_timestamps": (C.c_int, [_P]),
     "rldm_debug_block_times": (C.c_int, [_P, C.c_int]),

@@ -18,18 +18,21 @@ __device__ __forceinline__ void lds_barrier_b() {
 }
 }  // namespace
 
-// WM pixel parts (128 pixels each) x WN 32-channel tiles x KG k-groups = 8 waves
+// WM pixel parts (128 pixels each) x WN 32-channel tiles x KG k-groups = NW waves (8, or 4: round 4's half-size workgroups, two of
+// which are resident on a CU -- independent tiles at different points of their prologue -> K loop -> epilogue chains, so that one's
+// MFMAs run under the other's round trips; the per-wave K loop is the 8-wave instance's)
 // TRUNK = true: a phase of the persistent launch (trunk.hip): arguments from a phase record, activations and statistics another
 // workgroup of the image's cluster published are read past the L1, the phase ends by arriving on the cluster's counter.
-template <int WM, int WN, bool TRUNK>
+template <int WM, int WN, bool TRUNK, int NW = 8>
 __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt, const int mt, const int b, const TrunkSeam& seam) {
-    constexpr int NT = 512, CK = 64, MI = 4, KG = 8 / (WM * WN);
+    constexpr int NT = 64 * NW, CK = 64, MI = 4, KG = NW / (WM * WN);
     constexpr int BM = 128 * WM, BN = 32 * WN;
     constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
     constexpr int C8 = CK / 8;
     // 16-byte halo pieces per thread and chunk: 34 x 10 pixels (6); the 128-pixel instance 18 x 10 = 16 x 8 tiles, or 34 x 6 = 32 x 4
     // tiles for images of 4 beams (nuScenes' 128 x 4 level) (4)
-    constexpr int HALO_PX = WM == 1 ? (32 + 2) * (4 + 2) : (BM / 8 + 2) * 10;
+    // (the 4-wave instances take 16 x 8 tiles only: 180 positions, 6 pieces per thread like the 256-pixel instance)
+    constexpr int HALO_PX = WM == 1 ? (NW == 4 ? (16 + 2) * 10 : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10;
     constexpr int ACH = (HALO_PX * C8 + NT - 1) / NT;
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
     constexpr int ROW = 3 * SPT;               // ... per row of taps
@@ -37,7 +40,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     constexpr int G = KG == 4 ? CST : ROW;     // weight fragments in flight per wave (ring): a chunk (9) | a row of taps (12 | 6)
     constexpr int PFX = KG == 1 ? 2 : 3;       // pixel fragments read ahead; divides CST
     constexpr int ERS = BN * 2 + 16, NC8 = BN / 8;
-    static_assert(WM * WN * KG == 8 && CST % PFX == 0 && G <= 16, "wave grid");
+    static_assert(WM * WN * KG == NW && (NW == 4 || NW == 8) && CST % PFX == 0 && G <= 16, "wave grid");
+    constexpr int CPT = 512 / NT;              // channels per thread in the GroupNorm fold (Cin <= 512)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tid_ = threadIdx.x;
     if constexpr (TRUNK) asm volatile("" : "+v"(tid_));          // (opaque per phase: conv_small_body.h)
@@ -45,7 +49,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave / (WM * WN);
     const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
-    const int grp = wave >> 2;                 // the two waves of a SIMD are in different halves of the workgroup
+    const int grp = wave >> 2;                 // the two waves of a SIMD are in different halves of the workgroup (4 waves: one half)
     const int kh = lane >> 5, l31 = lane & 31;
 #ifdef RLDM_ABLATE
     unsigned long long tsv[12];
@@ -188,39 +192,53 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     if constexpr (TRUNK) trunk_wait(seam, tid);     // (everything above is independent of the previous phase)
     // ---- GroupNorm: the statistics partials of channel `tid`, gamma and beta are requested first, then the first halo
     // chunk; the fold runs while they are all in flight.  Every channel's thread folds its own group (no serial phase).
-    double gS = 0.0, gSS = 0.0;
-    float g_gamma = 0.f, g_beta = 0.f;
-    if (gn && tid < Cin) {
+    double gS[CPT], gSS[CPT];
+    float g_gamma[CPT], g_beta[CPT];
+#pragma unroll
+    for (int sl = 0; sl < CPT; ++sl) {
+        gS[sl] = 0.0; gSS[sl] = 0.0; g_gamma[sl] = 0.f; g_beta[sl] = 0.f;
+        const int ch = tid + sl * NT;
+        if (gn && ch < Cin) {
         const float2* const gs0p = p.st0;
         const float2* const gs1p = p.st1;
         const int nP0 = p.P0, nP1 = p.P1;
-        const bool first = tid < nC0;
-        const int c = first ? tid : tid - nC0;
+        const bool first = ch < nC0;
+        const int c = first ? ch : ch - nC0;
         const int C = first ? nC0 : nC1;
         const int P = RLDM_EXP_NOSTATS ? 0 : (first ? nP0 : nP1);
-        if (RLDM_EXP_NOSTATS) gSS = (double)(1.0f / p.gn_inv_n) / (Cin / p.gn_groups);       // (mean 0, variance 1: finite garbage)
+        if (RLDM_EXP_NOSTATS) gSS[sl] = (double)(1.0f / p.gn_inv_n) / (Cin / p.gn_groups);   // (mean 0, variance 1: finite garbage)
         const float2* src = (first ? gs0p : gs1p) + (size_t)b * P * C + c;
-        g_gamma = p.gn_gamma[tid];
-        g_beta = p.gn_beta[tid];
+        g_gamma[sl] = p.gn_gamma[ch];
+        g_beta[sl] = p.gn_beta[ch];
         int q = 0;
+        if constexpr (NW == 4) {                // (128-pixel tiles: 32 partials per image at the 256 x 16 level -- one round trip)
+            for (; q + 32 <= P; q += 32) {
+                float2 v[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * C);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) { gS[sl] += (double)v[j].x; gSS[sl] += (double)v[j].y; }
+            }
+        }
         for (; q + 16 <= P; q += 16) {          // 16 partials per round trip (P = pixel tiles per image of the producer)
             float2 v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * C);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { gS += (double)v[j].x; gSS += (double)v[j].y; }
+            for (int j = 0; j < 16; ++j) { gS[sl] += (double)v[j].x; gSS[sl] += (double)v[j].y; }
         }
         for (; q + 4 <= P; q += 4) {
             float2 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * C);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { gS += (double)v[j].x; gSS += (double)v[j].y; }
+            for (int j = 0; j < 4; ++j) { gS[sl] += (double)v[j].x; gSS[sl] += (double)v[j].y; }
         }
         for (; q < P; ++q) {
             const float2 v = ld_act8<TRUNK>(src + (size_t)q * C);
-            gS += (double)v.x;
-            gSS += (double)v.y;
+            gS[sl] += (double)v.x;
+            gSS[sl] += (double)v.y;
+        }
         }
     }
     float bias_v = 0.f;
@@ -254,27 +272,42 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     if (gn) {
         double* sD = reinterpret_cast<double*>(sA);             // scratch: [2][Cin] doubles (the halo is not written yet)
         const int cpg = Cin / p.gn_groups;
-        if (tid < Cin) {
-            sD[tid] = gS;
-            sD[Cin + tid] = gSS;
+#pragma unroll
+        for (int sl = 0; sl < CPT; ++sl) {
+            const int ch = tid + sl * NT;
+            if (ch < Cin) {
+                sD[ch] = gS[sl];
+                sD[Cin + ch] = gSS[sl];
+            }
         }
         __syncthreads();
-        float ga = 0.f, gs = 0.f;               // Cin <= NT
-        if (tid < Cin) {
-            const int g0 = ((tid * p.magic_cpg) >> 20) * cpg;
-            double S = 0.0, SS = 0.0;
-            for (int i = 0; i < cpg; ++i) {
-                S += sD[g0 + i];
-                SS += sD[Cin + g0 + i];
+        float ga[CPT], gs[CPT];                 // Cin <= CPT * NT
+#pragma unroll
+        for (int sl = 0; sl < CPT; ++sl) {
+            const int ch = tid + sl * NT;
+            ga[sl] = 0.f; gs[sl] = 0.f;
+            if (ch < Cin) {
+                const int g0 = ((ch * p.magic_cpg) >> 20) * cpg;
+                double S = 0.0, SS = 0.0;
+                for (int i = 0; i < cpg; ++i) {
+                    S += sD[g0 + i];
+                    SS += sD[Cin + g0 + i];
+                }
+                const double inv_n = (double)p.gn_inv_n;
+                const double mean = S * inv_n;
+                double var = SS * inv_n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                ga[sl] = g_gamma[sl] * __builtin_amdgcn_rsqf((float)var + p.gn_eps);
+                gs[sl] = g_beta[sl] - (float)mean * ga[sl];
             }
-            const double inv_n = (double)p.gn_inv_n;
-            const double mean = S * inv_n;
-            double var = SS * inv_n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            ga = g_gamma * __builtin_amdgcn_rsqf((float)var + p.gn_eps);
-            gs = g_beta - (float)mean * ga;
-            sGa[tid] = ga;                      // (sGa / sGs sit behind both halo buffers: disjoint from the scratch)
-            sGs[tid] = gs;
+        }
+#pragma unroll
+        for (int sl = 0; sl < CPT; ++sl) {
+            const int ch = tid + sl * NT;
+            if (ch < Cin) {
+                sGa[ch] = ga[sl];               // (sGa / sGs sit behind both halo buffers: disjoint from the scratch)
+                sGs[ch] = gs[sl];
+            }
         }
         __syncthreads();                        // affine visible; sD fully consumed before the halo is written
     }
@@ -318,18 +351,70 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
 #pragma unroll
         for (int j = 0; j < ROW; ++j) {
             const int c = ti * ROW + j, slot = c % G;
+#if RLDM_STREAM_ILV
+            // (round 4) each pixel fragment of step c + PFX is requested right behind the MFMA that consumed its register, not behind
+            // the step's last MFMA: ~100 cycles more lead per read.  A wave ALONE on its SIMD (the 4-wave instances while the other
+            // workgroup of the CU is outside its K loop) ran 236 cycles per k-step against 128 of matrix-pipe time -- waiting on LDS.
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xr[c % PFX][mi], acc[mi], 0, 0, 0);
+                if (c + PFX < CST && !RLDM_TDBG(p, 65536)) {
+                    const int r = j + PFX;
+                    xr[c % PFX][mi] = *reinterpret_cast<const bf16x8*>(smem + (r < ROW ? cur[mi] : nxt[mi]) + ((r % ROW) / SPT) * RS + (r % SPT) * 32);
+                }
+            }
+            if (!RLDM_TDBG(p, 32768)) wr[slot] = w_load(wptr, slot);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (c + PFX < CST) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#else
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xr[c % PFX][mi], acc[mi], 0, 0, 0);
             wr[slot] = w_load(wptr, slot);
             if (c + PFX < CST) x_read(cur, nxt, j + PFX, xr[c % PFX]);   // (no read-ahead across the chunk's barrier)
+#endif
             __builtin_amdgcn_sched_barrier(0);  // steps stay in program order: every wait then leaves G - 1 loads in flight
         }
         if ((ti * ROW + ROW) % G == 0) wptr += G * 1024;
     };
     static_assert(PFX <= ROW, "the read-ahead reaches at most into the next row of taps");
     RLDM_STAMP();
+    // (round-4 experiments on how the two workgroups of a CU share its matrix pipes; p.exp bits, stand-alone launches)
+    //   1 static priority for the first-dispatched half of the grid during its K loop; 2 a per-CU lock around the K loop;
+    //   4 priority by progress
+    int* cu_lock = nullptr;
+    if constexpr (NW == 4 && !TRUNK) {
+        if (p.exp >> 8) {                       // initial skew: the second workgroup of every CU starts (p.exp >> 8) x 1024 cycles late
+            const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (lin >= 256 && lin < 512)
+                for (int i = 0; i < (p.exp >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+        }
+        if (p.exp & 1) {
+            const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (2 * lin < (int)(gridDim.x * gridDim.y * gridDim.z)) __builtin_amdgcn_s_setprio(3);
+        }
+        if (p.exp & 4) __builtin_amdgcn_s_setprio(1);
+        if ((p.exp & 2) && p.cu_lock) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
+            cu_lock = p.cu_lock + ((xcc << 8) | hw);
+            if (tid == 0) {
+                for (int tries = 0; tries < 200000; ++tries) {          // (bounded: a lost lock only costs the overlap)
+                    int expect = 0;
+                    if (__hip_atomic_compare_exchange_strong(cu_lock, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+        }
+    }
     for (int cs = 0; cs < NCC; ++cs) {
+        if constexpr (NW == 4 && !TRUNK) { if ((p.exp & 4) && 2 * cs >= NCC) __builtin_amdgcn_s_setprio(2); }
         if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_next(cs + 1);    // next chunk (main or first residual): requested now, written below
         int cur[MI], nxt[MI];
         const int boff = (cs & 1) * abytes;
@@ -387,6 +472,11 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         }
     }
     RLDM_STAMP();
+    if constexpr (NW == 4 && !TRUNK) {
+        if (p.exp & 1) __builtin_amdgcn_s_setprio(0);
+        if (p.exp & 4) __builtin_amdgcn_s_setprio(3);
+        if (cu_lock && tid == 0) __hip_atomic_store(cu_lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     if constexpr (KG > 1) {
     // ---- epilogue of the k-group instance (conv_small.hip's), 64 pixels at a time: fp32 partials [k-group][pixel][channel] in
@@ -447,7 +537,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         }
     }
     if (p.y_stats) {
-        float* sS = reinterpret_cast<float*>(sT + HB * TRS);                // [8 waves][2][BN]
+        float* sS = reinterpret_cast<float*>(sT + HB * TRS);                // [NW waves][2][BN]
 #pragma unroll
         for (int d = NCP; d < 64; d <<= 1) {
             s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d);
@@ -462,7 +552,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             const int kind = tid / BN, c = tid - kind * BN;
             float S = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
+            for (int w = 0; w < NW; ++w) S += sS[(w * 2 + kind) * BN + c];
             reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
         }
     }
@@ -484,13 +574,13 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     lds_barrier_b();
     RLDM_STAMP();
     // thread (g = tid / 16, c8 = tid % 16) stores 16 bytes of pixels g, g + 32, ... (4 halo columns apart: a constant
-    // address step), then the statistics of the ROUNDED tile: lane = channel pair, 8 pixel groups, LDS fold over the waves
+    // address step; 4 waves: g + 16, ..., 2 columns), then the statistics of the ROUNDED tile: lane = channel pair, 8 pixel groups, LDS fold over the waves
     const int c8 = tid % NC8;
     const int chg = nt * BN + c8 * 8;
     {
         const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7)
         bf16_t* yp = p.y + (((size_t)b * p.Wout + w0 + (g >> 3)) * p.Hout + h0 + (g & 7)) * p.y_ld + chg;
-        const size_t ystep = (size_t)4 * p.Hout * p.y_ld;
+        const size_t ystep = (size_t)(NT / NC8 / 8) * p.Hout * p.y_ld;
 #pragma unroll
         for (int i = 0; i < BM / (NT / NC8); ++i) {
             *reinterpret_cast<uint4*>(yp) = *reinterpret_cast<const uint4*>(sE + (g + i * (NT / NC8)) * ERS + c8 * 16);
@@ -508,7 +598,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             s0 += a0; s1 += a1;
             q0 += a0 * a0; q1 += a1 * a1;
         }
-        float* sS = reinterpret_cast<float*>(sE + BM * ERS);                // [8 waves][2][BN]
+        float* sS = reinterpret_cast<float*>(sE + BM * ERS);                // [NW waves][2][BN]
         *reinterpret_cast<float2*>(sS + (wave * 2 + 0) * BN + cp * 2) = make_float2(s0, s1);
         *reinterpret_cast<float2*>(sS + (wave * 2 + 1) * BN + cp * 2) = make_float2(q0, q1);
         lds_barrier_b();
@@ -516,7 +606,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             const int kind = tid / BN, c = tid - kind * BN;
             float S = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) S += sS[(w * 2 + kind) * BN + c];
+            for (int w = 0; w < NW; ++w) S += sS[(w * 2 + kind) * BN + c];
             reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
         }
     }
@@ -528,13 +618,21 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         RLDM_STAMP();
         for (int i = 0; i < 12; ++i) seam.ts[i] = i < tsn ? tsv[i] : 0ull;
     }
-    if (!TRUNK && p.ts && blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z == 0 && tid == 0)
-        for (int i = 0; i < 12; ++i) p.ts[blockIdx.y * 64 + i] = i < tsn ? tsv[i] : 0ull;
     {
+        // stamps of four workgroups: dispatch ids 0, 1 (first round) and total / 2, total / 2 + 1 (with two workgroups per CU: the
+        // younger half); every workgroup's [start, end] on the shared 100 MHz counter, its CU (XCC id, HW_ID's SE / SH / CU) in the
+        // top 16 bits of `end`
         const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int total = gridDim.x * gridDim.y * gridDim.z;
+        const int slot = lin < 2 ? lin : (lin - total / 2 >= 0 && lin - total / 2 < 2 ? 2 + lin - total / 2 : -1);
+        if (!TRUNK && p.ts && slot >= 0 && tid == 0)
+            for (int i = 0; i < 12; ++i) p.ts[slot * 64 + i] = i < tsn ? tsv[i] : 0ull;
         if (!TRUNK && p.ts && tid == 0 && lin < 2048) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
             p.ts[256 + 2 * lin] = t_real0;
-            p.ts[257 + 2 * lin] = __builtin_amdgcn_s_memrealtime();
+            p.ts[257 + 2 * lin] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)((xcc << 8) | hw) << 48);
         }
     }
 #endif

@@ -236,17 +236,19 @@ int launch_stamp(unsigned long long* slot, hipStream_t stream) {
 }
 
 // Same-call failure signal of the persistent launches (trunk.hip): behind a sampler call's last copy, ONE workgroup reads the plan's
-// self-check word and, if a cluster wait gave up during the call, overwrites the head of the call's outputs with NaN -- a host that
+// self-check word and, if a cluster wait gave up during the call, overwrites ALL of the call's outputs with NaN (grid-stride over both
+// buffers; the kernel returns at once when the word is clear, so the sweep is paid only by a failed call) -- a host that
 // consumes the images without asking rldm_sampler_status never sees plausible-looking wrong pixels (ldm/pipelines.py:218-222, 463-464:
 // the reference's contract is a correct tensor or an exception).
 __global__ void __launch_bounds__(256) trunk_check_kernel(const int* err, float* a, long long na, float* b, long long nb) {
     if (*err == 0) return;
     const float nan = __int_as_float(0x7fc00000);
-    for (long long i = threadIdx.x; i < na && i < 4096; i += 256) a[i] = nan;
-    for (long long i = threadIdx.x; i < nb && i < 4096; i += 256) b[i] = nan;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = nan;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = nan;
 }
 int launch_trunk_check(const int* err, float* a, long long na, float* b, long long nb, hipStream_t stream) {
-    hipLaunchKernelGGL(trunk_check_kernel, dim3(1), dim3(256), 0, stream, err, a, a ? na : 0, b, b ? nb : 0);
+    hipLaunchKernelGGL(trunk_check_kernel, dim3(64), dim3(256), 0, stream, err, a, a ? na : 0, b, b ? nb : 0);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -102,6 +102,10 @@ struct ConvParams {
     int* step_inc;          // conv_igemm.hip: the sampler's device step index, advanced by the step's FIRST launch (conv_in, which does not read it) or null
     int nviews;             // conv_small.hip, image-owning tiles: normalised copies of the output for up to 3 consumers
     NormView nv[3];
+    int st_inst;            // conv_stream.hip: 0 the 8-wave instance the tile implies; round 4's 4-wave workgroups on 16 x 8 tiles, two
+                            // resident per CU: 1 = 128 pixels x 128 channels, 2 = 128 pixels x 64 channels x 2 k-groups
+    int exp;                // ... round-4 experiment switches (rldm_debug_set_flags2 >> 8; conv_stream_body.h)
+    int* cu_lock;           // ... [4096] zero-initialised per-CU locks (exp & 2)
 };
 
 struct ConvTile {
@@ -173,7 +177,9 @@ struct TrunkParams {
     int B, ranks;               // images; workgroups per image (its cluster): channel tiles x pixel tiles
     int ntile_n, nwn;           // channel tiles per image and 32-channel tiles per workgroup (N / 32 and 1 for image-owning tiles)
     int variant;                // kernel: 0 image-owning conv_small tiles, 1 multi-tile conv_small clusters, 2 conv_stream<256 px, 128 ch>,
-                                // 3 conv_stream<128 px, 64 ch> (each set of instances has its own register allocation)
+                                // 3 conv_stream<128 px, 64 ch> (each set of instances has its own register allocation),
+                                // 4 conv_stream<128 px, 128 ch> on 4 waves: 32 workgroups per image, two per CU (round 4)
+    int skew;                   // variant 4: start delay of the second image group, x 1024 cycles
     unsigned* counters;         // device [B][32] zero-initialised: [0] arrivals (monotonic), [1] rank 0's XCC id + 1, [3] launches so far
     int* error;                 // device flag: 1 a bounded wait gave up, 2 a cluster is spread over several XCDs
     const float* temb;          // the plan's time-embedding table (PlanIO), set per launch
@@ -294,6 +300,9 @@ int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream);    // the
 #endif
 #ifndef RLDM_EXP_NOWAIT
 #define RLDM_EXP_NOWAIT 0
+#endif
+#ifndef RLDM_STREAM_ILV
+#define RLDM_STREAM_ILV 1          /* conv_stream K loop: pixel-fragment reads interleaved with the step's MFMAs (round 4; 0 = behind them) */
 #endif
 #ifndef RLDM_RES_DEPTH
 #define RLDM_RES_DEPTH 1           /* residual chunks of a conv_stream tile in flight in registers (conv_stream_body.h); 2 and 3 measured the same */

@@ -8,6 +8,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -521,6 +522,15 @@ static int g_dbg_flags = getenv("RLDM_DBG_FLAGS") ? atoi(getenv("RLDM_DBG_FLAGS"
 // of a sampler whose persistent launches failed their self-check) -- scoped to that plan, unlike the process-wide word above
 static thread_local int t_plan_flags = 0;
 static inline int dbg() { return g_dbg_flags | t_plan_flags; }
+// second word of process-wide tuning switches (rldm_debug_set_flags2 / RLDM_DBG_FLAGS2), round 4:
+//   1 full-resolution conv_stream launches keep the 8-wave 256-pixel workgroups (default: 4-wave 128 x 128 workgroups, two per CU)
+//   2 the 128x8 level keeps the 8-wave 128 x 64 x 4-k-group workgroups (default: 4-wave 128 x 64 x 2 k-groups, two per CU)
+//   4 the VAE's 64-channel level keeps the 8-wave 256 x 64 instance
+//   8 the 4-wave full-resolution convs stay launches of their own (default: phases of trunk variant 4, two workgroups per CU)
+//   bits 8..15: conv_stream experiment switches (ConvParams::exp); bits 16..23: (n + 1) = trunk variant 4's start offset n
+static int g_dbg_flags2 = getenv("RLDM_DBG_FLAGS2") ? atoi(getenv("RLDM_DBG_FLAGS2")) : 0;
+static inline int dbg2() { return g_dbg_flags2; }
+static constexpr int kTrunkSkewDefault = 8;     // (trunk variant 4: the second image group starts ~8 k cycles late; RLDM_DBG_FLAGS2 = (n + 1) << 16: n)
 static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
@@ -750,6 +760,8 @@ struct Builder {
             tp.ntile_n = pend.nwn == 1 ? pend.ranks : pend.ntile_n;
             tp.nwn = pend.nwn;
             tp.variant = pend.variant;
+            // (variant 4's start offset between the two image groups, x 1024 cycles; RLDM_DBG_FLAGS2 bits 16..23 override the default)
+            tp.skew = pend.variant == 4 ? (((dbg2() >> 16) & 255) ? ((dbg2() >> 16) & 255) - 1 : kTrunkSkewDefault) : 0;
             tp.counters = ctrs->as<unsigned>();
             tp.error = plan->trunk_error.as<int>();
             tp.temb_ld = temb_ld;
@@ -766,7 +778,7 @@ struct Builder {
                 tp.ts = (ts_ok && getenv("RLDM_TS_TRUNK") && tp.nphases == atoi(getenv("RLDM_TS_TRUNK"))) ? g_ts_buf : nullptr;
                 return launch_trunk(tp, lds, st);
             }, std::string("trunk_kernel<") + (pend.variant == 0 ? "conv_small image tiles" : pend.variant == 1 ? "conv_small 64x64 clusters" :
-                                               pend.variant == 2 ? "conv_stream 256x128" : "conv_stream 128x64") +
+                                               pend.variant == 2 ? "conv_stream 256x128" : pend.variant == 3 ? "conv_stream 128x64" : "conv_stream 128x128 x2/CU") +
                    ", " + std::to_string(pend.phases.size()) + " phases>", pend.flops, pend.bytes});
         }
         pend = PendingTrunk();
@@ -780,7 +792,8 @@ struct Builder {
     static size_t trunk_attention_lds(int L, int C, int HG) { return attention_qkv2_lds_bytes(L, C, HG, 8); }
     bool trunk_attention_ok(const Tensor& x, bool pre) const {
         const int L = x.W * x.H, ranks = x.C / 32;
-        if (!trunk_enabled() || !pre || x.C % 32 != 0 || ranks < 2 || ranks > 16) return false;
+        // (x.C % 64: attention_qkv2_body loads x in coalesced 64-channel groups and projects in blocks of 4 k-steps, no tail)
+        if (!trunk_enabled() || !pre || x.C % 64 != 0 || ranks < 2 || ranks > 16) return false;
         const int HG = (x.C / 8) / ranks, wph = (L + 31) / 32;
         // 8 waves: one query tile per wave of a head (32-token images -- the lowest nuScenes level -- leave every second wave idle:
         // without the phase that level was five persistent launches with an attention launch between each pair)
@@ -803,7 +816,10 @@ struct Builder {
     // a persistent launch spin-waits on its own workgroups: ALL of them must be resident at once, whatever else the plan's owner runs
     // beside it -- a sampler's other chains (g_concurrent_plans: two 256-workgroup launches could each hold part of the chip and wait
     // for the rest) and the device's real CU count (partitions / smaller parts)
-    static bool trunk_grid_fits(int ranks, int B) { return 8 * ranks * ((B + 7) / 8) * std::max(1, g_concurrent_plans) <= device_cus(); }
+    // (per_cu = 2: the 4-wave conv_stream variant, whose workgroups are built for two per CU)
+    static bool trunk_grid_fits(int ranks, int B, int per_cu = 1) {
+        return 8 * ranks * ((B + 7) / 8) * std::max(1, g_concurrent_plans) <= device_cus() * per_cu;
+    }
     void trunk_begin(int B, int ranks, int ntile_n = 0, int nwn = 1, int variant = -1) {
         if (nwn == 1) ntile_n = ranks;
         if (variant < 0) variant = nwn == 1 ? 0 : 1;
@@ -1186,7 +1202,7 @@ struct Builder {
     // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels, or
     // (the 128x8 level) of 16 x 8 pixels x 64 channels
     static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, long long min_blocks,
-                                 long long max_blocks, ConvParams* q, int TH = 8) {
+                                 long long max_blocks, ConvParams* q, int TH = 8, int inst = 0) {
         if (dbg() & 2048) return false;
         if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
         if (Wout % TW != 0 || Hout % TH != 0) return false;
@@ -1199,6 +1215,7 @@ struct Builder {
         q->up = a.up; q->stride = 1; q->pad_lo = 1;
         q->Wout = Wout; q->Hout = Hout;
         q->TW = TW; q->TH = TH; q->th_shift = TH == 8 ? 3 : 2;
+        q->st_inst = inst;
         ConvTile t;
         t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
         q->colb = conv_halo_col_bytes(t, TH, 1);
@@ -1222,7 +1239,14 @@ struct Builder {
     static bool stream_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
         // 256-pixel tiles when they fill the chip; else the 4-k-group instance (it re-streams the weights per 128 pixels:
         // only where its grid is about one or two rounds); else 256-pixel tiles on at least half the chip
+        // (round 4) half-size workgroups, two per CU: 16 x 8 tiles x 128 channels on 4 waves where that grid is at least ~1.5 per CU
+        // (UNet 256x16 level at batch >= 12, the VAE decoder's 128 / 256-channel levels), x 64 channels x 2 k-groups for the 128x8
+        // level and the VAE's 64-channel level
+        const int N_ = a.layer->Cout;
+        if (!(dbg2() & 1) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 1)) return true;
+        if (!(dbg2() & 4) && N_ % 128 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 2)) return true;
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
+        if (!(dbg2() & 2) && !(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 257, 512, q, 8, 2)) return true;
         if (!(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
         // images of 4 beams (nuScenes' 128 x 4 level at batch 32): the same 128-pixel instance on 32 x 4 tiles (round 3; it ran on the
         // generic kernel at 27.8 us / 257 TFLOP/s per conv: 16 % of that configuration's step)
@@ -1244,6 +1268,15 @@ struct Builder {
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;   // ONE conv of a network
         p.ntile_n = N / conv_stream_bn(p);
+        p.exp = dbg2() >> 8;
+        if (p.exp & 2) {
+            static int* locks = nullptr;            // (experiment: never freed)
+            if (!locks) {
+                RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&locks), 4096 * sizeof(int)));
+                RLDM_HIP_CHECK(hipMemset(locks, 0, 4096 * sizeof(int)));
+            }
+            p.cu_lock = locks;
+        }
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img);
         const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
@@ -1252,11 +1285,15 @@ struct Builder {
         // full-resolution levels) form a cluster on one XCD; consecutive convs of a level hand over through its L2 -- no end-of-kernel
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
         const int ranks_s = p.tiles_img * p.ntile_n;
-        const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 &&
-                                       trunk_grid_fits(ranks_s, x0.B) && y.P <= kFoldAboveP && N % 128 == 0 &&
-                                       (p.TW * p.TH == 256 || (dbg() & (1 << 30)));      // (the 128x8 level's conv PAIRS measured slower as
-                                       // 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
-        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.TW * p.TH == 256 ? 4 : 2, p.TW * p.TH == 256 ? 2 : 3);
+        // (round 4) the 4-wave 128 x 128 instance: 32 workgroups per image, two per CU -- trunk variant 4; rldm_debug_set_flags2(8): launches
+        const int per_cu = p.st_inst == 1 ? 2 : 1;
+        const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 * per_cu &&
+                                       trunk_grid_fits(ranks_s, x0.B, per_cu) && y.P <= kFoldAboveP && N % 128 == 0 &&
+                                       ((p.st_inst == 0 && (p.TW * p.TH == 256 || (dbg() & (1 << 30)))) ||     // (the 128x8 level's conv
+                                        // PAIRS measured slower as 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
+                                        (p.st_inst == 1 && !(dbg2() & 8) && conv_stream_lds_bytes(p) <= 80 * 1024));
+        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.st_inst == 1 || p.TW * p.TH == 256 ? 4 : 2,
+                                           p.st_inst == 1 ? 4 : (p.TW * p.TH == 256 ? 2 : 3));
         else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
@@ -2522,7 +2559,7 @@ struct SamplerLane {
     long long n_latent = 0, n_image = 0, n_cond = 0;
     int* check_host = nullptr;                      // pinned: the persistent launches' self-check word of the last call (copied behind its
     bool check_pending = false;                     // last launch; read by rldm_sampler_status, the next call or the destructor)
-    bool call_recorded = false;                     // ev_out has been recorded at least once
+    std::atomic<bool> call_recorded{false};         // ev_out has been recorded at least once (read by other samplers' threads: in_flight)
     ~SamplerLane() {
         if (check_host) (void)hipHostFree(check_host);
         if (step_graph) (void)hipGraphExecDestroy(step_graph);
@@ -2543,7 +2580,11 @@ struct rldm_sampler {
     uint64_t unet_gen = 0, vae_gen = 0;             // generations of the weights the lanes' plans and graphs were built on
     int plan_flags = 0;                             // routing options of this sampler's plans (rldm_sampler_config::plan_flags | fall-backs)
     int device = 0;
-    hipStream_t last_caller = nullptr;              // stream of the last rldm_sample call (ordering against other samplers' calls)
+    std::atomic<hipStream_t> last_caller{nullptr};  // stream of the last rldm_sample call (ordering against other samplers' calls; read
+                                                    // by other samplers' host threads under g_samplers_mu -- atomics, not plain fields)
+    std::atomic<bool> shared_mark{false};           // another sampler found THIS one in flight beside its own call: drop the persistent
+                                                    // launches at the next call instead of meeting that sampler's launches again
+    int latched_error = 0;                          // self-check code of a call whose pending word was read while the plans were rebuilt
     int inject_error = 0;                           // tests: rldm_debug_inject_trunk_error (one shot)
     bool has_persistent() const {
         for (auto& ln : lanes)
@@ -2650,6 +2691,8 @@ static int sampler_build_plans(rldm_sampler* s) {
         g_concurrent_plans = (int)s->lanes.size();
         const int prc = unet_make_plan(unet, ln->nb, &ln->uplan, nullptr, s->plan_flags);
         g_concurrent_plans = 1;
+        // (the lane streams were synchronised above: a pending self-check word of the previous, asynchronous call has landed -- keep it)
+        if (ln->check_pending && ln->check_host && *ln->check_host != 0) s->latched_error = *ln->check_host;
         ln->check_pending = false;
         if (prc) return 1;
         PlanIO& io = ln->uplan->io;
@@ -3074,6 +3117,7 @@ int rldm_sampler_status(rldm_sampler* s) {
         ln->check_pending = false;
         if (*ln->check_host != 0) code = *ln->check_host;
     }
+    if (s->latched_error) { code = s->latched_error; s->latched_error = 0; }
     if (code == 0) return 0;
     if (sampler_drop_persistent(s, "a persistent launch of the last rldm_sample call failed its self-check", code)) return -1;
     set_error("a persistent launch of this rldm_sample call failed its self-check (code " + std::to_string(code) +
@@ -3115,16 +3159,26 @@ int rldm_sample(rldm_sampler* s, const float* x_T, const float* step_noise, cons
     }
     // persistent launches need the device to themselves: another sampler's call still in flight on a different stream ends them here
     if (s->has_persistent()) {
-        bool shared = false;
+        bool shared = s->shared_mark.exchange(false);
         {
             std::lock_guard<std::mutex> lk(g_samplers_mu);
             for (rldm_sampler* o : g_samplers)
-                if (o != s && o->device == s->device && o->last_caller != caller && o->in_flight()) shared = true;
+                if (o != s && o->device == s->device && o->last_caller.load() != caller && o->in_flight()) {
+                    shared = true;
+                    o->shared_mark.store(true);     // (the peer keeps its spin-waiting clusters for the call in flight; not for the next)
+                }
         }
         if (shared && sampler_drop_persistent(s, "another sampler is running on this device on a different stream: persistent launches "
                                                  "need the chip to themselves", 0)) return 1;
     }
-    s->last_caller = caller;
+    if (s->latched_error) {                         // found while the plans were rebuilt (sampler_build_plans): the previous call failed
+        const int code = s->latched_error;
+        s->latched_error = 0;
+        if (!(s->plan_flags & (1 << 24)) && sampler_drop_persistent(s, "a persistent launch of the PREVIOUS rldm_sample call failed its self-check", code)) return 1;
+        RLDM_REQUIRE(false, "a persistent launch of the PREVIOUS rldm_sample call failed its self-check (code " + std::to_string(code) +
+                                "): its outputs were invalid (NaN-marked); the sampler now runs one launch per layer: call again");
+    }
+    s->last_caller.store(caller);
     RLDM_HIP_CHECK(hipEventRecord(s->ev_in, caller));
     // per lane: inputs, (first call) eager warm step + graph capture
     for (auto& lnp : s->lanes) {
@@ -3381,6 +3435,10 @@ int rldm_test_conv_stats(const rldm_conv_desc* d, const float* x0, const float* 
     return 0;
 }
 
+int rldm_debug_set_flags2(int flags) {
+    g_dbg_flags2 = flags;
+    return 0;
+}
 int rldm_debug_set_flags(int flags) {
     g_dbg_flags = flags;
     return 0;

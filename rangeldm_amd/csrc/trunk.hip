@@ -212,8 +212,12 @@ __device__ __forceinline__ void gn_apply_phase(const ConvParams& cp, const int r
 
 // CL = false: image-owning tiles (kinds 0..6 + attention over a pre-normalised x); CL = true: multi-tile clusters (kinds 8..13).
 // Two kernels, so that each set of instances gets its own register allocation.
+// V == 4 (round 4): the full-resolution level on conv_stream's 4-wave 128 x 128 instance -- 32 workgroups of 256 threads per image,
+// TWO workgroups per CU (512 in all at 16 images: __launch_bounds__' second argument is waves per SIMD).  The two workgroups of a
+// CU belong to different images (block ids below 256 are images 0..7, the rest images 8..15), i.e. to clusters that are never
+// ordered against each other: one's statistics round trip / fold / first halo chunk / epilogue runs under the other's K loop.
 template <int V>
-__global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
+__global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kernel(const TrunkParams tp) {
     constexpr bool CL = V == 1, ST = V >= 2;
     // block id -> (image, channel tile): ids with the same (id % 8) share an XCD; an image's `ranks` tiles are 8 apart
     const int wg = blockIdx.x;
@@ -239,6 +243,13 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     if (rank == 0 && tid == 0) __hip_atomic_store(counter + 1, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+    if constexpr (V == 4) {
+        // the second image group starts tp.skew x 1024 cycles late: the two workgroups of a CU then alternate -- one in its K loop while
+        // the other is between two of them -- instead of asking for the matrix pipes at the same time (they share them fairly: an
+        // offset, once there, stays)
+        if (t / ranks != 0)
+            for (int i = 0; i < tp.skew; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     bf16x8 wpf[kTrunkPrefetch];
     unsigned rec = recs[lane];                  // phase 0's record
     auto wave_stream = [&](unsigned r) __attribute__((always_inline)) {
@@ -282,6 +293,8 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
             conv_stream_body<2, 4, true>(cp, nt, mt, b, seam);      // full-resolution level: 16 tiles of 256 pixels x 128 channels per image
         } else if constexpr (V == 3) {
             conv_stream_body<1, 2, true>(cp, nt, mt, b, seam);      // 128x8 level: 8 tiles of 128 pixels x 2 channel tiles of 64
+        } else if constexpr (V == 4) {
+            conv_stream_body<1, 4, true, 4>(cp, nt, mt, b, seam);   // full-resolution level: 32 tiles of 128 pixels x 128 channels per image, 4 waves
         } else if constexpr (!CL) {
             switch (kind) {
                 case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
@@ -350,18 +363,19 @@ __global__ void __launch_bounds__(512, 1) trunk_kernel(const TrunkParams tp) {
 }
 
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
-    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 && tp.B >= 1 && (tp.nwn == 1 || tp.nwn == 2 || tp.nwn == 4) && tp.ntile_n >= 1 &&
-                     tp.ranks % tp.ntile_n == 0, "trunk: bad parameters");
-    RLDM_REQUIRE(lds <= 160 * 1024, "trunk: LDS tile too large");
+    RLDM_REQUIRE(tp.variant >= 0 && tp.variant <= 4, "trunk: bad kernel variant");
+    const int per_cu = tp.variant == 4 ? 2 : 1;  // (variant 4: 256-thread workgroups, two per CU)
+    RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 * per_cu && tp.B >= 1 && (tp.nwn == 1 || tp.nwn == 2 || tp.nwn == 4) &&
+                     tp.ntile_n >= 1 && tp.ranks % tp.ntile_n == 0, "trunk: bad parameters");
+    RLDM_REQUIRE(lds <= (size_t)160 * 1024 / per_cu, "trunk: LDS tile too large");
     const int groups = (tp.B + 7) / 8;
     const int grid = 8 * tp.ranks * groups;
-    RLDM_REQUIRE(grid <= 256, "trunk: the grid must be co-resident (one workgroup per CU)");
-    static DynLdsLimit lds_limit[4];             // per instantiation and device, thread safe
-    RLDM_REQUIRE(tp.variant >= 0 && tp.variant <= 3, "trunk: bad kernel variant");
+    RLDM_REQUIRE(grid <= 256 * per_cu, "trunk: the grid must be co-resident (one workgroup per CU; two of the 4-wave variant)");
+    static DynLdsLimit lds_limit[5];             // per instantiation and device, thread safe
     const int cl = tp.variant;
-    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : trunk_kernel<3>));
+    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : (cl == 3 ? trunk_kernel<3> : trunk_kernel<4>)));
     RLDM_HIP_CHECK(lds_limit[cl].ensure(reinterpret_cast<const void*>(kern), lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, tp);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(cl == 4 ? 256 : 512), lds, stream, tp);
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;
 }

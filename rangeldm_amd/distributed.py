@@ -39,41 +39,119 @@ def shard_range(total, rank, world):
     return lo, min(total, lo + per)
 
 
-class Communicator:
-    """RCCL communicator behind the C ABI (include/rangeldm_hip.h: rldm_comm_*).  The 128-byte unique id is made by rank 0
-    and handed to the other ranks through torch.distributed's object broadcast (any backend; gloo is enough -- it carries 128
-    bytes once) or, without a process group, through a TCPStore at MASTER_ADDR:MASTER_PORT.  Collectives are issued on the
-    CURRENT torch stream of the device, i.e. stream-ordered behind the sampler / trainer launches."""
+class _GroupExchange:
+    """Bootstrap traffic of the C-ABI communicator over an initialised torch.distributed process group (any backend)."""
 
-    def __init__(self, rank=None, world=None, store=None):
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def agree(self, ok, tag):
+        box = [None] * self.world
+        dist.all_gather_object(box, bool(ok))
+        return all(box)
+
+    def broadcast_uid(self, raw):
+        box = [raw if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+
+class _StoreExchange:
+    """... without a process group: a TCPStore at MASTER_ADDR:MASTER_PORT + 1 (rank 0 hosts it).  Every wait is bounded by
+    `timeout` seconds: a rank that never arrives is a bootstrap failure on all the others, not a hang."""
+
+    def __init__(self, rank, world, store=None, timeout=120.0):
+        import datetime
+        self.rank, self.world = rank, world
+        self.store = store or dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                            int(os.environ.get("MASTER_PORT", "29500")) + 1, world, rank == 0,
+                                            timeout=datetime.timedelta(seconds=timeout))
+
+    def agree(self, ok, tag):
+        self.store.set(f"rldm_comm_{tag}_{self.rank}", b"1" if ok else b"0")
+        return all(self.store.get(f"rldm_comm_{tag}_{r}") == b"1" for r in range(self.world))
+
+    def broadcast_uid(self, raw):
+        if self.rank == 0:
+            self.store.set("rldm_comm_uid", raw)
+        return self.store.get("rldm_comm_uid")
+
+
+class CommunicatorUnavailable(RuntimeError):
+    """The C-ABI communicator cannot be used -- on THIS rank or on a peer; every rank raises it together (see Communicator)."""
+
+
+class Communicator:
+    """RCCL communicator behind the C ABI (include/rangeldm_hip.h: rldm_comm_*).  Replaces the reference's rank arithmetic over
+    files (ldm/inference.py:56,159-183) with one all-gather.  Bootstrap, in three steps so that the ranks never disagree about the
+    path they use (round 4; before, a rank whose librccl could not be bound fell back to torch.distributed ALONE while its peers
+    blocked inside ncclCommInitRank or issued RCCL collectives against its torch ones):
+      1. local and fallible: every rank binds RCCL and makes a unique id (`rldm_comm_unique_id`; only rank 0's is used);
+      2. agreement: the ranks exchange their step-1 outcome (`agree`); if ANY failed, ALL raise CommunicatorUnavailable -- nobody
+         enters the collective init;
+      3. collective: rank 0's 128-byte id is broadcast, every rank calls `rldm_comm_create` (ncclCommInitRank), and a second
+         agreement round confirms that all of them hold a communicator (else all destroy theirs and raise).
+    The traffic goes through torch.distributed's object collectives (any backend; gloo is enough) or, without a process group,
+    through a TCPStore at MASTER_ADDR:MASTER_PORT + 1.  Collectives are issued on the CURRENT torch stream of the device, i.e.
+    stream-ordered behind the sampler / trainer launches.  `lib` / `exchange` are injectable for the CPU tests."""
+
+    def __init__(self, rank=None, world=None, store=None, lib=None, exchange=None):
         import ctypes as C
         from . import _lib
         self._C, self._lib = C, _lib
+        self._cdll = lib if lib is not None else _lib.lib()
+        self._injected = lib is not None
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else int(os.environ.get("WORLD_SIZE", "1"))
         self.rank, self.world = rank, world
+        self._h = None
+        if exchange is None and world > 1:
+            exchange = _GroupExchange(rank, world) if dist.is_initialized() else _StoreExchange(rank, world, store)
+        self._exchange = exchange                        # (rank 0 hosts the TCPStore: it must outlive the peers' last reads)
+        # 1. local: bind RCCL, make an id
         uid = C.create_string_buffer(128)
-        if rank == 0:
-            _lib.check(_lib.lib().rldm_comm_unique_id(uid, 128), "rldm_comm_unique_id")
+        err = None
+        try:
+            self._check(self._cdll.rldm_comm_unique_id(uid, 128), "rldm_comm_unique_id")
+        except Exception as e:
+            err = e
+        # 2. agreement before anything collective
+        if world > 1 and not exchange.agree(err is None, "bind"):
+            raise CommunicatorUnavailable(f"rank {rank}: RCCL could not be bound on "
+                                          f"{'this rank: ' + str(err) if err else 'another rank'}; no rank creates a communicator")
+        if err is not None:
+            raise CommunicatorUnavailable(str(err))
+        # 3. collective init with rank 0's id, then confirm
         if world > 1:
-            if dist.is_initialized():
-                box = [uid.raw if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                uid = C.create_string_buffer(box[0], 128)
-            else:
-                store = store or dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                                               int(os.environ.get("MASTER_PORT", "29500")) + 1, world, rank == 0)
-                if rank == 0:
-                    store.set("rldm_comm_uid", uid.raw)
-                uid = C.create_string_buffer(store.get("rldm_comm_uid"), 128)
-        self._h = C.c_void_p()
-        _lib.check(_lib.lib().rldm_comm_create(uid, rank, world, C.byref(self._h)), "rldm_comm_create")
+            raw = exchange.broadcast_uid(uid.raw if rank == 0 else None)
+            if len(raw) != 128:
+                raise CommunicatorUnavailable(f"rank {rank}: unique id of {len(raw)} bytes (expected 128)")
+            uid = C.create_string_buffer(raw, 128)
+        h = C.c_void_p()
+        try:
+            self._check(self._cdll.rldm_comm_create(uid, rank, world, C.byref(h)), "rldm_comm_create")
+            self._h = h
+        except Exception as e:
+            err = e
+        if world > 1 and not exchange.agree(err is None, "init"):
+            self.close()
+            raise CommunicatorUnavailable(f"rank {rank}: rldm_comm_create failed on "
+                                          f"{'this rank: ' + str(err) if err else 'another rank'}; every rank falls back together")
+        if err is not None:
+            raise CommunicatorUnavailable(str(err))
+
+    def _check(self, rc, what):
+        if rc == 0:
+            return
+        if self._injected:                               # (tests: a fake library has no rldm_last_error)
+            raise RuntimeError(f"{what} failed ({rc})")
+        self._lib.check(rc, what)
 
     def rccl_origin(self):
         buf = self._C.create_string_buffer(256)
-        self._lib.check(self._lib.lib().rldm_comm_info(self._h, None, None, buf, 256), "rldm_comm_info")
+        self._check(self._cdll.rldm_comm_info(self._h, None, None, buf, 256), "rldm_comm_info")
         return buf.value.decode()
 
     def all_gather_images(self, local_images):
@@ -81,7 +159,7 @@ class Communicator:
         the result has the input's dtype like the torch.distributed path."""
         x = local_images.contiguous().float()
         out = torch.empty((self.world * x.shape[0], *x.shape[1:]), dtype=torch.float32, device=x.device)
-        self._lib.check(self._lib.lib().rldm_allgather_images(self._h, self._C.c_void_p(x.data_ptr()),
+        self._check(self._cdll.rldm_allgather_images(self._h, self._C.c_void_p(x.data_ptr()),
                                                               self._C.c_void_p(out.data_ptr()), x.numel(),
                                                               self._lib.stream_ptr(x.device)), "rldm_allgather_images")
         return out if local_images.dtype == torch.float32 else out.to(local_images.dtype)
@@ -89,7 +167,7 @@ class Communicator:
     def all_reduce_grads(self, flat, average=True):
         """in place over a contiguous fp32 slice of the flat gradient buffer (one bucket)"""
         assert flat.is_contiguous() and flat.dtype == torch.float32
-        self._lib.check(self._lib.lib().rldm_allreduce_grads(self._h, self._C.c_void_p(flat.data_ptr()), flat.numel(),
+        self._check(self._cdll.rldm_allreduce_grads(self._h, self._C.c_void_p(flat.data_ptr()), flat.numel(),
                                                              1 if average else 0, self._lib.stream_ptr(flat.device)),
                         "rldm_allreduce_grads")
         return flat
@@ -98,14 +176,14 @@ class Communicator:
         """(rank, world, origin of the RCCL copy) as the communicator itself reports them (rldm_comm_info)."""
         C = self._C
         r, w, buf = C.c_int(-1), C.c_int(-1), C.create_string_buffer(256)
-        self._lib.check(self._lib.lib().rldm_comm_info(self._h, C.byref(r), C.byref(w), buf, 256), "rldm_comm_info")
+        self._check(self._cdll.rldm_comm_info(self._h, C.byref(r), C.byref(w), buf, 256), "rldm_comm_info")
         return r.value, w.value, buf.value.decode()
 
     def close(self):
         """Destroy the communicator NOW (drivers call this before they exit: at interpreter shutdown torch may already have torn
         down RCCL / HIP under a destructor)."""
         if getattr(self, "_h", None):
-            self._lib.lib().rldm_comm_destroy(self._h)
+            self._cdll.rldm_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -141,18 +219,20 @@ def collective_choice():
 def cabi_communicator():
     """The process-wide Communicator of the C-ABI path, or None when collective_choice() says torch.  Works without a process
     group too (RANK / WORLD_SIZE / MASTER_* from the environment: the id travels through a TCPStore).  If RCCL cannot be bound or
-    bootstrapped the failure is printed once and the torch.distributed path is used (`comm_info()["collective"]` says which)."""
+    bootstrapped ON ANY RANK, every rank learns it in the bootstrap's agreement rounds (Communicator), the failure is printed once
+    and ALL ranks use torch.distributed (`comm_info()["collective"]` says which) -- unless RLDM_COLLECTIVE=cabi or
+    RLDM_REQUIRE_CABI=1 (bench.py sets it for --gpus N > 1) ask for an error instead of a fall-back."""
     global _COMM, _COMM_FAILED
     if collective_choice() != "cabi" or not torch.cuda.is_available() or _COMM_FAILED:
         return None
     if _COMM is None:
         try:
             _COMM = Communicator()
-        except Exception as e:                          # (a missing librccl, a bootstrap error: never silently, never fatally)
+        except Exception as e:                          # (a missing librccl, a bootstrap error: never silently, never on one rank alone)
             _COMM_FAILED = str(e)
             import sys
             print(f"rangeldm_amd.distributed: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-            if os.environ.get("RLDM_COLLECTIVE") == "cabi":
+            if os.environ.get("RLDM_COLLECTIVE") == "cabi" or os.environ.get("RLDM_REQUIRE_CABI") == "1":
                 raise
             return None
     return _COMM

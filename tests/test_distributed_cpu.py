@@ -79,3 +79,79 @@ def test_index_arithmetic_single_process():
     assert D.shard_range(16, 7, 8) == (14, 16) and D.shard_range(5, 3, 4) == (5, 5)
     x = torch.arange(6.).view(2, 3)
     assert D.all_gather_images(x) is x                   # world 1: no collective
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Bootstrap of the C-ABI RCCL communicator (rangeldm_amd.distributed.Communicator) with a fake library: the unique-id exchange through
+# a TCPStore (no process group), rank ordering, the 128-byte id, and the agreement rounds -- a failure on ONE rank must make EVERY rank
+# raise, before anything collective (the first real multi-GPU run is the driver's: this is its rehearsal without hardware).
+# ---------------------------------------------------------------------------------------------------------------------------------
+class _FakeRccl:
+    def __init__(self, rank, fail_bind=False, fail_create=False):
+        self.rank, self.fail_bind, self.fail_create = rank, fail_bind, fail_create
+        self.created, self.destroyed = [], 0
+
+    def rldm_comm_unique_id(self, buf, n):
+        if self.fail_bind:
+            return 1
+        import ctypes
+        ctypes.memmove(buf, bytes([0x40 + self.rank]) * n, n)       # (every rank makes one; only rank 0's may be used)
+        return 0
+
+    def rldm_comm_create(self, uid, rank, world, out):
+        self.created.append((bytes(uid.raw), rank, world))
+        if self.fail_create:
+            return 1
+        out._obj.value = 0x1000 + rank                              # (byref(c_void_p): a non-null handle)
+        return 0
+
+    def rldm_comm_destroy(self, h):
+        self.destroyed += 1
+
+
+def _bootstrap_ranks(world, port, fail_bind=(), fail_create=()):
+    import threading
+    out = [None] * world
+
+    def run(rank):
+        lib = _FakeRccl(rank, rank in fail_bind, rank in fail_create)
+        try:
+            ex = D._StoreExchange(rank, world, dist.TCPStore("127.0.0.1", port, world, rank == 0), timeout=60.0)
+            c = D.Communicator(rank=rank, world=world, lib=lib, exchange=ex)
+            out[rank] = ("ok", lib, c)
+        except D.CommunicatorUnavailable as e:
+            out[rank] = ("unavailable", lib, str(e), ex)            # (keep rank 0's store alive until every rank is through)
+        except Exception as e:                                      # pragma: no cover
+            out[rank] = ("error", lib, repr(e))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a rank hung in the bootstrap"
+    return out
+
+
+def test_cabi_bootstrap_exchanges_rank0_id_in_rank_order():
+    world = 3
+    res = _bootstrap_ranks(world, _free_port())
+    for rank, (status, lib, c) in enumerate(res):
+        assert status == "ok", (rank, c)
+        assert lib.created == [(bytes([0x40]) * 128, rank, world)]   # rank 0's 128-byte id, own rank, world -- on every rank
+        assert (c.rank, c.world) == (rank, world)
+        c._h = None                                                  # (nothing to destroy in the fake)
+
+
+def test_cabi_bootstrap_bind_failure_on_one_rank_stops_every_rank():
+    res = _bootstrap_ranks(2, _free_port(), fail_bind=(1,))
+    assert [r[0] for r in res] == ["unavailable", "unavailable"]
+    assert all(r[1].created == [] for r in res)                      # nobody entered the collective init
+    assert "another rank" in res[0][2] and "this rank" in res[1][2]
+
+
+def test_cabi_bootstrap_create_failure_is_agreed_and_cleaned_up():
+    res = _bootstrap_ranks(2, _free_port(), fail_create=(0,))
+    assert [r[0] for r in res] == ["unavailable", "unavailable"]
+    assert len(res[0][1].created) == 1 and len(res[1][1].created) == 1
+    assert res[1][1].destroyed == 1                                  # the rank that did get a communicator gave it back

@@ -60,6 +60,8 @@ CONV_CASES = [
     (2, 128, 64, 1024, 64, 3, 1, 0, False),    # conv_stream.hip <2, 2>: 64 output channels on 256-pixel tiles, 2 k-groups (VAE decoder, 128 -> 64)
     (1, 128, 64, 512, 32, 3, 1, 0, True),      # ... behind the folded nearest x2 (the decoder's last upsample is 128 -> 128; this is the shape check)
     (2, 64, 192, 64, 16, 3, 1, 0, False),      # ... (flag) three 64-channel tiles
+    (16, 256, 256, 128, 8, 3, 1, 0, False),    # conv_stream.hip, 4-wave 128 x 64 x 2 k-groups: the 128x8 level at the bench batch (512 workgroups, two per CU)
+    (3, 128, 128, 256, 16, 3, 1, 0, False),    # ... 4-wave 128 x 128 under "stream-any-grid" (96 workgroups), odd batch
 ]
 
 
@@ -104,11 +106,13 @@ GN_CASES = [(256, 256, 256, 32, 1), (128, 128, 128, 32, 16), (256, 128, 256, 16,
             (256, 128, 256, 64, 4), (128, 128, 128, 16, 4), (256, 128, 128, 128, 8), (128, 128, 128, 128, 8),
             (128, 64, 128, 64, 16), (64, 64, 256, 32, 8), (64, 64, 64, 32, 8), (128, 64, 64, 16, 16),
             (128, 128, 128, 1024, 4),       # (conv_stream.hip on 32 x 4 tiles: concat, GroupNorm, time embedding, residual)
-            (32, 32, 64, 1024, 64), (64, 64, 64, 256, 16)]   # (conv_stream.hip <2, 2>: 64 output channels, identity residual of 64)
+            (32, 32, 64, 1024, 64), (64, 64, 64, 256, 16),
+            (256, 256, 192, 32, 8), (256, 256, 128, 64, 8)]  # (4-wave conv_stream instances, 512 input channels: two channels per thread in the GroupNorm fold)   # (conv_stream.hip <2, 2>: 64 output channels, identity residual of 64)
 
 
-@pytest.fixture(params=[0, 1024, 4096, 256 + 2048, 524288, 1 << 22],
-                ids=["default", "small-128px-tiles", "stream-any-grid", "generic-only", "level3-64px-tiles", "own-image-tiles"])
+@pytest.fixture(params=[0, 1024, 4096, (4096, 7), 256 + 2048, 524288, 1 << 22],
+                ids=["default", "small-128px-tiles", "stream-any-grid", "stream-any-grid-8-waves", "generic-only", "level3-64px-tiles",
+                     "own-image-tiles"])
 def conv_flags(request):
     """Routing of the conv launches: 0 default; 1024 also sends the 128x8 level to conv_small.hip (128-pixel tiles);
     4096 sends every eligible 3x3 to conv_stream.hip regardless of the grid size (by default it needs >= 128 workgroups);
@@ -117,9 +121,12 @@ def conv_flags(request):
     do so and write two normalised copies of its output (producer-side GroupNorm epilogue; the copies are checked at network level:
     test_producer_side_groupnorm_matches_consumer_side)."""
     from rangeldm_amd import _lib
-    _lib.lib().rldm_debug_set_flags(request.param)
-    yield request.param
+    f1, f2 = request.param if isinstance(request.param, tuple) else (request.param, 0)
+    _lib.lib().rldm_debug_set_flags(f1)
+    _lib.lib().rldm_debug_set_flags2(f2)      # (7: round 4's 4-wave conv_stream workgroups off -> the 8-wave instances keep their coverage)
+    yield f1
     _lib.lib().rldm_debug_set_flags(0)
+    _lib.lib().rldm_debug_set_flags2(0)
 
 
 @pytest.mark.parametrize("C0,C1,Cout,W,H", GN_CASES)

@@ -16,9 +16,9 @@ from oracle import unet as o_unet, vae as o_vae, schedulers as o_sched, pipeline
 from tests.hip_util import rel_l2
 
 pytestmark = pytest.mark.gpu
-TOL_FWD = 2e-2
+TOL_FWD = 1.2e-2     # one network forward, teacher-forced (round 4: 2e-2 -> 1.2e-2; measured 4-8e-3, so a regression that doubles the error fails)
 TOL_TRAJ = 2e-2      # decoded image at the end of a free-running trajectory
-TOL_X0 = 1e-2        # final latent of the 50-step full-width sampler
+TOL_X0 = 5e-3        # final latent of the 50-step full-width sampler (round 4: 1e-2 -> 5e-3; measured 1.9-2.4e-3)
 
 
 def T(a):
@@ -452,7 +452,7 @@ def test_mid_run_cluster_failure_is_reported_by_the_same_call():
     _lib.check(_lib.lib().rldm_debug_inject_trunk_error(h2, 1), "inject")
     bad = pipe2(check=False, **kw)
     torch.cuda.synchronize()
-    assert torch.isnan(bad.flatten()[:64]).all()
+    assert torch.isnan(bad).all()                          # every image of the failed call, not just the head of the first
     with pytest.raises(RuntimeError, match="self-check"):
         pipe2._fused.status(h2)
     assert torch.equal(pipe2(**kw).cpu(), good)
@@ -562,7 +562,11 @@ def test_other_presets_full_size_match_reference(golden):
     m = hip_ref_unet(UNetConfig(**kw, **SGM_SINUSOID), "ref/rangedm.")
     out = m(T(g["presets_rangedm_x_f16"]).float().cuda(), 900).sample.cpu()
     assert out.shape == (1, 2, 1024, 64)
-    assert rel_l2(out, T(g["presets_rangedm_eps"])) < TOL_FWD
+    ref = T(g["presets_rangedm_eps"])
+    # (one sample: the worst-case gate is per output channel and per quarter of the azimuth instead of per sample)
+    worst = max(float(rel_l2(out[:, c, q * 256:(q + 1) * 256], ref[:, c, q * 256:(q + 1) * 256])) for c in range(2) for q in range(4))
+    print(f"RangeDM B=1: rel-L2 {float(rel_l2(out, ref)):.3e}, worst (channel, azimuth quarter) {worst:.3e}")
+    assert rel_l2(out, ref) < TOL_FWD and worst < 1.5 * TOL_FWD
 
 
 @pytest.mark.parametrize("sched", ["ddim", "ddpm"])
@@ -639,8 +643,9 @@ def test_other_configs_at_their_batch_match_reference_model(golden):
     x = T(normal(67, "b16/nusc_x", (4, 5, 256, 8))).cuda()
     ref = T(g["b16_nusc4_eps_t250"])
     out = m(x, 250).sample.cpu()
-    print(f"nuScenes B=4: rel-L2 {float(rel_l2(out, ref)):.3e}")
-    assert rel_l2(out, ref) < TOL_FWD and m.trunk_status(4) == 0
+    worst = max(float(rel_l2(out[j], ref[j])) for j in range(4))
+    print(f"nuScenes B=4: rel-L2 {float(rel_l2(out, ref)):.3e}, worst sample {worst:.3e}")
+    assert rel_l2(out, ref) < TOL_FWD and worst < 1.5 * TOL_FWD and m.trunk_status(4) == 0
     # ... and config 3's whole batch on one GPU (`eval_batch_size: 32`): clusters at every level, conv_stream on 32 x 4 tiles
     x = T(normal(68, "b16/nusc32_x", (32, 5, 256, 8))).cuda()
     ref = T(g["b16_nusc32_eps_t610_f16"]).float()

@@ -8,7 +8,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done
 for i in $(seq $N); do
   for l in "${LIBS[@]}"; do
     if [ "$l" = default ]; then unset RLDM_LIB; else export RLDM_LIB=$PWD/$l; fi
-    v=$(python bench.py --no-cpu-baseline --no-pipelined --steps 8 --warmup 2 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],2), round(d['ms_per_step'],3))")
+    v=$(python bench.py --no-cpu-baseline --no-pipelined --no-other-configs --steps 8 --warmup 2 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],2), round(d['ms_per_step'],3))")
     echo "$l $v"
   done
 done

@@ -185,15 +185,25 @@ def main():
                         nb = 2048
                         bt = (C.c_ulonglong * (2 * nb))()
                         if _lib.lib().rldm_debug_block_times(bt, nb) == 0:
+                            M48 = (1 << 48) - 1
                             st = [bt[2 * i] for i in range(nb) if bt[2 * i]]
-                            en = [bt[2 * i + 1] for i in range(nb) if bt[2 * i]]
+                            en = [bt[2 * i + 1] & M48 for i in range(nb) if bt[2 * i]]
+                            cu = [bt[2 * i + 1] >> 48 for i in range(nb) if bt[2 * i]]
                             if st:
                                 t0 = min(st)
                                 life = sorted((e - s_) * 0.01 for s_, e in zip(st, en))
                                 print(f"    {len(st)} workgroups: starts spread {(max(st) - t0) * 0.01:.2f} us, ends {(min(en) - t0) * 0.01:.2f} .. "
                                       f"{(max(en) - t0) * 0.01:.2f} us after the first start; lifetime min / median / max "
                                       f"{life[0]:.2f} / {life[len(life) // 2]:.2f} / {life[-1]:.2f} us", file=sys.stderr)
-                    for blk in range(2):
+                            if st:
+                                # workgroups of one CU, in start order: how do co-resident ones overlap?
+                                by_cu = collections.defaultdict(list)
+                                for s_, e_, c_ in zip(st, en, cu):
+                                    by_cu[c_].append(((s_ - t0) * 0.01, (e_ - t0) * 0.01))
+                                k0 = sorted(by_cu)[0]
+                                print(f"    {len(by_cu)} CUs seen; CU {k0:#x}: " + " ".join(f"[{a:.1f},{b:.1f}]" for a, b in sorted(by_cu[k0])[:12]),
+                                      file=sys.stderr)
+                    for blk in range(4):
                         v = [buf[blk * 64 + i] for i in range(64)]
                         v = [x for x in v if x]
                         print(f"    block {blk} stamps (cycles since start):", [int(x - v[0]) for x in v], file=sys.stderr)

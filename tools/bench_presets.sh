@@ -2,7 +2,7 @@
 # one bench.py line per BASELINE config that fits a single GPU (summary view); usage: tools/bench_presets.sh [extra bench.py flags]
 for a in "--preset RangeLDM --batch 16" "--preset upsample --batch 16" "--preset nuscenes --batch 4" "--preset nuscenes --batch 32" "--preset RangeDM --batch 1 --inference-steps 10" "--preset RangeDM --batch 4 --inference-steps 10"; do
   echo "== $a $*"
-  timeout 500 python bench.py $a --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined "$@" 2>&1 | tail -1 | python -c "
+  timeout 500 python bench.py $a --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --no-other-configs "$@" 2>&1 | tail -1 | python -c "
 import json,sys
 l=sys.stdin.read().strip()
 try:

@@ -7,7 +7,7 @@ TAG=${1:-vX}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined"
+BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-other-configs"
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/${TAG}_gpu_tests.txt
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/kt -o kt -- $BENCH > /tmp/prof_$TAG/kt.log 2>&1
