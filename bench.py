@@ -122,7 +122,7 @@ def roofline(pipe, sampler_handle, x_T, steps):
                    "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     traffic, traffic_src = None, None
-    for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):   # HBM bytes per launch from the rocprofv3 --pmc passes
+    for name in ("round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):   # HBM bytes per launch from the rocprofv3 --pmc passes
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             try:

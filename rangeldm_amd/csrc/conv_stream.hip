@@ -21,6 +21,7 @@
 // 8 waves = 2 channel tiles x 4 k-groups (k-group kg owns the kg-th 16-channel group of every tap of a chunk: one k-step
 // per tap, ring = the 9 steps of a chunk); the k-groups' fp32 partial tiles meet in LDS for the epilogue (conv_small.hip's).
 #include "conv_stream_body.h"
+#include "conv_stream_spec_body.h"
 
 namespace rldm {
 
@@ -45,6 +46,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_stream_kernel(c
     conv_stream_body<WM, WN, false, NW>(p, nt, mt, b, none);
 }
 
+// the 256 x 128 tile with specialised waves (conv_stream_spec_body.h): 4 matrix waves + 4 staging waves
+__global__ void __launch_bounds__(512, 1) conv_stream_spec_kernel(const ConvParams p) {
+    int nt, mt, b;
+    {
+        const int gx = p.ntile_n, gy = p.tiles_img;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int rid = (p.dbg & (1 << 21)) ? lin : xcd_remap(lin, gx * gy * p.B);
+        const int q = rid / gx;
+        nt = rid - q * gx;
+        b = q / gy;
+        mt = q - b * gy;
+    }
+    const TrunkSeam none = {};
+    conv_stream_spec_body<false>(p, nt, mt, b, none);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -55,14 +72,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_stream_kernel(c
 // full-resolution level, which ran on the generic kernel at 278 us per conv
 // (round 4) st_inst 1 / 2: 4-wave workgroups on 16 x 8 tiles -- 128 channels (one k-group) / 64 channels x 2 k-groups; two per CU
 int conv_stream_bn(const ConvParams& p) {
+    if (p.st_inst == 3) return 128;             // (3: the 256 x 128 tile with specialised waves)
     if (p.st_inst) return p.st_inst == 1 ? 128 : 64;
     return p.TW * p.TH == 256 && p.N % 128 == 0 ? 128 : 64;
 }
 int conv_stream_kgroups(const ConvParams& p) {
+    if (p.st_inst == 3) return 1;
     if (p.st_inst) return p.st_inst == 1 ? 1 : 2;
     return p.TW * p.TH == 256 ? (p.N % 128 == 0 ? 1 : 2) : 4;
 }
-int conv_stream_threads(const ConvParams& p) { return p.st_inst ? 256 : 512; }
+int conv_stream_threads(const ConvParams& p) { return p.st_inst == 1 || p.st_inst == 2 ? 256 : 512; }
 
 size_t conv_stream_lds_bytes(const ConvParams& p) {
     const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * p.TH;
@@ -81,10 +100,11 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     if (R != 0 && p.up != 1) return false;
     if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4)) || p.Win * p.up < 2) return false;
     if (p.N % conv_stream_bn(p) != 0 || Cin > 512) return false;
-    if (p.st_inst && (p.st_inst > 2 || p.TW != 16 || p.TH != 8)) return false;
+    if (p.st_inst == 3 && (p.TW != 32 || p.TH != 8 || p.N % 128 != 0)) return false;
+    if (p.st_inst && p.st_inst != 3 && (p.st_inst > 2 || p.TW != 16 || p.TH != 8)) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
-    return conv_stream_lds_bytes(p) <= (size_t)(p.st_inst ? 80 : 160) * 1024;      // (4-wave instances: two workgroups share the CU's LDS)
+    return conv_stream_lds_bytes(p) <= (size_t)(p.st_inst == 1 || p.st_inst == 2 ? 80 : 160) * 1024;      // (4-wave instances: two workgroups share the CU's LDS)
 }
 
 template <int WM, int WN, int NW = 8>
@@ -100,6 +120,14 @@ static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t strea
 int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(conv_stream_supported(p, 9), "conv_stream: unsupported shape");
     const size_t lds = conv_stream_lds_bytes(p);
+    if (p.st_inst == 3) {
+        auto kern = conv_stream_spec_kernel;
+        static DynLdsLimit lds_limit;
+        RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
+        hipLaunchKernelGGL(kern, dim3(p.N / 128, p.tiles_img, p.B), dim3(512), lds, stream, p);
+        RLDM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (p.st_inst == 1) return launch_stream_inst<1, 4, 4>(p, lds, stream);
     if (p.st_inst == 2) return launch_stream_inst<1, 2, 4>(p, lds, stream);
     if (p.TW * p.TH == 256) return p.N % 128 == 0 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<2, 2>(p, lds, stream);

@@ -1243,6 +1243,8 @@ struct Builder {
         // (UNet 256x16 level at batch >= 12, the VAE decoder's 128 / 256-channel levels), x 64 channels x 2 k-groups for the 128x8
         // level and the VAE's 64-channel level
         const int N_ = a.layer->Cout;
+        // (experiment, rldm_debug_set_flags2(32)) the 256 x 128 tile with specialised waves wherever the 8-wave 256 x 128 instance would run
+        if ((dbg2() & 32) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q, 8, 3)) return true;
         if (!(dbg2() & 1) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 1)) return true;
         if (!(dbg2() & 4) && N_ % 128 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 2)) return true;
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;

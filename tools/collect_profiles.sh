@@ -17,8 +17,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$TAG/$c -o pmc -- $BENCH > /tmp/prof_$TAG/$c.log 2>&1
   python tools/pmc_summary.py /tmp/prof_$TAG/$c > $OUT/${TAG}_pmc_$(echo $c | tr A-Z a-z).txt
 done
-python tools/traffic_json.py /tmp/prof_$TAG/FETCH_SIZE /tmp/prof_$TAG/WRITE_SIZE > $OUT/${TAG}_traffic.json; cp $OUT/${TAG}_traffic.json profiles/round3_traffic.json 2>/dev/null
-# (bench.py after the traffic passes: its roofline.traffic reads profiles/round2_traffic.json)
+python tools/traffic_json.py /tmp/prof_$TAG/FETCH_SIZE /tmp/prof_$TAG/WRITE_SIZE > $OUT/${TAG}_traffic.json; cp $OUT/${TAG}_traffic.json profiles/round4_traffic.json 2>/dev/null
+# (bench.py after the traffic passes: its roofline.traffic reads profiles/round4_traffic.json)
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --train --steps 20 --warmup 3 > $OUT/${TAG}_bench_train.json 2>> $OUT/${TAG}_bench.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_$TAG/mfma -o pmc -- $BENCH > /tmp/prof_$TAG/mfma.log 2>&1
