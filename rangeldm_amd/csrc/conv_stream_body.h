@@ -105,14 +105,23 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     const int atotal = TWv * THv * C8;
     int apix[ACH];
     const int my_c8 = (tid % C8) * 8;
+    // halo pieces of a chunk in registers between its request and its store: one set, or two for the short-chunk instance (KG == 4: a
+    // chunk is 9 k-steps per wave, ~2.5 k cycles -- less than the pieces' round trip, so chunk cs + 2 is requested during chunk cs and
+    // stored during chunk cs + 1; round 4: the 128x8 convs' K loops ran 5.5 k cycles per chunk for 2.3 k of matrix-pipe time, most of the
+    // rest was store_next waiting for loads issued ~400 cycles earlier)
+    constexpr bool PF2 = KG == 4 && RLDM_STREAM_PF2;
     uint4 areg[ACH];
+    uint4 areg2[ACH];                          // (second set: PF2 only -- never touched otherwise)
+    // (the sets are selected by a compile-time tag inside the lambdas: passing an array of uint4 by reference sends it to scratch)
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     const bool gn = p.st0 != nullptr;
     const bf16_t* const gx0 = p.x0;             // (locals: selecting between fields of `p` by address would copy it to scratch)
     const bf16_t* const gx1 = p.x1;
     const bf16_t* const gr0 = p.r0;
     const bf16_t* const gr1 = p.r1;
     const int nC0 = p.C0, nC1 = p.C1, nR0 = p.R0, nR1 = p.R1;
-    auto load_a = [&](int cs) __attribute__((always_inline)) {                  // chunk cs of the sequence main, residual
+    auto load_a = [&](int cs, auto W) __attribute__((always_inline)) {            // chunk cs of the sequence main, residual
         const bool main_phase = cs < NCC;
         const int c = (main_phase ? cs : cs - NCC) * CK + my_c8;
         const int split = main_phase ? nC0 : nR0;
@@ -124,10 +133,11 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int pix = apix[i] < 0 ? 0 : apix[i];
-            areg[i] = ld_act16<TRUNK>(base + (size_t)pix * ld);
+            const uint4 v = ld_act16<TRUNK>(base + (size_t)pix * ld);
+            if constexpr (decltype(W)::value == 0) areg[i] = v; else areg2[i] = v;
         }
     };
-    auto store_a = [&](int cs) __attribute__((always_inline)) {                 // GroupNorm + SiLU (main phase) -> LDS
+    auto store_a = [&](int cs, auto W) __attribute__((always_inline)) {           // GroupNorm + SiLU (main phase) -> LDS
         unsigned char* dstbuf = sA + (cs & 1) * abytes;
         const bool anorm = gn && cs < NCC && !RLDM_EXP_NONORM;
         float4 ga0, ga1, gs0, gs1;
@@ -140,7 +150,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         }
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            uint4 v = areg[i];
+            uint4 v;
+            if constexpr (decltype(W)::value == 0) v = areg[i]; else v = areg2[i];
             if (apix[i] < 0) {
                 v = make_uint4(0u, 0u, 0u, 0u);
             } else if (anorm) {
@@ -186,8 +197,16 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
 #pragma unroll
         for (int i = 0; i < RCH; ++i) *reinterpret_cast<uint4*>(dst + i * step) = rr[i];
     };
-    auto load_next = [&](int cs) __attribute__((always_inline)) { if (cs < NCC) load_a(cs); else load_r(cs, areg); };
-    auto store_next = [&](int cs) __attribute__((always_inline)) { if (cs < NCC) store_a(cs); else store_r(cs, areg); };
+    auto load_next = [&](int cs, auto W) __attribute__((always_inline)) {
+        if (cs < NCC) load_a(cs, W);
+        else if constexpr (decltype(W)::value == 0) load_r(cs, areg);
+        else load_r(cs, areg2);
+    };
+    auto store_next = [&](int cs, auto W) __attribute__((always_inline)) {
+        if (cs < NCC) store_a(cs, W);
+        else if constexpr (decltype(W)::value == 0) store_r(cs, areg);
+        else store_r(cs, areg2);
+    };
     RLDM_STAMP();
     if constexpr (TRUNK) trunk_wait(seam, tid);     // (everything above is independent of the previous phase)
     // ---- GroupNorm: the statistics partials of channel `tid`, gamma and beta are requested first, then the first halo
@@ -258,7 +277,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         const bool ok = q < atotal && vh >= 0 && vh < Hv;
         apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
     }
-    if (NCT > 0) load_a(0);
+    if (NCT > 0) load_a(0, Set0());
     RLDM_STAMP();
     bf16x8 wr[G];
 #pragma unroll
@@ -313,7 +332,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     }
     RLDM_STAMP();
     if (tid < BN) sBias[tid] = bias_v;
-    if (NCT > 0) store_a(0);
+    if (NCT > 0) store_a(0, Set0());
+    if constexpr (PF2) { if (1 < NCT) load_next(1, Set1()); }   // (requested a chunk ahead from the start)
     RLDM_STAMP();
 
     // ---- per-lane LDS offsets of the pixel fragments; accumulators start at bias + temb ---------------------------------
@@ -413,9 +433,15 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             __syncthreads();
         }
     }
-    for (int cs = 0; cs < NCC; ++cs) {
+    // one main chunk: `held` carries chunk cs + 1's pieces if they were requested earlier (PF2), `fresh` receives this iteration's request
+    auto main_chunk = [&](int cs, auto held, auto fresh) __attribute__((always_inline)) {
         if constexpr (NW == 4 && !TRUNK) { if ((p.exp & 4) && 2 * cs >= NCC) __builtin_amdgcn_s_setprio(2); }
-        if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_next(cs + 1);    // next chunk (main or first residual): requested now, written below
+        if constexpr (PF2) {
+            // chunk cs + 2 (main chunks and the FIRST residual chunk travel through these registers); chunk cs + 1 is in `held`
+            if (cs + 2 < NCT && cs + 2 <= NCC && !RLDM_TDBG(p, 16384)) load_next(cs + 2, fresh);
+        } else {
+            if (cs + 1 < NCT && !RLDM_TDBG(p, 16384)) load_next(cs + 1, held);   // next chunk (main or first residual): requested now, written below
+        }
         int cur[MI], nxt[MI];
         const int boff = (cs & 1) * abytes;
 #pragma unroll
@@ -426,15 +452,23 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             __builtin_amdgcn_sched_barrier(0);
         }
         tap_row(cur, nxt, 0);
-        if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1);
+        if (grp == 0 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1, held);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) { cur[mi] = nxt[mi]; nxt[mi] += colb; }
         tap_row(cur, nxt, 1);
-        if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1);
+        if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1, held);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) cur[mi] = nxt[mi];
         tap_row(cur, nxt, 2);
         lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
+    };
+    if constexpr (PF2) {
+        for (int cs = 0; cs < NCC; cs += 2) {   // (two chunks per trip: the register sets swap roles with static indices)
+            main_chunk(cs, Set1(), Set0());
+            if (cs + 1 < NCC) main_chunk(cs + 1, Set0(), Set1());
+        }
+    } else {
+        for (int cs = 0; cs < NCC; ++cs) main_chunk(cs, Set0(), Set1());
     }
     // residual phase: centre tap of the raw block input, SPT k-steps per chunk; ring slots continue (CST % G == 0).  A chunk is 16
     // MFMAs per wave -- far less than a round trip to the L2 -- so RD chunks are kept in flight in registers (the main loop's

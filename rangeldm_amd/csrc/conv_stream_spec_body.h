@@ -267,7 +267,6 @@ __device__ __forceinline__ void conv_stream_spec_body(const ConvParams& p, const
     };
     if (producer) {
         if (NCT > 0) store_a(0);
-        if (1 < NCT) load_next(1);              // requested a chunk ahead: in flight across the barrier and the matrix waves' chunk 0
     } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -283,8 +282,8 @@ __device__ __forceinline__ void conv_stream_spec_body(const ConvParams& p, const
     if (producer) {
         // ---- staging waves: chunk cs + 1 while the matrix waves consume chunk cs; one barrier per chunk on both sides -------------------------
         for (int cs = 0; cs < NCC; ++cs) {
-            if (cs + 1 < NCT) store_next(cs + 1);                   // (its pieces were requested during chunk cs - 1)
-            if (cs + 2 < NCT && cs + 2 <= NCC) load_next(cs + 2);   // main chunks and the FIRST residual chunk go through the halo registers
+            // (requesting chunk cs + 2 here and storing chunk cs + 1 from the previous request measured SLOWER: 58 spilled registers)
+            if (cs + 1 < NCT) { load_next(cs + 1); store_next(cs + 1); }
             lds_barrier_b();
         }
         // residual chunks are 32 MFMAs per matrix wave (~1 k cycles): three of them in flight in registers

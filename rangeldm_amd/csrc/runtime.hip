@@ -530,7 +530,8 @@ static inline int dbg() { return g_dbg_flags | t_plan_flags; }
 //   bits 8..15: conv_stream experiment switches (ConvParams::exp); bits 16..23: (n + 1) = trunk variant 4's start offset n
 static int g_dbg_flags2 = getenv("RLDM_DBG_FLAGS2") ? atoi(getenv("RLDM_DBG_FLAGS2")) : 0;
 static inline int dbg2() { return g_dbg_flags2; }
-static constexpr int kTrunkSkewDefault = 8;     // (trunk variant 4: the second image group starts ~8 k cycles late; RLDM_DBG_FLAGS2 = (n + 1) << 16: n)
+static constexpr int kTrunkSkewDefault = 0;     // (trunk variant 4: start offset of the second image group, x 1024 cycles; measured 0 / 4 / 8 / 16 /
+                                                //  24 -> 230.6 / 230.1 / 230.8 / 228.7 / 223.7 img/s; RLDM_DBG_FLAGS2 = (n + 1) << 16: n)
 static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
