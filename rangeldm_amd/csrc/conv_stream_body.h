@@ -23,24 +23,28 @@ __device__ __forceinline__ void lds_barrier_b() {
 // MFMAs run under the other's round trips; the per-wave K loop is the 8-wave instance's)
 // TRUNK = true: a phase of the persistent launch (trunk.hip): arguments from a phase record, activations and statistics another
 // workgroup of the image's cluster published are read past the L1, the phase ends by arriving on the cluster's counter.
-template <int WM, int WN, bool TRUNK, int NW = 8>
+// MI = 32-pixel fragments per wave (4; 2: round 4's 64-pixel x 128-channel x 2-k-group tile for the 128x8 level -- an 8 x 8 tile's halo is
+// 100 positions against 180 for 16 x 8, it is normalised once for all 128 output channels instead of once per 64, and two k-groups exchange half
+// the partial sums of four)
+template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4>
 __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt, const int mt, const int b, const TrunkSeam& seam) {
-    constexpr int NT = 64 * NW, CK = 64, MI = 4, KG = NW / (WM * WN);
-    constexpr int BM = 128 * WM, BN = 32 * WN;
+    constexpr int NT = 64 * NW, CK = 64, KG = NW / (WM * WN);
+    constexpr int BM = 32 * MI * WM, BN = 32 * WN;
     constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
     constexpr int C8 = CK / 8;
     // 16-byte halo pieces per thread and chunk: 34 x 10 pixels (6); the 128-pixel instance 18 x 10 = 16 x 8 tiles, or 34 x 6 = 32 x 4
     // tiles for images of 4 beams (nuScenes' 128 x 4 level) (4)
     // (the 4-wave instances take 16 x 8 tiles only: 180 positions, 6 pieces per thread like the 256-pixel instance)
-    constexpr int HALO_PX = WM == 1 ? (NW == 4 ? (16 + 2) * 10 : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10;
+    constexpr int HALO_PX = MI == 2 ? (8 + 2) * 10 : (WM == 1 ? (NW == 4 ? (16 + 2) * 10 : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
     constexpr int ACH = (HALO_PX * C8 + NT - 1) / NT;
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
     constexpr int ROW = 3 * SPT;               // ... per row of taps
     constexpr int CST = 9 * SPT;               // ... per chunk
-    constexpr int G = KG == 4 ? CST : ROW;     // weight fragments in flight per wave (ring): a chunk (9) | a row of taps (12 | 6)
+    // weight fragments in flight per wave (ring): a chunk (9) | a row of taps (12 | 6); MI == 2: a chunk (18) -- a k-step is 64 cycles of MFMAs
+    constexpr int G = (KG == 4 || MI == 2) ? CST : ROW;
     constexpr int PFX = KG == 1 ? 2 : 3;       // pixel fragments read ahead; divides CST
     constexpr int ERS = BN * 2 + 16, NC8 = BN / 8;
-    static_assert(WM * WN * KG == NW && (NW == 4 || NW == 8) && CST % PFX == 0 && G <= 16, "wave grid");
+    static_assert(WM * WN * KG == NW && (NW == 4 || NW == 8) && CST % PFX == 0 && G <= 18 && (MI == 4 || (MI == 2 && WM == 1 && NW == 8)), "wave grid");
     constexpr int CPT = 512 / NT;              // channels per thread in the GroupNorm fold (Cin <= 512)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tid_ = threadIdx.x;

@@ -161,8 +161,8 @@ struct ConvLayer {
     }
 
     // conv_stream.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per (32-channel tile, k-group):
-    // [Cout/32][KG][Cin_pad/64 chunks x 9 taps x 4/KG k-steps, then R/64 chunks x 4/KG k-steps][64 lanes][8 bf16] + 16 KiB
-    // of zeros (the ring's read-ahead past the last stream); k-group kg owns the k-steps [kg*4/KG, (kg+1)*4/KG) of every
+    // [Cout/32][KG][Cin_pad/64 chunks x 9 taps x 4/KG k-steps, then R/64 chunks x 4/KG k-steps][64 lanes][8 bf16] + 32 KiB
+    // of zeros (the ring's read-ahead past the last stream: up to 18 fragments of 1 KiB in the 64-pixel instance); k-group kg owns the k-steps [kg*4/KG, (kg+1)*4/KG) of every
     // tap of a chunk; lane l holds channel 32*t + (l & 31), k = 8*(l >> 5) .. +8 of the step
     int get_streampacked(int Cin_pad, int KG, Packed** out) {
         auto key = std::make_pair(-2, KG);
@@ -174,7 +174,7 @@ struct ConvLayer {
         }
         RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % 64 == 0 && R % 64 == 0, "conv " + name + ": not stream-packable");
         const int SPT = 4 / KG, NCC = Cin_pad / 64, NCB = R / 64, nsteps = (NCC * 9 + NCB) * SPT;
-        std::vector<bf16_t> img((size_t)(Cout / 32) * KG * nsteps * 512 + 8192, 0);
+        std::vector<bf16_t> img((size_t)(Cout / 32) * KG * nsteps * 512 + 16384, 0);
         auto at = [&](int n, int ks, int step, int k) -> bf16_t& {      // ks: 16-channel group within the 64-channel chunk
             const size_t stream = (size_t)(n / 32) * KG + ks / SPT;
             return img[((stream * nsteps + step + ks % SPT) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8];
@@ -526,6 +526,7 @@ static inline int dbg() { return g_dbg_flags | t_plan_flags; }
 //   1 full-resolution conv_stream launches keep the 8-wave 256-pixel workgroups (default: 4-wave 128 x 128 workgroups, two per CU)
 //   2 the 128x8 level keeps the 8-wave 128 x 64 x 4-k-group workgroups (default: 4-wave 128 x 64 x 2 k-groups, two per CU)
 //   4 the VAE's 64-channel level keeps the 8-wave 256 x 64 instance
+//  16 the 128x8 level keeps the 128 x 64 x 4-k-group tiles (default: 64 pixels x 128 channels x 2 k-groups)
 //   8 the 4-wave full-resolution convs stay launches of their own (default: phases of trunk variant 4, two workgroups per CU)
 //   bits 8..15: conv_stream experiment switches (ConvParams::exp); bits 16..23: (n + 1) = trunk variant 4's start offset n
 static int g_dbg_flags2 = getenv("RLDM_DBG_FLAGS2") ? atoi(getenv("RLDM_DBG_FLAGS2")) : 0;
@@ -1246,9 +1247,15 @@ struct Builder {
         const int N_ = a.layer->Cout;
         // (experiment, rldm_debug_set_flags2(32)) the 256 x 128 tile with specialised waves wherever the 8-wave 256 x 128 instance would run
         if ((dbg2() & 32) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q, 8, 3)) return true;
+        // (tests, rldm_debug_set_flags2(64)) the 64-pixel x 128-channel tile first, at any level it fits
+        if ((dbg2() & 64) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, 192, 512, q, 8, 4)) return true;
         if (!(dbg2() & 1) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 1)) return true;
         if (!(dbg2() & 4) && N_ % 128 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 2)) return true;
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
+        // (round 4) the 128x8 level: 64-pixel x 128-channel x 2-k-group tiles (8 x 8: a smaller halo, normalised once for all 128 channels,
+        // half the partial sums to exchange); rldm_debug_set_flags2(16) keeps the 128 x 64 x 4-k-group tiles
+        if (!(dbg2() & 16) && !(dbg() & 16384) && N_ % 128 == 0 && Hout == 8 &&
+            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, 192, 512, q, 8, 4)) return true;
         if (!(dbg2() & 2) && !(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 257, 512, q, 8, 2)) return true;
         if (!(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
         // images of 4 beams (nuScenes' 128 x 4 level at batch 32): the same 128-pixel instance on 32 x 4 tiles (round 3; it ran on the

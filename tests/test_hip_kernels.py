@@ -110,9 +110,9 @@ GN_CASES = [(256, 256, 256, 32, 1), (128, 128, 128, 32, 16), (256, 128, 256, 16,
             (256, 256, 192, 32, 8), (256, 256, 128, 64, 8)]  # (4-wave conv_stream instances, 512 input channels: two channels per thread in the GroupNorm fold)   # (conv_stream.hip <2, 2>: 64 output channels, identity residual of 64)
 
 
-@pytest.fixture(params=[0, 1024, 4096, (4096, 7), (4096, 7 + 32), 256 + 2048, 524288, 1 << 22],
+@pytest.fixture(params=[0, 1024, 4096, (4096, 7), (4096, 7 + 32), (4096, 64), 256 + 2048, 524288, 1 << 22],
                 ids=["default", "small-128px-tiles", "stream-any-grid", "stream-any-grid-8-waves", "stream-any-grid-specialised-waves",
-                     "generic-only", "level3-64px-tiles", "own-image-tiles"])
+                     "stream-any-grid-64px-tiles", "generic-only", "level3-64px-tiles", "own-image-tiles"])
 def conv_flags(request):
     """Routing of the conv launches: 0 default; 1024 also sends the 128x8 level to conv_small.hip (128-pixel tiles);
     4096 sends every eligible 3x3 to conv_stream.hip regardless of the grid size (by default it needs >= 128 workgroups);
@@ -124,7 +124,8 @@ def conv_flags(request):
     f1, f2 = request.param if isinstance(request.param, tuple) else (request.param, 0)
     _lib.lib().rldm_debug_set_flags(f1)
     _lib.lib().rldm_debug_set_flags2(f2)      # (7: round 4's 4-wave conv_stream workgroups off -> the 8-wave instances keep their coverage;
-                                              #  32: the 256 x 128 tile runs with specialised matrix / staging waves)
+                                              #  32: the 256 x 128 tile runs with specialised matrix / staging waves;
+                                              #  64: 8 x 8 tiles x 128 channels x 2 k-groups wherever 128 | N -- the 128x8 level's default)
     yield f1
     _lib.lib().rldm_debug_set_flags(0)
     _lib.lib().rldm_debug_set_flags2(0)
