@@ -531,6 +531,8 @@ static inline int dbg() { return g_dbg_flags | t_plan_flags; }
 //   bits 8..15: conv_stream experiment switches (ConvParams::exp); bits 16..23: (n + 1) = trunk variant 4's start offset n
 static int g_dbg_flags2 = getenv("RLDM_DBG_FLAGS2") ? atoi(getenv("RLDM_DBG_FLAGS2")) : 0;
 static inline int dbg2() { return g_dbg_flags2; }
+static const int kInst4MinBlocks = getenv("RLDM_INST4_MIN") ? atoi(getenv("RLDM_INST4_MIN")) : 96;    // (tuning; 192 -> 96: nuScenes at 4 images 87.4 -> 89.4,
+                                                                                           //  KITTI at 8 images 134.4 -> 137.5 img/s)
 static constexpr int kTrunkSkewDefault = 0;     // (trunk variant 4: start offset of the second image group, x 1024 cycles; measured 0 / 4 / 8 / 16 /
                                                 //  24 -> 230.6 / 230.1 / 230.8 / 228.7 / 223.7 img/s; RLDM_DBG_FLAGS2 = (n + 1) << 16: n)
 static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: device [4][64] s_memtime stamps
@@ -1254,8 +1256,8 @@ struct Builder {
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
         // (round 4) the 128x8 level: 64-pixel x 128-channel x 2-k-group tiles (8 x 8: a smaller halo, normalised once for all 128 channels,
         // half the partial sums to exchange); rldm_debug_set_flags2(16) keeps the 128 x 64 x 4-k-group tiles
-        if (!(dbg2() & 16) && !(dbg() & 16384) && N_ % 128 == 0 && Hout == 8 &&
-            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, 192, 512, q, 8, 4)) return true;
+        if (!(dbg2() & 16) && !(dbg() & 16384) && N_ % 128 == 0 && Hout == 8 &&       // (at the 256x16 level of small batches it breaks the clusters: -4 %)
+            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 512, q, 8, 4)) return true;
         if (!(dbg2() & 2) && !(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 257, 512, q, 8, 2)) return true;
         if (!(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
         // images of 4 beams (nuScenes' 128 x 4 level at batch 32): the same 128-pixel instance on 32 x 4 tiles (round 3; it ran on the
