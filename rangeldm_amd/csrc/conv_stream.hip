@@ -27,7 +27,7 @@ namespace rldm {
 
 // WM pixel parts (128 pixels each) x WN 32-channel tiles x KG k-groups = NW waves; the 4-wave instances are built for two workgroups
 // per CU (__launch_bounds__' second argument is waves per SIMD: 2 x 256 threads = 2)
-template <int WM, int WN, int NW = 8, int MI = 4>
+template <int WM, int WN, int NW = 8, int MI = 4, int S = 1>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_stream_kernel(const ConvParams p) {
     // Workgroups are dispatched x-fastest and land on XCD (linear id % 8).  Re-number them so that every XCD owns a contiguous
     // run of (image, pixel tile, channel tile) ids: the tiles of an image then share ONE L2, and the halo rows two neighbouring
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_stream_kernel(c
         mt = q - b * gy;
     }
     const TrunkSeam none = {};
-    conv_stream_body<WM, WN, false, NW, MI>(p, nt, mt, b, none);
+    conv_stream_body<WM, WN, false, NW, MI, S>(p, nt, mt, b, none);
 }
 
 // the 256 x 128 tile with specialised waves (conv_stream_spec_body.h): 4 matrix waves + 4 staging waves
@@ -73,13 +73,13 @@ __global__ void __launch_bounds__(512, 1) conv_stream_spec_kernel(const ConvPara
 // (round 4) st_inst 1 / 2: 4-wave workgroups on 16 x 8 tiles -- 128 channels (one k-group) / 64 channels x 2 k-groups; two per CU
 // (round 4) st_inst 4: 8 x 8 tiles, 64 pixels x 128 channels x 2 k-groups on 8 waves (two 32-pixel fragments per wave) for the 128x8 level
 int conv_stream_bn(const ConvParams& p) {
-    if (p.st_inst == 3 || p.st_inst == 4) return 128;       // (3: the 256 x 128 tile with specialised waves)
+    if (p.st_inst == 3 || p.st_inst == 4 || p.st_inst == 5) return 128;       // (3: the 256 x 128 tile with specialised waves; 5: 4 at stride 2)
     if (p.st_inst) return p.st_inst == 1 ? 128 : 64;
     return p.TW * p.TH == 256 && p.N % 128 == 0 ? 128 : 64;
 }
 int conv_stream_kgroups(const ConvParams& p) {
     if (p.st_inst == 3) return 1;
-    if (p.st_inst == 4) return 2;
+    if (p.st_inst == 4 || p.st_inst == 5) return 2;
     if (p.st_inst) return p.st_inst == 1 ? 1 : 2;
     return p.TW * p.TH == 256 ? (p.N % 128 == 0 ? 1 : 2) : 4;
 }
@@ -87,7 +87,7 @@ int conv_stream_threads(const ConvParams& p) { return p.st_inst == 1 || p.st_ins
 
 size_t conv_stream_lds_bytes(const ConvParams& p) {
     const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * p.TH;
-    const size_t a = (size_t)(p.TW + 2) * p.colb;
+    const size_t a = (size_t)((p.TW - 1) * p.stride + 3) * p.colb;
     const size_t main_bytes = 2 * a + (size_t)(p.C0 + p.C1) * 8 + BN * 4;
     const size_t gscratch = p.st0 ? (size_t)2 * (p.C0 + p.C1) * 8 : 0;
     const size_t epi = KG == 1 ? (size_t)BM * (BN * 2 + 16) + (size_t)8 * 2 * BN * 4
@@ -97,24 +97,25 @@ size_t conv_stream_lds_bytes(const ConvParams& p) {
 
 bool conv_stream_supported(const ConvParams& p, int taps) {
     const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
-    if (taps != 9 || p.stride != 1 || p.pad_lo != 1 || (p.up != 1 && p.up != 2) || p.y_nchw || p.ksplit > 1) return false;
+    if (taps != 9 || (p.stride != 1 && !(p.stride == 2 && p.st_inst == 5)) || p.pad_lo != 1 || (p.up != 1 && p.up != 2) || p.y_nchw || p.ksplit > 1) return false;
+    if (p.st_inst == 5 && (p.stride != 2 || p.up != 1 || R != 0)) return false;
     if (Cin % 64 != 0 || (p.C1 != 0 && p.C0 % 64 != 0) || R % 64 != 0 || (p.R1 != 0 && p.R0 % 64 != 0)) return false;
     if (R != 0 && p.up != 1) return false;
-    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4) || (p.st_inst == 4 && p.TW == 8 && p.TH == 8)) ||
+    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4) || ((p.st_inst == 4 || p.st_inst == 5) && p.TW == 8 && p.TH == 8)) ||
         p.Win * p.up < 2) return false;
     if (p.N % conv_stream_bn(p) != 0 || Cin > 512) return false;
     if (p.st_inst == 3 && (p.TW != 32 || p.TH != 8 || p.N % 128 != 0)) return false;
-    if (p.st_inst == 4 && (p.TW != 8 || p.TH != 8 || p.N % 128 != 0)) return false;
+    if ((p.st_inst == 4 || p.st_inst == 5) && (p.TW != 8 || p.TH != 8 || p.N % 128 != 0)) return false;
     if ((p.st_inst == 1 || p.st_inst == 2) && (p.TW != 16 || p.TH != 8)) return false;
-    if (p.st_inst < 0 || p.st_inst > 4) return false;
+    if (p.st_inst < 0 || p.st_inst > 5) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
     return conv_stream_lds_bytes(p) <= (size_t)(p.st_inst == 1 || p.st_inst == 2 ? 80 : 160) * 1024;      // (4-wave instances: two workgroups share the CU's LDS)
 }
 
-template <int WM, int WN, int NW = 8, int MI = 4>
+template <int WM, int WN, int NW = 8, int MI = 4, int S = 1>
 static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
-    auto kern = conv_stream_kernel<WM, WN, NW, MI>;
+    auto kern = conv_stream_kernel<WM, WN, NW, MI, S>;
     static DynLdsLimit lds_limit;                // per device, thread safe
     RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(p.N / (32 * WN), p.tiles_img, p.B), dim3(64 * NW), lds, stream, p);
@@ -134,6 +135,7 @@ int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
         return 0;
     }
     if (p.st_inst == 4) return launch_stream_inst<1, 4, 8, 2>(p, lds, stream);
+    if (p.st_inst == 5) return launch_stream_inst<1, 4, 8, 2, 2>(p, lds, stream);
     if (p.st_inst == 1) return launch_stream_inst<1, 4, 4>(p, lds, stream);
     if (p.st_inst == 2) return launch_stream_inst<1, 2, 4>(p, lds, stream);
     if (p.TW * p.TH == 256) return p.N % 128 == 0 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<2, 2>(p, lds, stream);

@@ -26,7 +26,8 @@ __device__ __forceinline__ void lds_barrier_b() {
 // MI = 32-pixel fragments per wave (4; 2: round 4's 64-pixel x 128-channel x 2-k-group tile for the 128x8 level -- an 8 x 8 tile's halo is
 // 100 positions against 180 for 16 x 8, it is normalised once for all 128 output channels instead of once per 64, and two k-groups exchange half
 // the partial sums of four)
-template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4>
+// STR = stride (1; 2: the UNet's Downsample2D, pad 1, on the 64-pixel tile: output (w, h) reads inputs (2w - 1 + i, 2h - 1 + j) -- a 17 x 17 halo)
+template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1>
 __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt, const int mt, const int b, const TrunkSeam& seam) {
     constexpr int NT = 64 * NW, CK = 64, KG = NW / (WM * WN);
     constexpr int BM = 32 * MI * WM, BN = 32 * WN;
@@ -35,7 +36,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     // 16-byte halo pieces per thread and chunk: 34 x 10 pixels (6); the 128-pixel instance 18 x 10 = 16 x 8 tiles, or 34 x 6 = 32 x 4
     // tiles for images of 4 beams (nuScenes' 128 x 4 level) (4)
     // (the 4-wave instances take 16 x 8 tiles only: 180 positions, 6 pieces per thread like the 256-pixel instance)
-    constexpr int HALO_PX = MI == 2 ? (8 + 2) * 10 : (WM == 1 ? (NW == 4 ? (16 + 2) * 10 : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
+    constexpr int HALO_PX = MI == 2 ? (STR == 2 ? 17 * 17 : (8 + 2) * 10) : (WM == 1 ? (NW == 4 ? (16 + 2) * 10 : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
     constexpr int ACH = (HALO_PX * C8 + NT - 1) / NT;
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
     constexpr int ROW = 3 * SPT;               // ... per row of taps
@@ -85,7 +86,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     const int NCBw = (p.R0 + p.R1) / CK;       // residual-phase chunks: centre tap, 4 k-steps, raw input
     const int NCB = RLDM_EXP_NORES ? 0 : NCBw;
     const int NCT = NCC + NCB;
-    const int THv = p.TH + 2, TWv = p.TW + 2;
+    const int THv = (p.TH - 1) * STR + 3, TWv = (p.TW - 1) * STR + 3;
+    static_assert(STR == 1 || (STR == 2 && MI == 2), "stride 2: the 64-pixel instance only");
     const int colb = p.colb;
     const int abytes = TWv * colb;
     const int Wv = p.Win * p.up, Hv = p.Hin * p.up;
@@ -275,8 +277,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         const int q = tid + i * NT;
         const int slot = q / C8;
         const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
-        const int vh = h0 - 1 + vhl;
-        int vw = w0 - 1 + vwl;
+        const int vh = h0 * STR - 1 + vhl;
+        int vw = w0 * STR - 1 + vwl;
         vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
         const bool ok = q < atotal && vh >= 0 && vh < Hv;
         apix[i] = ok ? ((b * p.Win + (vw >> upshift)) * p.Hin + (vh >> upshift)) : -1;
@@ -346,7 +348,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     for (int mi = 0; mi < MI; ++mi) {
         const int pidx = wm * (MI * 32) + mi * 32 + l31;
         const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        xoff[mi] = pw * colb + ph * RS + kh * 16 + kg * (SPT * 32);
+        xoff[mi] = (pw * STR) * colb + (ph * STR) * RS + kh * 16 + kg * (SPT * 32);
     }
     lds_barrier_b();                            // sBias and halo chunk 0 are written
     f32x16 acc[MI];

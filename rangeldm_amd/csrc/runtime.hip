@@ -526,6 +526,7 @@ static inline int dbg() { return g_dbg_flags | t_plan_flags; }
 //   1 full-resolution conv_stream launches keep the 8-wave 256-pixel workgroups (default: 4-wave 128 x 128 workgroups, two per CU)
 //   2 the 128x8 level keeps the 8-wave 128 x 64 x 4-k-group workgroups (default: 4-wave 128 x 64 x 2 k-groups, two per CU)
 //   4 the VAE's 64-channel level keeps the 8-wave 256 x 64 instance
+// 128 stride-2 convs stay on the generic kernel (default: the 64-pixel conv_stream tile where its grid fits)
 //  16 the 128x8 level keeps the 128 x 64 x 4-k-group tiles (default: 64 pixels x 128 channels x 2 k-groups)
 //   8 the 4-wave full-resolution convs stay launches of their own (default: phases of trunk variant 4, two workgroups per CU)
 //   bits 8..15: conv_stream experiment switches (ConvParams::exp); bits 16..23: (n + 1) = trunk variant 4's start offset n
@@ -1208,7 +1209,7 @@ struct Builder {
     static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, long long min_blocks,
                                  long long max_blocks, ConvParams* q, int TH = 8, int inst = 0) {
         if (dbg() & 2048) return false;
-        if (taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
+        if (taps != 9 || (a.stride != 1 && !(a.stride == 2 && inst == 5)) || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
         if (Wout % TW != 0 || Hout % TH != 0) return false;
         memset(q, 0, sizeof(*q));
         q->C0 = a.x0.C;
@@ -1216,16 +1217,19 @@ struct Builder {
         q->R0 = a.r0.valid() ? a.r0.C : 0;
         q->R1 = R_t - q->R0;
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
-        q->up = a.up; q->stride = 1; q->pad_lo = 1;
+        q->up = a.up; q->stride = a.stride; q->pad_lo = 1;
         q->Wout = Wout; q->Hout = Hout;
         q->TW = TW; q->TH = TH; q->th_shift = TH == 8 ? 3 : 2;
         q->st_inst = inst;
         ConvTile t;
         t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
-        q->colb = conv_halo_col_bytes(t, TH, 1);
+        q->colb = conv_halo_col_bytes(t, TH, a.stride);
         q->tiles_h = Hout / TH;
         q->tiles_img = (Wout / TW) * q->tiles_h;
-        q->magic_thv = ((1 << 20) + (TH + 2) - 1) / (TH + 2);
+        {
+            const int thv = (TH - 1) * a.stride + 3;
+            q->magic_thv = ((1 << 20) + thv - 1) / thv;
+        }
         const int cpg = std::max(1, Cin_t / a.groups);
         q->magic_cpg = ((1 << 20) + cpg - 1) / cpg;
         q->gn_inv_n = (float)(1.0 / ((double)a.x0.W * a.x0.H * cpg));
@@ -1247,6 +1251,11 @@ struct Builder {
         // (UNet 256x16 level at batch >= 12, the VAE decoder's 128 / 256-channel levels), x 64 channels x 2 k-groups for the 128x8
         // level and the VAE's 64-channel level
         const int N_ = a.layer->Cout;
+        // (round 4) stride 2 (Downsample2D, pad 1) on the 64-pixel x 128-channel tile with a 17 x 17 halo: the 256x16 -> 128x8 down-sampler ran on
+        // the generic kernel's half-empty 256-pixel tile; rldm_debug_set_flags2(128) keeps it there
+        if (a.stride == 2)
+            return !(dbg2() & 128) && N_ % 128 == 0 && R_t == 0 && a.up == 1 &&
+                   stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 512, q, 8, 5);
         // (experiment, rldm_debug_set_flags2(32)) the 256 x 128 tile with specialised waves wherever the 8-wave 256 x 128 instance would run
         if ((dbg2() & 32) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q, 8, 3)) return true;
         // (tests, rldm_debug_set_flags2(64)) the 64-pixel x 128-channel tile first, at any level it fits
@@ -1365,7 +1374,7 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_stream(p, s);
-            }, "conv_stream_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(conv_stream_bn(p)) + ",CK64,taps9>", fl, by};
+            }, "conv_stream_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(conv_stream_bn(p)) + ",CK64,taps9" + (p.stride == 2 ? ",s2" : "") + ">", fl, by};
             if (in_stream_cluster) pend.standalone.push_back(standalone);
             else plan->ops.push_back(standalone);
         }

@@ -62,6 +62,8 @@ CONV_CASES = [
     (2, 64, 192, 64, 16, 3, 1, 0, False),      # ... (flag) three 64-channel tiles
     (16, 256, 256, 128, 8, 3, 1, 0, False),    # conv_stream.hip, 4-wave 128 x 64 x 2 k-groups: the 128x8 level at the bench batch (512 workgroups, two per CU)
     (3, 128, 128, 256, 16, 3, 1, 0, False),    # ... 4-wave 128 x 128 under "stream-any-grid" (96 workgroups), odd batch
+    (16, 128, 128, 256, 16, 3, 2, 0, False),   # conv_stream.hip, stride 2 on 64-pixel x 128-channel tiles (17 x 17 halo): the 256x16 -> 128x8 down-sampler at the bench batch
+    (3, 256, 128, 64, 32, 3, 2, 0, False),     # ... four input chunks, odd batch (under "stream-any-grid")
 ]
 
 
