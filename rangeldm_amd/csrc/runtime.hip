@@ -1266,7 +1266,8 @@ struct Builder {
         // (round 4) the 128x8 level: 64-pixel x 128-channel x 2-k-group tiles (8 x 8: a smaller halo, normalised once for all 128 channels,
         // half the partial sums to exchange); rldm_debug_set_flags2(16) keeps the 128 x 64 x 4-k-group tiles
         if (!(dbg2() & 16) && !(dbg() & 16384) && N_ % 128 == 0 && Hout == 8 &&       // (at the 256x16 level of small batches it breaks the clusters: -4 %)
-            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 512, q, 8, 4)) return true;
+            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 320, q, 8, 4)) return true;      // (one round of 8-wave workgroups: at 512
+        // blocks -- the 256-channel up-sampler conv of the level -- two co-resident 4-wave workgroups per CU win, 23.6 against 27.1 us)
         if (!(dbg2() & 2) && !(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 257, 512, q, 8, 2)) return true;
         if (!(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 128, 512, q)) return true;
         // images of 4 beams (nuScenes' 128 x 4 level at batch 32): the same 128-pixel instance on 32 x 4 tiles (round 3; it ran on the
