@@ -1265,7 +1265,7 @@ struct Builder {
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
         // (round 4) the 128x8 level: 64-pixel x 128-channel x 2-k-group tiles (8 x 8: a smaller halo, normalised once for all 128 channels,
         // half the partial sums to exchange); rldm_debug_set_flags2(16) keeps the 128 x 64 x 4-k-group tiles
-        if (!(dbg2() & 16) && !(dbg() & 16384) && N_ % 128 == 0 && Hout == 8 &&       // (at the 256x16 level of small batches it breaks the clusters: -4 %)
+        if (!(dbg2() & 16) && !(dbg() & 16384) && N_ % 128 == 0 && Hout == 8 &&       // (at the 256x16 level of small batches it breaks the clusters: -4 %; RangeDM at batch 1: +1 %, not worth a rule)
             stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 320, q, 8, 4)) return true;      // (one round of 8-wave workgroups: at 512
         // blocks -- the 256-channel up-sampler conv of the level -- two co-resident 4-wave workgroups per CU win, 23.6 against 27.1 us)
         if (!(dbg2() & 2) && !(dbg() & 16384) && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 257, 512, q, 8, 2)) return true;
