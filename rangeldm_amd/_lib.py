@@ -165,6 +165,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                f"(hipcc --offload-arch=gfx950).  rangeldm_amd has no CPU fallback.")
+        # PyTorch first: its wheel carries its own libamdhip64, and the library's dependency on that soname must resolve to the copy
+        # torch loads -- loaded the other way round the process holds two HIP runtimes, and this one then finds "no ROCm-capable
+        # device" (seen with build() and smoke() in one process on a GPU box)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)           # AttributeError if the .so does not export a declared symbol

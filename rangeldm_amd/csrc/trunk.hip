@@ -255,7 +255,10 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
     auto wave_stream = [&](unsigned r) __attribute__((always_inline)) {
         return reinterpret_cast<const unsigned char*>(rl_ptr<const bf16_t>(r, TW_WPK)) + ((size_t)stream_id * rl(r, TW_NMINE)) * 1024;
     };
-    if constexpr (V == 0) {
+    // (round 4: the multi-tile clusters of variant 1 carry kClusterPrefetch fragments across phases too -- the kernel sits at 196 VGPRs since
+    //  round 2's hoisting fix, and its K loops start on weights that every XCD pulls from the Infinity Cache: 8.7 k cycles against 3 k stand-alone)
+    constexpr bool PFV = V == 0 || (V == 1 && kClusterPrefetch > 0);
+    if constexpr (PFV) {
         const unsigned char* w0 = wave_stream(rec);
         const int g0 = (int)rl(rec, TW_G);
 #pragma unroll
@@ -320,11 +323,22 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
             // multi-tile clusters (the 64x4 level: 4 pixel tiles x 4 channel tiles of 64 per image): GroupNorm + SiLU of the input
             // folded into the staging as in the stand-alone launch, from the statistics the previous phase published
             switch (kind) {
-                case TK_CL_3x3_256: conv_small_body<2, 4, 9, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
-                case TK_CL_3x3_384: conv_small_body<2, 6, 9, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
-                case TK_CL_3x3_512: conv_small_body<2, 8, 9, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
-                case TK_CL_1x1_256: conv_small_body<2, 4, 1, 2, true, 0>(cp, nt, mt, b, wpf, seam); break;
-                case TK_GN_APPLY: gn_apply_phase(cp, rank, ranks, b, seam); break;
+                case TK_CL_3x3_256: conv_small_body<2, 4, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
+                case TK_CL_3x3_384: conv_small_body<2, 6, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
+                case TK_CL_3x3_512: conv_small_body<2, 8, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
+                case TK_CL_1x1_256: conv_small_body<2, 4, 1, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
+                case TK_GN_APPLY: {
+                    gn_apply_phase(cp, rank, ranks, b, seam);
+                    if constexpr (kClusterPrefetch > 0) {       // (a phase without weights: the next conv's first fragments are requested here)
+                        const int next_g = (int)rl(nrec, TW_G);
+                        if (next_g > 0) {
+                            const unsigned char* nw = wave_stream(nrec);
+#pragma unroll
+                            for (int j = 0; j < kClusterPrefetch; ++j)
+                                if (j < next_g) wpf[j] = *reinterpret_cast<const bf16x8*>(nw + (unsigned)(j * 1024 + lane * 16));
+                        }
+                    }
+                } break;
                 default: conv_done = false; break;
             }
         }
@@ -345,7 +359,7 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
                     attention_qkv2_body<0, true>(ap, 8, Lp, (ap.C >> 3) / ranks, b, rank, seam);
                 }
                 // the next phase's first weight fragments (what a conv phase requests behind its K loop)
-                const int next_g = V != 0 ? 0 : (int)rl(nrec, TW_G);   // (multi-tile clusters carry no ring across phases)
+                const int next_g = PFV ? (int)rl(nrec, TW_G) : 0;
                 if (next_g > 0) {
                     const unsigned char* nw = wave_stream(nrec);
 #pragma unroll

@@ -9,7 +9,12 @@ namespace rldm {
 // has been acknowledged (s_waitcnt vmcnt(0)) is in the L2 they share, and a load that does not hit a stale line of the reader's L1
 // sees it: the consumer invalidates its CU's vector L1 once, behind the wait (buffer_inv sc0: the L1 only -- sc1 would also walk the
 // L2 and made the whole step 30 % slower), and then uses ordinary cached loads.
-constexpr int kTrunkPrefetch = RLDM_TRUNK_PREFETCH;            // weight fragments per wave requested one phase ahead (registers carried across phases)
+constexpr int kTrunkPrefetch = RLDM_TRUNK_PREFETCH;
+#ifndef RLDM_TRUNK_CL_PREFETCH
+#define RLDM_TRUNK_CL_PREFETCH 0    /* ... by the multi-tile clusters of trunk variant 1 (round 4 experiment: 12 fits since the kernel sits at 196 VGPRs,
+                                       measured 230.8 -> 229.6 img/s -- 252 VGPRs, 144 spilled SGPRs, and the K loop's wait is bandwidth, not the first round trip) */
+#endif
+constexpr int kClusterPrefetch = RLDM_TRUNK_CL_PREFETCH;            // weight fragments per wave requested one phase ahead (registers carried across phases)
 struct TrunkSeam {
     unsigned* counter;              // arrivals of this image's cluster (monotonic over the launch; zeroed by the launch before)
     unsigned wait_for;              // arrivals that must have happened before this phase reads activations
