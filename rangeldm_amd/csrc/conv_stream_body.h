@@ -414,10 +414,10 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     //   4 priority by progress
     int* cu_lock = nullptr;
     if constexpr (NW == 4 && !TRUNK) {
-        if (p.exp >> 8) {                       // initial skew: the second workgroup of every CU starts (p.exp >> 8) x 1024 cycles late
+        if (p.exp >> 4) {                       // initial skew: the second workgroup of every CU starts (p.exp >> 4) x 4096 cycles late
             const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
             if (lin >= 256 && lin < 512)
-                for (int i = 0; i < (p.exp >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+                for (int i = 0; i < 4 * (p.exp >> 4); ++i) __builtin_amdgcn_s_sleep(16);
         }
         if (p.exp & 1) {
             const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;

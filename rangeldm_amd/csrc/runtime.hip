@@ -1290,7 +1290,7 @@ struct Builder {
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;   // ONE conv of a network
         p.ntile_n = N / conv_stream_bn(p);
-        p.exp = dbg2() >> 8;
+        p.exp = (dbg2() >> 8) & 255;            // (bits 8..15 only: 16..23 are trunk variant 4's start offset)
         if (p.exp & 2) {
             static int* locks = nullptr;            // (experiment: never freed)
             if (!locks) {
