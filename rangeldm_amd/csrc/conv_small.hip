@@ -45,7 +45,7 @@ int conv_small_kgroups(int BN) { return 8 / (BN / 32); }
 
 size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN) {
     const int BM = 64, KG = conv_small_kgroups(BN);             // (epilogue: 64-pixel half-tiles)
-    const int Cin = p.C0, R = p.R0 + p.R1;
+    const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
     const size_t a = (size_t)(p.TW + (taps == 9 ? 2 : 0)) * p.colb;
     const size_t r = (size_t)p.TW * p.TH * (R * 2 + 16);
     const size_t main_bytes = a + r + BN * 4 + 3072;            // + read-ahead slack past the residual image
@@ -69,7 +69,8 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     if ((taps != 9 && taps != 1) || p.stride != 1 || (p.up != 1 && !(p.up == 2 && taps == 9 && p.R0 + p.R1 == 0 && !p.res)) ||
         p.pad_lo != (taps == 9 ? 1 : 0) || p.y_nchw || p.ksplit > 1)
         return false;
-    if (p.C1 != 0) return false;                                // one input tensor
+    // one input tensor, or (round 4) a concatenated 3x3 input whose GroupNorm is folded into the staging
+    if (p.C1 != 0 && !(taps == 9 && p.st0 != nullptr && p.C0 % 8 == 0 && p.C1 % 8 == 0)) return false;
     if (p.st0 != nullptr && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;   // GroupNorm (+ SiLU) folded into the staging
     const int KG = conv_small_kgroups(BN), cpt = small_cpt(Cin, taps, BN);
     if (cpt == 0 || p.N % BN != 0 || R % (16 * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
@@ -101,7 +102,7 @@ static int launch_small_inst(const ConvParams& p, size_t lds, hipStream_t stream
 int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream) {
     RLDM_REQUIRE(conv_small_supported(p, taps, BN), "conv_small: unsupported shape");
     const size_t lds = conv_small_lds_bytes(p, taps, BN);
-    const int cpt = small_cpt(p.C0, taps, BN);
+    const int cpt = small_cpt(p.C0 + p.C1, taps, BN);
     const int mi = p.TW * p.TH / 32;
 #define RLDM_SMALL4(NWN_, CPT_, TAPS_, MI_) \
     if (BN == 32 * NWN_ && cpt == CPT_ && taps == TAPS_ && mi == MI_) return launch_small_inst<NWN_, CPT_, TAPS_, MI_>(p, lds, stream);

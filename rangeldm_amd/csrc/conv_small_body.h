@@ -116,26 +116,34 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     const bool gn = (TRUNK && NWN == 1) ? false : p.st0 != nullptr;       // (image-owning trunk phases: pre-activated inputs only)
     double gS = 0.0, gSS = 0.0;
     float g_gamma = 0.f, g_beta = 0.f;
+    // (round 4) a CONCATENATED 3x3 input -- an up-block's conv1: cat[x0, x1] with C0 + C1 == CIN -- is normalised here as well instead of by a
+    // gn_apply launch / phase in front of the conv: channel tid belongs to x0 (statistics st0, P0 partials) or to x1 (st1, P1)
+    const int nC0 = p.C1 != 0 ? p.C0 : CIN, nC1 = p.C1;
     if (gn && tid < CIN) {
-        const float2* src = p.st0 + (size_t)b * p.P0 * CIN + tid;
-        const int P = p.P0;
+        const float2* const gs0p = p.st0;       // (locals: selecting between fields of `p` by address would copy it to scratch)
+        const float2* const gs1p = p.st1;
+        const int nP0 = p.P0, nP1 = p.P1;
+        const bool first_t = tid < nC0;
+        const int Ct = first_t ? nC0 : nC1;
+        const int P = first_t ? nP0 : nP1;
+        const float2* src = (first_t ? gs0p : gs1p) + (size_t)b * P * Ct + (first_t ? tid : tid - nC0);
         int q = 0;
         for (; q + 8 <= P; q += 8) {            // (8 pixel tiles per image -- 128x4 / 128x8 inputs: one round trip instead of two)
             float2 u[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * CIN);
+            for (int j = 0; j < 8; ++j) u[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * Ct);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { gS += (double)u[j].x; gSS += (double)u[j].y; }
         }
         for (; q + 4 <= P; q += 4) {
             float2 u[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * CIN);
+            for (int j = 0; j < 4; ++j) u[j] = ld_act8<TRUNK>(src + (size_t)(q + j) * Ct);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { gS += (double)u[j].x; gSS += (double)u[j].y; }
         }
         for (; q < P; ++q) {
-            const float2 u = ld_act8<TRUNK>(src + (size_t)q * CIN);
+            const float2 u = ld_act8<TRUNK>(src + (size_t)q * Ct);
             gS += (double)u.x;
             gSS += (double)u.y;
         }
@@ -224,7 +232,13 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     } else if constexpr (!TRUNK || NWN > 1) {
         const int c8 = lane & (LPS - 1), rsub = lane / LPS;
         const bool laneok = c8 < C8;
-        const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x0);
+        // this lane's 8 channels live in x0 or in x1 (a concatenated input; one tensor: always x0): per-lane base, pixel pitch, channel offset
+        const bf16_t* const gx0 = p.x0;
+        const bf16_t* const gx1 = p.x1;
+        const bool first_l = c8 * 8 < nC0;
+        const unsigned char* xg = reinterpret_cast<const unsigned char*>(first_l ? gx0 : gx1);
+        const unsigned pitch_l = (unsigned)(first_l ? nC0 : nC1) * 2u;
+        const unsigned choff_l = (unsigned)(first_l ? c8 * 8 : c8 * 8 - nC0) * 2u;
         const int KC = (THv + SPI - 1) / SPI;   // instructions per column
         const int ups = p.up - 1;               // nearest x2 folded into the source indexing
         float ga[8], gs[8];
@@ -247,7 +261,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
                 const int vh = h0 - HALO + vhl;                 // row / column of the (nearest-x2: virtual) input image
                 rowok[kb] = laneok && slot < THv;
                 inimg[kb] = rowok[kb] && vh >= 0 && vh < (p.Hin << ups);
-                const unsigned goff = (unsigned)((vh >> ups) * (CIN * 2) + c8 * 16);
+                const unsigned goff = (unsigned)(vh >> ups) * pitch_l + choff_l;
                 ldo[kb] = vhl * RSM + c8 * 16;
 #pragma unroll
                 for (int j = 0; j < NCW; ++j) {
@@ -259,7 +273,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
                     vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
                     // 32-bit byte offset of the column (uniform; the tensors on this route are far below 4 GiB): scalar base +
                     // one VGPR offset per load instead of a 64-bit pointer per column
-                    const unsigned coff = (unsigned)((b * p.Win + (vw >> ups)) * p.Hin) * (unsigned)(CIN * 2);
+                    const unsigned coff = (unsigned)((b * p.Win + (vw >> ups)) * p.Hin) * pitch_l;
                     if (inimg[kb]) v[kb][j] = ld_act16<TRUNK>(xg + (coff + goff));
                 }
             }

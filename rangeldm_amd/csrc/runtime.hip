@@ -933,7 +933,11 @@ struct Builder {
         if (Wout % tw != 0 || Hout % th != 0 || Wout < 2) return false;
         *epi_res = a.layer->sc_identity && a.r0.valid() && !a.r1.valid() && a.r0.C == a.layer->Cout;
         memset(q, 0, sizeof(*q));
-        q->C0 = Cin_t;                          // one input tensor (3x3: pre-activated by gn_apply)
+        {
+            const bool cat = taps == 9 && a.x1.valid() && small_gn_fused(a, taps);     // a concatenated input normalised by the conv's own staging
+            q->C0 = cat ? a.x0.C : Cin_t;       // (else one input tensor: single, or pre-activated by gn_apply)
+            q->C1 = cat ? Cin_t - a.x0.C : 0;
+        }
         q->R0 = *epi_res ? 0 : (a.r0.valid() ? a.r0.C : 0);
         q->R1 = *epi_res ? 0 : R_t - q->R0;
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
@@ -981,8 +985,15 @@ struct Builder {
     }
     // GroupNorm (+ SiLU) folded into the conv's staging: every 1x1, and the 3x3 convs over ONE input tensor (a concatenated
     // input keeps the separate gn_apply launch; rldm_debug_set_flags(131072) keeps it for every 3x3: A/B runs)
+    // (round 4) ... and a concatenated 3x3 input on tiles that do not own their image (the 64x4 level's cluster phases, the stand-alone
+    // launches of the small-batch configurations): the gn_apply phase / launch it replaces costs 12-23 k cycles, the four-fold repeated
+    // arithmetic in the staging ~4.7 k; RLDM_SMALL_CONCAT_GN=0 keeps gn_apply (A/B runs)
+    static bool small_concat_gn() { static const bool on = !(getenv("RLDM_SMALL_CONCAT_GN") && atoi(getenv("RLDM_SMALL_CONCAT_GN")) == 0); return on; }
     static bool small_gn_fused(const ConvArgs& a, int taps) {
-        return a.gn != nullptr && (taps == 1 || (!a.x1.valid() && !(dbg() & 131072)));
+        if (a.gn == nullptr) return false;
+        if (taps == 1) return true;
+        if (dbg() & 131072) return false;
+        return !a.x1.valid() || (small_concat_gn() && !a.own_image && a.x0.C % 8 == 0 && a.x1.C % 8 == 0);
     }
     bool small_route(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout) const {
         ConvParams q;
@@ -1116,6 +1127,11 @@ struct Builder {
                 p.P0 = a.x0.P;
                 p.gn_gamma = a.gn->gamma.as<float>();
                 p.gn_beta = a.gn->beta.as<float>();
+                if (p.C1 != 0) {                // concatenated input: the second tensor and its statistics
+                    p.x1 = tptr(a.x1);
+                    p.st1 = sptr(a.x1);
+                    p.P1 = a.x1.P;
+                }
             }
             p.y = tptr(y);
             p.y_ld = N;
@@ -1167,6 +1183,8 @@ struct Builder {
                     putf(TW_INVN, p.gn_inv_n); putf(TW_EPS, p.gn_eps);
                     ph.w[TW_SILU] = p.silu; ph.w[TW_TILES_H] = p.tiles_h; ph.w[TW_TILES_IMG] = p.tiles_img;
                     ph.w[TW_UP] = p.up;
+                    put64(TW_X1, p.x1); put64(TW_ST1, p.st1);
+                    ph.w[TW_C0] = p.C0; ph.w[TW_C1] = p.C1; ph.w[TW_P1] = p.P1;
                 } else {
                 const int cpt = Cin_t / 128, KG = 8;
                 const int G = (trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt);

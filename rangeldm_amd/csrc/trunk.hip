@@ -91,6 +91,10 @@ __device__ __forceinline__ void unpack_cluster_phase(ConvParams& q, unsigned rec
     q.tiles_h = (int)rl(rec, TW_TILES_H);
     q.tiles_img = (int)rl(rec, TW_TILES_IMG);
     q.up = max((int)rl(rec, TW_UP), 1);         // (nearest x2 folded into the staging of an up-sampler's conv)
+    // (round 4) a concatenated input normalised by the phase itself: second tensor, its statistics, the split (C1 == 0: one tensor)
+    q.x1 = rl_ptr<const bf16_t>(rec, TW_X1);
+    q.st1 = rl_ptr<const float2>(rec, TW_ST1);
+    q.C0 = (int)rl(rec, TW_C0); q.C1 = (int)rl(rec, TW_C1); q.P1 = (int)rl(rec, TW_P1);
 }
 
 // a conv_stream phase (kind TK_STREAM): the cluster words + the second input tensor of a concatenation, nearest-x2, halo divisor
