@@ -115,7 +115,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     // chunk is 9 k-steps per wave, ~2.5 k cycles -- less than the pieces' round trip, so chunk cs + 2 is requested during chunk cs and
     // stored during chunk cs + 1; round 4: the 128x8 convs' K loops ran 5.5 k cycles per chunk for 2.3 k of matrix-pipe time, most of the
     // rest was store_next waiting for loads issued ~400 cycles earlier)
-    constexpr bool PF2 = KG == 4 && RLDM_STREAM_PF2;
+    constexpr bool PF2 = (KG == 4 && RLDM_STREAM_PF2) || (MI == 2 && RLDM_STREAM_PF2_MI2);     // (MI == 2: two pieces per thread, 8 registers)
     uint4 areg[ACH];
     uint4 areg2[ACH];                          // (second set: PF2 only -- never touched otherwise)
     // (the sets are selected by a compile-time tag inside the lambdas: passing an array of uint4 by reference sends it to scratch)

@@ -305,6 +305,9 @@ int launch_attention_proj(const AttnQkvParams& p, hipStream_t stream);    // the
 #define RLDM_STREAM_PF2 0          /* conv_stream's 4-k-group instance: halo chunks requested two chunks ahead (round 4 experiment; measured
                                       SLOWER, 128x8 convs 13.4 -> 15.1 us: +16 VGPRs = 15 spills; the waits were not the loads') */
 #endif
+#ifndef RLDM_STREAM_PF2_MI2
+#define RLDM_STREAM_PF2_MI2 1      /* ... the same for the 64-pixel instance (a chunk is 18 k-steps of 64 cycles; the second set costs 8 registers) */
+#endif
 #ifndef RLDM_STREAM_ILV
 #define RLDM_STREAM_ILV 1          /* conv_stream K loop: pixel-fragment reads interleaved with the step's MFMAs (round 4; 0 = behind them) */
 #endif
