@@ -1056,7 +1056,7 @@ struct Builder {
         // ... or a phase of a MULTI-TILE cluster (the 64x4 level at batch <= 16): conv_small's default 64-pixel x 64-channel tiles, the
         // consumer-side GroupNorm fold stays inside the phase
         // (3x3 over 128 channels -- the all-taps-ring instance, 211 registers on its own -- does not fit beside the phase loop's state)
-        const int kind_c = (taps == 9 && Cin_t == 256) ? TK_CL_3x3_256 :
+        const int kind_c = (taps == 9 && Cin_t == 128 && !getenv("RLDM_NO_CL128")) ? TK_CL_3x3_128 : (taps == 9 && Cin_t == 256) ? TK_CL_3x3_256 :
                            (taps == 9 && Cin_t == 384) ? TK_CL_3x3_384 : (taps == 9 && Cin_t == 512) ? TK_CL_3x3_512 :
                            (taps == 1 && Cin_t == 256) ? TK_CL_1x1_256 : -1;
         const int ranks_c = cluster_ranks(x0.B, N, Wout * Hout);

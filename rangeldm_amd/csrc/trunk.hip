@@ -327,6 +327,9 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
             // multi-tile clusters (the 64x4 level: 4 pixel tiles x 4 channel tiles of 64 per image): GroupNorm + SiLU of the input
             // folded into the staging as in the stand-alone launch, from the statistics the previous phase published
             switch (kind) {
+                // (round 4: 128 input channels -- the first conv of the level, behind the stride-2 down-sampler; the kernel has had the registers
+                //  for its 18-fragment ring since round 2's hoisting fix)
+                case TK_CL_3x3_128: conv_small_body<2, 2, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
                 case TK_CL_3x3_256: conv_small_body<2, 4, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
                 case TK_CL_3x3_384: conv_small_body<2, 6, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
                 case TK_CL_3x3_512: conv_small_body<2, 8, 9, 2, true, kClusterPrefetch>(cp, nt, mt, b, wpf, seam); break;
