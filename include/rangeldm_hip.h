@@ -392,7 +392,9 @@ int rldm_debug_block_times(unsigned long long* host_out, int nblocks);   /* ABLA
  * a launch, 1 << 20 every GroupNorm on the consumer side.  0 restores the defaults. */
 int rldm_debug_set_flags(int flags);
 /* second word of the same kind (RLDM_DBG_FLAGS2 seeds it), round 4: 1 / 2 / 4 keep the 8-wave conv_stream workgroups at the
- * full-resolution levels / the 128x8 level / the VAE's 64-channel level (default: 4-wave workgroups, two resident per CU). */
+ * full-resolution levels / the 128x8 level / the VAE's 64-channel level (default: 4-wave workgroups, two resident per CU), 8 keeps the
+ * 4-wave full-resolution convs launches of their own, 16 / 128 keep the round-3 tiles of the 128x8 level / the generic kernel for the first
+ * down-sampler, 32 / 64 route to the specialised-wave experiment / the 64-pixel tile wherever it fits (tests). */
 int rldm_debug_set_flags2(int flags);
 /* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */
