@@ -101,11 +101,13 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     if (p.st_inst == 5 && (p.stride != 2 || p.up != 1 || R != 0)) return false;
     if (Cin % 64 != 0 || (p.C1 != 0 && p.C0 % 64 != 0) || R % 64 != 0 || (p.R1 != 0 && p.R0 % 64 != 0)) return false;
     if (R != 0 && p.up != 1) return false;
-    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4) || ((p.st_inst == 4 || p.st_inst == 5) && p.TW == 8 && p.TH == 8)) ||
+    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4) || ((p.st_inst == 4 || p.st_inst == 5) && p.TW == 8 && p.TH == 8) || (p.st_inst == 5 && p.TW == 16 && p.TH == 4)) ||
         p.Win * p.up < 2) return false;
     if (p.N % conv_stream_bn(p) != 0 || Cin > 512) return false;
     if (p.st_inst == 3 && (p.TW != 32 || p.TH != 8 || p.N % 128 != 0)) return false;
-    if ((p.st_inst == 4 || p.st_inst == 5) && (p.TW != 8 || p.TH != 8 || p.N % 128 != 0)) return false;
+    if (p.st_inst == 4 && (p.TW != 8 || p.TH != 8 || p.N % 128 != 0)) return false;
+    // (5: 8 x 8 tiles, or 16 x 4 for outputs of 4 beams -- a 33 x 9 halo, the same five pieces per thread)
+    if (p.st_inst == 5 && (!((p.TW == 8 && p.TH == 8) || (p.TW == 16 && p.TH == 4)) || p.N % 128 != 0)) return false;
     if ((p.st_inst == 1 || p.st_inst == 2) && (p.TW != 16 || p.TH != 8)) return false;
     if (p.st_inst < 0 || p.st_inst > 5) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;

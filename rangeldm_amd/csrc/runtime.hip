@@ -1271,9 +1271,12 @@ struct Builder {
         const int N_ = a.layer->Cout;
         // (round 4) stride 2 (Downsample2D, pad 1) on the 64-pixel x 128-channel tile with a 17 x 17 halo: the 256x16 -> 128x8 down-sampler ran on
         // the generic kernel's half-empty 256-pixel tile; rldm_debug_set_flags2(128) keeps it there
-        if (a.stride == 2)
-            return !(dbg2() & 128) && N_ % 128 == 0 && R_t == 0 && a.up == 1 &&
-                   stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 512, q, 8, 5);
+        if (a.stride == 2) {
+            if ((dbg2() & 128) || N_ % 128 != 0 || R_t != 0 || a.up != 1) return false;
+            if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, kInst4MinBlocks, 512, q, 8, 5)) return true;
+            // outputs of 4 beams (the 128x8 -> 64x4 down-sampler): 16 x 4 tiles, from 48 workgroups on
+            return Hout == 4 && !getenv("RLDM_NO_S2_H4") && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 48, 512, q, 4, 5);
+        }
         // (experiment, rldm_debug_set_flags2(32)) the 256 x 128 tile with specialised waves wherever the 8-wave 256 x 128 instance would run
         if ((dbg2() & 32) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q, 8, 3)) return true;
         // (tests, rldm_debug_set_flags2(64)) the 64-pixel x 128-channel tile first, at any level it fits

@@ -64,6 +64,7 @@ CONV_CASES = [
     (3, 128, 128, 256, 16, 3, 1, 0, False),    # ... 4-wave 128 x 128 under "stream-any-grid" (96 workgroups), odd batch
     (16, 128, 128, 256, 16, 3, 2, 0, False),   # conv_stream.hip, stride 2 on 64-pixel x 128-channel tiles (17 x 17 halo): the 256x16 -> 128x8 down-sampler at the bench batch
     (3, 256, 128, 64, 32, 3, 2, 0, False),     # ... four input chunks, odd batch (under "stream-any-grid")
+    (16, 128, 128, 128, 8, 3, 2, 0, False),    # ... 16 x 4 tiles for an output of 4 beams (the 128x8 -> 64x4 down-sampler at the bench batch)
 ]
 
 
