@@ -394,7 +394,10 @@ int rldm_debug_set_flags(int flags);
 /* second word of the same kind (RLDM_DBG_FLAGS2 seeds it), round 4: 1 / 2 / 4 keep the 8-wave conv_stream workgroups at the
  * full-resolution levels / the 128x8 level / the VAE's 64-channel level (default: 4-wave workgroups, two resident per CU), 8 keeps the
  * 4-wave full-resolution convs launches of their own, 16 / 128 keep the round-3 tiles of the 128x8 level / the generic kernel for the first
- * down-sampler, 32 / 64 route to the specialised-wave experiment / the 64-pixel tile wherever it fits (tests). */
+ * down-sampler, 32 / 64 route to the specialised-wave experiment / the 64-pixel tile wherever it fits (tests); 1 << 24 keeps the VAE
+ * decoder's 64 -> 64 convs and conv_out on the per-tile kernels (default: conv_regw.hip -- weights resident in registers, a run of tiles per
+ * workgroup), 1 << 25 caps that kernel's grid at 8 runs (tests: runs of several tiles on small images), 1 << 26 makes a test / bench conv of
+ * <= 4 output channels an fp32-NCHW output layer like the decoder's conv_out (rldm_test_conv, rldm_bench_conv). */
 int rldm_debug_set_flags2(int flags);
 /* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */

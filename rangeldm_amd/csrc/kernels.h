@@ -141,6 +141,15 @@ size_t conv_stream_lds_bytes(const ConvParams& p);
 bool conv_stream_supported(const ConvParams& p, int taps);
 int launch_conv_stream(const ConvParams& p, hipStream_t stream);
 
+// conv_regw.hip (round 4): 64 -> 64 channel 3x3 / stride 1 convs over 16 x 8 tiles with the weights resident in registers and a persistent
+// tile loop per workgroup (the VAE decoder's full-resolution level).  `p` as for conv_stream (st_inst 2's tile); the output statistics are
+// ONE partial per workgroup: y_stats is [B][conv_regw_wg_per_image(p)][N].
+size_t conv_regw_lds_bytes();
+int conv_regw_wg_per_image(const ConvParams& p);
+int conv_regw_partials(const ConvParams& p);
+bool conv_regw_supported(const ConvParams& p);
+int launch_conv_regw(const ConvParams& p, hipStream_t stream);
+
 // Persistent trunk launch (trunk.hip): consecutive conv_small launches whose tile owns a whole image (<= 64 pixels, 32-channel
 // tiles) as the phases of ONE launch; the N / 32 workgroups of an image hand their outputs to each other through the L2 of the
 // XCD they share.  `kind`: 0 = 3x3 over 256 channels, 1 = 3x3 over 512, 2 = 1x1 over 256 (conv_small instances <1,2,9,2>,

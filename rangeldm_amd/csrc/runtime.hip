@@ -172,9 +172,10 @@ struct ConvLayer {
             *out = it->second.get();
             return 0;
         }
-        RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % 64 == 0 && R % 64 == 0, "conv " + name + ": not stream-packable");
+        RLDM_REQUIRE(ksize == 3 && (Cout % 32 == 0 || Cout < 32) && Cin_pad % 64 == 0 && R % 64 == 0, "conv " + name + ": not stream-packable");
         const int SPT = 4 / KG, NCC = Cin_pad / 64, NCB = R / 64, nsteps = (NCC * 9 + NCB) * SPT;
-        std::vector<bf16_t> img((size_t)(Cout / 32) * KG * nsteps * 512 + 16384, 0);
+        const int ntile32 = (Cout + 31) / 32;        // (fewer than 32 output channels -- conv_regw.hip's conv_out: one tile, zero rows and zero bias behind them)
+        std::vector<bf16_t> img((size_t)ntile32 * KG * nsteps * 512 + 16384, 0);
         auto at = [&](int n, int ks, int step, int k) -> bf16_t& {      // ks: 16-channel group within the 64-channel chunk
             const size_t stream = (size_t)(n / 32) * KG + ks / SPT;
             return img[((stream * nsteps + step + ks % SPT) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8];
@@ -190,7 +191,9 @@ struct ConvLayer {
         }
         auto pk = std::make_unique<Packed>();
         if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
-        if (upload(pk->bias, b.data(), b.size() * sizeof(float))) return 1;
+        std::vector<float> bias((size_t)ntile32 * 32, 0.f);
+        for (int n = 0; n < Cout; ++n) bias[n] = b[n];
+        if (upload(pk->bias, bias.data(), bias.size() * sizeof(float))) return 1;
         pk->ntile_n = 0;
         pk->Cin_pad = Cin_pad;
         *out = pk.get();
@@ -1404,6 +1407,97 @@ struct Builder {
         return 0;
     }
 
+    // conv_regw.hip route (round 4): 64 -> 64 channel 3x3 convs over many 16 x 8 tiles (the VAE decoder's full-resolution level) -- the weights stay
+    // in registers, a workgroup walks a run of tiles; rldm_debug_set_flags2(1 << 24) keeps them on conv_stream's per-tile instance
+    static bool regw_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+        const int N_ = a.layer->Cout;
+        if ((dbg2() & (1 << 24)) || (dbg() & 2048) || g_force_bm || taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.up != 1) return false;
+        if (a.x1.valid() || a.temb_off >= 0 || Cin_t != 64 || a.layer->Cin != 64 || a.first_of_step) return false;
+        if (a.out_f32_nchw ? (N_ > 4 || R_t != 0 || getenv("RLDM_NO_RW_OUT") != nullptr) : N_ != 64) return false;
+        if (R_t != 0 && !(a.layer->sc_identity && R_t == 64 && a.r0.valid() && a.r0.C == 64)) return false;
+        if (Wout % 16 != 0 || Hout % 8 != 0) return false;
+        memset(q, 0, sizeof(*q));
+        q->C0 = 64; q->R0 = R_t;
+        q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
+        q->up = 1; q->stride = 1; q->pad_lo = 1;
+        q->Wout = Wout; q->Hout = Hout;
+        q->TW = 16; q->TH = 8; q->th_shift = 3;
+        ConvTile t;
+        t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
+        q->colb = conv_halo_col_bytes(t, 8, 1);
+        q->tiles_h = Hout / 8;
+        q->tiles_img = (Wout / 16) * q->tiles_h;
+        q->magic_thv = ((1 << 20) + 9) / 10;
+        const int cpg = std::max(1, Cin_t / a.groups);
+        q->magic_cpg = ((1 << 20) + cpg - 1) / cpg;
+        q->gn_inv_n = (float)(1.0 / ((double)a.x0.W * a.x0.H * cpg));
+        q->N = N_;
+        q->silu = a.silu;
+        q->gn_eps = a.eps;
+        q->gn_groups = a.groups;
+        q->ksplit = 1;
+        q->exp = ((dbg2() & (1 << 25)) ? 8 : 0) | (getenv("RLDM_RW_ABL") ? atoi(getenv("RLDM_RW_ABL")) << 16 : 0);   // (tests: at most 8 team runs, so that small images give runs of several tiles; tuning)
+        if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only their presence matters to the shape check)
+        if (a.out_f32_nchw) q->y_nchw = reinterpret_cast<float*>(q);
+        const bool ok = conv_regw_supported(*q);
+        q->st0 = nullptr;
+        q->y_nchw = nullptr;
+        return ok;
+    }
+    int conv_regw(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
+        ConvLayer* L = a.layer;
+        const int N = L->Cout;
+        const Tensor& x0 = a.x0;
+        ConvParams p;
+        RLDM_REQUIRE(regw_params(a, Cin_t, R_t, 9, Wout, Hout, &p), "conv " + L->name + ": conv_regw route lost");
+        if (a.gn) {
+            RLDM_REQUIRE(a.gn->C == Cin_t && Cin_t % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
+            RLDM_REQUIRE(x0.P > 0, "conv " + L->name + ": GroupNorm input without statistics");
+        }
+        p.dbg = dbg();
+        p.ntile_n = 1;
+        Tensor y;
+        if (!a.out_f32_nchw) {
+            y = make(x0.B, Wout, Hout, N);
+            if (a.want_stats) add_stats(y, conv_regw_partials(p));
+        }
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * 9;
+        plan->flops += fl;
+        note_launch();
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_streampacked(Cin_t, 1, &pk)) return 1;
+            p.x0 = tptr(x0);
+            p.r0 = tptr(a.r0);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            if (a.gn) {
+                p.st0 = sptr(x0);
+                p.P0 = x0.P;
+                p.gn_gamma = a.gn->gamma.as<float>();
+                p.gn_beta = a.gn->beta.as<float>();
+            }
+            if (y.valid()) {
+                p.y = tptr(y);
+                p.y_ld = N;
+                p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
+            }
+            const double by = (double)x0.B * x0.W * x0.H * Cin_t * 2.0 + (double)N * L->Cin * 9 * 2.0 +
+                              (double)x0.B * Wout * Hout * N * (a.out_f32_nchw ? 4.0 : 2.0) + (double)x0.B * Wout * Hout * R_t * 2.0;
+            Plan* pl = plan;
+            const bool f32out = a.out_f32_nchw;
+            plan->ops.push_back({[p, pl, f32out](hipStream_t s) mutable {
+                if (f32out) {
+                    RLDM_REQUIRE(pl->io.sch.coef_table == nullptr, "conv_regw: a scheduler step fused into this output layer");
+                    p.y_nchw = pl->io.out;
+                }
+                return launch_conv_regw(p, s);
+            }, std::string("conv_regw_kernel<128,") + (f32out ? "32" : "64") + ",taps9>", fl, by});
+        }
+        *out = y;
+        return 0;
+    }
+
     // Statistics of a tensor with many pixel tiles per image are folded once, by one small launch, instead of by every
     // workgroup of every consumer (gn_fold_kernel); RLDM_DBG_FLAGS=262144 keeps the raw partials for A/B runs.
     static inline const int kFoldAboveP = getenv("RLDM_FOLD_ABOVE") ? atoi(getenv("RLDM_FOLD_ABOVE")) : 32;   // (env: tuning runs)
@@ -1487,6 +1581,10 @@ struct Builder {
         const int N = L->Cout;
         // (conv_in stays on the generic kernel: it is the launch that advances the sampler's step index)
         if (!a.first_of_step && small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, taps, Wout, Hout, out);
+        {
+            ConvParams q;
+            if (regw_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_regw(a, Cin_t, R_t, Wout, Hout, out);
+        }
         if (!a.first_of_step) {
             ConvParams q;
             if (stream_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_stream(a, Cin_t, R_t, Wout, Hout, out);
@@ -3423,6 +3521,12 @@ int make_conv_case(ConvCase& cc, const rldm_conv_desc* d, const float* weight, c
         a.temb_off = with_temb ? 0 : -1;
         a.r0 = cc.tr;
         a.want_stats = true;
+        // rldm_debug_set_flags2(1 << 26): a conv of <= 4 output channels is a network OUTPUT layer -- fp32 NCHW into plan.io.out (the VAE
+        // decoder's conv_out), no bf16 tensor, no statistics
+        if ((dbg2() & (1 << 26)) && d->Cout <= 4 && !with_res && !with_temb) {
+            a.out_f32_nchw = true;
+            a.want_stats = false;
+        }
         return bb.conv(a, &cc.out);
     };
     return build_plan(&cc.plan, d->Cout, walk);
@@ -3445,8 +3549,9 @@ int rldm_test_conv(const rldm_conv_desc* d, const float* x0, const float* x1, co
     cc.plan.io.temb = tembd.as<float>();
     cc.plan.io.temb_rows_per_step = d->B;
     cc.plan.io.temb_per_sample = 1;
+    if (!cc.out.valid()) cc.plan.io.out = y;         // (an output layer: fp32 NCHW straight into the caller's buffer)
     if (cc.plan.run(st)) return 1;
-    if (launch_nhwc_bf16_to_nchw_f32(tp(cc.out), y, d->B, d->Cout, cc.Wout, cc.Hout, d->Cout, st)) return 1;
+    if (cc.out.valid() && launch_nhwc_bf16_to_nchw_f32(tp(cc.out), y, d->B, d->Cout, cc.Wout, cc.Hout, d->Cout, st)) return 1;
     RLDM_HIP_CHECK(hipStreamSynchronize(st));
     return 0;
 }
@@ -3568,6 +3673,11 @@ int rldm_bench_conv(const rldm_conv_desc* d, int with_res, int with_temb, int wa
     cc.plan.io.temb = tembd.as<float>();
     cc.plan.io.temb_rows_per_step = d->B;
     cc.plan.io.temb_per_sample = 1;
+    DevBuf outd;
+    if (!cc.out.valid()) {
+        if (outd.alloc((size_t)d->B * d->Cout * cc.Wout * cc.Hout * sizeof(float))) return 1;
+        cc.plan.io.out = outd.as<float>();
+    }
     RLDM_REQUIRE(!cc.plan.ops.empty(), "internal: empty plan");
     // the timed unit: the conv launch, plus the GroupNorm+SiLU launch in front of it on the conv_small.hip route
     size_t last = cc.plan.ops.size() - 1;           // the conv itself: the last op whose name starts with "conv_" (a gn_fold of

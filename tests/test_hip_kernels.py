@@ -156,6 +156,79 @@ def test_conv_gn_silu_concat_temb_residual(C0, C1, Cout, W, H, conv_flags):
     assert rel_l2(y, ref(lambda t: t)) < TOL_F
 
 
+@pytest.fixture(params=[0, 1 << 25, 1 << 24], ids=["default", "runs-of-8-workgroups", "per-tile-kernel"])
+def regw_flags(request):
+    """conv_regw.hip (64 -> 64 channels, weights in registers, a run of 16 x 8 tiles per workgroup): by default where an image batch has at
+    least 2048 tiles; 1 << 25 caps the grid at 8 workgroups so that small images are walked in runs too; 1 << 24 keeps conv_stream's
+    per-tile instance (the comparison)."""
+    from rangeldm_amd import _lib
+    _lib.lib().rldm_debug_set_flags2(request.param)
+    yield request.param
+    _lib.lib().rldm_debug_set_flags2(0)
+
+
+@pytest.mark.parametrize("B,W,H,gn,res", [(4, 512, 64, True, False), (4, 512, 64, True, True), (2, 128, 16, True, True), (2, 128, 16, False, False),
+                                          (3, 64, 32, True, True), (1, 256, 8, True, False), (2, 1024, 64, False, True)])
+def test_conv_c64_register_weights(B, W, H, gn, res, regw_flags):
+    """The VAE decoder's full-resolution ResnetBlock convs (64 -> 64): GroupNorm(32) + SiLU -> conv3x3 -> + bias (+ x)."""
+    x = _rand(B, 64, W, H, seed=50) * 1.3 + 0.2
+    w = _rand(64, 64, 3, 3, seed=51, scale=(64 * 9) ** -0.5)
+    b = _rand(64, seed=52, scale=0.1)
+    gamma, beta = (1 + 0.2 * _rand(64, seed=53), 0.2 * _rand(64, seed=54)) if gn else (None, None)
+    r = _rand(B, 64, W, H, seed=55) if res else None
+    y = hip_conv(x, w, b, gamma=gamma, beta=beta, silu=gn, eps=1e-6, res=r)
+
+    def ref(q):
+        h = q(ops.group_norm_silu(q(x), gamma, beta, 32, 1e-6)) if gn else q(x)
+        out = ops.circ_conv2d(h, q(w), b)
+        return out + q(r) if res else out
+
+    assert rel_l2(y, ref(bf16r)) < TOL_Q
+    assert rel_l2(y, ref(lambda t: t)) < TOL_F
+    # per image and channel: a wrong tile of a run, a stale halo buffer or a lost residual is a local error the L2 norm forgives
+    d = (y - ref(bf16r)).abs().amax(dim=(2, 3))
+    assert float(d.max()) < 0.05
+
+
+@pytest.mark.parametrize("B,W,H,N", [(4, 512, 64, 2), (2, 128, 16, 2), (3, 64, 32, 4), (2, 1024, 64, 2), (2, 128, 16, 1)])
+@pytest.mark.parametrize("flags", [1 << 26, (1 << 26) | (1 << 25), (1 << 26) | (1 << 24)], ids=["default", "runs-of-8-workgroups", "generic-kernel"])
+def test_conv_out_fp32_nchw(B, W, H, N, flags):
+    """The VAE decoder's output layer: GroupNorm(32) + SiLU -> conv3x3 (64 -> 2) written as fp32 NCHW by the kernel itself
+    (rldm_debug_set_flags2(1 << 26) makes the test conv such an output layer): conv_regw.hip's one-tile variant, or the generic kernel."""
+    from rangeldm_amd import _lib
+    x = _rand(B, 64, W, H, seed=70) * 1.3 + 0.2
+    w = _rand(N, 64, 3, 3, seed=71, scale=(64 * 9) ** -0.5)
+    b = _rand(N, seed=72, scale=0.1)
+    gamma, beta = 1 + 0.2 * _rand(64, seed=73), 0.2 * _rand(64, seed=74)
+    _lib.lib().rldm_debug_set_flags2(flags)
+    try:
+        y = hip_conv(x, w, b, gamma=gamma, beta=beta, silu=True, eps=1e-6)
+    finally:
+        _lib.lib().rldm_debug_set_flags2(0)
+
+    def ref(q):
+        return ops.circ_conv2d(q(ops.group_norm_silu(q(x), gamma, beta, 32, 1e-6)), q(w), b)
+
+    # fp32 outputs (no bf16 rounding of the result): the quantised reference is met to accumulation order
+    assert rel_l2(y, ref(bf16r)) < 2e-3
+    assert rel_l2(y, ref(lambda t: t)) < TOL_F
+    assert float((y - ref(bf16r)).abs().max()) < 0.02
+
+
+@pytest.mark.parametrize("B,W,H", [(4, 512, 64), (2, 128, 16), (3, 64, 32)])
+def test_conv_c64_register_weights_statistics(B, W, H, regw_flags):
+    """... its (sum, sumsq) side output: one partial per workgroup, accumulated over the run."""
+    x = _rand(B, 64, W, H, seed=60)
+    w = _rand(64, 64, 3, 3, seed=61, scale=(64 * 9) ** -0.5)
+    b = _rand(64, seed=62, scale=0.5)
+    y = hip_conv(x, w, b)
+    st = hip_conv_stats(x, w, b)
+    ref_s = y.double().sum(dim=(2, 3))
+    ref_q = (y.double() ** 2).sum(dim=(2, 3))
+    assert float((st[..., 0].double() - ref_s).abs().max()) < 1e-4 * W * H
+    assert float(((st[..., 1].double() - ref_q).abs() / (ref_q + 1e-6)).max()) < 1e-4
+
+
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
                                                 (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3),
                                                 (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1), (2, 128, 128, 128, 8, 3),
