@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(kRwTeam * TEAMS, TEAMS == 1 ? 2 : 1) conv_regw
     const int kh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.x / wg_per_image, part = blockIdx.x - b * wg_per_image;
     const int t_first = (part * TEAMS + team) * tiles_per_team;
+    const unsigned long long ts_core0 = __builtin_amdgcn_s_memtime(), ts_real0 = __builtin_amdgcn_s_memrealtime();   // (tuning: the launch's clock)
     const int abl = p.exp >> 16;                        // (tuning: RLDM_RW_ABL -- 1 no K loop, 2 no staging arithmetic, 4 no output stores, 8 no halo loads, 16 start offset)
 
     unsigned char* const sA = smem + team * kRwTeamBytes;               // this team's halo (normalised), then its waves' landing zones
@@ -383,6 +384,10 @@ __global__ void __launch_bounds__(kRwTeam * TEAMS, TEAMS == 1 ? 2 : 1) conv_regw
         phase_barrier();
     }
     if (TEAMS == 2 && team == 0) phase_barrier();
+    if (p.ts && blockIdx.x == 0 && tid == 0) {          // rldm_debug_timestamps: workgroup 0's lifetime on the core clock and on the 100 MHz counter
+        p.ts[0] = ts_core0; p.ts[1] = __builtin_amdgcn_s_memtime();
+        p.ts[2] = ts_real0; p.ts[3] = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- the workgroup's statistics: one partial (both teams' runs) ---------------------------------------------------------------------
     if (WN == 2 && p.y_stats) {
         s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); q0 += __shfl_xor(q0, 16); q1 += __shfl_xor(q1, 16);

@@ -1455,6 +1455,7 @@ struct Builder {
             RLDM_REQUIRE(x0.P > 0, "conv " + L->name + ": GroupNorm input without statistics");
         }
         p.dbg = dbg();
+        p.ts = g_ts_buf;
         p.ntile_n = 1;
         Tensor y;
         if (!a.out_f32_nchw) {
