@@ -27,8 +27,17 @@ __device__ __forceinline__ void lds_barrier_b() {
 // 100 positions against 180 for 16 x 8, it is normalised once for all 128 output channels instead of once per 64, and two k-groups exchange half
 // the partial sums of four)
 // STR = stride (1; 2: the UNet's Downsample2D, pad 1, on the 64-pixel tile: output (w, h) reads inputs (2w - 1 + i, 2h - 1 + j) -- a 17 x 17 halo)
-template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1>
-__device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt, const int mt, const int b, const TrunkSeam& seam) {
+// SUB = true: nearest x2 + 3x3 as FOUR 2x2 convolutions over the input (sub-pixel form).  Output pixel (2w + a, 2h + c) of the 3x3 over the
+// up-sampled image reads only the inputs (w - 1 + a .. w + a) x (h - 1 + c .. h + c), each through the SUM of the taps that land on it
+// (parity a = 0: {k[0]}, {k[1] + k[2]}; a = 1: {k[0] + k[1]}, {k[2]} along each axis; zero rows above / below the image stay zero, the wrap
+// is the input's): 4 taps instead of 9 per output pixel.  The tiles are INPUT tiles; `nt_` = channel tile * 4 + parity; the weight stream of a
+// (32-channel tile, parity) is [chunks][2 x 2 taps][4 k-steps] of summed weights (ConvLayer::get_subpixpacked)
+template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1, bool SUB = false, bool T4 = false>
+__device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt_, const int mt, const int b, const TrunkSeam& seam) {
+    static_assert(!SUB || (!TRUNK && STR == 1 && NW / (WM * WN) == 1), "sub-pixel form: the one-k-group launches");
+    constexpr int TAPW = SUB ? 2 : 3;          // taps per row / rows of taps
+    const int nt = SUB ? nt_ >> 2 : nt_;
+    const int par_w = SUB ? (nt_ >> 1) & 1 : 0, par_h = SUB ? nt_ & 1 : 0;
     constexpr int NT = 64 * NW, CK = 64, KG = NW / (WM * WN);
     constexpr int BM = 32 * MI * WM, BN = 32 * WN;
     constexpr int RS = CK * 2 + 16;            // halo row stride (bytes): 9 16-byte slots
@@ -36,11 +45,12 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     // 16-byte halo pieces per thread and chunk: 34 x 10 pixels (6); the 128-pixel instance 18 x 10 = 16 x 8 tiles, or 34 x 6 = 32 x 4
     // tiles for images of 4 beams (nuScenes' 128 x 4 level) (4)
     // (the 4-wave instances take 16 x 8 tiles only: 180 positions, 6 pieces per thread like the 256-pixel instance)
-    constexpr int HALO_PX = MI == 2 ? (STR == 2 ? 17 * 17 : (8 + 2) * 10) : (WM == 1 ? (NW == 4 ? (16 + 2) * 10 : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
+    // (T4: the sub-pixel instance on 32 x 4 tiles -- inputs of 4 beams: 34 x 6 = 204 positions, 7 pieces per thread)
+    constexpr int HALO_PX = MI == 2 ? (STR == 2 ? 17 * 17 : (8 + 2) * 10) : (WM == 1 ? (NW == 4 ? (T4 ? (32 + 2) * (4 + 2) : (16 + 2) * 10) : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
     constexpr int ACH = (HALO_PX * C8 + NT - 1) / NT;
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
-    constexpr int ROW = 3 * SPT;               // ... per row of taps
-    constexpr int CST = 9 * SPT;               // ... per chunk
+    constexpr int ROW = TAPW * SPT;            // ... per row of taps
+    constexpr int CST = TAPW * TAPW * SPT;     // ... per chunk
     // weight fragments in flight per wave (ring): a chunk (9) | a row of taps (12 | 6); MI == 2: a chunk (18) -- a k-step is 64 cycles of MFMAs
     constexpr int G = (KG == 4 || MI == 2) ? CST : ROW;
     constexpr int PFX = KG == 1 ? 2 : 3;       // pixel fragments read ahead; divides CST
@@ -101,7 +111,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     // ---- this wave's weight stream (channel tile WN*nt + wn, k-group kg): [NCC][9 taps][SPT k-steps] then [NCB][SPT], 1 KiB each
     const int nsteps = NCC * CST + NCBw * SPT;
     const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk) +
-                                (size_t)((nt * WN + wn) * KG + kg) * nsteps * 1024;
+                                (size_t)(SUB ? (nt * WN + wn) * 4 + (par_w * 2 + par_h) : (nt * WN + wn) * KG + kg) * nsteps * 1024;
     const unsigned woff = lane * 16 + 4096;     // lane offset: immediates of +-4 KiB around it reach 8 fragments
     auto w_load = [&](const unsigned char* base, int idx) __attribute__((always_inline)) {      // fragment idx in [0, 16)
         return *reinterpret_cast<const bf16x8*>(base + (idx / 8) * 8192 + woff + ((idx % 8) * 1024 - 4096));
@@ -348,7 +358,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     for (int mi = 0; mi < MI; ++mi) {
         const int pidx = wm * (MI * 32) + mi * 32 + l31;
         const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
-        xoff[mi] = (pw * STR) * colb + (ph * STR) * RS + kh * 16 + kg * (SPT * 32);
+        xoff[mi] = (pw * STR + par_w) * colb + (ph * STR + par_h) * RS + kh * 16 + kg * (SPT * 32);
     }
     lds_barrier_b();                            // sBias and halo chunk 0 are written
     f32x16 acc[MI];
@@ -463,9 +473,11 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
         for (int mi = 0; mi < MI; ++mi) { cur[mi] = nxt[mi]; nxt[mi] += colb; }
         tap_row(cur, nxt, 1);
         if (grp == 1 && cs + 1 < NCT && !RLDM_TDBG(p, 8192)) store_next(cs + 1, held);
+        if constexpr (TAPW == 3) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) cur[mi] = nxt[mi];
-        tap_row(cur, nxt, 2);
+            for (int mi = 0; mi < MI; ++mi) cur[mi] = nxt[mi];
+            tap_row(cur, nxt, 2);
+        }
         lds_barrier_b();                        // chunk cs consumed by everyone, chunk cs + 1 written by everyone
     };
     if constexpr (PF2) {
@@ -618,9 +630,11 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     const int c8 = tid % NC8;
     const int chg = nt * BN + c8 * 8;
     {
-        const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7)
-        bf16_t* yp = p.y + (((size_t)b * p.Wout + w0 + (g >> 3)) * p.Hout + h0 + (g & 7)) * p.y_ld + chg;
-        const size_t ystep = (size_t)(NT / NC8 / 8) * p.Hout * p.y_ld;
+        const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7) on tiles of 8 rows
+        const int us = SUB ? 2 : 1;                                          // (sub-pixel form: input pixel (w, h) -> output (2w + parity, 2h + parity))
+        constexpr int ts = T4 ? 2 : 3;                                       // (... on tiles of 4 rows)
+        bf16_t* yp = p.y + (((size_t)b * p.Wout + (w0 + (g >> ts)) * us + par_w) * p.Hout + (h0 + (g & ((1 << ts) - 1))) * us + par_h) * p.y_ld + chg;
+        const size_t ystep = (size_t)((NT / NC8) >> ts) * us * p.Hout * p.y_ld;
 #pragma unroll
         for (int i = 0; i < BM / (NT / NC8); ++i) {
             *reinterpret_cast<uint4*>(yp) = *reinterpret_cast<const uint4*>(sE + (g + i * (NT / NC8)) * ERS + c8 * 16);
@@ -647,7 +661,9 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             float S = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) S += sS[(w * 2 + kind) * BN + c];
-            reinterpret_cast<float*>(p.y_stats + ((size_t)b * tiles_img + mt) * p.N + nt * BN + c)[kind] = S;
+            // (sub-pixel form: one partial per (tile, parity))
+            const size_t part = SUB ? ((size_t)b * tiles_img + mt) * 4 + (par_w * 2 + par_h) : (size_t)b * tiles_img + mt;
+            reinterpret_cast<float*>(p.y_stats + part * p.N + nt * BN + c)[kind] = S;
         }
     }
     }

@@ -201,6 +201,44 @@ struct ConvLayer {
         return 0;
     }
 
+    // conv_stream.hip, sub-pixel form of nearest x2 + 3x3 (conv_stream_body.h, SUB): per (32-channel tile, parity pw * 2 + ph) one stream
+    // [Cin_pad/64 chunks][2 x 2 taps (w-major)][4 k-steps][64 lanes][8 bf16] of SUMMED weights -- along each axis parity 0 reads inputs
+    // (x - 1, x) through (k[0], k[1] + k[2]), parity 1 reads (x, x + 1) through (k[0] + k[1], k[2]); summed in fp32, rounded once
+    int get_subpixpacked(int Cin_pad, Packed** out) {
+        auto key = std::make_pair(-3, 1);
+        auto it = packed.find(key);
+        if (it != packed.end()) {
+            RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
+            *out = it->second.get();
+            return 0;
+        }
+        RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin_pad % 64 == 0 && R == 0, "conv " + name + ": not sub-pixel-packable");
+        const int NCC = Cin_pad / 64, nsteps = NCC * 16;
+        std::vector<bf16_t> img((size_t)(Cout / 32) * 4 * nsteps * 512 + 16384, 0);
+        static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};    // [parity][tap]: original taps lo .. hi summed
+        for (int n = 0; n < Cout; ++n)
+            for (int c = 0; c < Cin; ++c)
+                for (int pw = 0; pw < 2; ++pw)
+                    for (int ph = 0; ph < 2; ++ph)
+                        for (int i = 0; i < 2; ++i)
+                            for (int j = 0; j < 2; ++j) {
+                                float v = 0.f;
+                                for (int a = lo[pw][i]; a <= hi[pw][i]; ++a)
+                                    for (int bb = lo[ph][j]; bb <= hi[ph][j]; ++bb) v += w[((size_t)n * Cin + c) * 9 + a * 3 + bb];
+                                const size_t stream = (size_t)(n / 32) * 4 + pw * 2 + ph;
+                                const int step = ((c / 64) * 4 + i * 2 + j) * 4 + (c % 64) / 16, k = c % 16;
+                                img[((stream * nsteps + step) * 64 + (k / 8) * 32 + n % 32) * 8 + k % 8] = f32_to_bf16(v);
+                            }
+        auto pk = std::make_unique<Packed>();
+        if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(pk->bias, b.data(), b.size() * sizeof(float))) return 1;
+        pk->ntile_n = 0;
+        pk->Cin_pad = Cin_pad;
+        *out = pk.get();
+        packed[key] = std::move(pk);
+        return 0;
+    }
+
     // conv_small.hip image: MFMA A-fragment order, one contiguous stream of 1 KiB k-steps per (32-channel tile, k-group):
     // [Cout/32][KG][taps*CPT main steps (tap-major) + RPT residual steps][64 lanes][8 bf16] + one zero fragment; k-group kg
     // owns the 16-channel groups kg, kg + KG, ... of every tap; lane l of a step holds channel 32*t + (l & 31),
@@ -1227,10 +1265,17 @@ struct Builder {
 
     // conv_stream.hip route: 3x3 / stride 1 convs whose output has at least 128 tiles of 32 x 8 pixels x 128 channels, or
     // (the 128x8 level) of 16 x 8 pixels x 64 channels
+    static inline const int kSubMinBlocks = getenv("RLDM_SUB_MIN") ? atoi(getenv("RLDM_SUB_MIN")) : 96;     // (env: tuning runs)
     static bool stream_params_tw(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, int TW, long long min_blocks,
                                  long long max_blocks, ConvParams* q, int TH = 8, int inst = 0) {
         if (dbg() & 2048) return false;
         if (taps != 9 || (a.stride != 1 && !(a.stride == 2 && inst == 5)) || a.pad_mode != 0 || a.out_f32_nchw || g_force_bm) return false;
+        // (inst 6, round 4: nearest x2 + 3x3 in its sub-pixel form -- the tiles are INPUT tiles, four parity workgroups each)
+        const bool sub = inst == 6;
+        if (sub) {
+            if (a.up != 2 || R_t != 0 || Wout != 2 * a.x0.W || Hout != 2 * a.x0.H) return false;
+            Wout = a.x0.W; Hout = a.x0.H;
+        }
         if (Wout % TW != 0 || Hout % TH != 0) return false;
         memset(q, 0, sizeof(*q));
         q->C0 = a.x0.C;
@@ -1238,8 +1283,8 @@ struct Builder {
         q->R0 = a.r0.valid() ? a.r0.C : 0;
         q->R1 = R_t - q->R0;
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
-        q->up = a.up; q->stride = a.stride; q->pad_lo = 1;
-        q->Wout = Wout; q->Hout = Hout;
+        q->up = sub ? 1 : a.up; q->stride = a.stride; q->pad_lo = 1;
+        q->Wout = sub ? 2 * Wout : Wout; q->Hout = sub ? 2 * Hout : Hout;
         q->TW = TW; q->TH = TH; q->th_shift = TH == 8 ? 3 : 2;
         q->st_inst = inst;
         ConvTile t;
@@ -1260,7 +1305,7 @@ struct Builder {
         q->gn_groups = a.groups;
         q->ksplit = 1;
         if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only its presence matters to the shape check)
-        const long long blocks = (long long)q->B * q->tiles_img * (q->N / conv_stream_bn(*q));
+        const long long blocks = (long long)q->B * q->tiles_img * (q->N / conv_stream_bn(*q)) * (sub ? 4 : 1);
         const bool ok = conv_stream_supported(*q, 9) && ((dbg() & 4096) || (blocks >= min_blocks && blocks <= max_blocks));
         q->st0 = nullptr;
         return ok;
@@ -1284,6 +1329,11 @@ struct Builder {
         if ((dbg2() & 32) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q, 8, 3)) return true;
         // (tests, rldm_debug_set_flags2(64)) the 64-pixel x 128-channel tile first, at any level it fits
         if ((dbg2() & 64) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, 192, 512, q, 8, 4)) return true;
+        // (round 4) nearest x2 + 3x3 as four 2x2 convs over the input (sub-pixel form: 4 taps instead of 9 per output pixel) on the 4-wave
+        // 128 x 128 tile; rldm_debug_set_flags2(1 << 27) keeps the 3x3 over the up-sampled halo
+        if (!(dbg2() & (1 << 27)) && !(dbg2() & 1) && a.up == 2 && N_ % 128 == 0 &&
+            (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, kSubMinBlocks, 1ll << 40, q, 8, 6) ||
+             (a.x0.H % 8 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, kSubMinBlocks, 1ll << 40, q, 4, 6)))) return true;   // (inputs of 4 beams: 32 x 4 tiles)
         if (!(dbg2() & 1) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 1)) return true;
         if (!(dbg2() & 4) && N_ % 128 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 2)) return true;
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
@@ -1313,7 +1363,8 @@ struct Builder {
         p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;   // ONE conv of a network
-        p.ntile_n = N / conv_stream_bn(p);
+        const bool sub = p.st_inst == 6;
+        p.ntile_n = N / conv_stream_bn(p) * (sub ? 4 : 1);      // (grid x: channel tiles x parities)
         p.exp = (dbg2() >> 8) & 255;            // (bits 8..15 only: 16..23 are trunk variant 4's start offset)
         if (p.exp & 2) {
             static int* locks = nullptr;            // (experiment: never freed)
@@ -1324,13 +1375,13 @@ struct Builder {
             p.cu_lock = locks;
         }
         Tensor y = make(x0.B, Wout, Hout, N);
-        if (a.want_stats) add_stats(y, p.tiles_img);
-        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
+        if (a.want_stats) add_stats(y, p.tiles_img * (sub ? 4 : 1));
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));      // (the reference's count: 9 taps)
         plan->flops += fl;
         // a phase of the persistent launch (trunk.hip, variants 2 / 3): the image's tiles_img x ntile_n workgroups (16 at both
         // full-resolution levels) form a cluster on one XCD; consecutive convs of a level hand over through its L2 -- no end-of-kernel
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
-        const int ranks_s = p.tiles_img * p.ntile_n;
+        const int ranks_s = sub ? 0 : p.tiles_img * p.ntile_n;
         // (round 4) the 4-wave 128 x 128 instance: 32 workgroups per image, two per CU -- trunk variant 4; rldm_debug_set_flags2(8): launches
         const int per_cu = p.st_inst == 1 ? 2 : 1;
         const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 * per_cu &&
@@ -1343,7 +1394,7 @@ struct Builder {
         else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
-            if (L->get_streampacked(Cin_t, conv_stream_kgroups(p), &pk)) return 1;
+            if (sub ? L->get_subpixpacked(Cin_t, &pk) : L->get_streampacked(Cin_t, conv_stream_kgroups(p), &pk)) return 1;
             p.x0 = tptr(x0);
             p.x1 = tptr(a.x1);
             p.r0 = tptr(a.r0);
@@ -1399,7 +1450,7 @@ struct Builder {
                     p.temb_per_sample = pl->io.temb_per_sample;
                 }
                 return launch_conv_stream(p, s);
-            }, "conv_stream_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(conv_stream_bn(p)) + ",CK64,taps9" + (p.stride == 2 ? ",s2" : "") + ">", fl, by};
+            }, "conv_stream_kernel<" + std::to_string(p.TW * p.TH) + "," + std::to_string(conv_stream_bn(p)) + ",CK64,taps9" + (p.stride == 2 ? ",s2" : "") + (p.st_inst == 6 ? ",sub" : "") + ">", fl, by};
             if (in_stream_cluster) pend.standalone.push_back(standalone);
             else plan->ops.push_back(standalone);
         }

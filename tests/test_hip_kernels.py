@@ -65,6 +65,11 @@ CONV_CASES = [
     (16, 128, 128, 256, 16, 3, 2, 0, False),   # conv_stream.hip, stride 2 on 64-pixel x 128-channel tiles (17 x 17 halo): the 256x16 -> 128x8 down-sampler at the bench batch
     (3, 256, 128, 64, 32, 3, 2, 0, False),     # ... four input chunks, odd batch (under "stream-any-grid")
     (16, 128, 128, 128, 8, 3, 2, 0, False),    # ... 16 x 4 tiles for an output of 4 beams (the 128x8 -> 64x4 down-sampler at the bench batch)
+    (16, 128, 128, 128, 8, 3, 1, 0, True),     # conv_stream.hip, sub-pixel form of nearest x2 + 3x3 (four 2x2 convs over the input): the 128x8 -> 256x16 up-sampler at the bench batch
+    (2, 256, 256, 256, 16, 3, 1, 0, True),     # ... the VAE decoder's first up-sampler (4 chunks, two channel tiles)
+    (3, 128, 256, 64, 8, 3, 1, 0, True),       # ... odd batch, one tile row (zero rows above and below every tile)
+    (16, 256, 256, 64, 4, 3, 1, 0, True),      # ... inputs of 4 beams on 32 x 4 tiles: the 64x4 -> 128x8 up-sampler at the bench batch
+    (2, 128, 128, 128, 4, 3, 1, 0, True),      # ... (flag) nuScenes' 128x4 -> 256x8
 ]
 
 

@@ -25,10 +25,15 @@ def op_name(k):
     if m:
         nwn, _, taps, mi = map(int, m.groups())
         return f"conv_small_kernel<{32 * mi},{32 * nwn},taps{taps}>"
-    m = re.match(r"conv_stream_kernel<(\d+), (\d+)(?:, (\d+))?(?:, (\d+))?(?:, (\d+))?>", k)
-    if m:       # (round 4: third argument = waves, fourth = 32-pixel fragments per wave; the 4- and 8-wave instances of one tile share bench.py's name)
+    m = re.match(r"conv_stream_kernel<(\d+), (\d+)(?:, (\d+))?(?:, (\d+))?(?:, (\d+))?(?:, (true|false))?(?:, (true|false))?>", k)
+    if m:       # (round 4: third argument = waves, fourth = 32-pixel fragments per wave; the 4- and 8-wave instances of one tile share bench.py's name;
+                #  sixth = the sub-pixel form of nearest x2 + 3x3)
         wm, wn, mi = int(m.group(1)), int(m.group(2)), int(m.group(4) or 4)
-        return f"conv_stream_kernel<{32 * mi * wm},{32 * wn},CK64,taps9{',s2' if (m.group(5) or '1') == '2' else ''}>"
+        return (f"conv_stream_kernel<{32 * mi * wm},{32 * wn},CK64,taps9{',s2' if (m.group(5) or '1') == '2' else ''}"
+                f"{',sub' if m.group(6) == 'true' else ''}>")
+    m = re.match(r"conv_regw_kernel<(\d+), (\d+)>", k)
+    if m:
+        return f"conv_regw_kernel<128,{32 * int(m.group(2))},taps9>"
     m = re.match(r"trunk_kernel<(\d+)>", k)
     if m:       # persistent launches: one entry per kernel variant (bench.py scales it by a launch's share of the variant's phases)
         return "trunk_kernel<" + ("conv_small image tiles", "conv_small 64x64 clusters", "conv_stream 256x128", "conv_stream 128x64",
