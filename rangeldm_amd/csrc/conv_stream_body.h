@@ -34,7 +34,7 @@ __device__ __forceinline__ void lds_barrier_b() {
 // (32-channel tile, parity) is [chunks][2 x 2 taps][4 k-steps] of summed weights (ConvLayer::get_subpixpacked)
 template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1, bool SUB = false, bool T4 = false>
 __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt_, const int mt, const int b, const TrunkSeam& seam) {
-    static_assert(!SUB || (!TRUNK && STR == 1 && NW / (WM * WN) == 1), "sub-pixel form: the one-k-group launches");
+    static_assert(!SUB || (STR == 1 && NW / (WM * WN) == 1), "sub-pixel form: the one-k-group instances");
     constexpr int TAPW = SUB ? 2 : 3;          // taps per row / rows of taps
     const int nt = SUB ? nt_ >> 2 : nt_;
     const int par_w = SUB ? (nt_ >> 1) & 1 : 0, par_h = SUB ? nt_ & 1 : 0;

@@ -1381,16 +1381,16 @@ struct Builder {
         // a phase of the persistent launch (trunk.hip, variants 2 / 3): the image's tiles_img x ntile_n workgroups (16 at both
         // full-resolution levels) form a cluster on one XCD; consecutive convs of a level hand over through its L2 -- no end-of-kernel
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
-        const int ranks_s = sub ? 0 : p.tiles_img * p.ntile_n;
+        const int ranks_s = p.tiles_img * p.ntile_n;            // (sub-pixel form: input tiles x parities, one 128-channel tile)
         // (round 4) the 4-wave 128 x 128 instance: 32 workgroups per image, two per CU -- trunk variant 4; rldm_debug_set_flags2(8): launches
-        const int per_cu = p.st_inst == 1 ? 2 : 1;
+        const int per_cu = p.st_inst == 1 || sub ? 2 : 1;
         const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 * per_cu &&
                                        trunk_grid_fits(ranks_s, x0.B, per_cu) && y.P <= kFoldAboveP && N % 128 == 0 &&
                                        ((p.st_inst == 0 && (p.TW * p.TH == 256 || (dbg() & (1 << 30)))) ||     // (the 128x8 level's conv
                                         // PAIRS measured slower as 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
-                                        (p.st_inst == 1 && !(dbg2() & 8) && conv_stream_lds_bytes(p) <= 80 * 1024));
-        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, p.ntile_n, p.st_inst == 1 || p.TW * p.TH == 256 ? 4 : 2,
-                                           p.st_inst == 1 ? 4 : (p.TW * p.TH == 256 ? 2 : 3));
+                                        ((p.st_inst == 1 || (sub && N == 128 && p.TH == 8 && !(dbg2() & (1 << 28)))) && !(dbg2() & 8) && conv_stream_lds_bytes(p) <= 80 * 1024));
+        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, sub ? 1 : p.ntile_n, p.st_inst == 1 || sub || p.TW * p.TH == 256 ? 4 : 2,
+                                           p.st_inst == 1 || sub ? 4 : (p.TW * p.TH == 256 ? 2 : 3));
         else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
@@ -1436,7 +1436,7 @@ struct Builder {
                 ph.w[TW_MAGIC_CPG] = p.magic_cpg; ph.w[TW_GROUPS] = p.gn_groups; ph.w[TW_SILU] = p.silu;
                 putf(TW_INVN, p.gn_inv_n); putf(TW_EPS, p.gn_eps);
                 ph.w[TW_N] = p.N; ph.w[TW_YLD] = p.y_ld;
-                ph.w[TW_KIND] = TK_STREAM; ph.w[TW_TEMBOFF] = (unsigned)temb_off;
+                ph.w[TW_KIND] = TK_STREAM; ph.w[TW_TEMBOFF] = (unsigned)temb_off; ph.w[TW_SUB] = sub ? 1 : 0;
                 pend.phases.push_back(ph);
                 pend.lds = std::max(pend.lds, conv_stream_lds_bytes(p));
                 pend.flops += fl;

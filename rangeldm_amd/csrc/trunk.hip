@@ -301,7 +301,10 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
         } else if constexpr (V == 3) {
             conv_stream_body<1, 2, true>(cp, nt, mt, b, seam);      // 128x8 level: 8 tiles of 128 pixels x 2 channel tiles of 64
         } else if constexpr (V == 4) {
-            conv_stream_body<1, 4, true, 4>(cp, nt, mt, b, seam);   // full-resolution level: 32 tiles of 128 pixels x 128 channels per image, 4 waves
+            // full-resolution level: 32 tiles of 128 pixels x 128 channels per image, 4 waves; the level's up-sampler conv in its sub-pixel
+            // form: 8 INPUT tiles x 4 parities
+            if (rl(rec, TW_SUB)) conv_stream_body<1, 4, true, 4, 4, 1, true>(cp, rank & 3, rank >> 2, b, seam);
+            else conv_stream_body<1, 4, true, 4>(cp, nt, mt, b, seam);
         } else if constexpr (!CL) {
             switch (kind) {
                 case 0: conv_small_body<1, 2, 9, 2, true>(cp, rank, 0, b, wpf, seam); break;
