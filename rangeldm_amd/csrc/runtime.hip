@@ -1376,8 +1376,10 @@ struct Builder {
         }
         Tensor y = make(x0.B, Wout, Hout, N);
         if (a.want_stats) add_stats(y, p.tiles_img * (sub ? 4 : 1));
-        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));      // (the reference's count: 9 taps)
-        plan->flops += fl;
+        const double fl_ref = 2.0 * (double)x0.B * Wout * Hout * N * ((double)L->Cin * 9 + (L->sc_identity ? 0.0 : (double)L->R));
+        plan->flops += fl_ref;                  // (the network's nominal count: 9 taps)
+        // what THIS launch / phase executes (the bench line's roofline is priced with it): the sub-pixel form multiplies 4 taps per output pixel
+        const double fl = sub ? fl_ref * 4.0 / 9.0 : fl_ref;
         // a phase of the persistent launch (trunk.hip, variants 2 / 3): the image's tiles_img x ntile_n workgroups (16 at both
         // full-resolution levels) form a cluster on one XCD; consecutive convs of a level hand over through its L2 -- no end-of-kernel
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
