@@ -195,6 +195,20 @@ def test_conv_c64_register_weights(B, W, H, gn, res, regw_flags):
     assert float(d.max()) < 0.05
 
 
+def test_conv_c64_register_weights_ping_pong_variant():
+    """RLDM_RW_TEAMS=2 (read once per process: a child process): conv_regw.hip as ONE 8-wave workgroup per CU whose two teams swap roles at
+    barriers -- the measured alternative of DESIGN.md section 3.11 stays a working switch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RLDM_RW_TEAMS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
+                        "test_conv_c64_register_weights and not ping_pong and (512 or 128)", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("B,W,H,N", [(4, 512, 64, 2), (2, 128, 16, 2), (3, 64, 32, 4), (2, 1024, 64, 2), (2, 128, 16, 1)])
 @pytest.mark.parametrize("flags", [1 << 26, (1 << 26) | (1 << 25), (1 << 26) | (1 << 24)], ids=["default", "runs-of-8-workgroups", "generic-kernel"])
 def test_conv_out_fp32_nchw(B, W, H, N, flags):
