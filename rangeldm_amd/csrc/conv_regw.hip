@@ -408,6 +408,157 @@ __global__ void __launch_bounds__(kRwTeam * TEAMS, TEAMS == 1 ? 2 : 1) conv_regw
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_c16_kernel: the network's INPUT layer -- 3x3 / stride 1 over 16 (padded) input channels, 128 output channels per workgroup
+// (UNet conv_in: 5 -> 128 over cat[x_t, positional encoding], ldm/inference.py:120-138 / diffusers UNet2DModel.conv_in; the decoder's
+// conv_in: 4 -> 256).  K = 9 taps x 16 channels = 9 k-steps, no channel chunks, no weight ring, no barrier per tap: a
+// wave keeps the 9 tap fragments of its 32-channel tile in registers, and the layer is a load, 36 MFMAs per wave and a store.  It ran on the generic kernel
+// (one barrier per tap, 256-pixel tiles, 256 workgroups) at 20 us for 0.75 GFLOP; it is also the launch that advances the sampler's step
+// index (ConvParams::step_inc: nothing in it reads the index).
+namespace {
+constexpr int kC16Colb = 10 * 32 + 16;                  // halo column pitch (bytes): 10 rows of 32 bytes + a slot (bank spread)
+constexpr int kC16ERS = 128 * 2 + 16;                   // epilogue staging row: [pixel][128 channels] bf16
+}  // namespace
+
+__global__ void __launch_bounds__(256, 2) conv_c16_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);            // the wave's 32-channel tile of the group's 128
+    const int kh = lane >> 5, l31 = lane & 31;
+    int ng, mt, b;
+    {
+        const int gx = p.ntile_n, gy = p.tiles_img;                      // (128-channel groups, pixel tiles)
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int rid = xcd_remap(lin, gx * gy * p.B);
+        const int q = rid / gx;
+        ng = rid - q * gx;
+        b = q / gy;
+        mt = q - b * gy;
+    }
+    if (p.step_inc && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) *p.step_inc += 1;
+    const int tiles_h = p.tiles_h;
+    const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
+    const int w0 = tw * 16, h0 = th * 8;
+    unsigned char* const sA = smem;                                     // halo: 18 columns
+    unsigned char* const sE = smem + 18 * kC16Colb;                     // epilogue staging
+    float* const sS = reinterpret_cast<float*>(sE + 128 * kC16ERS);     // [4 waves][2][128]
+
+    // ---- halo: 18 x 10 pixels x two 16-byte pieces, requested first ------------------------------------------------------------------
+    uint4 hv[2];
+    int hdst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + i * 256;
+        const int slot = q >> 1, c8 = q & 1;
+        const int vwl = (slot * 6554) >> 16, vhl = slot - vwl * 10;
+        const int vh = h0 - 1 + vhl;
+        int vw = w0 - 1 + vwl;
+        vw = vw < 0 ? vw + p.Win : (vw >= p.Win ? vw - p.Win : vw);
+        const bool ok = q < 360 && vh >= 0 && vh < p.Hin;
+        hdst[i] = q < 360 ? vwl * kC16Colb + vhl * 32 + c8 * 16 : -1;
+        hv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) hv[i] = *reinterpret_cast<const uint4*>(p.x0 + ((size_t)(b * p.Win + vw) * p.Hin + vh) * 16 + c8 * 8);
+    }
+    // ---- the wave's weights: the 9 tap fragments of ITS 32-channel tile (wave = channel tile: a fragment is fetched by one wave of the
+    // workgroup, 9 KB per wave; the first version gave every wave all 36 fragments of the 128 channels and a quarter of the pixels -- 4 x the
+    // weight traffic for a quarter of the LDS reads, 10.1 against 9.x us) --------------------------------------------------------------------
+    const int nt = wm;
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)(ng * 4 + nt) * (9 * 1024) + lane * 16;
+    bf16x8 wr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wr[i] = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
+    f32x16 acc[4];                                                      // four 32-pixel fragments of the tile
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + ng * 128 + nt * 32 + 8 * r4 + 4 * kh);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            acc[mi][r4 * 4 + 0] = bv.x; acc[mi][r4 * 4 + 1] = bv.y; acc[mi][r4 * 4 + 2] = bv.z; acc[mi][r4 * 4 + 3] = bv.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (hdst[i] >= 0) *reinterpret_cast<uint4*>(sA + hdst[i]) = hv[i];
+    __syncthreads();
+    // ---- 9 taps x 4 pixel fragments ----------------------------------------------------------------------------------------------------
+    const unsigned char* xp[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int pidx = mi * 32 + l31;
+        xp[mi] = sA + (pidx >> 3) * kC16Colb + (pidx & 7) * 32 + kh * 16;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp[mi] + (tap / 3) * kC16Colb + (tap % 3) * 32);
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[tap], xf, acc[mi], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: bf16 -> LDS [pixel][channel] -> 16-byte stores; statistics of the rounded tile --------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            uint2 o;
+            o.x = pack_bf16x2(acc[mi][r4 * 4 + 0], acc[mi][r4 * 4 + 1]);
+            o.y = pack_bf16x2(acc[mi][r4 * 4 + 2], acc[mi][r4 * 4 + 3]);
+            *reinterpret_cast<uint2*>(sE + (mi * 32 + l31) * kC16ERS + (nt * 32 + 8 * r4 + 4 * kh) * 2) = o;
+        }
+    __syncthreads();
+    {
+        const int g = tid >> 4, c8 = tid & 15;                          // 16 pixels per pass, 8 passes
+        bf16_t* yp = p.y + (((size_t)b * p.Wout + w0 + (g >> 3)) * p.Hout + h0 + (g & 7)) * p.y_ld + ng * 128 + c8 * 8;
+        const size_t ystep = (size_t)2 * p.Hout * p.y_ld;               // 16 pixels = 2 columns of the tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<uint4*>(yp) = *reinterpret_cast<const uint4*>(sE + (g + 16 * i) * kC16ERS + c8 * 16);
+            yp += ystep;
+        }
+    }
+    if (p.y_stats) {
+        const int cp = tid & 63, pg = tid >> 6;                         // channel pair, pixel group of 32
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sE + (pg * 32 + j) * kC16ERS + cp * 4);
+            const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+            s0 += a0; s1 += a1;
+            q0 += a0 * a0; q1 += a1 * a1;
+        }
+        *reinterpret_cast<float2*>(sS + (pg * 2 + 0) * 128 + cp * 2) = make_float2(s0, s1);
+        *reinterpret_cast<float2*>(sS + (pg * 2 + 1) * 128 + cp * 2) = make_float2(q0, q1);
+        __syncthreads();
+        {
+            const int kind = tid >> 7, c = tid & 127;
+            float S = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) S += sS[(w * 2 + kind) * 128 + c];
+            reinterpret_cast<float*>(p.y_stats + ((size_t)b * p.tiles_img + mt) * p.N + ng * 128 + c)[kind] = S;
+        }
+    }
+}
+
+size_t conv_c16_lds_bytes() { return 18 * kC16Colb + 128 * kC16ERS + 4 * 2 * 128 * sizeof(float); }
+
+bool conv_c16_supported(const ConvParams& p) {
+    if (p.C0 != 16 || p.C1 != 0 || p.R0 != 0 || p.R1 != 0 || p.N % 128 != 0 || p.up != 1 || p.stride != 1 || p.pad_lo != 1) return false;
+    if (p.st0 || p.temb || p.y_nchw || p.ksplit > 1 || p.TW != 16 || p.TH != 8) return false;
+    if (p.Win != p.Wout || p.Hin != p.Hout || p.Wout % 16 != 0 || p.Hout % 8 != 0 || (p.tiles_h & (p.tiles_h - 1)) != 0) return false;
+    return p.B <= 65535 && p.tiles_img <= 65535;
+}
+
+int launch_conv_c16(const ConvParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(conv_c16_supported(p), "conv_c16: unsupported shape");
+    const size_t lds = conv_c16_lds_bytes();
+    auto kern = conv_c16_kernel;
+    static DynLdsLimit lds_limit;
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(p.N / 128, p.tiles_img, p.B), dim3(256), lds, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int regw_teams() { static const int t = getenv("RLDM_RW_TEAMS") ? atoi(getenv("RLDM_RW_TEAMS")) : 1; return t == 2 ? 2 : 1; }
 size_t conv_regw_lds_bytes() { return regw_teams() * kRwTeamBytes + (3 * 64 + 8 * 2 * 32) * sizeof(float) + 2 * (regw_teams() == 2 ? 12 : 8) * 1024; }
 

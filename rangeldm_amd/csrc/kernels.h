@@ -149,6 +149,11 @@ int conv_regw_wg_per_image(const ConvParams& p);
 int conv_regw_partials(const ConvParams& p);
 bool conv_regw_supported(const ConvParams& p);
 int launch_conv_regw(const ConvParams& p, hipStream_t stream);
+// conv_regw.hip, conv_c16_kernel (round 4): the network's input layer -- 3x3 / stride 1 over 16 (padded) input channels, 128 | N, 16 x 8 tiles;
+// weights [N / 32][9 taps][64 lanes][8 bf16] (ConvLayer::get_c16packed); advances ConvParams::step_inc like the generic kernel
+size_t conv_c16_lds_bytes();
+bool conv_c16_supported(const ConvParams& p);
+int launch_conv_c16(const ConvParams& p, hipStream_t stream);
 
 // Persistent trunk launch (trunk.hip): consecutive conv_small launches whose tile owns a whole image (<= 64 pixels, 32-channel
 // tiles) as the phases of ONE launch; the N / 32 workgroups of an image hand their outputs to each other through the L2 of the

@@ -201,6 +201,31 @@ struct ConvLayer {
         return 0;
     }
 
+    // conv_regw.hip, conv_c16_kernel (the input layer: <= 16 input channels): [Cout / 32][9 taps][64 lanes][8 bf16] -- lane l of a fragment holds
+    // channel 32 t + (l & 31), input channels 8 (l >> 5) .. + 8
+    int get_c16packed(Packed** out) {
+        auto key = std::make_pair(-4, 1);
+        auto it = packed.find(key);
+        if (it != packed.end()) {
+            *out = it->second.get();
+            return 0;
+        }
+        RLDM_REQUIRE(ksize == 3 && Cout % 32 == 0 && Cin <= 16 && R == 0, "conv " + name + ": not a 16-channel input layer");
+        std::vector<bf16_t> img((size_t)(Cout / 32) * 9 * 512, 0);
+        for (int n = 0; n < Cout; ++n)
+            for (int c = 0; c < Cin; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    img[(((size_t)(n / 32) * 9 + tap) * 64 + (c / 8) * 32 + n % 32) * 8 + c % 8] = f32_to_bf16(w[((size_t)n * Cin + c) * 9 + tap]);
+        auto pk = std::make_unique<Packed>();
+        if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(pk->bias, b.data(), b.size() * sizeof(float))) return 1;
+        pk->ntile_n = 0;
+        pk->Cin_pad = 16;
+        *out = pk.get();
+        packed[key] = std::move(pk);
+        return 0;
+    }
+
     // conv_stream.hip, sub-pixel form of nearest x2 + 3x3 (conv_stream_body.h, SUB): per (32-channel tile, parity pw * 2 + ph) one stream
     // [Cin_pad/64 chunks][2 x 2 taps (w-major)][4 k-steps][64 lanes][8 bf16] of SUMMED weights -- along each axis parity 0 reads inputs
     // (x - 1, x) through (k[0], k[1] + k[2]), parity 1 reads (x, x + 1) through (k[0] + k[1], k[2]); summed in fp32, rounded once
@@ -1460,6 +1485,57 @@ struct Builder {
         return 0;
     }
 
+    // conv_regw.hip, conv_c16_kernel (round 4): the network's input layer (16 padded input channels, 128 | N, no norm / residual / time
+    // embedding): every weight in one wave's registers; RLDM_NO_C16=1 keeps the generic kernel
+    static bool c16_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+        static const bool off = getenv("RLDM_NO_C16") != nullptr;
+        if (off || (dbg() & 2048) || g_force_bm || taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.up != 1 || a.out_f32_nchw) return false;
+        if (a.x1.valid() || a.gn || a.temb_off >= 0 || R_t != 0 || Cin_t != 16 || a.layer->Cout % 128 != 0 || Wout % 16 != 0 || Hout % 8 != 0) return false;
+        memset(q, 0, sizeof(*q));
+        q->C0 = 16;
+        q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
+        q->up = 1; q->stride = 1; q->pad_lo = 1;
+        q->Wout = Wout; q->Hout = Hout;
+        q->TW = 16; q->TH = 8; q->th_shift = 3;
+        q->tiles_h = Hout / 8;
+        q->tiles_img = (Wout / 16) * q->tiles_h;
+        q->N = a.layer->Cout;
+        q->ntile_n = q->N / 128;
+        q->ksplit = 1;
+        return conv_c16_supported(*q) && (long long)q->B * q->tiles_img * q->ntile_n >= 64;
+    }
+    int conv_c16(const ConvArgs& a, int Wout, int Hout, Tensor* out) {
+        ConvLayer* L = a.layer;
+        const int N = L->Cout;
+        const Tensor& x0 = a.x0;
+        ConvParams p;
+        RLDM_REQUIRE(c16_params(a, x0.C, 0, 9, Wout, Hout, &p), "conv " + L->name + ": conv_c16 route lost");
+        Tensor y = make(x0.B, Wout, Hout, N);
+        if (a.want_stats) add_stats(y, p.tiles_img);
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * 9;
+        plan->flops += fl;
+        note_launch();
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_c16packed(&pk)) return 1;
+            p.x0 = tptr(x0);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            p.y = tptr(y);
+            p.y_ld = N;
+            p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
+            const double by = (double)x0.B * x0.W * x0.H * 16 * 2.0 + (double)N * L->Cin * 9 * 2.0 + (double)x0.B * Wout * Hout * N * 2.0;
+            Plan* pl = plan;
+            const bool first_of_step = a.first_of_step;
+            plan->ops.push_back({[p, pl, first_of_step](hipStream_t s) mutable {
+                p.step_inc = (first_of_step && pl->io.pack_fused) ? pl->io.step_inc : nullptr;
+                return launch_conv_c16(p, s);
+            }, "conv_c16_kernel<128,128,taps9>", fl, by});
+        }
+        *out = y;
+        return 0;
+    }
+
     // conv_regw.hip route (round 4): 64 -> 64 channel 3x3 convs over many 16 x 8 tiles (the VAE decoder's full-resolution level) -- the weights stay
     // in registers, a workgroup walks a run of tiles; rldm_debug_set_flags2(1 << 24) keeps them on conv_stream's per-tile instance
     static bool regw_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
@@ -1637,6 +1713,7 @@ struct Builder {
         if (!a.first_of_step && small_route(a, Cin_t, R_t, taps, Wout, Hout)) return conv_small(a, Cin_t, R_t, taps, Wout, Hout, out);
         {
             ConvParams q;
+            if (c16_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_c16(a, Wout, Hout, out);
             if (regw_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_regw(a, Cin_t, R_t, Wout, Hout, out);
         }
         if (!a.first_of_step) {

@@ -70,6 +70,9 @@ CONV_CASES = [
     (3, 128, 256, 64, 8, 3, 1, 0, True),       # ... odd batch, one tile row (zero rows above and below every tile)
     (16, 256, 256, 64, 4, 3, 1, 0, True),      # ... inputs of 4 beams on 32 x 4 tiles: the 64x4 -> 128x8 up-sampler at the bench batch
     (2, 128, 128, 128, 4, 3, 1, 0, True),      # ... (flag) nuScenes' 128x4 -> 256x8
+    (16, 5, 128, 256, 16, 3, 1, 0, False),     # conv_regw.hip, conv_c16_kernel: the UNet's conv_in at the bench batch (5 real input channels of 16)
+    (3, 4, 256, 256, 16, 3, 1, 0, False),      # ... the decoder's conv_in (two 128-channel groups, odd batch)
+    (1, 16, 128, 1024, 8, 3, 1, 0, False),     # ... all 16 channels real, one tile row, 64 tiles across the wrap
 ]
 
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10, help="sampler steps (the trace keeps the last one)")
     ap.add_argument("--top", type=int, default=200)
+    ap.add_argument("--preset", default="RangeLDM", help="RangeLDM | nuscenes | RangeDM (config.PRESETS)")
     a = ap.parse_args()
     _lib.require_gpu()
     _lib.lib().rldm_debug_set_flags(8192 | a.flags)
@@ -35,7 +36,7 @@ def main():
     from rangeldm_amd.schedulers import DDIMSchedulerHIP
     from rangeldm_amd.synth import latent_noise
     dev = torch.device("cuda", 0)
-    p, unet, vae, _, _ = bench.build_models("RangeLDM", 20240310)
+    p, unet, vae, _, _ = bench.build_models(a.preset, 20240310)
     pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=p["pos_encoding"])
     shape = (p["unet"].out_channels, *p["unet"].sample_size)
     x = torch.from_numpy(np.stack([latent_noise(1, j, shape) for j in range(a.batch)])).to(dev)
