@@ -559,6 +559,218 @@ int launch_conv_c16(const ConvParams& p, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_o4_kernel: the UNet's OUTPUT layer -- GroupNorm + SiLU -> 3x3 over 128 channels -> <= 4 channels as fp32 NCHW, with the sampler's
+// scheduler step in the epilogue (diffusers UNet2DModel.conv_norm_out / conv_act / conv_out; DDIMScheduler.step / DDPMScheduler.step as in
+// conv_igemm.hip's epilogue).  On the generic kernel (256-pixel tiles x one 32-channel tile, 4 k-groups) it was 26-28 us of statistics
+// round trip, 48 normalised elements per thread and chunk with nothing to hide under, and a four-pass epilogue.  Here a workgroup is 4 waves
+// on a 16 x 8 tile and a wave is a K-GROUP: it owns 32 of the 128 input channels for all 128 pixels -- it normalises ITS channels of the halo
+// into its own LDS region (no barrier between staging and K loop), keeps its 18 weight fragments in registers, runs 72 MFMAs, and hands
+// 4 floats per pixel to the reduction; 128 threads then own one pixel each for the scheduler arithmetic.
+namespace {
+constexpr int kO4RS = 32 * 2 + 16;                      // a wave's halo row: 32 channels + a slot
+constexpr int kO4Colb = 10 * kO4RS + 16;                // ... column pitch
+constexpr int kO4Wave = 18 * kO4Colb;                   // ... region
+}  // namespace
+
+__global__ void __launch_bounds__(256, 2) conv_o4_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kg = __builtin_amdgcn_readfirstlane(tid >> 6);            // the wave's 32 input channels: [32 kg, 32 kg + 32)
+    const int kh = lane >> 5, l31 = lane & 31;
+    int mt, b;
+    {
+        const int gy = p.tiles_img;
+        const int rid = xcd_remap(blockIdx.x + gy * blockIdx.y, gy * p.B);
+        b = rid / gy;
+        mt = rid - b * gy;
+    }
+    const int tiles_h = p.tiles_h;
+    const int tw = mt >> (31 - __builtin_clz(tiles_h)), th = mt & (tiles_h - 1);
+    const int w0 = tw * 16, h0 = th * 8;
+    unsigned char* const sW = smem + kg * kO4Wave;                      // this wave's halo
+    float* const sGa = reinterpret_cast<float*>(smem + 4 * kO4Wave);    // [128]
+    float* const sGs = sGa + 128;
+    double* const sD = reinterpret_cast<double*>(sGs + 128);            // [2][128] statistics scratch
+    float4* const sP = reinterpret_cast<float4*>(sD + 256);             // [4 k-groups][128 pixels] partial outputs (4 channels)
+
+    // ---- requests first: the statistics partials of channel `tid`, the wave's halo pieces (12 per lane), its 18 weight fragments ---------
+    const bool gn = p.st0 != nullptr;
+    double S = 0.0, SS = 0.0;
+    float gamma = 0.f, beta = 0.f;
+    if (gn && tid < 128) {
+        const float2* src = p.st0 + (size_t)b * p.P0 * 128 + tid;
+        gamma = p.gn_gamma[tid];
+        beta = p.gn_beta[tid];
+        int q = 0;
+        for (; q + 16 <= p.P0; q += 16) {
+            float2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(q + j) * 128];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { S += (double)v[j].x; SS += (double)v[j].y; }
+        }
+        for (; q < p.P0; ++q) {
+            const float2 v = src[(size_t)q * 128];
+            S += (double)v.x;
+            SS += (double)v.y;
+        }
+    }
+    constexpr int NP = 12;                                              // 180 pixels x 4 pieces of 8 channels = 720 = 11.25 per lane
+    uint4 hv[NP];
+    const int c8 = lane & 3;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int slot = (lane >> 2) + i * 16;                          // halo pixel
+        const int vwl = (slot * 6554) >> 16, vhl = slot - vwl * 10;
+        const int vh = h0 - 1 + vhl;
+        int vw = w0 - 1 + vwl;
+        vw = vw < 0 ? vw + p.Win : (vw >= p.Win ? vw - p.Win : vw);
+        const bool ok = slot < 180 && vh >= 0 && vh < p.Hin;
+        hv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) hv[i] = *reinterpret_cast<const uint4*>(p.x0 + ((size_t)(b * p.Win + vw) * p.Hin + vh) * 128 + kg * 32 + c8 * 8);
+    }
+    // (stream-packed with 2 k-groups: [tile 0][k-group][2 chunks x 9 taps x 2 k-steps] -- channels 32 kg .. are chunk kg / 2, k-group kg % 2)
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.wpk) + ((size_t)(kg & 1) * 36 + (kg >> 1) * 18) * 1024 + lane * 16;
+    bf16x8 wr[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wr[i] = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
+
+    // ---- GroupNorm fold -> affine per channel ----------------------------------------------------------------------------------------
+    if (gn) {
+        if (tid < 128) { sD[tid] = S; sD[128 + tid] = SS; }
+        __syncthreads();
+        if (tid < 128) {
+            const int cpg = 128 / p.gn_groups;
+            const int g0 = (tid / cpg) * cpg;
+            double Sg = 0.0, SSg = 0.0;
+            for (int i = 0; i < cpg; ++i) { Sg += sD[g0 + i]; SSg += sD[128 + g0 + i]; }
+            const double inv_n = (double)p.gn_inv_n;
+            const double mean = Sg * inv_n;
+            double var = SSg * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const float a = gamma * __builtin_amdgcn_rsqf((float)var + p.gn_eps);
+            sGa[tid] = a;
+            sGs[tid] = beta - (float)mean * a;
+        }
+        __syncthreads();
+    }
+    // ---- the wave normalises its 32 channels of the halo into its own region (wave private: no workgroup barrier) ----------------------
+    {
+        float4 ga0, ga1, gs0, gs1;
+        if (gn) {
+            ga0 = *reinterpret_cast<const float4*>(sGa + kg * 32 + c8 * 8);
+            ga1 = *reinterpret_cast<const float4*>(sGa + kg * 32 + c8 * 8 + 4);
+            gs0 = *reinterpret_cast<const float4*>(sGs + kg * 32 + c8 * 8);
+            gs1 = *reinterpret_cast<const float4*>(sGs + kg * 32 + c8 * 8 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int slot = (lane >> 2) + i * 16;
+            const int vwl = (slot * 6554) >> 16, vhl = slot - vwl * 10;
+            const int vh = h0 - 1 + vhl;
+            const bool pad = vh < 0 || vh >= p.Hin;
+            uint4 v = hv[i];
+            if (gn) {
+                float f0 = bf16lo(v.x) * ga0.x + gs0.x, f1 = bf16hi(v.x) * ga0.y + gs0.y;
+                float f2 = bf16lo(v.y) * ga0.z + gs0.z, f3 = bf16hi(v.y) * ga0.w + gs0.w;
+                float f4 = bf16lo(v.z) * ga1.x + gs1.x, f5 = bf16hi(v.z) * ga1.y + gs1.y;
+                float f6 = bf16lo(v.w) * ga1.z + gs1.z, f7 = bf16hi(v.w) * ga1.w + gs1.w;
+                if (p.silu) silu_x8(f0, f1, f2, f3, f4, f5, f6, f7);
+                v.x = pack_bf16x2(f0, f1); v.y = pack_bf16x2(f2, f3);
+                v.z = pack_bf16x2(f4, f5); v.w = pack_bf16x2(f6, f7);
+            }
+            v.x = pad ? 0u : v.x; v.y = pad ? 0u : v.y; v.z = pad ? 0u : v.z; v.w = pad ? 0u : v.w;
+            if (slot < 180) *reinterpret_cast<uint4*>(sW + vwl * kO4Colb + vhl * kO4RS + c8 * 16) = v;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (the wave's own stores: visible to the wave's own reads)
+    // ---- K loop: 9 taps x 2 k-steps x 4 pixel fragments, the wave's slice of K ---------------------------------------------------------
+    f32x16 acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    {
+        const unsigned char* xp[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int pidx = mi * 32 + l31;
+            xp[mi] = sW + (pidx >> 3) * kO4Colb + (pidx & 7) * kO4RS + kh * 16;
+        }
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int tap = step >> 1, ks = step & 1;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp[mi] + (tap / 3) * kO4Colb + (tap % 3) * kO4RS + ks * 32);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[step], xf, acc[mi], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the k-groups' partial outputs (channels 0..3: the first register quad of lanes 0..31) -> LDS -> one thread per pixel ------------
+    if (kh == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) sP[kg * 128 + mi * 32 + l31] = make_float4(acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float e[4] = {p.bias[0], p.bias[1], p.bias[2], p.bias[3]};      // (bias padded to 32)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                   // fixed order: deterministic
+            const float4 v = sP[g * 128 + tid];
+            e[0] += v.x; e[1] += v.y; e[2] += v.z; e[3] += v.w;
+        }
+        // fused scheduler step (sched_step_kernel's arithmetic on the value just computed; conv_igemm.hip's epilogue)
+        const bool sched = p.sch.coef_table != nullptr;
+        float c0 = 1.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
+        const float* nz = nullptr;
+        if (sched) {
+            const int step = *p.sch.step_ptr;
+            const float* c = p.sch.coef_table + 5 * step;
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4];
+            if (p.sch.noise && c4 != 0.f) nz = p.sch.noise + (size_t)step * p.sch.noise_step_stride;
+        }
+        const int ow = w0 + (tid >> 3), oh = h0 + (tid & 7);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < p.N) {
+                const size_t i = (((size_t)b * p.N + ch) * p.Wout + ow) * p.Hout + oh;
+                p.y_nchw[i] = e[ch];
+                if (sched) {
+                    const float x = p.sch.x[i];
+                    const float x0 = (x - c1 * e[ch]) / c0;
+                    float prev = (p.sch.mode == 0) ? c2 * x0 + c3 * e[ch] : c2 * x0 + c3 * x;
+                    if (nz) prev += c4 * nz[i];
+                    p.sch.x_prev[i] = prev;
+                    if (p.sch.pack) p.sch.pack[(((size_t)b * p.Wout + ow) * p.Hout + oh) * p.sch.pack_ld + ch] = f32_to_bf16(prev);
+                }
+            }
+        }
+    }
+}
+
+size_t conv_o4_lds_bytes() { return 4 * kO4Wave + 2 * 128 * sizeof(float) + 2 * 128 * sizeof(double) + 4 * 128 * sizeof(float4); }
+
+bool conv_o4_supported(const ConvParams& p) {
+    if (p.C0 != 128 || p.C1 != 0 || p.R0 != 0 || p.R1 != 0 || p.N < 1 || p.N > 4 || p.up != 1 || p.stride != 1 || p.pad_lo != 1) return false;
+    if (!p.y_nchw || p.temb || p.ksplit > 1 || p.TW != 16 || p.TH != 8 || p.y_stats) return false;
+    if (p.st0 && (p.gn_groups <= 0 || 128 % p.gn_groups != 0)) return false;
+    if (p.Win != p.Wout || p.Hin != p.Hout || p.Wout % 16 != 0 || p.Hout % 8 != 0 || (p.tiles_h & (p.tiles_h - 1)) != 0) return false;
+    return p.B <= 65535 && p.tiles_img <= 65535;
+}
+
+int launch_conv_o4(const ConvParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(conv_o4_supported(p), "conv_o4: unsupported shape");
+    const size_t lds = conv_o4_lds_bytes();
+    auto kern = conv_o4_kernel;
+    static DynLdsLimit lds_limit;
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(p.tiles_img, p.B), dim3(256), lds, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int regw_teams() { static const int t = getenv("RLDM_RW_TEAMS") ? atoi(getenv("RLDM_RW_TEAMS")) : 1; return t == 2 ? 2 : 1; }
 size_t conv_regw_lds_bytes() { return regw_teams() * kRwTeamBytes + (3 * 64 + 8 * 2 * 32) * sizeof(float) + 2 * (regw_teams() == 2 ? 12 : 8) * 1024; }
 

@@ -154,6 +154,11 @@ int launch_conv_regw(const ConvParams& p, hipStream_t stream);
 size_t conv_c16_lds_bytes();
 bool conv_c16_supported(const ConvParams& p);
 int launch_conv_c16(const ConvParams& p, hipStream_t stream);
+// conv_regw.hip, conv_o4_kernel (round 4): the UNet's output layer -- GroupNorm + SiLU -> 3x3 over 128 channels -> <= 4 channels, fp32 NCHW +
+// ConvParams::sch (the scheduler step); weights stream-packed with 2 k-groups (ConvLayer::get_streampacked(128, 2))
+size_t conv_o4_lds_bytes();
+bool conv_o4_supported(const ConvParams& p);
+int launch_conv_o4(const ConvParams& p, hipStream_t stream);
 
 // Persistent trunk launch (trunk.hip): consecutive conv_small launches whose tile owns a whole image (<= 64 pixels, 32-channel
 // tiles) as the phases of ONE launch; the N / 32 workgroups of an image hand their outputs to each other through the L2 of the

@@ -1536,6 +1536,72 @@ struct Builder {
         return 0;
     }
 
+    // conv_regw.hip, conv_o4_kernel (round 4): the UNet's output layer (GroupNorm + SiLU -> 3x3 over 128 channels -> <= 4 channels, fp32 NCHW + the
+    // scheduler step); RLDM_NO_O4=1 keeps the generic kernel
+    static bool o4_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+        static const bool off = getenv("RLDM_NO_O4") != nullptr;
+        if (off || (dbg() & 2048) || g_force_bm || taps != 9 || a.stride != 1 || a.pad_mode != 0 || a.up != 1 || !a.out_f32_nchw) return false;
+        if (a.x1.valid() || a.temb_off >= 0 || R_t != 0 || Cin_t != 128 || a.layer->Cin != 128 || a.layer->Cout > 4 || Wout % 16 != 0 || Hout % 8 != 0) return false;
+        memset(q, 0, sizeof(*q));
+        q->C0 = 128;
+        q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
+        q->up = 1; q->stride = 1; q->pad_lo = 1;
+        q->Wout = Wout; q->Hout = Hout;
+        q->TW = 16; q->TH = 8; q->th_shift = 3;
+        q->tiles_h = Hout / 8;
+        q->tiles_img = (Wout / 16) * q->tiles_h;
+        const int cpg = std::max(1, Cin_t / a.groups);
+        q->gn_inv_n = (float)(1.0 / ((double)a.x0.W * a.x0.H * cpg));
+        q->N = a.layer->Cout;
+        q->ntile_n = 1;
+        q->silu = a.silu;
+        q->gn_eps = a.eps;
+        q->gn_groups = a.groups;
+        q->ksplit = 1;
+        if (a.gn) q->st0 = reinterpret_cast<const float2*>(q);      // (only their presence matters to the shape check)
+        q->y_nchw = reinterpret_cast<float*>(q);
+        const bool ok = conv_o4_supported(*q) && (long long)q->B * q->tiles_img >= 64;
+        q->st0 = nullptr;
+        q->y_nchw = nullptr;
+        return ok;
+    }
+    int conv_o4(const ConvArgs& a, int Wout, int Hout, Tensor* out) {
+        ConvLayer* L = a.layer;
+        const int N = L->Cout;
+        const Tensor& x0 = a.x0;
+        ConvParams p;
+        RLDM_REQUIRE(o4_params(a, x0.C, 0, 9, Wout, Hout, &p), "conv " + L->name + ": conv_o4 route lost");
+        if (a.gn) {
+            RLDM_REQUIRE(a.gn->C == 128 && 128 % a.groups == 0, "conv " + L->name + ": GroupNorm channel mismatch");
+            RLDM_REQUIRE(x0.P > 0, "conv " + L->name + ": GroupNorm input without statistics");
+        }
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * 9;
+        plan->flops += fl;
+        note_launch();
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_streampacked(128, 2, &pk)) return 1;
+            p.x0 = tptr(x0);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            if (a.gn) {
+                p.st0 = sptr(x0);
+                p.P0 = x0.P;
+                p.gn_gamma = a.gn->gamma.as<float>();
+                p.gn_beta = a.gn->beta.as<float>();
+            }
+            const double by = (double)x0.B * x0.W * x0.H * 128 * 2.0 + (double)N * L->Cin * 9 * 2.0 + (double)x0.B * Wout * Hout * N * 4.0;
+            Plan* pl = plan;
+            plan->ops.push_back({[p, pl](hipStream_t s) mutable {
+                p.y_nchw = pl->io.out;
+                p.sch = pl->io.sch;
+                return launch_conv_o4(p, s);
+            }, "conv_o4_kernel<128,32,taps9>", fl, by});
+        }
+        *out = Tensor();
+        return 0;
+    }
+
     // conv_regw.hip route (round 4): 64 -> 64 channel 3x3 convs over many 16 x 8 tiles (the VAE decoder's full-resolution level) -- the weights stay
     // in registers, a workgroup walks a run of tiles; rldm_debug_set_flags2(1 << 24) keeps them on conv_stream's per-tile instance
     static bool regw_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
@@ -1714,6 +1780,7 @@ struct Builder {
         {
             ConvParams q;
             if (c16_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_c16(a, Wout, Hout, out);
+            if (o4_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_o4(a, Wout, Hout, out);
             if (regw_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_regw(a, Cin_t, R_t, Wout, Hout, out);
         }
         if (!a.first_of_step) {

@@ -237,6 +237,33 @@ def test_conv_out_fp32_nchw(B, W, H, N, flags):
     assert float((y - ref(bf16r)).abs().max()) < 0.02
 
 
+@pytest.mark.parametrize("B,W,H,N", [(16, 256, 16, 4), (3, 256, 16, 2), (2, 1024, 8, 4), (1, 1024, 64, 2)])
+@pytest.mark.parametrize("route", ["conv_o4", "generic"])
+def test_unet_output_layer_fp32_nchw(B, W, H, N, route):
+    """The UNet's conv_out: GroupNorm(32) + SiLU over 128 channels -> conv3x3 -> N <= 4 channels as fp32 NCHW (conv_regw.hip's conv_o4_kernel:
+    a wave per 32 input channels; RLDM_NO_O4 is read once per process, so the generic kernel is reached through its force-tile switch)."""
+    from rangeldm_amd import _lib
+    x = _rand(B, 128, W, H, seed=80) * 1.2 - 0.1
+    w = _rand(N, 128, 3, 3, seed=81, scale=(128 * 9) ** -0.5)
+    b = _rand(N, seed=82, scale=0.1)
+    gamma, beta = 1 + 0.2 * _rand(128, seed=83), 0.2 * _rand(128, seed=84)
+    _lib.lib().rldm_debug_set_flags2(1 << 26)
+    if route == "generic":
+        _lib.lib().rldm_debug_set_flags(256 + 2048)
+    try:
+        y = hip_conv(x, w, b, gamma=gamma, beta=beta, silu=True, eps=1e-5)
+    finally:
+        _lib.lib().rldm_debug_set_flags2(0)
+        _lib.lib().rldm_debug_set_flags(0)
+
+    def ref(q):
+        return ops.circ_conv2d(q(ops.group_norm_silu(q(x), gamma, beta, 32, 1e-5)), q(w), b)
+
+    assert rel_l2(y, ref(bf16r)) < 2e-3
+    assert rel_l2(y, ref(lambda t: t)) < TOL_F
+    assert float((y - ref(bf16r)).abs().max()) < 0.02
+
+
 @pytest.mark.parametrize("B,W,H", [(4, 512, 64), (2, 128, 16), (3, 64, 32)])
 def test_conv_c64_register_weights_statistics(B, W, H, regw_flags):
     """... its (sum, sumsq) side output: one partial per workgroup, accumulated over the run."""
