@@ -771,6 +771,142 @@ int launch_conv_o4(const ConvParams& p, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_ds2_kernel: 3x3 / stride 2 / pad 1 over 256 channels onto a FEW pixels (the UNet's 64x4 -> 32x2 Downsample2D, ldm/utils.py:76-116: a
+// convolution of the raw input, no norm).  1 024 output pixels x 256 channels with K = 2 304: on the generic kernel 64-128 workgroups walked K
+// alone (21 us in the step graph).  conv_o4's wave grid: a workgroup is a 32-pixel output row x 32 output channels and its 8 waves are K-GROUPS --
+// wave kg owns input channels [32 kg, 32 kg + 32): it copies its channels of the 65 x 3 input footprint into its own LDS region, keeps its 18
+// weight fragments in registers, runs 18 MFMAs; the eight partial tiles meet in LDS.  (conv_small.hip cannot take a stride: it holds ALL input
+// channels of its tile in LDS, and a stride-2 footprint of 64 pixels x 256 channels is 166 KB.)
+namespace {
+constexpr int kDsRS = 32 * 2 + 16;                      // a wave's halo row: 32 channels + a slot
+constexpr int kDsColb = 272;                            // ... column pitch: 3 rows + padding; lanes read columns 2 l apart: 136 dwords = 8 (mod 64)
+constexpr int kDsWave = 65 * kDsColb;                   // ... region (17 680 bytes)
+}  // namespace
+
+__global__ void __launch_bounds__(512, 1) conv_ds2_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = lane >> 5, l31 = lane & 31;
+    int nt, mt, b;
+    {
+        const int gx = p.ntile_n, gy = p.tiles_img;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int rid = xcd_remap(lin, gx * gy * p.B);
+        const int q = rid / gx;
+        nt = rid - q * gx;
+        b = q / gy;
+        mt = q - b * gy;
+    }
+    const int tw = mt / p.Hout, oh = mt - tw * p.Hout;                  // the tile: output pixels (32 tw .. + 32, oh)
+    const int w0 = tw * 32;
+    unsigned char* const sW = smem + kg * kDsWave;
+
+    // ---- the wave's channels of the footprint: 65 columns x 3 rows x 4 pieces = 780 pieces, 13 per lane (zero rows above / below the image) ----
+    constexpr int NP = 13;
+    uint4 hv[NP];
+    const int c8 = lane & 3;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int slot = (lane >> 2) + i * 16;                          // footprint pixel: column slot / 3, row slot % 3
+        const int vwl = (slot * 21846) >> 16, vhl = slot - vwl * 3;     // slot / 3 for slot < 32768
+        const int vh = 2 * oh - 1 + vhl;
+        int vw = 2 * w0 - 1 + vwl;
+        vw = vw < 0 ? vw + p.Win : (vw >= p.Win ? vw - p.Win : vw);
+        const bool ok = slot < 195 && vh >= 0 && vh < p.Hin;
+        hv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) hv[i] = *reinterpret_cast<const uint4*>(p.x0 + ((size_t)(b * p.Win + vw) * p.Hin + vh) * 256 + kg * 32 + c8 * 8);
+    }
+    // (stream-packed with 2 k-groups: [32-channel tile][k-group][4 chunks x 9 taps x 2 k-steps] -- input channels 32 kg .. are chunk kg / 2, k-group kg % 2)
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.wpk) +
+                                      ((size_t)(nt * 2 + (kg & 1)) * 72 + (kg >> 1) * 18) * 1024 + lane * 16;
+    bf16x8 wr[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wr[i] = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int slot = (lane >> 2) + i * 16;
+        const int vwl = (slot * 21846) >> 16, vhl = slot - vwl * 3;
+        if (slot < 195) *reinterpret_cast<uint4*>(sW + vwl * kDsColb + vhl * kDsRS + c8 * 16) = hv[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (the wave's own stores: visible to the wave's own reads)
+    // ---- 9 taps x 2 k-steps: output pixel l reads footprint column 2 l + tap column ----------------------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned char* const xp = sW + (2 * l31) * kDsColb + kh * 16;
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+        const int tap = step >> 1, ks = step & 1;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + (tap / 3) * kDsColb + (tap % 3) * kDsRS + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[step], xf, acc, 0, 0, 0);
+    }
+    // ---- the k-groups' partial tiles [pixel][32 channels] fp32 into the head of each wave's own region, then 256 threads sum them --------
+    __syncthreads();                                                    // (every wave has consumed its footprint)
+    constexpr int FRS = 32 * 4 + 16;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(sW + l31 * FRS + (8 * r4 + 4 * kh) * 4) = make_float4(acc[r4 * 4 + 0], acc[r4 * 4 + 1], acc[r4 * 4 + 2], acc[r4 * 4 + 3]);
+    __syncthreads();
+    unsigned char* const sT = smem + 8 * kDsWave;                       // the rounded tile [32 pixels][32 channels] bf16, row 80 bytes
+    if (tid < 256) {
+        const int px = tid >> 3, c4 = tid & 7;
+        float4 sum = *reinterpret_cast<const float4*>(p.bias + nt * 32 + c4 * 4);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                                   // fixed order: deterministic
+            const float4 v = *reinterpret_cast<const float4*>(smem + g * kDsWave + px * FRS + c4 * 16);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        uint2 o;
+        o.x = pack_bf16x2(sum.x, sum.y);
+        o.y = pack_bf16x2(sum.z, sum.w);
+        *reinterpret_cast<uint2*>(p.y + (((size_t)b * p.Wout + w0 + px) * p.Hout + oh) * p.y_ld + nt * 32 + c4 * 4) = o;
+        *reinterpret_cast<uint2*>(sT + px * 80 + c4 * 8) = o;
+    }
+    if (p.y_stats) {
+        __syncthreads();
+        if (tid < 64) {                                                 // (channel pair tid % 16, 8 pixels each; folded across the 4 groups by shuffles)
+            const int cp = tid & 15, pg = tid >> 4;
+            float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(sT + (pg * 8 + j) * 80 + cp * 4);
+                const float a0 = bf16lo(w2), a1 = bf16hi(w2);
+                s0 += a0; s1 += a1;
+                q0 += a0 * a0; q1 += a1 * a1;
+            }
+            s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); q0 += __shfl_xor(q0, 16); q1 += __shfl_xor(q1, 16);
+            s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+            if (tid < 16) {
+                float2* dst = p.y_stats + ((size_t)b * p.tiles_img + mt) * p.N + nt * 32 + cp * 2;
+                dst[0] = make_float2(s0, q0);
+                dst[1] = make_float2(s1, q1);
+            }
+        }
+    }
+}
+
+size_t conv_ds2_lds_bytes() { return 8 * kDsWave + 32 * 80; }
+
+bool conv_ds2_supported(const ConvParams& p) {
+    if (p.C0 != 256 || p.C1 != 0 || p.R0 != 0 || p.R1 != 0 || p.N % 32 != 0 || p.up != 1 || p.stride != 2 || p.pad_lo != 1) return false;
+    if (p.st0 || p.temb || p.y_nchw || p.ksplit > 1) return false;
+    if (p.Win != 2 * p.Wout || p.Hin != 2 * p.Hout || p.Wout % 32 != 0) return false;
+    return p.B <= 65535 && p.tiles_img <= 65535 && p.tiles_img == (p.Wout / 32) * p.Hout;
+}
+
+int launch_conv_ds2(const ConvParams& p, hipStream_t stream) {
+    RLDM_REQUIRE(conv_ds2_supported(p), "conv_ds2: unsupported shape");
+    const size_t lds = conv_ds2_lds_bytes();
+    auto kern = conv_ds2_kernel;
+    static DynLdsLimit lds_limit;
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(p.N / 32, p.tiles_img, p.B), dim3(512), lds, stream, p);
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int regw_teams() { static const int t = getenv("RLDM_RW_TEAMS") ? atoi(getenv("RLDM_RW_TEAMS")) : 1; return t == 2 ? 2 : 1; }
 size_t conv_regw_lds_bytes() { return regw_teams() * kRwTeamBytes + (3 * 64 + 8 * 2 * 32) * sizeof(float) + 2 * (regw_teams() == 2 ? 12 : 8) * 1024; }
 

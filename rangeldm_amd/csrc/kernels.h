@@ -159,6 +159,11 @@ int launch_conv_c16(const ConvParams& p, hipStream_t stream);
 size_t conv_o4_lds_bytes();
 bool conv_o4_supported(const ConvParams& p);
 int launch_conv_o4(const ConvParams& p, hipStream_t stream);
+// conv_regw.hip, conv_ds2_kernel (round 4): 3x3 / stride 2 / pad 1 over 256 channels, no norm, on 32 x 1 output tiles x 32 channels with the 8
+// waves as k-groups (the UNet's 64x4 -> 32x2 down-sampler); weights stream-packed with 2 k-groups; one statistics partial per tile
+size_t conv_ds2_lds_bytes();
+bool conv_ds2_supported(const ConvParams& p);
+int launch_conv_ds2(const ConvParams& p, hipStream_t stream);
 
 // Persistent trunk launch (trunk.hip): consecutive conv_small launches whose tile owns a whole image (<= 64 pixels, 32-channel
 // tiles) as the phases of ONE launch; the N / 32 workgroups of an image hand their outputs to each other through the L2 of the

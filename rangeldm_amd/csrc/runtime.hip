@@ -1602,6 +1602,53 @@ struct Builder {
         return 0;
     }
 
+    // conv_regw.hip, conv_ds2_kernel (round 4): stride-2 convs of 256 raw channels onto few pixels (the 64x4 -> 32x2 down-sampler); RLDM_NO_DS2=1 keeps
+    // the generic kernel
+    static bool ds2_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
+        static const bool off = getenv("RLDM_NO_DS2") != nullptr;
+        if (off || (dbg() & 2048) || g_force_bm || taps != 9 || a.stride != 2 || a.pad_mode != 0 || a.up != 1 || a.out_f32_nchw) return false;
+        if (a.x1.valid() || a.gn || a.temb_off >= 0 || R_t != 0 || Cin_t != 256 || a.layer->Cin != 256 || a.layer->Cout % 32 != 0 || Wout % 32 != 0) return false;
+        memset(q, 0, sizeof(*q));
+        q->C0 = 256;
+        q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
+        q->up = 1; q->stride = 2; q->pad_lo = 1;
+        q->Wout = Wout; q->Hout = Hout;
+        q->TW = 32; q->TH = 1;
+        q->tiles_h = Hout;
+        q->tiles_img = (Wout / 32) * Hout;
+        q->N = a.layer->Cout;
+        q->ntile_n = q->N / 32;
+        q->ksplit = 1;
+        const long long blocks = (long long)q->B * q->tiles_img * q->ntile_n;
+        return conv_ds2_supported(*q) && blocks >= 32 && blocks <= 512;      // (more: conv_stream's stride-2 instance or the generic kernel fill the chip)
+    }
+    int conv_ds2(const ConvArgs& a, int Wout, int Hout, Tensor* out) {
+        ConvLayer* L = a.layer;
+        const int N = L->Cout;
+        const Tensor& x0 = a.x0;
+        ConvParams p;
+        RLDM_REQUIRE(ds2_params(a, x0.C, 0, 9, Wout, Hout, &p), "conv " + L->name + ": conv_ds2 route lost");
+        Tensor y = make(x0.B, Wout, Hout, N);
+        if (a.want_stats) add_stats(y, p.tiles_img);
+        const double fl = 2.0 * (double)x0.B * Wout * Hout * N * (double)L->Cin * 9;
+        plan->flops += fl;
+        note_launch();
+        if (!dry) {
+            ConvLayer::Packed* pk = nullptr;
+            if (L->get_streampacked(256, 2, &pk)) return 1;
+            p.x0 = tptr(x0);
+            p.wpk = pk->w.as<bf16_t>();
+            p.bias = pk->bias.as<float>();
+            p.y = tptr(y);
+            p.y_ld = N;
+            p.y_stats = y.P ? ptr<float2>(y.st_off) : nullptr;
+            const double by = (double)x0.B * x0.W * x0.H * 256 * 2.0 + (double)N * L->Cin * 9 * 2.0 + (double)x0.B * Wout * Hout * N * 2.0;
+            plan->ops.push_back({[p](hipStream_t s) { return launch_conv_ds2(p, s); }, "conv_ds2_kernel<32,32,taps9,s2>", fl, by});
+        }
+        *out = y;
+        return 0;
+    }
+
     // conv_regw.hip route (round 4): 64 -> 64 channel 3x3 convs over many 16 x 8 tiles (the VAE decoder's full-resolution level) -- the weights stay
     // in registers, a workgroup walks a run of tiles; rldm_debug_set_flags2(1 << 24) keeps them on conv_stream's per-tile instance
     static bool regw_params(const ConvArgs& a, int Cin_t, int R_t, int taps, int Wout, int Hout, ConvParams* q) {
@@ -1781,6 +1828,7 @@ struct Builder {
             ConvParams q;
             if (c16_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_c16(a, Wout, Hout, out);
             if (o4_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_o4(a, Wout, Hout, out);
+            if (!a.first_of_step && ds2_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_ds2(a, Wout, Hout, out);
             if (regw_params(a, Cin_t, R_t, taps, Wout, Hout, &q)) return conv_regw(a, Cin_t, R_t, Wout, Hout, out);
         }
         if (!a.first_of_step) {

@@ -73,6 +73,9 @@ CONV_CASES = [
     (16, 5, 128, 256, 16, 3, 1, 0, False),     # conv_regw.hip, conv_c16_kernel: the UNet's conv_in at the bench batch (5 real input channels of 16)
     (3, 4, 256, 256, 16, 3, 1, 0, False),      # ... the decoder's conv_in (two 128-channel groups, odd batch)
     (1, 16, 128, 1024, 8, 3, 1, 0, False),     # ... all 16 channels real, one tile row, 64 tiles across the wrap
+    (16, 256, 256, 64, 4, 3, 2, 0, False),     # conv_regw.hip, conv_ds2_kernel: the 64x4 -> 32x2 down-sampler at the bench batch (8 waves = 8 k-groups)
+    (3, 256, 64, 128, 2, 3, 2, 0, False),      # ... one output row (zero rows above AND below), two tiles across the wrap, odd batch
+    (4, 256, 256, 64, 8, 3, 2, 0, False),      # ... four output rows
 ]
 
 
@@ -198,6 +201,20 @@ def test_conv_c64_register_weights(B, W, H, gn, res, regw_flags):
     assert float(d.max()) < 0.05
 
 
+@pytest.mark.parametrize("B,N,W,H", [(16, 256, 64, 4), (3, 64, 128, 2)])
+def test_conv_stride2_kgroup_waves_statistics(B, N, W, H):
+    """conv_regw.hip's conv_ds2_kernel: the (sum, sumsq) side output of the stride-2 down-sampler (one partial per 32 x 1 output tile)."""
+    x = _rand(B, 256, W, H, seed=90)
+    w = _rand(N, 256, 3, 3, seed=91, scale=(256 * 9) ** -0.5)
+    b = _rand(N, seed=92, scale=0.5)
+    y = hip_conv(x, w, b, stride=2)
+    st = hip_conv_stats(x, w, b, stride=2)
+    ref_s = y.double().sum(dim=(2, 3))
+    ref_q = (y.double() ** 2).sum(dim=(2, 3))
+    assert float((st[..., 0].double() - ref_s).abs().max()) < 1e-4 * W * H
+    assert float(((st[..., 1].double() - ref_q).abs() / (ref_q + 1e-6)).max()) < 1e-4
+
+
 def test_conv_c64_register_weights_ping_pong_variant():
     """RLDM_RW_TEAMS=2 (read once per process: a child process): conv_regw.hip as ONE 8-wave workgroup per CU whose two teams swap roles at
     barriers -- the measured alternative of DESIGN.md section 3.11 stays a working switch."""
@@ -281,7 +298,7 @@ def test_conv_c64_register_weights_statistics(B, W, H, regw_flags):
 @pytest.mark.parametrize("B,Cin,Cout,W,H,k", [(2, 128, 128, 64, 16, 3), (3, 64, 256, 32, 2, 3), (2, 32, 64, 16, 8, 1),
                                                 (1, 128, 128, 256, 16, 3), (2, 256, 256, 64, 4, 3), (16, 128, 256, 32, 2, 3),
                                                 (2, 256, 256, 64, 4, 1), (16, 128, 128, 128, 8, 1), (2, 128, 128, 128, 8, 3),
-                                                (4, 256, 256, 32, 1, 3), (2, 256, 256, 32, 1, 1), (1, 64, 64, 1024, 64, 3)])
+                                                (4, 256, 256, 32, 1, 3), (2, 256, 256, 32, 1, 1), (1, 64, 64, 1024, 64, 3), (16, 5, 128, 256, 16, 3)])
 def test_conv_epilogue_statistics(B, Cin, Cout, W, H, k):
     """The per-channel (sum, sumsq) side output that replaces a separate GroupNorm statistics pass: it must equal
     the sums over the bf16 values the conv stored (fixed-order fp32 partial sums -> tight tolerance)."""
