@@ -32,12 +32,15 @@ def main():
     a = ap.parse_args()
     _lib.require_gpu()
     _lib.lib().rldm_debug_set_flags(8192 | a.flags)
-    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.pipelines import LDMPipelineRange, DDIMPipelineRange
     from rangeldm_amd.schedulers import DDIMSchedulerHIP
     from rangeldm_amd.synth import latent_noise
     dev = torch.device("cuda", 0)
     p, unet, vae, _, _ = bench.build_models(a.preset, 20240310)
-    pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=p["pos_encoding"])
+    if vae is not None:
+        pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=p["pos_encoding"])
+    else:       # (pixel space: RangeDM)
+        pipe = DDIMPipelineRange(unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=p["pos_encoding"])
     shape = (p["unet"].out_channels, *p["unet"].sample_size)
     x = torch.from_numpy(np.stack([latent_noise(1, j, shape) for j in range(a.batch)])).to(dev)
     for _ in range(2):
