@@ -27,7 +27,7 @@ namespace rldm {
 
 // WM pixel parts (128 pixels each) x WN 32-channel tiles x KG k-groups = NW waves; the 4-wave instances are built for two workgroups
 // per CU (__launch_bounds__' second argument is waves per SIMD: 2 x 256 threads = 2)
-template <int WM, int WN, int NW = 8, int MI = 4, int S = 1, bool SUB = false, bool T4 = false>
+template <int WM, int WN, int NW = 8, int MI = 4, int S = 1, bool SUB = false, bool T4 = false, bool FH = false>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_stream_kernel(const ConvParams p) {
     // Workgroups are dispatched x-fastest and land on XCD (linear id % 8).  Re-number them so that every XCD owns a contiguous
     // run of (image, pixel tile, channel tile) ids: the tiles of an image then share ONE L2, and the halo rows two neighbouring
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_stream_kernel(c
         mt = q - b * gy;
     }
     const TrunkSeam none = {};
-    conv_stream_body<WM, WN, false, NW, MI, S, SUB, T4>(p, nt, mt, b, none);
+    conv_stream_body<WM, WN, false, NW, MI, S, SUB, T4, FH>(p, nt, mt, b, none);
 }
 
 // the 256 x 128 tile with specialised waves (conv_stream_spec_body.h): 4 matrix waves + 4 staging waves
@@ -75,16 +75,16 @@ __global__ void __launch_bounds__(512, 1) conv_stream_spec_kernel(const ConvPara
 // (round 4) st_inst 4: 8 x 8 tiles, 64 pixels x 128 channels x 2 k-groups on 8 waves (two 32-pixel fragments per wave) for the 128x8 level
 int conv_stream_bn(const ConvParams& p) {
     if (p.st_inst == 3 || p.st_inst == 4 || p.st_inst == 5) return 128;       // (3: the 256 x 128 tile with specialised waves; 5: 4 at stride 2)
-    if (p.st_inst) return p.st_inst == 1 || p.st_inst == 6 ? 128 : 64;
+    if (p.st_inst) return p.st_inst == 1 || p.st_inst == 6 || p.st_inst == 7 ? 128 : 64;
     return p.TW * p.TH == 256 && p.N % 128 == 0 ? 128 : 64;
 }
 int conv_stream_kgroups(const ConvParams& p) {
     if (p.st_inst == 3) return 1;
     if (p.st_inst == 4 || p.st_inst == 5) return 2;
-    if (p.st_inst) return p.st_inst == 1 || p.st_inst == 6 ? 1 : 2;
+    if (p.st_inst) return p.st_inst == 1 || p.st_inst == 6 || p.st_inst == 7 ? 1 : 2;
     return p.TW * p.TH == 256 ? (p.N % 128 == 0 ? 1 : 2) : 4;
 }
-int conv_stream_threads(const ConvParams& p) { return p.st_inst == 1 || p.st_inst == 2 || p.st_inst == 6 ? 256 : 512; }
+int conv_stream_threads(const ConvParams& p) { return p.st_inst == 1 || p.st_inst == 2 || p.st_inst == 6 || p.st_inst == 7 ? 256 : 512; }
 
 size_t conv_stream_lds_bytes(const ConvParams& p) {
     const int BN = conv_stream_bn(p), KG = conv_stream_kgroups(p), BM = p.TW * p.TH;
@@ -102,7 +102,7 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     if (p.st_inst == 5 && (p.stride != 2 || p.up != 1 || R != 0)) return false;
     if (Cin % 64 != 0 || (p.C1 != 0 && p.C0 % 64 != 0) || R % 64 != 0 || (p.R1 != 0 && p.R0 % 64 != 0)) return false;
     if (R != 0 && p.up != 1) return false;
-    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4) || ((p.st_inst == 4 || p.st_inst == 5) && p.TW == 8 && p.TH == 8) || (p.st_inst == 5 && p.TW == 16 && p.TH == 4)) ||
+    if (!((p.TW == 32 && p.TH == 8) || (p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4) || (p.st_inst == 7 && p.TW == 8 && p.TH == 16) || ((p.st_inst == 4 || p.st_inst == 5) && p.TW == 8 && p.TH == 8) || (p.st_inst == 5 && p.TW == 16 && p.TH == 4)) ||
         p.Win * p.up < 2) return false;
     if (p.N % conv_stream_bn(p) != 0 || Cin > 512) return false;
     if (p.st_inst == 3 && (p.TW != 32 || p.TH != 8 || p.N % 128 != 0)) return false;
@@ -113,15 +113,17 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     if (p.st_inst == 6 && !((p.TW == 16 && p.TH == 8) || (p.TW == 32 && p.TH == 4))) return false;
     // (6, round 4: nearest x2 + 3x3 in its sub-pixel form -- tiles over the INPUT, four parities per tile, Wout = 2 Win)
     if (p.st_inst == 6 && (p.up != 1 || R != 0 || p.N % 128 != 0 || p.Wout != 2 * p.Win || p.Hout != 2 * p.Hin)) return false;
-    if (p.st_inst < 0 || p.st_inst > 6) return false;
+    // (7, round 4: st_inst 1 on 8 x 16 tiles as tall as the image -- the halo rows above / below are never staged)
+    if (p.st_inst == 7 && (p.TW != 8 || p.TH != 16 || p.Hout != 16 || p.up != 1 || p.N % 128 != 0)) return false;
+    if (p.st_inst < 0 || p.st_inst > 7) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;
-    return conv_stream_lds_bytes(p) <= (size_t)(p.st_inst == 1 || p.st_inst == 2 || p.st_inst == 6 ? 80 : 160) * 1024;      // (4-wave instances: two workgroups share the CU's LDS)
+    return conv_stream_lds_bytes(p) <= (size_t)(p.st_inst == 1 || p.st_inst == 2 || p.st_inst == 6 || p.st_inst == 7 ? 80 : 160) * 1024;      // (4-wave instances: two workgroups share the CU's LDS)
 }
 
-template <int WM, int WN, int NW = 8, int MI = 4, int S = 1, bool SUB = false, bool T4 = false>
+template <int WM, int WN, int NW = 8, int MI = 4, int S = 1, bool SUB = false, bool T4 = false, bool FH = false>
 static int launch_stream_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
-    auto kern = conv_stream_kernel<WM, WN, NW, MI, S, SUB, T4>;
+    auto kern = conv_stream_kernel<WM, WN, NW, MI, S, SUB, T4, FH>;
     static DynLdsLimit lds_limit;                // per device, thread safe
     RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(p.N / (32 * WN) * (SUB ? 4 : 1), p.tiles_img, p.B), dim3(64 * NW), lds, stream, p);
@@ -143,6 +145,7 @@ int launch_conv_stream(const ConvParams& p, hipStream_t stream) {
     if (p.st_inst == 4) return launch_stream_inst<1, 4, 8, 2>(p, lds, stream);
     if (p.st_inst == 5) return launch_stream_inst<1, 4, 8, 2, 2>(p, lds, stream);
     if (p.st_inst == 6) return p.TH == 4 ? launch_stream_inst<1, 4, 4, 4, 1, true, true>(p, lds, stream) : launch_stream_inst<1, 4, 4, 4, 1, true>(p, lds, stream);
+    if (p.st_inst == 7) return launch_stream_inst<1, 4, 4, 4, 1, false, false, true>(p, lds, stream);
     if (p.st_inst == 1) return launch_stream_inst<1, 4, 4>(p, lds, stream);
     if (p.st_inst == 2) return launch_stream_inst<1, 2, 4>(p, lds, stream);
     if (p.TW * p.TH == 256) return p.N % 128 == 0 ? launch_stream_inst<2, 4>(p, lds, stream) : launch_stream_inst<2, 2>(p, lds, stream);

@@ -32,9 +32,13 @@ __device__ __forceinline__ void lds_barrier_b() {
 // (parity a = 0: {k[0]}, {k[1] + k[2]}; a = 1: {k[0] + k[1]}, {k[2]} along each axis; zero rows above / below the image stay zero, the wrap
 // is the input's): 4 taps instead of 9 per output pixel.  The tiles are INPUT tiles; `nt_` = channel tile * 4 + parity; the weight stream of a
 // (32-channel tile, parity) is [chunks][2 x 2 taps][4 k-steps] of summed weights (ConvLayer::get_subpixpacked)
-template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1, bool SUB = false, bool T4 = false>
+// FH = true (round 4): tiles as tall as the image (8 x 16 on 16-beam images): the halo rows above and below the tile are the image's zero padding, ALWAYS --
+// they are zeroed once per launch / phase and never staged, and the staged part (10 x 16 positions) is exactly five pieces per thread where the 16 x 8
+// tile's 18 x 10 were six with 18 of them padding (the staging is VALU-issue bound: section 3.10)
+template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1, bool SUB = false, bool T4 = false, bool FH = false>
 __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int nt_, const int mt, const int b, const TrunkSeam& seam) {
     static_assert(!SUB || (STR == 1 && NW / (WM * WN) == 1), "sub-pixel form: the one-k-group instances");
+    static_assert(!FH || (STR == 1 && !SUB && NW == 4 && WM == 1), "full-height tiles: the 4-wave stride-1 instance");
     constexpr int TAPW = SUB ? 2 : 3;          // taps per row / rows of taps
     const int nt = SUB ? nt_ >> 2 : nt_;
     const int par_w = SUB ? (nt_ >> 1) & 1 : 0, par_h = SUB ? nt_ & 1 : 0;
@@ -46,7 +50,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     // tiles for images of 4 beams (nuScenes' 128 x 4 level) (4)
     // (the 4-wave instances take 16 x 8 tiles only: 180 positions, 6 pieces per thread like the 256-pixel instance)
     // (T4: the sub-pixel instance on 32 x 4 tiles -- inputs of 4 beams: 34 x 6 = 204 positions, 7 pieces per thread)
-    constexpr int HALO_PX = MI == 2 ? (STR == 2 ? 17 * 17 : (8 + 2) * 10) : (WM == 1 ? (NW == 4 ? (T4 ? (32 + 2) * (4 + 2) : (16 + 2) * 10) : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
+    constexpr int HALO_PX = MI == 2 ? (STR == 2 ? 17 * 17 : (8 + 2) * 10) : (WM == 1 ? (NW == 4 ? (T4 ? (32 + 2) * (4 + 2) : (FH ? (8 + 2) * 16 : (16 + 2) * 10)) : (32 + 2) * (4 + 2)) : (BM / 8 + 2) * 10);
     constexpr int ACH = (HALO_PX * C8 + NT - 1) / NT;
     constexpr int SPT = 4 / KG;                // k-steps per tap of this wave
     constexpr int ROW = TAPW * SPT;            // ... per row of taps
@@ -118,7 +122,8 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     };
     RLDM_STAMP();
     // ---- halo staging: thread-constant source pixel of each of its ACH 16-byte pieces ---------------------------------
-    const int atotal = TWv * THv * C8;
+    const int THs = FH ? p.TH : THv;            // staged rows per halo column (FH: the tile's own rows -- p.magic_thv divides by THs)
+    const int atotal = TWv * THs * C8;
     int apix[ACH];
     const int my_c8 = (tid % C8) * 8;
     // halo pieces of a chunk in registers between its request and its store: one set, or two for the short-chunk instance (KG == 4: a
@@ -183,7 +188,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
             }
             const int q = tid + i * NT;
             const int slot = q / C8, c8 = q - slot * C8;
-            const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
+            const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THs + (FH ? 1 : 0);
             if (q < atotal) *reinterpret_cast<uint4*>(dstbuf + vwl * colb + vhl * RS + c8 * 16) = v;
         }
     };
@@ -286,7 +291,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     for (int i = 0; i < ACH; ++i) {
         const int q = tid + i * NT;
         const int slot = q / C8;
-        const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THv;
+        const int vwl = (slot * p.magic_thv) >> 20, vhl = slot - vwl * THs + (FH ? 1 : 0);
         const int vh = h0 * STR - 1 + vhl;
         int vw = w0 * STR - 1 + vwl;
         vw = vw < 0 ? vw + Wv : (vw >= Wv ? vw - Wv : vw);
@@ -348,6 +353,16 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     }
     RLDM_STAMP();
     if (tid < BN) sBias[tid] = bias_v;
+    if constexpr (FH) {
+        // the zero rows above and below the image, both buffers: TWv columns x 2 rows x 2 buffers x 9 slots of 16 bytes (never written again;
+        // the k-group-less epilogue's staging overwrites them only after the last chunk)
+        const int nz = TWv * 2 * 2 * (RS / 16);
+        for (int q = tid; q < nz; q += NT) {
+            const int sl = q % (RS / 16), r = q / (RS / 16);
+            const int col = r >> 2, which = r & 3;                       // (buffer, top / bottom)
+            *reinterpret_cast<uint4*>(sA + (which >> 1) * abytes + col * colb + ((which & 1) ? (THv - 1) * RS : 0) + sl * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     if (NCT > 0) store_a(0, Set0());
     if constexpr (PF2) { if (1 < NCT) load_next(1, Set1()); }   // (requested a chunk ahead from the start)
     RLDM_STAMP();
@@ -632,7 +647,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     {
         const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7) on tiles of 8 rows
         const int us = SUB ? 2 : 1;                                          // (sub-pixel form: input pixel (w, h) -> output (2w + parity, 2h + parity))
-        constexpr int ts = T4 ? 2 : 3;                                       // (... on tiles of 4 rows)
+        constexpr int ts = T4 ? 2 : (FH ? 4 : 3);                            // (... on tiles of 4 rows; full-height tiles of 16)
         bf16_t* yp = p.y + (((size_t)b * p.Wout + (w0 + (g >> ts)) * us + par_w) * p.Hout + (h0 + (g & ((1 << ts) - 1))) * us + par_h) * p.y_ld + chg;
         const size_t ystep = (size_t)((NT / NC8) >> ts) * us * p.Hout * p.y_ld;
 #pragma unroll

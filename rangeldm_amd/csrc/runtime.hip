@@ -1310,7 +1310,7 @@ struct Builder {
         q->B = a.x0.B; q->Win = a.x0.W; q->Hin = a.x0.H;
         q->up = sub ? 1 : a.up; q->stride = a.stride; q->pad_lo = 1;
         q->Wout = sub ? 2 * Wout : Wout; q->Hout = sub ? 2 * Hout : Hout;
-        q->TW = TW; q->TH = TH; q->th_shift = TH == 8 ? 3 : 2;
+        q->TW = TW; q->TH = TH; q->th_shift = TH == 16 ? 4 : (TH == 8 ? 3 : 2);
         q->st_inst = inst;
         ConvTile t;
         t.BM = 256; t.BN = 128; t.CK = 64; t.taps = 9;
@@ -1318,7 +1318,7 @@ struct Builder {
         q->tiles_h = Hout / TH;
         q->tiles_img = (Wout / TW) * q->tiles_h;
         {
-            const int thv = (TH - 1) * a.stride + 3;
+            const int thv = inst == 7 ? TH : (TH - 1) * a.stride + 3;       // (7: only the tile's own rows are staged)
             q->magic_thv = ((1 << 20) + thv - 1) / thv;
         }
         const int cpg = std::max(1, Cin_t / a.groups);
@@ -1359,6 +1359,10 @@ struct Builder {
         if (!(dbg2() & (1 << 27)) && !(dbg2() & 1) && a.up == 2 && N_ % 128 == 0 &&
             (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, kSubMinBlocks, 1ll << 40, q, 8, 6) ||
              (a.x0.H % 8 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, kSubMinBlocks, 1ll << 40, q, 4, 6)))) return true;   // (inputs of 4 beams: 32 x 4 tiles)
+        // (round 4) images of 16 beams: 8 x 16 tiles as tall as the image -- five staged pieces per thread instead of six; rldm_debug_set_flags2(1 << 29):
+        // the 16 x 8 tiles
+        if (!(dbg2() & 1) && !(dbg2() & (1 << 29)) && N_ % 128 == 0 && Hout == 16 && a.up == 1 &&
+            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, 384, 1ll << 40, q, 16, 7)) return true;
         if (!(dbg2() & 1) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 1)) return true;
         if (!(dbg2() & 4) && N_ % 128 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 2)) return true;
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
@@ -1410,14 +1414,15 @@ struct Builder {
         // write-back of the 16.8 MB outputs, no argument fetch / cold start per layer.  rldm_debug_set_flags(1 << 28): separate launches
         const int ranks_s = p.tiles_img * p.ntile_n;            // (sub-pixel form: input tiles x parities, one 128-channel tile)
         // (round 4) the 4-wave 128 x 128 instance: 32 workgroups per image, two per CU -- trunk variant 4; rldm_debug_set_flags2(8): launches
-        const int per_cu = p.st_inst == 1 || sub ? 2 : 1;
+        const bool inst1 = p.st_inst == 1 || p.st_inst == 7;      // (the 4-wave 128 x 128 tile: 16 x 8, or 8 x 16 as tall as the image)
+        const int per_cu = inst1 || sub ? 2 : 1;
         const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 * per_cu &&
                                        trunk_grid_fits(ranks_s, x0.B, per_cu) && y.P <= kFoldAboveP && N % 128 == 0 &&
                                        ((p.st_inst == 0 && (p.TW * p.TH == 256 || (dbg() & (1 << 30)))) ||     // (the 128x8 level's conv
                                         // PAIRS measured slower as 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
-                                        ((p.st_inst == 1 || (sub && N == 128 && p.TH == 8 && !(dbg2() & (1 << 28)))) && !(dbg2() & 8) && conv_stream_lds_bytes(p) <= 80 * 1024));
-        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, sub ? 1 : p.ntile_n, p.st_inst == 1 || sub || p.TW * p.TH == 256 ? 4 : 2,
-                                           p.st_inst == 1 || sub ? 4 : (p.TW * p.TH == 256 ? 2 : 3));
+                                        ((inst1 || (sub && N == 128 && p.TH == 8 && !(dbg2() & (1 << 28)))) && !(dbg2() & 8) && conv_stream_lds_bytes(p) <= 80 * 1024));
+        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, sub ? 1 : p.ntile_n, inst1 || sub || p.TW * p.TH == 256 ? 4 : 2,
+                                           inst1 || sub ? 4 : (p.TW * p.TH == 256 ? 2 : 3));
         else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
