@@ -114,7 +114,7 @@ bool conv_stream_supported(const ConvParams& p, int taps) {
     // (6, round 4: nearest x2 + 3x3 in its sub-pixel form -- tiles over the INPUT, four parities per tile, Wout = 2 Win)
     if (p.st_inst == 6 && (p.up != 1 || R != 0 || p.N % 128 != 0 || p.Wout != 2 * p.Win || p.Hout != 2 * p.Hin)) return false;
     // (7, round 4: st_inst 1 on 8 x 16 tiles as tall as the image -- the halo rows above / below are never staged)
-    if (p.st_inst == 7 && (p.TW != 8 || p.TH != 16 || p.Hout != 16 || p.up != 1 || p.N % 128 != 0)) return false;
+    if (p.st_inst == 7 && (!((p.TW == 8 && p.TH == 16) || (p.TW == 16 && p.TH == 8)) || p.Hout != p.TH || p.up != 1 || p.N % 128 != 0)) return false;
     if (p.st_inst < 0 || p.st_inst > 7) return false;
     if (p.st0 && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;
     if ((p.tiles_h & (p.tiles_h - 1)) != 0 || p.B > 65535 || p.tiles_img > 65535) return false;

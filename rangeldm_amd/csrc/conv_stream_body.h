@@ -32,7 +32,7 @@ __device__ __forceinline__ void lds_barrier_b() {
 // (parity a = 0: {k[0]}, {k[1] + k[2]}; a = 1: {k[0] + k[1]}, {k[2]} along each axis; zero rows above / below the image stay zero, the wrap
 // is the input's): 4 taps instead of 9 per output pixel.  The tiles are INPUT tiles; `nt_` = channel tile * 4 + parity; the weight stream of a
 // (32-channel tile, parity) is [chunks][2 x 2 taps][4 k-steps] of summed weights (ConvLayer::get_subpixpacked)
-// FH = true (round 4): tiles as tall as the image (8 x 16 on 16-beam images): the halo rows above and below the tile are the image's zero padding, ALWAYS --
+// FH = true (round 4): tiles as tall as the image (8 x 16 on 16-beam images, 16 x 8 on 8-beam ones): the halo rows above and below the tile are the image's zero padding, ALWAYS --
 // they are zeroed once per launch / phase and never staged, and the staged part (10 x 16 positions) is exactly five pieces per thread where the 16 x 8
 // tile's 18 x 10 were six with 18 of them padding (the staging is VALU-issue bound: section 3.10)
 template <int WM, int WN, bool TRUNK, int NW = 8, int MI = 4, int STR = 1, bool SUB = false, bool T4 = false, bool FH = false>
@@ -647,7 +647,7 @@ __device__ __forceinline__ void conv_stream_body(const ConvParams& p, const int 
     {
         const int g = tid / NC8;                                            // pixel 0..31 of the pass: (pw, ph) = (g >> 3, g & 7) on tiles of 8 rows
         const int us = SUB ? 2 : 1;                                          // (sub-pixel form: input pixel (w, h) -> output (2w + parity, 2h + parity))
-        constexpr int ts = T4 ? 2 : (FH ? 4 : 3);                            // (... on tiles of 4 rows; full-height tiles of 16)
+        const int ts = T4 ? 2 : (FH ? p.th_shift : 3);                       // (... on tiles of 4 rows; full-height tiles of 16 or 8 rows)
         bf16_t* yp = p.y + (((size_t)b * p.Wout + (w0 + (g >> ts)) * us + par_w) * p.Hout + (h0 + (g & ((1 << ts) - 1))) * us + par_h) * p.y_ld + chg;
         const size_t ystep = (size_t)((NT / NC8) >> ts) * us * p.Hout * p.y_ld;
 #pragma unroll

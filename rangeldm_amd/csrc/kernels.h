@@ -184,7 +184,8 @@ enum TrunkWord {
     // conv_stream phases (kind 15: the full-resolution levels as clusters of 16 pixel tiles / 8 pixel tiles x 2 channel tiles)
     TW_X1 = 48, TW_ST1 = 50,                                    // 64-bit pointers
     TW_C0 = 52, TW_C1, TW_P1, TW_MAGIC_THV, TW_UP,
-    TW_SUB,                 // conv_stream phases of variant 4: 1 = the sub-pixel form of nearest x2 + 3x3 (rank = input tile * 4 + parity, 128 output channels)
+    TW_SUB,                 // conv_stream phases of variant 4: 1 = the sub-pixel form of nearest x2 + 3x3 (rank = input tile * 4 + parity, 128 output channels),
+                            // 2 = tiles as tall as the image (st_inst 7)
     TW_WORDS = 64
 };
 // phase kinds: 0..2 / 4..6 image-owning conv_small tiles (64 / 32 pixels), 3 attention over a pre-normalised x,

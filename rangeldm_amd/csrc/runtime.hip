@@ -1361,8 +1361,8 @@ struct Builder {
              (a.x0.H % 8 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, kSubMinBlocks, 1ll << 40, q, 4, 6)))) return true;   // (inputs of 4 beams: 32 x 4 tiles)
         // (round 4) images of 16 beams: 8 x 16 tiles as tall as the image -- five staged pieces per thread instead of six; rldm_debug_set_flags2(1 << 29):
         // the 16 x 8 tiles
-        if (!(dbg2() & 1) && !(dbg2() & (1 << 29)) && N_ % 128 == 0 && Hout == 16 && a.up == 1 &&
-            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 8, 384, 1ll << 40, q, 16, 7)) return true;
+        if (!(dbg2() & 1) && !(dbg2() & (1 << 29)) && N_ % 128 == 0 && (Hout == 16 || Hout == 8) && a.up == 1 &&
+            stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, Hout == 16 ? 8 : 16, 384, 1ll << 40, q, Hout, 7)) return true;       // (8 beams: 16 x 8)
         if (!(dbg2() & 1) && N_ % 128 == 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 1)) return true;
         if (!(dbg2() & 4) && N_ % 128 != 0 && stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 16, 384, 1ll << 40, q, 8, 2)) return true;
         if (stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 200, 1ll << 40, q)) return true;
@@ -1468,7 +1468,7 @@ struct Builder {
                 ph.w[TW_MAGIC_CPG] = p.magic_cpg; ph.w[TW_GROUPS] = p.gn_groups; ph.w[TW_SILU] = p.silu;
                 putf(TW_INVN, p.gn_inv_n); putf(TW_EPS, p.gn_eps);
                 ph.w[TW_N] = p.N; ph.w[TW_YLD] = p.y_ld;
-                ph.w[TW_KIND] = TK_STREAM; ph.w[TW_TEMBOFF] = (unsigned)temb_off; ph.w[TW_SUB] = sub ? 1 : 0;
+                ph.w[TW_KIND] = TK_STREAM; ph.w[TW_TEMBOFF] = (unsigned)temb_off; ph.w[TW_SUB] = sub ? 1 : (p.st_inst == 7 ? 2 : 0);
                 pend.phases.push_back(ph);
                 pend.lds = std::max(pend.lds, conv_stream_lds_bytes(p));
                 pend.flops += fl;

@@ -303,8 +303,9 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
         } else if constexpr (V == 4) {
             // full-resolution level: 32 tiles of 128 pixels x 128 channels per image, 4 waves; the level's up-sampler conv in its sub-pixel
             // form: 8 INPUT tiles x 4 parities
-            if (rl(rec, TW_SUB)) conv_stream_body<1, 4, true, 4, 4, 1, true>(cp, rank & 3, rank >> 2, b, seam);
-            else if (cp.TH == 16) conv_stream_body<1, 4, true, 4, 4, 1, false, false, true>(cp, nt, mt, b, seam);      // 8 x 16 tiles as tall as the image
+            const unsigned form = rl(rec, TW_SUB);                      // (the host's choice of instance: 0 | 1 sub-pixel | 2 tiles as tall as the image)
+            if (form == 1u) conv_stream_body<1, 4, true, 4, 4, 1, true>(cp, rank & 3, rank >> 2, b, seam);
+            else if (form == 2u) conv_stream_body<1, 4, true, 4, 4, 1, false, false, true>(cp, nt, mt, b, seam);
             else conv_stream_body<1, 4, true, 4>(cp, nt, mt, b, seam);
         } else if constexpr (!CL) {
             switch (kind) {

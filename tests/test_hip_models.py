@@ -202,6 +202,36 @@ def test_persistent_trunk_matches_separate_launches(B, size):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B,size", [(16, (256, 16)), (32, (256, 8))])
+def test_full_height_tiles_in_and_out_of_the_persistent_launch(B, size):
+    """conv_stream's tiles as tall as the image (8 x 16 on 16-beam levels, 16 x 8 on 8-beam ones: the halo rows above / below are never
+    staged) against the 16 x 8 tiles with a staged halo ring (rldm_debug_set_flags2(1 << 29)), each as phases of the persistent launch and as
+    launches of their own (rldm_debug_set_flags(1 << 24)).  The kernel picks its instance from the phase record, not from the tile's shape:
+    a 16 x 8 tile on an 8-beam level is BOTH shapes."""
+    from rangeldm_amd import _lib
+    cfg = UNetConfig(sample_size=size)
+    x = T(normal(17, "x", (B, cfg.in_channels, *cfg.sample_size))).cuda()
+    outs = {}
+    for f2 in (0, 1 << 29):
+        for f1 in (0, 1 << 24):
+            _lib.lib().rldm_debug_set_flags(f1)
+            _lib.lib().rldm_debug_set_flags2(f2)
+            try:
+                m, _ = hip_unet(cfg, "fh.")
+                o = m(x, 411).sample.cpu()
+                assert m.trunk_status(B) == 0
+                assert torch.isfinite(o).all()
+                outs[(f2, f1)] = o
+            finally:
+                _lib.lib().rldm_debug_set_flags(0)
+                _lib.lib().rldm_debug_set_flags2(0)
+    for f2 in (0, 1 << 29):
+        assert torch.equal(outs[(f2, 0)], outs[(f2, 1 << 24)])
+    # two tilings of the same sums: the statistics partials are grouped differently, nothing else (bf16 roundings flip and travel through
+    # the network: measured 2.6e-3; the same bound as the other plan variants)
+    assert rel_l2(outs[(0, 0)], outs[(1 << 29, 0)]) < TOL_FWD / 2
+
+
 def test_unet_errors():
     cfg = UNetConfig(**SMALL)
     from rangeldm_amd.unet import UNet2DModelHIP
