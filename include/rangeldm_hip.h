@@ -399,7 +399,8 @@ int rldm_debug_set_flags(int flags);
  * workgroup), 1 << 25 caps that kernel's grid at 8 runs (tests: runs of several tiles on small images), 1 << 26 makes a test / bench conv of
  * <= 4 output channels an fp32-NCHW output layer like the decoder's conv_out (rldm_test_conv, rldm_bench_conv); 1 << 27 keeps nearest x2 +
  * 3x3 convs as a 3x3 over the up-sampled halo (default: the sub-pixel form -- four 2x2 convs over the input with summed weights), 1 << 28
- * keeps the 256x16 level's sub-pixel up-sampler a launch of its own (default: a phase of that level's persistent launch). */
+ * keeps the 256x16 level's sub-pixel up-sampler a launch of its own (default: a phase of that level's persistent launch), 1 << 29 keeps the
+ * 16 x 8 tiles with a staged halo ring at the 16- / 8-beam levels (default: tiles as tall as the image). */
 int rldm_debug_set_flags2(int flags);
 /* in-graph timeline of the UNet ops of the sampler's step graph (debug flag 8192 set before rldm_sampler_create) */
 int rldm_debug_graph_trace(unsigned long long* stamps, int cap, char* names, size_t names_cap);   /* kernel ablation switches, see ConvParams::dbg */
