@@ -20,6 +20,21 @@ def pos_encoding_channel(B, W, H):
 
 
 @torch.no_grad()
+def ddpm_pipeline(unet, scheduler, x_T, num_inference_steps=1000, step_noise=None, generator=None, trajectory=None):
+    """Pixel-space ancestral sampling, no pos-encoding channel.  ldm/pipelines.py:81-108: x_T has the UNet's
+    `in_channels`; `scheduler.step(model_output, t, image, generator=generator)` draws one z per step with t > 0."""
+    image = x_T.clone()
+    scheduler.set_timesteps(num_inference_steps)
+    for i, t in enumerate(scheduler.timesteps):
+        eps = unet(image, t).sample
+        if trajectory is not None:
+            trajectory.append((image.clone(), eps.clone()))
+        image = scheduler.step(eps, t, image, generator=generator,
+                               noise=None if step_noise is None else step_noise[i]).prev_sample
+    return image
+
+
+@torch.no_grad()
 def ddim_pipeline(unet, scheduler, x_T, num_inference_steps=50, eta=0.0, pos_encoding=True, step_noise=None,
                   trajectory=None):
     """Pixel-space DDIM (RangeDM).  ldm/pipelines.py:224-248."""

@@ -281,6 +281,23 @@ def main():
     mine2 = o_pipe.ddim_pipeline(unet2, o_sched.OracleDDIMScheduler(), x_T2, 5, eta=0.0, pos_encoding=True)
     check("DDIMPipelineRange (eta=0, 5 steps)", mine2, ref2, 0.0)
     gold["ddim_x_T"], gold["ddim_image_ref"] = x_T2.numpy(), ref2.numpy()
+    # DDPMPipelineRange (pixel space, ancestral, no pos-encoding: x_T has in_channels) on a 3-in/3-out UNet; the
+    # reference loop hands its generator to scheduler.step, so x_T and the step noise come off ONE stream in loop order
+    small_px = UNetConfig(sample_size=(32, 8), in_channels=3, out_channels=3, block_out_channels=(32, 32, 64, 64))
+    usd4 = synth_state_dict(unet_param_shapes(small_px), prefix="smallpx.")
+    unet4 = o_unet.OracleUNet(small_px, usd4)
+    pipe4 = lp.DDPMPipelineRange(unet=unet4, scheduler=o_sched.OracleDDPMScheduler())
+    g = torch.Generator().manual_seed(41)
+    ref4 = pipe4(batch_size=2, generator=g, num_inference_steps=4, output_type="torch")
+    g = torch.Generator().manual_seed(41)
+    x_T4 = torch.randn((2, 3, 32, 8), generator=g)
+    zs4 = [torch.randn((2, 3, 32, 8), generator=g) for _ in range(3)] + [None]     # the t = 0 step draws nothing
+    mine4 = o_pipe.ddpm_pipeline(unet4, o_sched.OracleDDPMScheduler(), x_T4, 4, step_noise=zs4)
+    check("DDPMPipelineRange (4 steps)", mine4, ref4, 0.0)
+    g = torch.Generator().manual_seed(41)
+    ref4np = pipe4(batch_size=2, generator=g, num_inference_steps=4, output_type="np").images
+    gold["ddpmpix_x_T"], gold["ddpmpix_step_noise"] = x_T4.numpy(), torch.stack(zs4[:3]).numpy()
+    gold["ddpmpix_image_ref"], gold["ddpmpix_image_np_ref"] = ref4.numpy(), ref4np
     # LDMUpscalePipelineRange with SparseRangeImageEncoder2 condition
     small_up = UNetConfig(sample_size=(32, 8), in_channels=12, out_channels=4, block_out_channels=(32, 32, 64, 64))
     usd3 = synth_state_dict(unet_param_shapes(small_up), prefix="smallup.")

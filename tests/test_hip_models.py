@@ -342,6 +342,38 @@ def test_ddim_pipeline_matches_reference_loop(golden):
         pipe(batch_size=2, generator=[torch.Generator()], num_inference_steps=2)
 
 
+def test_ddpm_pipeline_matches_reference_loop(golden):
+    """DDPMPipelineRange (ldm/pipelines.py:34-117: pixel space, ancestral, x_T with the UNet's in_channels, the caller's
+    generator handed to every scheduler.step) vs the image the REFERENCE's loop produced from the same CPU generator."""
+    from rangeldm_amd.pipelines import DDPMPipelineRange, ImagePipelineOutput
+    from rangeldm_amd.schedulers import DDPMSchedulerHIP
+    g = golden("ddpmpix")
+    unet, cfg = _small_unet(3, 3, "smallpx.")
+    pipe = DDPMPipelineRange(unet=unet, scheduler=DDPMSchedulerHIP())
+    ref = T(g["ddpmpix_image_ref"])
+    # (a) the generator the golden was drawn with: x_T, then one z per step with t > 0, all off one stream
+    for fused in (True, False):
+        gen = torch.Generator().manual_seed(41)
+        img = pipe(batch_size=2, generator=gen, num_inference_steps=4, output_type="torch", fused=fused).cpu()
+        assert img.shape == (2, 3, 32, 8)
+        assert rel_l2(img, ref) < TOL_TRAJ, (fused, rel_l2(img, ref))
+    # (b) the same noise injected from device buffers
+    zs = torch.cat([T(g["ddpmpix_step_noise"]), torch.zeros(1, 2, 3, 32, 8)], 0).cuda()
+    fused = pipe(batch_size=2, num_inference_steps=4, latents=T(g["ddpmpix_x_T"]), step_noise=zs, output_type="torch").cpu()
+    loop = pipe(batch_size=2, num_inference_steps=4, latents=T(g["ddpmpix_x_T"]), step_noise=zs, output_type="torch",
+                fused=False).cpu()
+    assert rel_l2(fused, ref) < TOL_TRAJ and rel_l2(loop, ref) < TOL_TRAJ
+    assert rel_l2(fused, loop) < 1e-5              # same kernels, graph vs per-call
+    assert rel_l2(fused, img) < 1e-5               # injected == drawn
+    # (c) the output_type tail (ldm/pipelines.py:109-117): (x/2+0.5).clamp(0,1), NHWC numpy
+    gen = torch.Generator().manual_seed(41)
+    out = pipe(batch_size=2, generator=gen, num_inference_steps=4, output_type="np")
+    assert isinstance(out, ImagePipelineOutput) and out.images.shape == (2, 32, 8, 3)
+    assert np.abs(out.images - g["ddpmpix_image_np_ref"]).max() < 2e-2
+    with pytest.raises(ValueError):
+        pipe(batch_size=2, num_inference_steps=4, latents=torch.zeros(2, 2, 32, 8))
+
+
 def test_upscale_pipeline_matches_reference_loop(golden):
     from rangeldm_amd.pipelines import LDMUpscalePipelineRange
     from rangeldm_amd.schedulers import DDPMSchedulerHIP

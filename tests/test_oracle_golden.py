@@ -153,6 +153,15 @@ def test_pipelines_match_reference_loops(golden):
     g = golden("ddim")
     img = o_pipe.ddim_pipeline(_small(3, 2, "smalldm."), o_sched.OracleDDIMScheduler(), T(g["ddim_x_T"]), 5)
     assert (img - T(g["ddim_image_ref"])).abs().max() < 1e-4
+    g = golden("ddpmpix")
+    zs = [z for z in T(g["ddpmpix_step_noise"])] + [None]
+    img = o_pipe.ddpm_pipeline(_small(3, 3, "smallpx."), o_sched.OracleDDPMScheduler(), T(g["ddpmpix_x_T"]), 4,
+                               step_noise=zs)
+    assert (img - T(g["ddpmpix_image_ref"])).abs().max() < 1e-4
+    drawn = o_pipe.ddpm_pipeline(_small(3, 3, "smallpx."), o_sched.OracleDDPMScheduler(),
+                                 torch.randn((2, 3, 32, 8), generator=(gen := torch.Generator().manual_seed(41))), 4,
+                                 generator=gen)
+    assert (drawn - T(g["ddpmpix_image_ref"])).abs().max() < 1e-4
     g = golden("up")
     zs = [z for z in T(g["up_step_noise"])] + [None]
     img = o_pipe.ldm_pipeline(vae, _small(12, 4, "smallup."), o_sched.OracleDDPMScheduler(), T(g["up_x_T"]), 3,
