@@ -16,8 +16,11 @@ batch of 16 (whole samples are sharded; no collective on the data path except th
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline     -- dominant kernel: algorithmic FLOPs of its launches / HIP-event time of those launches, measured in this
                   process right after the timed region by an instrumented eager pass on the sampler's stream
+  roofline_worst -- the kernel maximising (share of kernel time) x (1 - fraction of its roofline), with its counter traffic ratio
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference path; kind "port") timed on this host's
-                  cores on a bounded sample of the same workload
+                  cores on a bounded sample of the same workload (2 warm-ups, median of 3; host_cores / threads / cpu_model stated)
+  cpu_baseline_c1 -- BASELINE config 1 in full on the host: RangeDM, 10-step DDIM, batch 1 (the GPU leg is in other_configs)
+  fell_back    -- whether any persistent launch failed its self-check during the run (plans rebuilt as one launch per layer)
 """
 import argparse
 import ctypes as C
@@ -55,38 +58,106 @@ def build_models(preset, seed):
     return p, unet, vae, usd, vsd
 
 
+def host_info():
+    """CPU model, physical cores (unique (package, core id) pairs of /proc/cpuinfo) and logical CPUs of this host."""
+    model, pairs, phys, core, logical = "unknown", set(), None, None, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                pairs.add((phys, v))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return {"cpu_model": model, "host_cores": len(pairs) or logical, "logical_cpus": logical}
+
+
+def _median_timed(fn, warm=2, runs=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
 def cpu_baseline(p, usd, vsd, batch, steps):
-    """Oracle on the host cores: `nstep` UNet steps at the full batch + VAE decode of `ndec` images, extrapolated to a
-    batch.  Thread count: torch's fp32 conv path scales to ~16-32 threads on the GPU box's EPYC host and gets slower
-    beyond (probe: 8 thr 1.68 s, 16 thr 1.24 s, 32 thr 1.46 s, 128 thr 9.0 s per UNet forward at batch 16), so the
-    baseline uses min(32, cores) threads -- the fastest setting, stated in `cores`."""
+    """The headline workload on the host cores (BASELINE.md section 3 protocol: fp32, 2 warm-ups, median of 3): the oracle's UNet
+    forward at the full batch and its VAE decode of `ndec` images, extrapolated to `steps` steps + a decode of the batch.
+    Thread count: torch's fp32 conv path scales to ~16-32 threads on the GPU box's EPYC host and gets slower beyond (probe,
+    tools/cpu_threads.py: 8 thr 1.68 s, 16 thr 1.24 s, 32 thr 1.46 s, 128 thr 9.0 s per UNet forward at batch 16), so the
+    baseline uses min(32, physical cores) threads -- `cores` is the number of threads used, `host_cores` what the host has."""
     from oracle.unet import OracleUNet
     from oracle.vae import OracleVAE
     from rangeldm_amd.synth import normal
-    threads = min(32, os.cpu_count() or 1)
+    hi = host_info()
+    threads = max(1, min(32, hi["host_cores"]))
     torch.set_num_threads(threads)
     ucfg, vcfg = p["unet"], p["vae"]
     ou = OracleUNet(ucfg, usd)
     x = torch.from_numpy(normal(1, "cpu/x", (batch, ucfg.in_channels, *ucfg.sample_size)))
-    ou(x[:1], 480)                                   # warm the allocator / thread pool
-    nstep = 3
-    t0 = time.perf_counter()
-    for i in range(nstep):
-        ou(x, 480 - 20 * i)
-    t_unet = (time.perf_counter() - t0) / nstep
-    t_dec, ndec = 0.0, 2
+    ts = iter([480, 460, 440, 420, 400])
+    t_unet, unet_runs = _median_timed(lambda: ou(x, next(ts)))
+    t_dec, ndec, dec_runs = 0.0, 2, []
     if vcfg is not None:
         ov = OracleVAE(vcfg, vsd)
         z = torch.from_numpy(normal(1, "cpu/z", (ndec, vcfg.z_channels, *ucfg.sample_size)))
-        t0 = time.perf_counter()
-        ov.decode(z)
-        t_dec = time.perf_counter() - t0
+        t_dec, dec_runs = _median_timed(lambda: ov.decode(z))
     per_batch = steps * t_unet + (batch / ndec) * t_dec
-    return {"value": batch / per_batch, "unit": "range-images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch {torch.__version__} fp32 CPU, {threads} threads): {nstep} of {steps} UNet steps at "
-                      f"batch {batch} ({t_unet:.2f} s each) + VAE decode of {ndec} of {batch} images ({t_dec:.2f} s), "
-                      f"extrapolated",
-            "seconds_per_batch_extrapolated": per_batch}
+    return dict(hi, **{
+        "value": batch / per_batch, "unit": "range-images/sec", "cores": threads, "threads": threads, "kind": "port",
+        "sample": f"oracle (torch {torch.__version__} fp32 CPU, {threads} threads on {hi['host_cores']} physical cores of "
+                  f"{hi['cpu_model']}): UNet forward at batch {batch}, 2 warm-ups + median of 3 ({t_unet:.2f} s) x {steps} steps + "
+                  f"VAE decode of {ndec} of {batch} images, 2 warm-ups + median of 3 ({t_dec:.2f} s) x {batch // ndec}, extrapolated",
+        "unet_forward_s": [round(t, 3) for t in unet_runs], "decode_s": [round(t, 3) for t in dec_runs],
+        "seconds_per_batch_extrapolated": per_batch})
+
+
+def cpu_baseline_c1(seed, budget_s=40.0):
+    """BASELINE config 1 AS BASELINE DEFINES IT: RangeDM (ldm/configs/RangeDM.yaml, pixel space 3 -> 2 channels at 1024 x 64),
+    10-step DDIM, batch 1, on the host -- the oracle's restatement of the reference loop (ldm/pipelines.py:224-248) IN FULL, no
+    extrapolation.  2 warm-up forwards, then the whole 10-step loop `runs` times (3 when the first took under a third of the time
+    budget, else 1 -- stated in `runs`); value = 1 / median."""
+    from oracle.unet import OracleUNet
+    from oracle.schedulers import OracleDDIMScheduler
+    from oracle.pipelines import ddim_pipeline
+    from rangeldm_amd.config import PRESETS
+    from rangeldm_amd.params import unet_param_shapes
+    from rangeldm_amd.synth import synth_state_dict, latent_noise
+    hi = host_info()
+    threads = max(1, min(32, hi["host_cores"]))
+    torch.set_num_threads(threads)
+    p = PRESETS["RangeDM"]
+    ucfg = p["unet"]
+    ou = OracleUNet(ucfg, synth_state_dict(unet_param_shapes(ucfg), seed=seed))
+    x_T = torch.from_numpy(latent_noise(seed, 0, (ucfg.out_channels, *ucfg.sample_size)))[None]
+    warm = torch.cat([x_T, torch.zeros(1, ucfg.in_channels - ucfg.out_channels, *ucfg.sample_size)], 1)
+    for t in (900, 800):
+        ou(warm, t)
+    runs = []
+    while True:
+        t0 = time.perf_counter()
+        img = ddim_pipeline(ou, OracleDDIMScheduler(), x_T, 10, eta=0.0, pos_encoding=p["pos_encoding"])
+        runs.append(time.perf_counter() - t0)
+        if len(runs) >= 3 or runs[0] * 3 > budget_s:
+            break
+    assert torch.isfinite(img).all()
+    med = float(np.median(runs))
+    return dict(hi, **{
+        "value": 1.0 / med, "unit": "range-images/sec", "cores": threads, "threads": threads, "kind": "port",
+        "workload": "config 1 in full: RangeDM 64x1024 pixel space, 10-step DDIM, batch 1, fp32 on the host",
+        "runs": len(runs), "seconds_per_image": [round(t, 3) for t in runs],
+        "sample": f"oracle (torch {torch.__version__} fp32 CPU, {threads} threads): the whole 10-step loop, 2 warm-up forwards + "
+                  f"median of {len(runs)} full runs ({med:.2f} s per image), nothing extrapolated"})
 
 
 def roofline(pipe, sampler_handle, x_T, steps):
@@ -121,28 +192,37 @@ def roofline(pipe, sampler_handle, x_T, steps):
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
                    "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
-    traffic, traffic_src = None, None
-    for name in ("round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):   # HBM bytes per launch from the rocprofv3 --pmc passes
-        tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath):
+    # HBM bytes per launch from the rocprofv3 --pmc passes (tools/collect_profiles.sh), newest round first
+    import glob
+    import re
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")),
+                    key=lambda f: -int(re.search(r"round(\d+)_traffic", f).group(1)))
+
+    def counter_traffic(kname):
+        """(bytes per launch, file) of `kname` from the newest traffic file that knows it."""
+        for tpath in tfiles:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(dom)
-                if traffic is None and dom.startswith("trunk_kernel<"):
+                t = tj.get(kname)
+                if t is None and kname.startswith("trunk_kernel<"):
                     # persistent launches: the counters know the kernel VARIANT only ("trunk_kernel<conv_stream 256x128>": bytes per
                     # launch averaged over its launches of 4 and 7 phases); this launch's share = its phases / the variant's mean
-                    variant = dom.split(",")[0] + ">"
+                    variant = kname.split(",")[0] + ">"
                     phases = lambda k: int(k.split(",")[1].split()[0])
-                    same = {k: v for k, v in tot.items() if k.startswith(dom.split(",")[0] + ",")}
+                    same = {k: v for k, v in tot.items() if k.startswith(kname.split(",")[0] + ",")}
                     mean_ph = sum(phases(k) * v["launches"] for k, v in same.items()) / max(1, sum(v["launches"] for v in same.values()))
                     if tj.get(variant) is not None and mean_ph > 0:
-                        traffic = int(tj[variant] * phases(dom) / mean_ph)
+                        t = int(tj[variant] * phases(kname) / mean_ph)
+                if t is not None:
+                    return t, os.path.basename(tpath)
             except (OSError, ValueError, IndexError):
-                traffic = None
-            if traffic is not None:
-                traffic_src = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/collect_profiles.sh), " \
-                              f"not re-measured in this run"
-                break
+                pass
+        return None, None
+
+    traffic, tname = counter_traffic(dom)
+    traffic_src = None if traffic is None else (
+        f"profiles/{tname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/collect_profiles.sh), "
+        f"not re-measured in this run")
     step_launches = sum(v["launches"] for v in prof.get("unet_step", {}).values())      # what the captured step really launches
     rl = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -150,7 +230,28 @@ def roofline(pipe, sampler_handle, x_T, steps):
           "alg_flops_per_launch": d["flops"] / d["launches"], "alg_bytes_per_launch": d["bytes"] / d["launches"],
           "launches_per_batch": d["launches"], "eager_kernel_ms_per_batch": round(all_ms, 3),
           "concurrent_chains": lanes, "chain_batch": prof.get("lane_batch"), "step_launches": step_launches}
-    return rl, kernels
+    # the kernel that costs the step most: share of the kernel time x distance from ITS roofline (MFMA for the contractions, HBM for
+    # the elementwise launches -- whichever fraction is larger)
+    def frac_of(v):
+        sec = v["ms"] * 1e-3
+        return max(v["flops"] / sec / 1e12 / PEAK_BF16_TFLOPS, v["bytes"] / sec / 1e9 / PEAK_HBM_GBS)
+    worst = max(tot, key=lambda k: tot[k]["ms"] / all_ms * (1.0 - min(1.0, frac_of(tot[k]))))
+    w = tot[worst]
+    wsec = w["ms"] * 1e-3
+    w_mfma = w["flops"] / wsec / 1e12 / PEAK_BF16_TFLOPS >= w["bytes"] / wsec / 1e9 / PEAK_HBM_GBS
+    w_traffic, w_tname = counter_traffic(worst)
+    w_alg = w["bytes"] / w["launches"]
+    rl_worst = {"kernel": worst, "share": round(w["ms"] / all_ms, 4), "bound": "mfma" if w_mfma else "hbm",
+                "achieved": round(w["flops"] / wsec / 1e12 if w_mfma else w["bytes"] / wsec / 1e9, 2),
+                "peak": PEAK_BF16_TFLOPS if w_mfma else PEAK_HBM_GBS, "unit": "TFLOP/s" if w_mfma else "GB/s",
+                "frac": round(frac_of(w), 4), "score_share_x_distance": round(w["ms"] / all_ms * (1.0 - min(1.0, frac_of(w))), 4),
+                "avg_launch_us": round(w["ms"] * 1e3 / w["launches"], 2), "launches_per_batch": w["launches"],
+                "alg_flops_per_launch": w["flops"] / w["launches"], "alg_bytes_per_launch": w_alg,
+                "traffic": w_traffic, "traffic_ratio": None if not w_traffic or not w_alg else round(w_traffic / w_alg, 2),
+                "traffic_source": None if w_traffic is None else f"profiles/{w_tname}"}
+    rl["fell_back"] = bool(prof.get("fell_back", False))
+    rl["plan_flags"] = prof.get("plan_flags")
+    return rl, kernels, rl_worst
 
 
 def other_configs(seed, dev):
@@ -392,9 +493,14 @@ def main():
         }
         if True:                                        # (per-GPU figures, measured on rank 0's GPU for every N)
             h = pipe._fused.get(unet, vae, sched, B, S, 0 if args.sampler == "ddim" else 1, p["pos_encoding"], p["cond_channels"])
-            rl, kernels = roofline(pipe, h, xs[0], S)
+            rl, kernels, rl_worst = roofline(pipe, h, xs[0], S)
             gflop_per_image = (S * unet.flops(B) + (vae.decode_flops(B, *lat_shape[1:]) if vae else 0.0)) / B / 1e9
             res["roofline"] = rl
+            res["roofline_worst"] = rl_worst
+            # did any persistent launch fail its self-check (the sampler then rebuilt itself as one launch per layer: correct images,
+            # 4-5 % slower)?  `plan_flags` = the routing bits in effect at the end of the timed loop, 0 = the defaults
+            res["fell_back"] = rl.pop("fell_back")
+            res["plan_flags"] = rl.pop("plan_flags")
             res["kernels"] = kernels
             res["gflop_per_image"] = round(gflop_per_image, 1)
             res["end_to_end_tflops"] = round(res["value"] * gflop_per_image / 1e3, 1)
@@ -402,6 +508,8 @@ def main():
             res["unet_launches_per_step"] = rl.pop("step_launches") or unet.num_launches(B)
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(p, usd, vsd, B, S)
+                if args.preset == "RangeLDM" and not strong:
+                    res["cpu_baseline_c1"] = cpu_baseline_c1(args.seed)
             if world == 1 and not args.no_pipelined and args.preset == "RangeLDM" and B == 16 and zs is None and conds is None:
                 # NOT `value`: the same kernels with THREE batch-16 requests in flight (three chains of 16 on separate HIP streams,
                 # one pipeline call of 48 samples) -- what a throughput driver that does not wait for batch i before it starts

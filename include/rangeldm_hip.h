@@ -162,7 +162,10 @@ int rldm_sampler_status(rldm_sampler* s);
  * the system librccl. */
 #define RLDM_UNIQUE_ID_BYTES 128
 typedef struct rldm_comm rldm_comm;
-int rldm_comm_unique_id(void* id_out, size_t cap);
+/* binds RCCL and nothing else: what every rank but 0 calls to learn whether it CAN take part (rldm_comm_unique_id would also open
+ * ncclGetUniqueId's listening socket and root thread, which only the rank whose id is used should own) */
+int rldm_comm_bind(void);
+int rldm_comm_unique_id(void* id_out, size_t cap);          /* rank 0 only */
 int rldm_comm_create(const void* unique_id, int rank, int world, rldm_comm** out);     /* collective over all ranks */
 void rldm_comm_destroy(rldm_comm* c);
 int rldm_comm_info(const rldm_comm* c, int* rank, int* world, char* rccl_origin, size_t cap);
@@ -346,8 +349,9 @@ int rldm_unet_num_launches(rldm_unet* m, int B);
 
 /* Instrumented pass used by bench.py for the roofline: runs ONE UNet step (+ one VAE decode) eagerly on the sampler's
  * stream with a HIP event pair around every kernel launch and writes JSON
- *   {"unet_step": {kernel: {launches, ms, flops, bytes}, ...}, "vae_decode": {...}}
- * (flops/bytes = algorithmic work of those launches) into json_out. */
+ *   {"unet_step": {kernel: {launches, ms, flops, bytes}, ...}, "vae_decode": {...}, "plan_flags": F, "fell_back": bool, ...}
+ * (flops/bytes = algorithmic work of those launches; plan_flags = the routing bits in effect for this sampler's plans,
+ * fell_back = the library added bits of its own, i.e. a persistent launch failed its self-check earlier) into json_out. */
 int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size_t cap);
 
 /* low-level op entry points (used by the parity tests to check each kernel in isolation) */

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "rldm_sampler_status": (C.c_int, [_P]),
     "rldm_unet_set_plan_flags": (C.c_int, [_P, C.c_int]),
     "rldm_debug_inject_trunk_error": (C.c_int, [_P, C.c_int]),
+    "rldm_comm_bind": (C.c_int, []),
     "rldm_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
     "rldm_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "rldm_comm_destroy": (None, [_P]),

@@ -101,6 +101,8 @@ using namespace rldm;
 
 extern "C" {
 
+int rldm_comm_bind(void) { return bind_rccl(); }
+
 int rldm_comm_unique_id(void* id_out, size_t cap) {
     RLDM_REQUIRE(id_out && cap >= (size_t)kUniqueIdBytes, "unique id buffer must hold RLDM_UNIQUE_ID_BYTES (128) bytes");
     if (bind_rccl()) return 1;

@@ -937,6 +937,18 @@ bool conv_regw_supported(const ConvParams& p) {
     return tiles / wpi >= 4;                    // (runs of at least four tiles per team; shorter: the per-tile kernel's grid is as good)
 }
 
+// one launcher -- and one DynLdsLimit -- per kernel instance: the four instances share the pointer type void(*)(ConvParams, int, int),
+// so a limit kept inside a generic lambda over the pointer would be ONE limit for all of them, and the instance launched second
+// would never get its hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+template <int TEAMS, int WN>
+static int launch_regw_inst(const ConvParams& p, int wpi, int tiles, size_t lds, hipStream_t stream) {
+    auto kern = conv_regw_kernel<TEAMS, WN>;
+    static DynLdsLimit lds_limit;
+    RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(wpi / TEAMS * p.B), dim3(TEAMS * kRwTeam), lds, stream, p, wpi / TEAMS, tiles / wpi);
+    return 0;
+}
+
 int launch_conv_regw(const ConvParams& p, hipStream_t stream) {
     RLDM_REQUIRE(conv_regw_supported(p), "conv_regw: unsupported shape");
     RLDM_REQUIRE(p.colb == kRwColb, "conv_regw: halo column pitch");
@@ -944,15 +956,9 @@ int launch_conv_regw(const ConvParams& p, hipStream_t stream) {
     const int tiles = (p.Wout / kRwTW) * (p.Hout / kRwTH);
     const size_t lds = conv_regw_lds_bytes();
     // (wpi = team runs per image: the statistics partials are one per WORKGROUP)
-    auto go = [&](auto kern, int teams) -> int {
-        static DynLdsLimit lds_limit;
-        RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
-        hipLaunchKernelGGL(kern, dim3(wpi / teams * p.B), dim3(teams * kRwTeam), lds, stream, p, wpi / teams, tiles / wpi);
-        return 0;
-    };
     int rc;
-    if (regw_teams() == 2) rc = p.y_nchw ? go(conv_regw_kernel<2, 1>, 2) : go(conv_regw_kernel<2, 2>, 2);
-    else rc = p.y_nchw ? go(conv_regw_kernel<1, 1>, 1) : go(conv_regw_kernel<1, 2>, 1);
+    if (regw_teams() == 2) rc = p.y_nchw ? launch_regw_inst<2, 1>(p, wpi, tiles, lds, stream) : launch_regw_inst<2, 2>(p, wpi, tiles, lds, stream);
+    else rc = p.y_nchw ? launch_regw_inst<1, 1>(p, wpi, tiles, lds, stream) : launch_regw_inst<1, 2>(p, wpi, tiles, lds, stream);
     if (rc) return rc;
     RLDM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -214,6 +214,7 @@ struct TrunkParams {
     unsigned long long* ts;     // ABLATE builds: [phase][16] s_memtime stamps of workgroup 0 (rldm_debug_timestamps buffer) or null
 };
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream);
+int trunk_max_resident(int variant, size_t lds);   // workgroups of that kernel per CU by the runtime's occupancy query (< 0: query failed)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-channel statistics (norm.hip) for tensors that did not come out of a conv epilogue (tests, external inputs):

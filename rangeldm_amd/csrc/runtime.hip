@@ -810,7 +810,19 @@ struct Builder {
         if (!trunk_open) return 0;
         trunk_open = false;
         int rc = 0;
-        if (!dry && pend.phases.size() == 1 && pend.standalone.size() == 1 && !(dbg() & (1 << 29))) {
+        // the runtime's own answer to "are all these workgroups resident at once?" (variant 4: two per CU) -- asked here, at plan build,
+        // not left to the launch's bounded-wait self-check.  A query that FAILS (< 0) changes nothing; a clear "no" keeps the layers launches.
+        const int need_per_cu = pend.variant == 4 ? 2 : 1;
+        const int resident = (!dry && pend.phases.size() > 1 && !(dbg() & (1 << 29))) ? trunk_max_resident(pend.variant, pend.lds) : need_per_cu;
+        const bool not_resident = resident >= 0 && resident < need_per_cu && pend.standalone.size() == pend.phases.size();
+        if (not_resident) {
+            static bool said = false;
+            if (!said) fprintf(stderr, "librangeldm_hip: trunk_kernel<%d> with %zu bytes of LDS: %d workgroup(s) per CU resident, %d needed; "
+                               "these layers run as launches of their own\n", pend.variant, pend.lds, resident, need_per_cu);
+            said = true;
+            launches += (int)pend.standalone.size() - 1;
+            for (auto& op : pend.standalone) plan->ops.push_back(op);
+        } else if (!dry && pend.phases.size() == 1 && pend.standalone.size() == 1 && !(dbg() & (1 << 29))) {
             plan->ops.push_back(pend.standalone[0]);
         } else if (!dry && !pend.phases.empty()) {
             auto recs = std::make_unique<DevBuf>();
@@ -3706,6 +3718,8 @@ int rldm_sampler_profile(rldm_sampler* s, const float* x_T, char* json_out, size
     dump("unet_step", unet_stats);
     js += ", ";
     dump("vae_decode", vae_stats);
+    // routing bits in effect (rldm_sampler_config::plan_flags | the library's own fall-backs) and whether a fall-back engaged
+    js += ", \"plan_flags\": " + std::to_string(s->plan_flags) + ", \"fell_back\": " + (s->plan_flags != s->cfg.plan_flags ? "true" : "false");
     js += ", \"lanes\": " + std::to_string(s->lanes.size()) + ", \"lane_batch\": " + std::to_string(ln->nb) + "}";
     RLDM_REQUIRE(js.size() + 1 <= cap, "profile buffer too small");
     memcpy(json_out, js.c_str(), js.size() + 1);

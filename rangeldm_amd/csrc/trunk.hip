@@ -388,6 +388,24 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
     if (rank == 0 && tid == 0) counter[3] = epoch + 1u;
 }
 
+// workgroups of trunk_kernel<variant> the runtime will keep resident on ONE CU with `lds` bytes of dynamic LDS each (< 0: the query
+// failed).  The plan builder asks before it commits a segment to a persistent launch: a spin-waiting grid that is not co-resident
+// only fails through the bounded-wait self-check, which is a slow way to find out (variant 4 needs TWO per CU: 2 x 80 KiB is the
+// whole LDS, so any static LDS, scratch or a partitioned CU would halve it).
+int trunk_max_resident(int variant, size_t lds) {
+    if (variant < 0 || variant > 4) return -1;
+    static DynLdsLimit lds_limit[5];
+    const int cl = variant;
+    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : (cl == 3 ? trunk_kernel<3> : trunk_kernel<4>)));
+    if (lds_limit[cl].ensure(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return -1;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), cl == 4 ? 256 : 512, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return n;
+}
+
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
     RLDM_REQUIRE(tp.variant >= 0 && tp.variant <= 4, "trunk: bad kernel variant");
     const int per_cu = tp.variant == 4 ? 2 : 1;  // (variant 4: 256-thread workgroups, two per CU)

@@ -55,10 +55,21 @@ class _GroupExchange:
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    def finish(self):
+        pass                                             # (the collectives above are their own rendezvous)
+
+
+_LIVE_STORES = []        # TCPStore servers this process hosts stay referenced: a slower peer may still be reading its last key
+
 
 class _StoreExchange:
     """... without a process group: a TCPStore at MASTER_ADDR:MASTER_PORT + 1 (rank 0 hosts it).  Every wait is bounded by
-    `timeout` seconds: a rank that never arrives is a bootstrap failure on all the others, not a hang."""
+    `timeout` seconds: a rank that never arrives is a bootstrap failure on all the others, not a hang.
+    Keys carry a GENERATION (this rank's n-th bootstrap on this store: `store.add` on a per-rank counter; the ranks build their
+    communicators in the same order, so generation n is the same bootstrap everywhere) -- a second Communicator on the same store
+    never reads the first one's answers.  `finish()` is the last thing a bootstrap does, on success and on failure: every rank
+    posts a `done` key and rank 0, which hosts the store, waits for all of them before it returns or raises, so the server cannot
+    disappear under a peer's pending read."""
 
     def __init__(self, rank, world, store=None, timeout=120.0):
         import datetime
@@ -66,15 +77,27 @@ class _StoreExchange:
         self.store = store or dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                             int(os.environ.get("MASTER_PORT", "29500")) + 1, world, rank == 0,
                                             timeout=datetime.timedelta(seconds=timeout))
+        if rank == 0:
+            _LIVE_STORES.append(self.store)
+        self.gen = int(self.store.add(f"rldm_comm_gen_r{rank}", 1))
+
+    def _key(self, what, rank=None):
+        return f"rldm_comm_g{self.gen}_{what}" + ("" if rank is None else f"_{rank}")
 
     def agree(self, ok, tag):
-        self.store.set(f"rldm_comm_{tag}_{self.rank}", b"1" if ok else b"0")
-        return all(self.store.get(f"rldm_comm_{tag}_{r}") == b"1" for r in range(self.world))
+        self.store.set(self._key(tag, self.rank), b"1" if ok else b"0")
+        return all(self.store.get(self._key(tag, r)) == b"1" for r in range(self.world))
 
     def broadcast_uid(self, raw):
         if self.rank == 0:
-            self.store.set("rldm_comm_uid", raw)
-        return self.store.get("rldm_comm_uid")
+            self.store.set(self._key("uid"), raw)
+        return self.store.get(self._key("uid"))
+
+    def finish(self):
+        self.store.set(self._key("done", self.rank), b"1")
+        if self.rank == 0:
+            for r in range(self.world):
+                self.store.get(self._key("done", r))
 
 
 class CommunicatorUnavailable(RuntimeError):
@@ -86,20 +109,25 @@ class Communicator:
     files (ldm/inference.py:56,159-183) with one all-gather.  Bootstrap, in three steps so that the ranks never disagree about the
     path they use (round 4; before, a rank whose librccl could not be bound fell back to torch.distributed ALONE while its peers
     blocked inside ncclCommInitRank or issued RCCL collectives against its torch ones):
-      1. local and fallible: every rank binds RCCL and makes a unique id (`rldm_comm_unique_id`; only rank 0's is used);
+      1. local and fallible: every rank loads librangeldm_hip and binds RCCL (`rldm_comm_bind`); rank 0 alone makes the unique
+         id (`rldm_comm_unique_id`: ncclGetUniqueId opens a listening socket and a root thread, which only the rank whose id is
+         used should own).  A missing .so, a missing librccl, a failed id: all are outcomes of THIS step, not exceptions;
       2. agreement: the ranks exchange their step-1 outcome (`agree`); if ANY failed, ALL raise CommunicatorUnavailable -- nobody
          enters the collective init;
-      3. collective: rank 0's 128-byte id is broadcast, every rank calls `rldm_comm_create` (ncclCommInitRank), and a second
-         agreement round confirms that all of them hold a communicator (else all destroy theirs and raise).
-    The traffic goes through torch.distributed's object collectives (any backend; gloo is enough) or, without a process group,
-    through a TCPStore at MASTER_ADDR:MASTER_PORT + 1.  Collectives are issued on the CURRENT torch stream of the device, i.e.
-    stream-ordered behind the sampler / trainer launches.  `lib` / `exchange` are injectable for the CPU tests."""
+      3. collective: rank 0's 128-byte id is broadcast, every rank calls `rldm_comm_create` (ncclCommInitRank) -- a rank that
+         received a malformed id does NOT raise in between (its peers would block in the init) but skips the init and reports a
+         failure -- and a second agreement round confirms that all of them hold a communicator (else all destroy theirs and raise).
+    Nothing between the first agreement round and the last can raise on one rank alone; a failure of the exchange itself (the
+    TCPStore cannot be reached, a peer never arrives within the bounded wait) surfaces as CommunicatorUnavailable on every rank
+    that is waiting.  The traffic goes through torch.distributed's object collectives (any backend; gloo is enough) or, without a
+    process group, through a TCPStore at MASTER_ADDR:MASTER_PORT + 1.  Collectives are issued on the CURRENT torch stream of the
+    device, i.e. stream-ordered behind the sampler / trainer launches.  `lib` / `exchange` are injectable for the CPU tests."""
 
     def __init__(self, rank=None, world=None, store=None, lib=None, exchange=None):
         import ctypes as C
         from . import _lib
         self._C, self._lib = C, _lib
-        self._cdll = lib if lib is not None else _lib.lib()
+        self._cdll = lib
         self._injected = lib is not None
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
@@ -107,16 +135,40 @@ class Communicator:
             world = dist.get_world_size() if dist.is_initialized() else int(os.environ.get("WORLD_SIZE", "1"))
         self.rank, self.world = rank, world
         self._h = None
-        if exchange is None and world > 1:
-            exchange = _GroupExchange(rank, world) if dist.is_initialized() else _StoreExchange(rank, world, store)
-        self._exchange = exchange                        # (rank 0 hosts the TCPStore: it must outlive the peers' last reads)
-        # 1. local: bind RCCL, make an id
+        err = None
+        try:
+            self._bootstrap(rank, world, store, exchange)
+        except CommunicatorUnavailable as e:
+            err = e
+        except Exception as e:                           # (the exchange itself failed: store unreachable, a peer timed out)
+            self.close()
+            err = CommunicatorUnavailable(f"rank {rank}: bootstrap exchange failed: {e!r}")
+        ex = getattr(self, "_exchange", None)
+        if ex is not None:
+            try:
+                ex.finish()                              # (rank 0 keeps its store until every rank is through, also on failure)
+            except Exception:
+                pass
+        if err is not None:
+            raise err
+
+    def _bootstrap(self, rank, world, store, exchange):
+        C = self._C
+        # 1. local: load the library, bind RCCL, (rank 0) make an id -- every failure here is an OUTCOME the peers learn in step 2
         uid = C.create_string_buffer(128)
         err = None
         try:
-            self._check(self._cdll.rldm_comm_unique_id(uid, 128), "rldm_comm_unique_id")
+            if self._cdll is None:
+                self._cdll = self._lib.lib()
+            if rank == 0:
+                self._check(self._cdll.rldm_comm_unique_id(uid, 128), "rldm_comm_unique_id")
+            else:
+                self._check(self._cdll.rldm_comm_bind(), "rldm_comm_bind")
         except Exception as e:
             err = e
+        if exchange is None and world > 1:
+            exchange = _GroupExchange(rank, world) if dist.is_initialized() else _StoreExchange(rank, world, store)
+        self._exchange = exchange                        # (rank 0 hosts the TCPStore: it must outlive the peers' last reads)
         # 2. agreement before anything collective
         if world > 1 and not exchange.agree(err is None, "bind"):
             raise CommunicatorUnavailable(f"rank {rank}: RCCL could not be bound on "
@@ -126,15 +178,17 @@ class Communicator:
         # 3. collective init with rank 0's id, then confirm
         if world > 1:
             raw = exchange.broadcast_uid(uid.raw if rank == 0 else None)
-            if len(raw) != 128:
-                raise CommunicatorUnavailable(f"rank {rank}: unique id of {len(raw)} bytes (expected 128)")
-            uid = C.create_string_buffer(raw, 128)
-        h = C.c_void_p()
-        try:
-            self._check(self._cdll.rldm_comm_create(uid, rank, world, C.byref(h)), "rldm_comm_create")
-            self._h = h
-        except Exception as e:
-            err = e
+            if not isinstance(raw, (bytes, bytearray)) or len(raw) != 128:
+                err = RuntimeError(f"unique id of {len(raw) if hasattr(raw, '__len__') else '?'} bytes (expected 128)")
+            else:
+                uid = C.create_string_buffer(bytes(raw), 128)
+        if err is None:
+            h = C.c_void_p()
+            try:
+                self._check(self._cdll.rldm_comm_create(uid, rank, world, C.byref(h)), "rldm_comm_create")
+                self._h = h
+            except Exception as e:
+                err = e
         if world > 1 and not exchange.agree(err is None, "init"):
             self.close()
             raise CommunicatorUnavailable(f"rank {rank}: rldm_comm_create failed on "
@@ -259,6 +313,12 @@ def all_gather_images(local_images, world=None):
                            "communicator is available")
     world = dist.get_world_size()
     local_images = local_images.contiguous()
+    if local_images.is_cuda and dist.get_backend() == "gloo":
+        # the one-GPU rehearsal of an N-rank run (RLDM_DIST_BACKEND=gloo: RCCL refuses two ranks on one device); gloo gathers host tensors
+        host = local_images.cpu()
+        out = torch.empty((world * host.shape[0], *host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(local_images.device)
     out = torch.empty((world * local_images.shape[0], *local_images.shape[1:]), dtype=local_images.dtype,
                       device=local_images.device)
     dist.all_gather_into_tensor(out, local_images)

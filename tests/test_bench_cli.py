@@ -1,0 +1,58 @@
+"""The driver's commands, rehearsed: `bench.py` under torch.distributed.run with TWO ranks on ONE GPU (gloo carries the rendezvous and
+the gather: RCCL refuses two ranks per device), so that the round-end SCALE command cannot fail on argument plumbing.  What is checked
+is the CONTRACT of the JSON line -- world / ranks_seen from a real collective, `value` = global images / max-over-ranks time -- not a
+rate (two ranks time-share one GPU here; persistent launches are off for the same reason: RLDM_DBG_FLAGS = 1 << 24)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_bench(nproc, extra, timeout=900):
+    env = dict(os.environ, RLDM_DIST_BACKEND="gloo", RLDM_DBG_FLAGS=str(1 << 24), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-pipelined", "--no-other-configs"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_weak_scaling_line():
+    """`bench.py --gpus 2` as the driver launches it: every rank samples its own batch of 16"""
+    res = _run_bench(2, [])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 2 and res["warmup"] == 1
+    assert res["comm"]["world"] == 2 and res["comm"]["ranks_seen"] == [0, 1]
+    assert res["config"]["global_batch"] == 32 and res["config"]["batch_per_gpu"] == 16
+    # value = ALL ranks' images / the max-over-ranks wall time of the K steps
+    assert abs(res["value"] - 2 * 16 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["value"]
+    assert res["metric"].startswith("range-images/sec") and res["unit"] == "range-images/sec" and res["higher_is_better"] is True
+    assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
+    assert res["roofline_worst"]["kernel"] and res["fell_back"] is False
+    assert "cpu_baseline" not in res                               # rank 0 at N = 1 only
+
+
+def test_bench_two_ranks_strong_scaling_config3_line():
+    """BASELINE config 3: ONE global batch of 32 nuScenes images sharded over the ranks"""
+    res = _run_bench(2, ["--scaling", "strong", "--preset", "nuscenes", "--batch", "32"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert res["comm"]["world"] == 2 and res["comm"]["ranks_seen"] == [0, 1]
+    assert res["config"]["global_batch"] == 32 and res["config"]["batch_per_gpu"] == 16
+    assert abs(res["value"] - 32 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["value"]
+    assert res["comm"]["allgather_bytes_per_rank"] == 16 * 2 * 1024 * 32 * 4

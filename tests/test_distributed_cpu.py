@@ -87,15 +87,20 @@ def test_index_arithmetic_single_process():
 # raise, before anything collective (the first real multi-GPU run is the driver's: this is its rehearsal without hardware).
 # ---------------------------------------------------------------------------------------------------------------------------------
 class _FakeRccl:
-    def __init__(self, rank, fail_bind=False, fail_create=False):
-        self.rank, self.fail_bind, self.fail_create = rank, fail_bind, fail_create
-        self.created, self.destroyed = [], 0
+    def __init__(self, rank, fail_bind=False, fail_create=False, short_uid=False):
+        self.rank, self.fail_bind, self.fail_create, self.short_uid = rank, fail_bind, fail_create, short_uid
+        self.created, self.destroyed, self.ids_made, self.binds = [], 0, 0, 0
+
+    def rldm_comm_bind(self):
+        self.binds += 1
+        return 1 if self.fail_bind else 0
 
     def rldm_comm_unique_id(self, buf, n):
         if self.fail_bind:
             return 1
         import ctypes
-        ctypes.memmove(buf, bytes([0x40 + self.rank]) * n, n)       # (every rank makes one; only rank 0's may be used)
+        self.ids_made += 1
+        ctypes.memmove(buf, bytes([0x40 + self.rank]) * n, n)
         return 0
 
     def rldm_comm_create(self, uid, rank, world, out):
@@ -109,18 +114,29 @@ class _FakeRccl:
         self.destroyed += 1
 
 
-def _bootstrap_ranks(world, port, fail_bind=(), fail_create=()):
+class _ShortUidExchange(D._StoreExchange):
+    """rank `bad` receives a truncated id (a broken side channel)"""
+    bad = 1
+
+    def broadcast_uid(self, raw):
+        got = super().broadcast_uid(raw)
+        return got[:100] if self.rank == self.bad else got
+
+
+def _bootstrap_ranks(world, port, fail_bind=(), fail_create=(), exchange_cls=None, rounds=1):
     import threading
     out = [None] * world
 
     def run(rank):
         lib = _FakeRccl(rank, rank in fail_bind, rank in fail_create)
         try:
-            ex = D._StoreExchange(rank, world, dist.TCPStore("127.0.0.1", port, world, rank == 0), timeout=60.0)
-            c = D.Communicator(rank=rank, world=world, lib=lib, exchange=ex)
+            store = dist.TCPStore("127.0.0.1", port, world, rank == 0)
+            for _ in range(rounds):                                 # (rounds > 1: several communicators over ONE store)
+                ex = (exchange_cls or D._StoreExchange)(rank, world, store, timeout=60.0)
+                c = D.Communicator(rank=rank, world=world, lib=lib, exchange=ex)
             out[rank] = ("ok", lib, c)
         except D.CommunicatorUnavailable as e:
-            out[rank] = ("unavailable", lib, str(e), ex)            # (keep rank 0's store alive until every rank is through)
+            out[rank] = ("unavailable", lib, str(e))                # (nothing kept alive: rank 0's finish() waits for the peers)
         except Exception as e:                                      # pragma: no cover
             out[rank] = ("error", lib, repr(e))
 
@@ -140,6 +156,7 @@ def test_cabi_bootstrap_exchanges_rank0_id_in_rank_order():
         assert status == "ok", (rank, c)
         assert lib.created == [(bytes([0x40]) * 128, rank, world)]   # rank 0's 128-byte id, own rank, world -- on every rank
         assert (c.rank, c.world) == (rank, world)
+        assert lib.ids_made == (1 if rank == 0 else 0) and lib.binds == (0 if rank == 0 else 1)   # only rank 0 makes an id
         c._h = None                                                  # (nothing to destroy in the fake)
 
 
@@ -155,3 +172,54 @@ def test_cabi_bootstrap_create_failure_is_agreed_and_cleaned_up():
     assert [r[0] for r in res] == ["unavailable", "unavailable"]
     assert len(res[0][1].created) == 1 and len(res[1][1].created) == 1
     assert res[1][1].destroyed == 1                                  # the rank that did get a communicator gave it back
+
+
+def test_cabi_bootstrap_malformed_id_on_one_rank_is_agreed_not_raised_alone():
+    """a rank that receives a bad id must not raise between the agreement rounds (its peers would sit in ncclCommInitRank):
+    it skips the init, reports the failure, and every rank gives its communicator back"""
+    res = _bootstrap_ranks(2, _free_port(), exchange_cls=_ShortUidExchange)
+    assert [r[0] for r in res] == ["unavailable", "unavailable"]
+    assert len(res[0][1].created) == 1 and res[0][1].destroyed == 1   # rank 0 did initialise -- and gave it back
+    assert res[1][1].created == []                                    # the rank with the bad id never entered the init
+    assert "expected 128" in res[1][2] and "another rank" in res[0][2]
+
+
+def test_cabi_bootstrap_twice_on_one_store_uses_fresh_keys():
+    """generation-tagged keys: a second Communicator over the same store waits for its peers instead of reading the first one's answers"""
+    world = 2
+    res = _bootstrap_ranks(world, _free_port(), rounds=2)
+    for rank, r in enumerate(res):
+        assert r[0] == "ok", r
+        assert [c[1:] for c in r[1].created] == [(rank, world)] * 2
+        assert r[2]._exchange.gen == 2
+        r[2]._h = None
+
+
+def test_cabi_bootstrap_missing_library_is_an_outcome_not_an_exception(monkeypatch):
+    """the .so cannot be loaded on rank 1: both ranks raise CommunicatorUnavailable together, nobody initialises"""
+    import threading
+    from rangeldm_amd import _lib
+    world, port, out = 2, _free_port(), [None, None]
+
+    def boom():
+        raise RuntimeError("librangeldm_hip.so not found")
+    monkeypatch.setattr(_lib, "lib", boom)
+
+    def run(rank):
+        lib = _FakeRccl(rank) if rank == 0 else None                 # rank 1 goes through _lib.lib()
+        try:
+            ex = D._StoreExchange(rank, world, dist.TCPStore("127.0.0.1", port, world, rank == 0), timeout=60.0)
+            D.Communicator(rank=rank, world=world, lib=lib, exchange=ex)
+            out[rank] = ("ok",)
+        except D.CommunicatorUnavailable as e:
+            out[rank] = ("unavailable", str(e), lib)
+        except Exception as e:                                       # pragma: no cover
+            out[rank] = ("error", repr(e))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert [o[0] for o in out] == ["unavailable", "unavailable"], out
+    assert out[0][2].created == [] and "not found" in out[1][1]
