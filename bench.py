@@ -195,8 +195,10 @@ def roofline(pipe, sampler_handle, x_T, steps):
     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/collect_profiles.sh), newest round first
     import glob
     import re
-    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")),
-                    key=lambda f: -int(re.search(r"round(\d+)_traffic", f).group(1)))
+    def tkey(f):                                    # round5_traffic.json > round5_v2_traffic.json > round4_traffic.json > ...
+        m = re.search(r"round(\d+)(?:_v(\d+))?_traffic", os.path.basename(f))
+        return (-int(m.group(1)), -(int(m.group(2)) if m.group(2) else 1 << 20)) if m else (0, 0)
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), key=tkey)
 
     def counter_traffic(kname):
         """(bytes per launch, file) of `kname` from the newest traffic file that knows it."""
