@@ -495,6 +495,9 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][mi][r] += acc[a][mi][r];
     RLDM_STAMP();
+    // (multi-tile clusters: the next phase's weights are touched into the XCD's L2 now -- trunk_seam.h)
+    TrunkWarm warm;
+    if constexpr (TRUNK && (NWN > 1 || RLDM_TRUNK_WARM0)) trunk_warm_next(seam, tid, NT, warm);
     lds_barrier_s();                            // everyone is done with the input images: LDS is reused below
     RLDM_STAMP();
 
@@ -634,6 +637,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         }
     }
     RLDM_STAMP();
+    if constexpr (TRUNK && (NWN > 1 || RLDM_TRUNK_WARM0)) trunk_warm_done(warm);
     if constexpr (TRUNK) trunk_arrive(seam, tid);
     if constexpr (TRUNK && PF > 0) {            // the next phase's first fragments: requested behind the arrive (its vmcnt(0) must not
                                                 // wait for them), in flight during the seam and the next gather

@@ -186,6 +186,8 @@ enum TrunkWord {
     TW_C0 = 52, TW_C1, TW_P1, TW_MAGIC_THV, TW_UP,
     TW_SUB,                 // conv_stream phases of variant 4: 1 = the sub-pixel form of nearest x2 + 3x3 (rank = input tile * 4 + parity, 128 output channels),
                             // 2 = tiles as tall as the image (st_inst 7)
+    TW_WBYTES = 58,         // bytes of the phase's packed weights (TW_WPK ...): what the PREVIOUS phase touches, one dword per 128-byte line,
+                            // so that they wait in the XCD's L2 (round 5: trunk_warm_next; 0: nothing to warm)
     TW_WORDS = 64
 };
 // phase kinds: 0..2 / 4..6 image-owning conv_small tiles (64 / 32 pixels), 3 attention over a pre-normalised x,

@@ -940,6 +940,7 @@ struct Builder {
         put64(TW_X0, ap.x); put64(TW_WPK, ap.wfrag); put64(TW_BIAS, ap.bias); put64(TW_Y, ap.out);
         ph.w[TW_WIN] = ap.L; ph.w[TW_N] = ap.C;
         ph.w[TW_KIND] = ap.st ? TK_ATTN_FOLD : TK_ATTN; ph.w[TW_G] = 0; ph.w[TW_NMINE] = 0; ph.w[TW_TEMBOFF] = (unsigned)-1;
+        ph.w[TW_WBYTES] = (unsigned)(3 * ap.C * ap.C * 2);          // q / k / v projection fragments (attention_body.h)
         if (ap.st) {                    // the consumer-side GroupNorm of x (multi-tile clusters)
             put64(TW_ST0, ap.st); put64(TW_GAMMA, ap.gamma); put64(TW_BETA, ap.beta);
             ph.w[TW_P0] = ap.P; ph.w[TW_GROUPS] = ap.groups; ph.w[TW_MAGIC_CPG] = ap.magic_cpg;
@@ -1255,6 +1256,7 @@ struct Builder {
                     ph.w[TW_KIND] = kind_c;
                     ph.w[TW_G] = std::min(TPG * cpt, RLDM_TRUNK_PREFETCH);
                     ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
+                    ph.w[TW_WBYTES] = (unsigned)((N / 32) * KG * ph.w[TW_NMINE]) * 1024u;
                     RLDM_REQUIRE(p.nviews == 0, "conv " + L->name + ": a multi-tile cluster phase writes no views");
                     put64(TW_ST0, p.st0); put64(TW_GAMMA, p.gn_gamma); put64(TW_BETA, p.gn_beta);
                     ph.w[TW_P0] = p.P0; ph.w[TW_GROUPS] = p.gn_groups; ph.w[TW_MAGIC_CPG] = p.magic_cpg;
@@ -1269,6 +1271,7 @@ struct Builder {
                 ph.w[TW_KIND] = trunk_kind;
                 ph.w[TW_G] = std::min(G, RLDM_TRUNK_PREFETCH);       // == kTrunkPrefetch (conv_small_body.h)
                 ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
+                ph.w[TW_WBYTES] = (unsigned)((N / 32) * KG * ph.w[TW_NMINE]) * 1024u;
                 }
                 ph.w[TW_TEMBOFF] = (unsigned)temb_off;
                 for (int v = 0; v < p.nviews; ++v) {

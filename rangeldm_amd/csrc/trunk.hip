@@ -295,6 +295,8 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
         // (the next record has long arrived when the K loop ends: its weight stream is resolved inside the body, behind the K loop)
         seam.next_rec = nrec;
         seam.next_rank_kg = stream_id;
+        seam.rank = rank;
+        seam.ranks = ranks;
         bool conv_done = true;
         if constexpr (V == 2) {
             conv_stream_body<2, 4, true>(cp, nt, mt, b, seam);      // full-resolution level: 16 tiles of 256 pixels x 128 channels per image

@@ -21,6 +21,7 @@ struct TrunkSeam {
     int has_wait;                   // (0: the launch's first phase -- its inputs crossed a kernel boundary)
     unsigned next_rec;              // lane l: word l of the next phase's record (kernels.h TrunkWord), or 0 behind the last phase
     int next_rank_kg;               // this wave's weight stream of a layer = (channel tile * k-groups + k-group)
+    int rank, ranks;                // this workgroup's place in the image's cluster
     int* error;                     // device flag: a bounded poll gave up (the host refuses the plan's results)
     unsigned long long* ts;         // ABLATE builds: 16 stamp slots of this phase (workgroup 0) or null
     // the phase's time-embedding row (the launch's arguments, not the phase record: the table belongs to the caller of the plan)
@@ -56,6 +57,48 @@ __device__ __forceinline__ void trunk_arrive(const TrunkSeam& s, int tid) {
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(s.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- L2 warm-up of the NEXT phase's weights (round 5) ------------------------------------------------------------------------------
+// With image <-> XCD every XCD pulls every layer's weights through its own L2, and a layer's first touch is an Infinity-Cache round trip
+// (~4 k cycles) per ring slot: the K loop of a 64x4 cluster phase ran 17-22 k cycles against 5.6 k of matrix-pipe time
+// (profiles/round5_trunk_timeline_before.txt).  Each workgroup of the cluster therefore touches its 1/ranks share of the next phase's
+// weight bytes -- one dword per 128-byte line, kWarmLoads loads per thread -- once its own K loop has ended: the loads land under the
+// epilogue (the arrive waits for vmcnt(0) anyway), nothing younger than them is waited for before that, and the next phase's ring
+// then hits the L2.  The values are kept alive until trunk_warm_done (an unused load result would be a register the compiler reuses
+// while the load is still in flight).
+#ifndef RLDM_TRUNK_WARM
+#define RLDM_TRUNK_WARM 3           /* loads per thread (0: off): 16 ranks x 512 threads x 3 x 128 B = 3 MiB >= the largest layer */
+#endif
+#ifndef RLDM_TRUNK_WARM0
+#define RLDM_TRUNK_WARM0 0          /* 1: the image-owning phases of variant 0 warm their successor's weights too */
+#endif
+constexpr int kWarmLoads = RLDM_TRUNK_WARM;
+struct TrunkWarm { unsigned v[kWarmLoads > 0 ? kWarmLoads : 1]; };
+__device__ __forceinline__ void trunk_warm_next(const TrunkSeam& s, int tid, int nthreads, TrunkWarm& w) {
+    if constexpr (kWarmLoads > 0) {
+        const unsigned nr = s.next_rec;
+        const unsigned bytes = (unsigned)__builtin_amdgcn_readlane((int)nr, TW_WBYTES);
+        const unsigned long long wp = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)nr, TW_WPK + 1) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)nr, TW_WPK);
+        typedef __attribute__((address_space(1))) const unsigned char* global_bytes_t;
+        const unsigned char* base = (const unsigned char*)(global_bytes_t)wp;
+        const unsigned lines = bytes >> 7;
+        const unsigned share = (lines + (unsigned)s.ranks - 1u) / (unsigned)s.ranks;
+        const unsigned first = (unsigned)s.rank * share;
+#pragma unroll
+        for (int j = 0; j < kWarmLoads; ++j) {
+            const unsigned l = (unsigned)tid + (unsigned)(j * nthreads);
+            w.v[j] = 0u;
+            if (l < share && first + l < lines) w.v[j] = *reinterpret_cast<const unsigned*>(base + ((size_t)(first + l) << 7));
+        }
+    }
+}
+__device__ __forceinline__ void trunk_warm_done(TrunkWarm& w) {
+    if constexpr (kWarmLoads > 0) {
+#pragma unroll
+        for (int j = 0; j < kWarmLoads; ++j) asm volatile("" :: "v"(w.v[j]));
+    }
+}
+
 // activation loads: past the L1 inside the trunk (another CU of the cluster wrote the line during this launch)
 template <bool BYPASS> __device__ __forceinline__ uint4 ld_act16(const void* p) {
     if constexpr (BYPASS && !RLDM_TRUNK_PLAIN_LOADS) {
