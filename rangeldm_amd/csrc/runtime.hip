@@ -606,6 +606,7 @@ static unsigned long long* g_ts_buf = nullptr;   // rldm_debug_timestamps: devic
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static int g_split_auto = 0;     // automatic split-K is off: the in-launch combine costs more than the idle CUs     // rldm_debug_force_tile: tuning override (0: automatic)
 
+static constexpr bool kStreamPairs64Default = false;
 static thread_local int g_concurrent_plans = 1;   // plans being built will share the device with this many of their kind (sampler chains)
 
 struct TileChoice {
@@ -861,7 +862,7 @@ struct Builder {
                 tp.ts = (ts_ok && getenv("RLDM_TS_TRUNK") && tp.nphases == atoi(getenv("RLDM_TS_TRUNK"))) ? g_ts_buf : nullptr;
                 return launch_trunk(tp, lds, st);
             }, std::string("trunk_kernel<") + (pend.variant == 0 ? "conv_small image tiles" : pend.variant == 1 ? "conv_small 64x64 clusters" :
-                                               pend.variant == 2 ? "conv_stream 256x128" : pend.variant == 3 ? "conv_stream 128x64" : "conv_stream 128x128 x2/CU") +
+                                               pend.variant == 2 ? "conv_stream 256x128" : pend.variant == 3 ? "conv_stream 128x64" : pend.variant == 5 ? "conv_stream 64x128" : "conv_stream 128x128 x2/CU") +
                    ", " + std::to_string(pend.phases.size()) + " phases>", pend.flops, pend.bytes});
         }
         pend = PendingTrunk();
@@ -1394,6 +1395,9 @@ struct Builder {
         return stream_params_tw(a, Cin_t, R_t, taps, Wout, Hout, 32, 128, 1ll << 40, q);
     }
 
+    // (round 5) the conv pairs of the 128x8 level -- 64-pixel x 128-channel tiles, 16 workgroups per image -- as 2-phase persistent launches
+    // (trunk variant 5); RLDM_STREAM_PAIRS64=0 / 1 overrides the default
+    static bool stream_pairs64() { static const bool on = getenv("RLDM_STREAM_PAIRS64") ? atoi(getenv("RLDM_STREAM_PAIRS64")) != 0 : kStreamPairs64Default; return on; }
     int conv_stream(const ConvArgs& a, int Cin_t, int R_t, int Wout, int Hout, Tensor* out) {
         ConvLayer* L = a.layer;
         const int N = L->Cout;
@@ -1433,11 +1437,12 @@ struct Builder {
         const int per_cu = inst1 || sub ? 2 : 1;
         const bool in_stream_cluster = cluster_enabled() && !(dbg() & (1 << 28)) && ranks_s >= 2 && ranks_s <= 16 * per_cu &&
                                        trunk_grid_fits(ranks_s, x0.B, per_cu) && y.P <= kFoldAboveP && N % 128 == 0 &&
-                                       ((p.st_inst == 0 && (p.TW * p.TH == 256 || (dbg() & (1 << 30)))) ||     // (the 128x8 level's conv
+                                       ((p.st_inst == 4 && stream_pairs64()) ||       // (round 5: the 128x8 level's 64-pixel x 128-channel tile as phases)
+                                        (p.st_inst == 0 && (p.TW * p.TH == 256 || (dbg() & (1 << 30)))) ||     // (the 128x8 level's conv
                                         // PAIRS measured slower as 2-phase launches than as two launches, 216.9 against 220.0 img/s: off unless 1 << 30)
                                         ((inst1 || (sub && N == 128 && p.TH == 8 && !(dbg2() & (1 << 28)))) && !(dbg2() & 8) && conv_stream_lds_bytes(p) <= 80 * 1024));
-        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, sub ? 1 : p.ntile_n, inst1 || sub || p.TW * p.TH == 256 ? 4 : 2,
-                                           inst1 || sub ? 4 : (p.TW * p.TH == 256 ? 2 : 3));
+        if (in_stream_cluster) trunk_begin(x0.B, ranks_s, sub ? 1 : p.ntile_n, inst1 || sub || p.TW * p.TH == 256 || p.st_inst == 4 ? 4 : 2,
+                                           inst1 || sub ? 4 : (p.st_inst == 4 ? 5 : (p.TW * p.TH == 256 ? 2 : 3)));
         else note_launch();
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;

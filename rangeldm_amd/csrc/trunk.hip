@@ -302,6 +302,9 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
             conv_stream_body<2, 4, true>(cp, nt, mt, b, seam);      // full-resolution level: 16 tiles of 256 pixels x 128 channels per image
         } else if constexpr (V == 3) {
             conv_stream_body<1, 2, true>(cp, nt, mt, b, seam);      // 128x8 level: 8 tiles of 128 pixels x 2 channel tiles of 64
+        } else if constexpr (V == 5) {
+            // (round 5) 128x8 level on round 4's tile: 16 tiles of 64 pixels (8 x 8) x 128 channels x 2 k-groups per image
+            conv_stream_body<1, 4, true, 8, 2>(cp, nt, mt, b, seam);
         } else if constexpr (V == 4) {
             // full-resolution level: 32 tiles of 128 pixels x 128 channels per image, 4 waves; the level's up-sampler conv in its sub-pixel
             // form: 8 INPUT tiles x 4 parities
@@ -395,10 +398,10 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
 // only fails through the bounded-wait self-check, which is a slow way to find out (variant 4 needs TWO per CU: 2 x 80 KiB is the
 // whole LDS, so any static LDS, scratch or a partitioned CU would halve it).
 int trunk_max_resident(int variant, size_t lds) {
-    if (variant < 0 || variant > 4) return -1;
-    static DynLdsLimit lds_limit[5];
+    if (variant < 0 || variant > 5) return -1;
+    static DynLdsLimit lds_limit[6];
     const int cl = variant;
-    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : (cl == 3 ? trunk_kernel<3> : trunk_kernel<4>)));
+    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : (cl == 3 ? trunk_kernel<3> : (cl == 4 ? trunk_kernel<4> : trunk_kernel<5>))));
     if (lds_limit[cl].ensure(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return -1;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), cl == 4 ? 256 : 512, lds) != hipSuccess) {
@@ -409,7 +412,7 @@ int trunk_max_resident(int variant, size_t lds) {
 }
 
 int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
-    RLDM_REQUIRE(tp.variant >= 0 && tp.variant <= 4, "trunk: bad kernel variant");
+    RLDM_REQUIRE(tp.variant >= 0 && tp.variant <= 5, "trunk: bad kernel variant");
     const int per_cu = tp.variant == 4 ? 2 : 1;  // (variant 4: 256-thread workgroups, two per CU)
     RLDM_REQUIRE(tp.nphases >= 1 && tp.ranks >= 1 && tp.ranks <= 16 * per_cu && tp.B >= 1 && (tp.nwn == 1 || tp.nwn == 2 || tp.nwn == 4) &&
                      tp.ntile_n >= 1 && tp.ranks % tp.ntile_n == 0, "trunk: bad parameters");
@@ -417,9 +420,9 @@ int launch_trunk(const TrunkParams& tp, size_t lds, hipStream_t stream) {
     const int groups = (tp.B + 7) / 8;
     const int grid = 8 * tp.ranks * groups;
     RLDM_REQUIRE(grid <= 256 * per_cu, "trunk: the grid must be co-resident (one workgroup per CU; two of the 4-wave variant)");
-    static DynLdsLimit lds_limit[5];             // per instantiation and device, thread safe
+    static DynLdsLimit lds_limit[6];             // per instantiation and device, thread safe
     const int cl = tp.variant;
-    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : (cl == 3 ? trunk_kernel<3> : trunk_kernel<4>)));
+    auto kern = cl == 0 ? trunk_kernel<0> : (cl == 1 ? trunk_kernel<1> : (cl == 2 ? trunk_kernel<2> : (cl == 3 ? trunk_kernel<3> : (cl == 4 ? trunk_kernel<4> : trunk_kernel<5>))));
     RLDM_HIP_CHECK(lds_limit[cl].ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(cl == 4 ? 256 : 512), lds, stream, tp);
     RLDM_HIP_CHECK(hipGetLastError());

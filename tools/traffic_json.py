@@ -37,7 +37,11 @@ def op_name(k):
     m = re.match(r"trunk_kernel<(\d+)>", k)
     if m:       # persistent launches: one entry per kernel variant (bench.py scales it by a launch's share of the variant's phases)
         return "trunk_kernel<" + ("conv_small image tiles", "conv_small 64x64 clusters", "conv_stream 256x128", "conv_stream 128x64",
-                                 "conv_stream 128x128 x2/CU")[int(m.group(1))] + ">"
+                                 "conv_stream 128x128 x2/CU", "conv_stream 64x128")[int(m.group(1))] + ">"
+    if re.match(r"attention_qkv2_d8_kernel<1>", k):      # bench.py's name of the 1024-token launch with its fused output projection
+        return "attention_qkv_d8_kernel + to_out"
+    if re.match(r"attention_qkv2_d8_kernel<0>", k):
+        return "attention_qkv_d8_kernel"
     return re.sub(r"\(.*$", "", k)
 
 
