@@ -6,6 +6,12 @@
 #include "kernels.h"
 #include "trunk_seam.h"
 
+#include <type_traits>
+
+#ifndef RLDM_ATTN_WEAVE
+#define RLDM_ATTN_WEAVE 1           /* 0: the round-2 block form of the two-chain key loop (A/B builds) */
+#endif
+
 namespace rldm {
 
 // One 32-query tile against all Lp keys staged in LDS (sK rows, sVt = V^T in consumption order + ones + zero rows).
@@ -509,12 +515,92 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
     f32x16 oA, oB, sA, sB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oA[r] = 0.f; oB[r] = 0.f; }
+    uint4 v0, v1;
+#if RLDM_ATTN_WEAVE
+    if constexpr (PAIR) {
+        // (round 5) the two chains WOVEN at instruction granularity instead of block by block: in the block form a wave issued
+        // [24 VALU][PV][PV][S] per chain and stalled twice per chain at the matrix pipe (PV2 behind PV1 on the same accumulator, S behind
+        // PV2: SQ_WAIT_INST_ANY 34 % of the wave cycles, profiles/round5_v1_pmc_valu.txt; 207 cycles per 32 x 32 tile against 144 of VALU).
+        // Here no two MFMAs of a wave are closer than four exponentials (32 cycles = one 32x32x16 on the pipe) and every MFMA's operands
+        // were produced >= 8 VALU instructions earlier:
+        //   expA 0-3 | S_B(k0) | expA 4-7, packs | PV_A1 | expA 8-15, packs | PV_A2 | expB 0-3 | S_A(k0 + 32) | expB 4-7, packs | PV_B1 |
+        //   expB 8-15, packs | PV_B2 | (next iteration's expA 0-3 cover PV_B2)
+        // On entry of iteration k0: sA = S_A(k0), kf = K(k0) (S_B(k0) is issued inside the iteration), v0 / v1 = V^T(k0).
+        // Same MFMAs on the same operands in the same per-accumulator order as the block form: identical results bit for bit.
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[0]), zero, 0, 0, 0);
+        v0 = *reinterpret_cast<const uint4*>(vptr);
+        v1 = *reinterpret_cast<const uint4*>(vptr + 16);
+        auto ex = [](f32x16& s, const int r0, const int r1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r >= r0 && r < r1) s[r] = __builtin_amdgcn_exp2f(s[r]);
+        };
+        auto pk4 = [](const f32x16& s, const int r0) __attribute__((always_inline)) {
+            return make_uint4(pack_bf16x2(s[r0], s[r0 + 1]), pack_bf16x2(s[r0 + 2], s[r0 + 3]), pack_bf16x2(s[r0 + 4], s[r0 + 5]),
+                              pack_bf16x2(s[r0 + 6], s[r0 + 7]));
+        };
+        // (two copies of the loop: with keys past L to mask in the last tile, and without -- the mask's index arithmetic is otherwise hoisted
+        //  to the top of EVERY iteration: 18 extra VALU instructions beside 48)
+        auto key_loop = [&](auto ragged_c) __attribute__((always_inline)) {
+        constexpr bool RG = decltype(ragged_c)::value;
+        for (int k0 = 0; k0 < Lp; k0 += 32) {
+            const bool last_ragged = RG && k0 + 32 > L;
+            if (last_ragged) {                                // last tile: keys >= L get -inf scores
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) sA[r] = -1e30f;
+            }
+            ex(sA, 0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[TPW - 1]), zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            kf = *reinterpret_cast<const uint4*>(kptr);      // K(k0 + 32): consumed by S_A(k0 + 32) half an iteration from now
+            kptr += kstep;
+            ex(sA, 4, 8);
+            uint4 pa = pk4(sA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            oA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), __builtin_bit_cast(bf16x8, pa), oA, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ex(sA, 8, 16);
+            pa = pk4(sA, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            oA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), __builtin_bit_cast(bf16x8, pa), oA, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (last_ragged) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) sB[r] = -1e30f;
+            }
+            ex(sB, 0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[0]), zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ex(sB, 4, 8);
+            uint4 pb = pk4(sB, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            oB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), __builtin_bit_cast(bf16x8, pb), oB, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ex(sB, 8, 16);
+            pb = pk4(sB, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            oB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), __builtin_bit_cast(bf16x8, pb), oB, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // next iteration's V^T fragments (first used behind eight exponentials of the next iteration)
+            v0 = *reinterpret_cast<const uint4*>(vptr + k0 + 32);
+            v1 = *reinterpret_cast<const uint4*>(vptr + k0 + 48);
+        }
+        };
+        if (ragged) key_loop(std::true_type{});
+        else key_loop(std::false_type{});
+    } else
+#endif
+    {
     sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[0]), zero, 0, 0, 0);
     if (PAIR) sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qB[TPW - 1]), zero, 0, 0, 0);
     kf = *reinterpret_cast<const uint4*>(kptr);
     kptr += kstep;
-    uint4 v0 = *reinterpret_cast<const uint4*>(vptr);
-    uint4 v1 = *reinterpret_cast<const uint4*>(vptr + 16);
+    v0 = *reinterpret_cast<const uint4*>(vptr);
+    v1 = *reinterpret_cast<const uint4*>(vptr + 16);
     for (int k0 = 0; k0 < Lp; k0 += 32) {
         if (ragged && k0 + 32 > L) {                      // last tile: keys >= L get -inf scores
 #pragma unroll
@@ -547,6 +633,7 @@ __device__ __forceinline__ void attention_qkv2_body(const AttnQkvParams& p, cons
         kptr += kstep;
         v0 = *reinterpret_cast<const uint4*>(vptr + k0 + 32);
         v1 = *reinterpret_cast<const uint4*>(vptr + k0 + 48);
+    }
     }
     RLDM_ASTAMP();                                        // 6: key loop done
 #ifdef RLDM_ABLATE
