@@ -24,11 +24,11 @@
 
 namespace rldm {
 
-template <int NWN, int CPT, int TAPS, int MI>
+template <int NWN, int CPT, int TAPS, int MI, bool H16 = false>
 __global__ void __launch_bounds__(512, 1) conv_small_kernel(const ConvParams p) {
     bf16x8 wpf[kTrunkPrefetch];                             // (persistent trunk only: unused here)
     const TrunkSeam none = {};
-    conv_small_body<NWN, CPT, TAPS, MI, false>(p, blockIdx.x, blockIdx.y, blockIdx.z, wpf, none);
+    conv_small_body<NWN, CPT, TAPS, MI, false, kTrunkPrefetch, H16>(p, blockIdx.x, blockIdx.y, blockIdx.z, wpf, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -41,7 +41,7 @@ int conv_small_col_bytes(int Cin, int TH, int taps) {
     return slots * 16;
 }
 
-int conv_small_kgroups(int BN) { return 8 / (BN / 32); }
+int conv_small_kgroups(int BN) { return BN <= 32 ? 8 : 8 / (BN / 32); }     // (16-channel tiles: 8 k-groups of 32-channel steps)
 
 size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN) {
     const int BM = 64, KG = conv_small_kgroups(BN);             // (epilogue: 64-pixel half-tiles)
@@ -56,6 +56,7 @@ size_t conv_small_lds_bytes(const ConvParams& p, int taps, int BN) {
 
 // k-steps per tap of one k-group, or 0 if the kernel is not instantiated for this (taps, BN, Cin)
 static int small_cpt(int Cin, int taps, int BN) {
+    if (BN == 16) return (Cin == 256 || (Cin == 512 && taps == 9)) ? Cin / 256 : 0;      // (k-steps of 32 channels x 8 k-groups)
     const int KG = conv_small_kgroups(BN);
     if (Cin % (16 * KG) != 0 || Cin > 512) return 0;
     const int cpt = Cin / (16 * KG);
@@ -65,7 +66,9 @@ static int small_cpt(int Cin, int taps, int BN) {
 
 bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     const int Cin = p.C0 + p.C1, R = p.R0 + p.R1;
-    if (BN != 32 && BN != 64 && BN != 128) return false;
+    if (BN != 16 && BN != 32 && BN != 64 && BN != 128) return false;
+    // (round 5) 16-channel tiles: image-owning 64-pixel tiles only, pre-activated or plain input (no statistics fold in the staging)
+    if (BN == 16 && (p.TW * p.TH != 64 || p.tiles_img != 1 || p.up != 1 || p.st0 != nullptr || p.C1 != 0)) return false;
     if ((taps != 9 && taps != 1) || p.stride != 1 || (p.up != 1 && !(p.up == 2 && taps == 9 && p.R0 + p.R1 == 0 && !p.res)) ||
         p.pad_lo != (taps == 9 ? 1 : 0) || p.y_nchw || p.ksplit > 1)
         return false;
@@ -73,9 +76,10 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     if (p.C1 != 0 && !(taps == 9 && p.st0 != nullptr && p.C0 % 8 == 0 && p.C1 % 8 == 0)) return false;
     if (p.st0 != nullptr && (p.gn_groups > 64 || Cin % p.gn_groups != 0)) return false;   // GroupNorm (+ SiLU) folded into the staging
     const int KG = conv_small_kgroups(BN), cpt = small_cpt(Cin, taps, BN);
-    if (cpt == 0 || p.N % BN != 0 || R % (16 * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
-    const int G = (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;
-    if (R / (16 * KG) > std::min(G, 8)) return false;
+    const int ksc = BN == 16 ? 32 : 16;
+    if (cpt == 0 || p.N % BN != 0 || R % (ksc * KG) != 0 || p.R0 % 8 != 0 || R > 512) return false;
+    const int G = BN == 16 ? (taps == 1 ? 1 : 9) * cpt : (taps == 1 ? 1 : (cpt <= 4 ? 3 : 1)) * cpt;
+    if (R / (ksc * KG) > std::min(G, 8)) return false;
     const int BMpx = p.TW * p.TH;
     if ((BMpx != 32 && BMpx != 64 && BMpx != 128) || (p.TH < 2 && BMpx != 32) || p.TW + 2 > 40 || p.Win * p.up < 2) return false;
     // 32-pixel tiles (32x1 images): the 256- / 512-channel 3x3 convs and the 256-channel pointwise conv, 32-channel tiles
@@ -89,9 +93,9 @@ bool conv_small_supported(const ConvParams& p, int taps, int BN) {
     return conv_small_lds_bytes(p, taps, BN) <= 160 * 1024;
 }
 
-template <int NWN, int CPT, int TAPS, int MI>
+template <int NWN, int CPT, int TAPS, int MI, bool H16 = false>
 static int launch_small_inst(const ConvParams& p, size_t lds, hipStream_t stream) {
-    auto kern = conv_small_kernel<NWN, CPT, TAPS, MI>;
+    auto kern = conv_small_kernel<NWN, CPT, TAPS, MI, H16>;
     static DynLdsLimit lds_limit;                // per device, thread safe
     RLDM_HIP_CHECK(lds_limit.ensure(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(p.ntile_n, p.tiles_img, p.B), dim3(512), lds, stream, p);
@@ -104,6 +108,12 @@ int launch_conv_small(const ConvParams& p, int taps, int BN, hipStream_t stream)
     const size_t lds = conv_small_lds_bytes(p, taps, BN);
     const int cpt = small_cpt(p.C0 + p.C1, taps, BN);
     const int mi = p.TW * p.TH / 32;
+    if (BN == 16) {                             // (round 5) 16-channel image-owning tiles
+        if (cpt == 1 && taps == 9) return launch_small_inst<1, 1, 9, 2, true>(p, lds, stream);
+        if (cpt == 2 && taps == 9) return launch_small_inst<1, 2, 9, 2, true>(p, lds, stream);
+        if (cpt == 1 && taps == 1) return launch_small_inst<1, 1, 1, 2, true>(p, lds, stream);
+        RLDM_REQUIRE(false, "conv_small: no 16-channel instance");
+    }
 #define RLDM_SMALL4(NWN_, CPT_, TAPS_, MI_) \
     if (BN == 32 * NWN_ && cpt == CPT_ && taps == TAPS_ && mi == MI_) return launch_small_inst<NWN_, CPT_, TAPS_, MI_>(p, lds, stream);
 #define RLDM_SMALL(NWN_, CPT_, TAPS_) RLDM_SMALL4(NWN_, CPT_, TAPS_, 2)

@@ -7,6 +7,10 @@
 #include "kernels.h"
 #include "trunk_seam.h"
 
+#ifndef RLDM_H16_NB
+#define RLDM_H16_NB 3               /* k-steps of pixel fragments per LDS block of the 16-channel K loop (x 4 fragments each) */
+#endif
+
 namespace rldm {
 
 __device__ __forceinline__ void lds_barrier_s() {
@@ -17,11 +21,17 @@ __device__ __forceinline__ void lds_barrier_s() {
 // BM = 32 * MI pixels (64: the 64x4 / 32x2 levels and the pointwise convs; 128: the 128x8 level; 32: 32x1 images -- the lowest nuScenes level), BN = 32 * NWN channels, C_in = 16 * KG * CPT channels (CPT = a k-group's steps per tap), 512 threads.
 // TAPS == 9: 3x3 over a pre-activated input.  TAPS == 1: pointwise (attention q/k/v and output projections); there the
 // GroupNorm affine (no separate launch: one FMA per element while the tile is on its way to LDS) is folded in.
-template <int NWN, int CPT, int TAPS, int MI, bool TRUNK, int PF = kTrunkPrefetch>
+// (round 5) H16: a 16-channel tile -- an image of the 32x2 level is then 16 workgroups, the level runs on all 256 CUs at batch 16 and a
+// workgroup's K loop, weight stream and epilogue halve.  v_mfma_f32_16x16x32_bf16: a k-step is 32 channels of a tap (k-group kg owns the
+// 32-channel groups kg, kg + 8, ...), a weight fragment (16 channels x 32 k = 1 KiB, lane l: channel l & 15, k = 8 (l >> 4) .. + 8) feeds the
+// tile's four 16-pixel fragments; only image-owning 64-pixel tiles (NWN == 1, MI == 2), C_in = 256 * CPT.
+template <int NWN, int CPT, int TAPS, int MI, bool TRUNK, int PF = kTrunkPrefetch, bool H16 = false>
 __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int nt, const int mt, const int b, bf16x8 (&wpf)[kTrunkPrefetch],
                                                 const TrunkSeam& seam) {
-    constexpr int NT = 512, KG = 8 / NWN, BM = 32 * MI, BN = 32 * NWN;
-    constexpr int CIN = 16 * KG * CPT, C8 = CIN / 8;
+    static_assert(!H16 || (NWN == 1 && MI == 2 && CPT <= 2), "16-channel tiles: image-owning 64-pixel tiles over 256 / 512 input channels");
+    constexpr int NT = 512, KG = 8 / NWN, BM = 32 * MI, BN = H16 ? 16 : 32 * NWN;
+    constexpr int KSC = H16 ? 32 : 16;          // input channels per k-step
+    constexpr int CIN = KSC * KG * CPT, C8 = CIN / 8;
     constexpr int RSM = CIN * 2 + 16;          // image row stride (bytes): C8 + 1 16-byte slots, odd
     constexpr int HALO = TAPS == 9 ? 1 : 0;
     // taps per unrolled group: all nine when a k-group has <= 2 steps per tap (the ring then holds the wave's WHOLE main stream --
@@ -40,7 +50,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     // staging batch: columns per wave x row groups in flight (128-pixel tiles are 16 wide: 18 halo columns, 3 per wave,
     // and all of a wave's pieces are requested before the first is stored)
     constexpr int NCW = MI >= 4 ? 3 : 5, KB = MI >= 4 ? (10 + SPI - 1) / SPI : 4;
-    static_assert(C8 <= 64 && G % PFX == 0 && TAPS % TPG == 0 && PFX <= G, "shape");
+    static_assert(C8 <= 64 && TAPS % TPG == 0 && (H16 || (G % PFX == 0 && PFX <= G)), "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tid_ = threadIdx.x;
     // (a phase of the persistent launch: the thread index is made opaque per phase, or every lane-dependent constant of every
@@ -154,7 +164,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     RLDM_STAMP();                               // small requests (bias, statistics partials, affines) issued
     // ---- this wave's weight stream: [9 * CPT main steps (tap-major)][RPT residual steps], 1 KiB each; lane l holds channel
     // l & 31, k = 8 * (l >> 5) .. + 8 of the step.  The first G fragments are requested before anything else.
-    const int RPT = (R >> 4) / KG;              // residual steps of this k-group (<= RMAX)
+    const int RPT = (R / KSC) / KG;             // residual steps of this k-group (<= RMAX)
     const int nmine = TAPS * CPT + RPT;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wpk) +
                                  ((size_t)((nt * NWN + wn) * KG + kg) * nmine) * 1024;      // uniform
@@ -375,7 +385,16 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
     RLDM_STAMP();
 
     // ---- accumulators: k-group 0 carries bias + temb ---------------------------------------------------------------
-    f32x16 acc[AS][MI];
+    f32x16 acc[H16 ? 1 : AS][H16 ? 1 : MI];
+    constexpr int PT = 2 * MI;                  // (H16) 16-pixel fragments of the tile
+    f32x4 acc16[H16 ? PT : 1];
+    const int l15 = lane & 15, k4 = lane >> 4;  // (H16) lane = (pixel / channel l15, 8-wide k slot / 4-channel row group k4)
+    if constexpr (H16) {
+        float4 bv = *reinterpret_cast<const float4*>(sBias + 4 * k4);
+        if (kg != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) { acc16[pt][0] = bv.x; acc16[pt][1] = bv.y; acc16[pt][2] = bv.z; acc16[pt][3] = bv.w; }
+    } else {
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         float4 bv = *reinterpret_cast<const float4*>(sBias + wn * 32 + 8 * r4 + 4 * kh);
@@ -388,6 +407,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
                 acc[a][mi][r4 * 4 + 0] = bv.x * z; acc[a][mi][r4 * 4 + 1] = bv.y * z;
                 acc[a][mi][r4 * 4 + 2] = bv.z * z; acc[a][mi][r4 * 4 + 3] = bv.w * z;
             }
+    }
     }
 
     // ---- identity residual (y = conv + x): fetched now, added in fp32 in the epilogue ------------------------------------
@@ -407,6 +427,65 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         }
 
     // ---- barrier-free K loop ------------------------------------------------------------------------------------------
+    if constexpr (H16) {
+        // the ring holds the wave's WHOLE main stream (9 * CPT <= 18 fragments: requested by the previous phase / at entry), so the loop is
+        // one straight run: per k-step four MFMAs on one weight fragment, the pixel fragments at column base + immediate
+        int xc[PT][TAPS == 9 ? 3 : 1], xres16[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int pidx = pt * 16 + l15;
+            const int pw = pidx >> p.th_shift, ph = pidx - (pw << p.th_shift);
+            const int x0 = pw * colb + ph * RSM + k4 * 16 + kg * 64;
+#pragma unroll
+            for (int j = 0; j < (TAPS == 9 ? 3 : 1); ++j) xc[pt][j] = x0 + j * colb;
+            xres16[pt] = abytes + pidx * RSR + k4 * 16 + kg * 64;
+        }
+        const unsigned char* wres = wbase + TAPS * CPT * 1024;
+        // pixel fragments in blocks of NB k-steps, double-buffered: 16 ds_read_b128 per wave in flight while the previous block's 16 MFMAs
+        // run (the loop is LDS-bound -- 64 pixels x K x 2 B = 295 KB per workgroup and phase -- and the LDS only reaches its rate with
+        // >= 16 reads per wait, MI355X_MICROARCH.md; with 2-3 reads ahead the K loop + barrier took 2.9 k cycles whatever the MFMA count)
+        constexpr int NB = RLDM_H16_NB, NBLK = (G + NB - 1) / NB;
+        bf16x8 xb[2][NB * PT];
+        auto issue = [&](const int blk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = blk * NB + j;
+                if (idx >= G) continue;
+                const int tap = idx / CPT, cs = idx % CPT;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    xb[blk & 1][j * PT + pt] = *reinterpret_cast<const bf16x8*>(smem + xc[pt][TAPS == 9 ? tap / 3 : 0] +
+                                                                                 (TAPS == 9 ? (tap % 3) * RSM : 0) + cs * (KG * 64));
+            }
+        };
+        issue(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            if (blk + 1 < NBLK) issue(blk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = blk * NB + j;
+                if (idx >= G) continue;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc16[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[idx], xb[blk & 1][j * PT + pt], acc16[pt], 0, 0, 0);
+                if (idx < RMAX) wr[idx] = *reinterpret_cast<const bf16x8*>(wres + (unsigned)(lane * 16 + max(min(idx, RPT - 1), 0) * 1024));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int idx = 0; idx < RMAX; ++idx) {
+            if (idx < RPT) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(smem + xres16[pt] + idx * (KG * 64));
+                    acc16[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[idx], xv, acc16[pt], 0, 0, 0);
+                }
+            }
+        }
+    } else {
     // NGRP groups of TPG taps; step idx of a group = tap idx / CPT of the group, 16-channel group kg + (idx % CPT) * KG.
     // Per-lane LDS addresses: xa[mi][t] = pixel (mi, lane) at tap t of the current group, xn = the same for the next group.
     int xa[MI][TPG], xn[MI][TPG], xres[MI];
@@ -494,6 +573,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][mi][r] += acc[a][mi][r];
+    }
     RLDM_STAMP();
     // (multi-tile clusters: the next phase's weights are touched into the XCD's L2 now -- trunk_seam.h)
     TrunkWarm warm;
@@ -516,6 +596,12 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
 #pragma unroll
     for (int hp = 0; hp < NHALF; ++hp) {
         if (hp > 0) lds_barrier_s();            // the previous half-tile has been consumed
+        if constexpr (H16) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)     // lane (pixel pt * 16 + l15) holds channels 4 k4 .. + 3
+                *reinterpret_cast<float4*>(sE + (kg * HB + pt * 16 + l15) * FRS + k4 * 16) =
+                    make_float4(acc16[pt][0], acc16[pt][1], acc16[pt][2], acc16[pt][3]);
+        } else {
 #pragma unroll
         for (int m2 = 0; m2 < (MI < 2 ? 1 : 2); ++m2) {
             const int mi = hp * 2 + m2, pl = m2 * 32 + l31;
@@ -525,6 +611,7 @@ __device__ __forceinline__ void conv_small_body(const ConvParams& p, const int n
                 *reinterpret_cast<float4*>(sE + (kg * HB + pl) * FRS + chl * 4) =
                     make_float4(acc[0][mi][r4 * 4 + 0], acc[0][mi][r4 * 4 + 1], acc[0][mi][r4 * 4 + 2], acc[0][mi][r4 * 4 + 3]);
             }
+        }
         }
         lds_barrier_s();
         if (hp == 0) { RLDM_STAMP(); }

@@ -195,7 +195,8 @@ enum TrunkWord {
 // 13 attention with the GroupNorm fold inside (two query tiles per wave)
 // 14 GroupNorm (+ SiLU) of a concatenated input as a phase of its own (norm.hip's gn_apply_kernel; record: x0 / x1 in TW_X0 / TW_R0,
 // their channels in TW_R0C / TW_R1C, statistics in TW_ST0 / TW_RES with TW_P0 / TW_TILES_H partials, pixels per image in TW_WIN)
-enum TrunkKind { TK_ATTN = 3, TK_CL_3x3_128 = 8, TK_CL_3x3_256, TK_CL_3x3_384, TK_CL_3x3_512, TK_CL_1x1_256, TK_ATTN_FOLD, TK_GN_APPLY, TK_STREAM };
+// (round 5) 16..18: the image-owning 64-pixel kinds 0..2 on 16-channel tiles (conv_small_body's H16 instances)
+enum TrunkKind { TK_H16 = 16, TK_ATTN = 3, TK_CL_3x3_128 = 8, TK_CL_3x3_256, TK_CL_3x3_384, TK_CL_3x3_512, TK_CL_1x1_256, TK_ATTN_FOLD, TK_GN_APPLY, TK_STREAM };
 struct TrunkPhase {
     unsigned w[TW_WORDS];
 };

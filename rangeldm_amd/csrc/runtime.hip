@@ -302,6 +302,45 @@ struct ConvLayer {
         packed[key] = std::move(pk);
         return 0;
     }
+
+    // (round 5) conv_small.hip's 16-channel tiles: one stream of 1 KiB k-steps per (16-channel tile, k-group of 8):
+    // [Cout/16][8][taps*CPT main steps (tap-major) + RPT residual steps][64 lanes][8 bf16] + one zero fragment; a k-step is 32 input
+    // channels (v_mfma_f32_16x16x32_bf16: lane l holds channel 16*t + (l & 15), k = 8*(l >> 4) .. +8); k-group kg owns the 32-channel
+    // groups kg, kg + 8, ... of every tap.
+    int get_fragpacked16(int Cin_pad, bool no_res, Packed** out) {
+        auto key = std::make_pair(no_res ? -6 : -5, 16);
+        auto it = packed.find(key);
+        if (it != packed.end()) {
+            RLDM_REQUIRE(it->second->Cin_pad == Cin_pad, "conv layer reused with a different channel padding");
+            *out = it->second.get();
+            return 0;
+        }
+        const int taps = ksize * ksize, Rp = no_res ? 0 : R, KG = 8;
+        RLDM_REQUIRE(Cout % 16 == 0 && Cin_pad % (32 * KG) == 0 && Rp % (32 * KG) == 0, "conv " + name + ": not 16-channel fragment-packable");
+        const int CPT = Cin_pad / 32 / KG, RPT = Rp / 32 / KG, nmine = taps * CPT + RPT;
+        std::vector<bf16_t> img((size_t)(Cout / 16) * KG * nmine * 512 + 512, 0);
+        auto at = [&](int n, int step, int c32, int k) -> bf16_t& {     // step within the stream of k-group c32 % KG
+            const size_t stream = (size_t)(n / 16) * KG + c32 % KG;
+            return img[((stream * nmine + step) * 64 + (k / 8) * 16 + n % 16) * 8 + k % 8];
+        };
+        for (int n = 0; n < Cout; ++n) {
+            for (int c = 0; c < Cin; ++c)
+                for (int tap = 0; tap < taps; ++tap)
+                    at(n, tap * CPT + (c / 32) / KG, c / 32, c % 32) = f32_to_bf16(w[((size_t)n * Cin + c) * taps + tap]);
+            for (int c = 0; c < Rp; ++c) {
+                const float v = sc_identity ? (c == n ? 1.f : 0.f) : sc_w[(size_t)n * R + c];
+                at(n, taps * CPT + (c / 32) / KG, c / 32, c % 32) = f32_to_bf16(v);
+            }
+        }
+        auto pk = std::make_unique<Packed>();
+        if (upload(pk->w, img.data(), img.size() * sizeof(bf16_t))) return 1;
+        if (upload(pk->bias, b.data(), b.size() * sizeof(float))) return 1;
+        pk->ntile_n = 0;
+        pk->Cin_pad = Cin_pad;
+        *out = pk.get();
+        packed[key] = std::move(pk);
+        return 0;
+    }
 };
 
 // (ConvLayer::get_streampacked is defined with the struct above)
@@ -875,7 +914,7 @@ struct Builder {
     // attention core as a trunk phase: x arrives normalised, C / 8 heads split over N / 32 = C / 32 workgroups of 8 waves
     static size_t trunk_attention_lds(int L, int C, int HG) { return attention_qkv2_lds_bytes(L, C, HG, 8); }
     bool trunk_attention_ok(const Tensor& x, bool pre) const {
-        const int L = x.W * x.H, ranks = x.C / 32;
+        const int L = x.W * x.H, ranks = x.C / own_tile_channels(x.B, L, x.C);
         // (x.C % 64: attention_qkv2_body loads x in coalesced 64-channel groups and projects in blocks of 4 k-steps, no tail)
         if (!trunk_enabled() || !pre || x.C % 64 != 0 || ranks < 2 || ranks > 16) return false;
         const int HG = (x.C / 8) / ranks, wph = (L + 31) / 32;
@@ -901,6 +940,13 @@ struct Builder {
     // beside it -- a sampler's other chains (g_concurrent_plans: two 256-workgroup launches could each hold part of the chip and wait
     // for the rest) and the device's real CU count (partitions / smaller parts)
     // (per_cu = 2: the 4-wave conv_stream variant, whose workgroups are built for two per CU)
+    // (round 5) channels per image-owning tile: 16 for the 64-pixel images of the KITTI network's 32x2 level (256 output channels -> 16
+    // workgroups per image), when that grid is resident at once; 32 otherwise.  RLDM_OWN16=0 keeps 32 everywhere (A/B runs).
+    static bool own16_enabled() { static const bool on = !(getenv("RLDM_OWN16") && atoi(getenv("RLDM_OWN16")) == 0); return on; }
+    static int own_tile_channels(int B, int npix, int N) {
+        return (own16_enabled() && trunk_tiles() && npix == 64 && N == 256 && trunk_grid_fits(16, B)) ? 16 : 32;    // (trunk_tiles(), not trunk_enabled():
+        // the per-layer fall-back -- 1 << 24 -- keeps the persistent launches' tiles, so its results stay identical)
+    }
     static bool trunk_grid_fits(int ranks, int B, int per_cu = 1) {
         return 8 * ranks * ((B + 7) / 8) * std::max(1, g_concurrent_plans) <= device_cus() * per_cu;
     }
@@ -1100,8 +1146,11 @@ struct Builder {
         p.dbg = dbg();
         p.ts = (getenv("RLDM_TS_ATTN_L") || getenv("RLDM_TS_TRUNK")) ? nullptr : g_ts_buf;      // (the attention timeline owns the buffer then)
         if (getenv("RLDM_TS_ORD")) p.ts = atoi(getenv("RLDM_TS_ORD")) == conv_ord - 1 ? g_ts_buf : nullptr;
-        const int BN = small_bn(p, taps, gn_fused, a.own_image);
+        int BN = small_bn(p, taps, gn_fused, a.own_image);
         RLDM_REQUIRE(BN != 0, "conv " + L->name + ": conv_small route lost its instance");
+        // (round 5) image-owning tiles of the 32x2 level: 16 channels per workgroup -- the level's persistent launch then runs on 16
+        // workgroups per image (all 256 CUs at batch 16) with half the K loop, weight stream and epilogue per workgroup
+        if (BN == 32 && a.own_image && own_tile_channels(x0.B, p.TW * p.TH, N) == 16 && !gn_fused && conv_small_supported(p, taps, 16)) BN = 16;
         p.ntile_n = N / BN;
 
         Tensor y = make(x0.B, Wout, Hout, N);
@@ -1124,9 +1173,9 @@ struct Builder {
         const int cpt_t = Cin_t / 128;
         const int px_t = p.TW * p.TH;
         const int kind_l = (taps == 9 && Cin_t == 256) ? 0 : ((taps == 9 && Cin_t == 512) ? 1 : ((taps == 1 && Cin_t == 256) ? 2 : -1));
-        const int trunk_kind = kind_l < 0 ? -1 : kind_l + (px_t == 32 ? 4 : 0);      // (+4: the 32-pixel instances)
-        const int ranks_t = N / 32;
-        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && BN == 32 && (px_t == 64 || px_t == 32) && !gn_fused &&
+        const int trunk_kind = kind_l < 0 ? -1 : kind_l + (BN == 16 ? TK_H16 : (px_t == 32 ? 4 : 0));      // (+4: the 32-pixel instances; +16: 16-channel tiles)
+        const int ranks_t = N / BN;
+        bool in_trunk = trunk_enabled() && a.own_image && p.tiles_img == 1 && (BN == 32 || BN == 16) && (px_t == 64 || px_t == 32) && !gn_fused &&
                         trunk_kind >= 0 && p.up == 1 && ranks_t >= 2 && ranks_t <= 16 && trunk_grid_fits(ranks_t, x0.B) &&
                         2 * p.TH * (Cin_t / 8) <= 512 && vts.size() <= 2;
         // (a concatenated input is normalised by a gn_apply phase in front of the conv's -- or the conv stays a launch of its own)
@@ -1195,7 +1244,7 @@ struct Builder {
         (void)cpt_t;
         if (!dry) {
             ConvLayer::Packed* pk = nullptr;
-            if (L->get_fragpacked(Cin_t, conv_small_kgroups(BN), epi_res, &pk)) return 1;
+            if (BN == 16 ? L->get_fragpacked16(Cin_t, epi_res, &pk) : L->get_fragpacked(Cin_t, conv_small_kgroups(BN), epi_res, &pk)) return 1;
             p.x0 = tptr(x0);
             p.r0 = epi_res ? nullptr : tptr(a.r0);
             p.r1 = epi_res ? nullptr : tptr(a.r1);
@@ -1267,12 +1316,12 @@ struct Builder {
                     put64(TW_X1, p.x1); put64(TW_ST1, p.st1);
                     ph.w[TW_C0] = p.C0; ph.w[TW_C1] = p.C1; ph.w[TW_P1] = p.P1;
                 } else {
-                const int cpt = Cin_t / 128, KG = 8;
-                const int G = (trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt);
+                const int KG = 8, ksc = BN == 16 ? 32 : 16, cpt = Cin_t / (ksc * KG);
+                const int G = BN == 16 ? (taps == 9 ? 9 : 1) * cpt : ((trunk_kind & 3) == 0 ? 18 : ((trunk_kind & 3) == 1 ? 12 : cpt));
                 ph.w[TW_KIND] = trunk_kind;
                 ph.w[TW_G] = std::min(G, RLDM_TRUNK_PREFETCH);       // == kTrunkPrefetch (conv_small_body.h)
-                ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / 16) / KG;
-                ph.w[TW_WBYTES] = (unsigned)((N / 32) * KG * ph.w[TW_NMINE]) * 1024u;
+                ph.w[TW_NMINE] = taps * cpt + ((p.R0 + p.R1) / ksc) / KG;
+                ph.w[TW_WBYTES] = (unsigned)((N / BN) * KG * ph.w[TW_NMINE]) * 1024u;
                 }
                 ph.w[TW_TEMBOFF] = (unsigned)temb_off;
                 for (int v = 0; v < p.nviews; ++v) {
@@ -2292,7 +2341,7 @@ struct NetCommon {
             b.plan->flops += fl;
             bool in_trunk = b.trunk_attention_ok(x, pre);           // a phase of the persistent trunk launch (trunk.hip)
             const int cl_ranks = in_trunk ? 0 : b.cluster_attention_ranks(x, pre);
-            if (in_trunk) b.trunk_begin(x.B, x.C / 32);
+            if (in_trunk) b.trunk_begin(x.B, x.C / Builder::own_tile_channels(x.B, Lt, x.C));
             else if (cl_ranks) b.trunk_begin(x.B, cl_ranks, x.C / 64, 2);
             else b.note_launch();
             in_trunk = in_trunk || cl_ranks != 0;

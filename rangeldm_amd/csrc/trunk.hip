@@ -321,6 +321,10 @@ __global__ void __launch_bounds__(V == 4 ? 256 : 512, V == 4 ? 2 : 1) trunk_kern
                 case 4: conv_small_body<1, 2, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
                 case 5: conv_small_body<1, 4, 9, 1, true>(cp, rank, 0, b, wpf, seam); break;
                 case 6: conv_small_body<1, 2, 1, 1, true>(cp, rank, 0, b, wpf, seam); break;
+                // (round 5) 16-channel tiles: 16 workgroups per image (C_in 256 / 512 for the 3x3, 256 for the pointwise conv)
+                case TK_H16 + 0: conv_small_body<1, 1, 9, 2, true, kTrunkPrefetch, true>(cp, rank, 0, b, wpf, seam); break;
+                case TK_H16 + 1: conv_small_body<1, 2, 9, 2, true, kTrunkPrefetch, true>(cp, rank, 0, b, wpf, seam); break;
+                case TK_H16 + 2: conv_small_body<1, 1, 1, 2, true, kTrunkPrefetch, true>(cp, rank, 0, b, wpf, seam); break;
                 case TK_GN_APPLY: {             // (a phase without weights: the next conv's first fragments are requested here)
                     gn_apply_phase(cp, rank, ranks, b, seam);
                     const int next_g = (int)rl(nrec, TW_G);
