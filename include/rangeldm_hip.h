@@ -272,6 +272,56 @@ int rldm_train_gn_forward(const float* x, int B, int npix, int C, int groups, fl
 int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, int B, int npix, int C, int groups,
                            const float* gamma, const float* beta, int silu, float* scratch /*[B][groups][2]*/, float* dx,
                            int accumulate, float* dgamma, float* dbeta, void* stream);
+/* ---- fused tape (round 5): GroupNorm never runs as a tensor pass of its own ----------------------------------------------
+ * A tensor's GroupNorm statistics travel as per-(image, channel) pairs cs [B][C][2] = (sum, sum of squares), accumulated
+ * (atomically, into a buffer the caller zeroed) by the epilogue of the conv that produced the tensor.  Consumers rebuild
+ * act(GroupNorm(x)) from x + cs while they stage x -- the reference's `F.silu(norm(x))` in front of every ResnetBlock2D conv
+ * and `group_norm(x)` in front of to_q/k/v (sgm model.py:93-125, diffusers ResnetBlock2D / Attention) -- and a concatenated
+ * input (`torch.cat([h, skip], 1)` of the up blocks) is read from its two sources in place.  Backward: the data-gradient conv
+ * whose output is d act(GN(g)) turns it into dz = dy act'(z) in its epilogue and accumulates gs [B][C][2] = (sum dz, sum dz
+ * xhat); rldm_train_gn_backward_apply finishes dx (+ residual gradient, split over the two sources) and d gamma / d beta. */
+typedef struct rldm_train_fuse {
+    /* input side (conv, wgrad: the `x` operand) */
+    const float* x1;            /* second source: channels [C0, Cin) of the input (NULL: `x` holds all Cin)                */
+    int32_t C0;                 /* channels of `x` when x1 != NULL (a multiple of 64 -- 32 when Cin % 64 != 0)             */
+    const float* cs0;           /* (sum, sumsq) pairs of x / x1; cs0 == NULL: the input is used as it is                   */
+    const float* cs1;
+    const float* gamma;         /* GroupNorm affine over the Cin channels                                                  */
+    const float* beta;
+    int32_t silu, groups;
+    float eps;
+    /* output side (conv only; at most one of the two) */
+    float* cs_out;              /* += (sum, sumsq) of y per (image, channel): [B][N][2]                                    */
+    const float* g0;            /* data gradient: y = d act(GN(cat(g0, g1))); stored as dz, gs_out [B][N][2] += sums       */
+    const float* g1;
+    int32_t G0;                 /* channels of g0 when g1 != NULL                                                          */
+    const float* gcs0;          /* (sum, sumsq) pairs of g0 / g1                                                           */
+    const float* gcs1;
+    const float* ggamma;
+    const float* gbeta;
+    int32_t gsilu, ggroups;
+    float geps;
+    float* gs_out;
+} rldm_train_fuse;
+/* rldm_train_conv with the above folded in.  prezeroed: as `accumulate` of rldm_train_conv for split launches (y is a zeroed
+ * buffer of the caller); a fused epilogue never adds onto an existing y.  _ok: 1 if the shape has a fused instance. */
+int rldm_train_conv_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* f, int rowadd_ld);
+int rldm_train_conv_fused(const rldm_train_conv_desc* d, const rldm_train_fuse* f, const float* x, const void* w_packed,
+                          const float* bias, const float* rowadd, int rowadd_ld, const float* res, float* y, int prezeroed,
+                          void* stream);
+/* rldm_train_wgrad_bias with x = act(GN(cat(x, x1))) rebuilt while staging (input side of `f` only). */
+int rldm_train_wgrad_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* f);
+int rldm_train_wgrad_fused(const rldm_train_conv_desc* d, const rldm_train_fuse* f, const float* dy, const float* x, float* dw,
+                           float* rows, int rows_ld, int rows_accumulate, float* total, void* stream);
+/* cs [B][C][2] += (sum, sumsq) per (image, channel) of x [B][npix][C]: for tensors no fused conv produced. */
+int rldm_train_chan_stats(const float* x, int B, int npix, int C, float* cs, void* stream);
+/* dx = rstd (gamma dz - mean_g(gamma dz) - xhat mean_g(gamma dz xhat)) + res, the GroupNorm over cat(x0, x1) [C0 | C - C0
+ * channels]; written (accumulate == 0) or added to dx0 / dx1; dgamma[c] += sum_b gs[b][c].y, dbeta[c] += sum_b gs[b][c].x
+ * (both may be NULL).  res: [B][npix][C] or NULL. */
+int rldm_train_gn_backward_apply(const float* dz, const float* x0, const float* x1, int C0, const float* cs0, const float* cs1,
+                                 const float* gs, int B, int npix, int C, int groups, float eps, const float* gamma,
+                                 const float* res, float* dx0, int accumulate0, float* dx1, int accumulate1, float* dgamma,
+                                 float* dbeta, void* stream);
 /* Linear layers on B <= 16 rows (TimestepEmbedding MLP, ResnetBlock2D.time_emb_proj): y[b][n] (+)= sum_k x[b][k]
  * W[n][k] + bias[n] with W the packed bf16 copy [N][ceil16(K)] (forward copy; the transposed copy gives the data gradient);
  * x / y rows may be slices of wider matrices (ldx / ldy in floats).  _wgrad: dw [N][K] fp32 += dy^T x, dbias[n] += sum_b dy. */

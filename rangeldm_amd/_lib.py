@@ -48,6 +48,15 @@ class TrainConvDescC(C.Structure):
                 ("taps", C.c_int32), ("stride", C.c_int32), ("mode", C.c_int32)]
 
 
+class TrainFuseC(C.Structure):
+    """rldm_train_fuse (include/rangeldm_hip.h): what a fused conv / weight-gradient launch folds in."""
+    _fields_ = [("x1", C.c_void_p), ("C0", C.c_int32), ("cs0", C.c_void_p), ("cs1", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("silu", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float), ("cs_out", C.c_void_p),
+                ("g0", C.c_void_p), ("g1", C.c_void_p), ("G0", C.c_int32), ("gcs0", C.c_void_p), ("gcs1", C.c_void_p),
+                ("ggamma", C.c_void_p), ("gbeta", C.c_void_p), ("gsilu", C.c_int32), ("ggroups", C.c_int32), ("geps", C.c_float),
+                ("gs_out", C.c_void_p)]
+
+
 class PackDescC(C.Structure):
     _fields_ = [("first", C.c_int64), ("param_offset", C.c_int64), ("w_forward", C.c_void_p), ("w_transposed", C.c_void_p),
                 ("N", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("pad_", C.c_int32)]
@@ -115,6 +124,13 @@ PROTOTYPES = {
     "rldm_train_gn_forward": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P]),
     "rldm_train_gn_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int,
                                          _P, _P, _P]),
+    "rldm_train_conv_fused_ok": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), C.c_int]),
+    "rldm_train_conv_fused": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "rldm_train_wgrad_fused_ok": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC)]),
+    "rldm_train_wgrad_fused": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_chan_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_gn_backward_apply": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P,
+                                               _P, C.c_int, _P, C.c_int, _P, _P, _P]),
     "rldm_train_linear_rows": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rldm_train_linear_rows_wgrad": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rldm_train_attention_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -81,6 +81,137 @@ struct TrConv {
     int B, Win, Hin, Cin, Cin_pad, Wout, Hout, N, taps, stride, mode, rowadd_ld, accumulate;
 };
 
+// (round 5) what the fused launches fold into a conv / weight-gradient kernel (include/rangeldm_hip.h: rldm_train_fuse).  A tensor's
+// GroupNorm statistics travel as per-(image, channel) (sum, sum of squares) pairs "cs" [B][C][2], accumulated by the epilogue of the
+// conv that produced the tensor; a consumer derives (mean, rstd) of its groups from them (a concatenated input = two sources with their
+// own pairs: groups may straddle the seam).  The GroupNorm backward sums travel the same way: "gs" [B][C][2] = (sum dz, sum dz xhat).
+struct TrFuse {
+    const float* x1; int C0;                       // second source of the input: channels [C0, Cin) (null: one source)
+    const float* cs0; const float* cs1;            // input = act(GroupNorm(cat(x, x1))) built while staging (cs0 null: plain input)
+    const float* gamma; const float* beta; int silu, groups; float eps;
+    float* cs_out;                                 // += (sum, sumsq) of y per (image, channel)
+    const float* g0; const float* g1; int G0;      // data-gradient epilogue: y = d act(GroupNorm(cat(g0, g1))) -> dz = y act'(z) stored,
+    const float* gcs0; const float* gcs1;          //   gs_out += (sum dz, sum dz xhat)
+    const float* ggamma; const float* gbeta; int gsilu, ggroups; float geps;
+    float* gs_out;
+    unsigned* tickets;                             // split-K launches: a zeroed arrival counter per output tile (left zeroed)
+};
+
+// (v_exp_f32 + v_rcp_f32: the IEEE division of 1.f / x costs ten more instructions per element of every staged tile)
+__device__ inline float tr_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+
+// y = x * a + b = GroupNorm(x) for the channels [c_lo, c_hi) of image `img` of a (possibly two-source) tensor with npix pixels per
+// image: sc[c] = (a, b).  Every thread sums its own channel's group from global memory (<= 24 pairs, L2 hits): no barrier inside, the
+// caller synchronises before sc is read.
+__device__ inline void tr_gn_coeffs(float2* sc, int c_lo, int c_hi, const float* cs0, const float* cs1, int C0, int C, int img, int groups,
+                                    float eps, int npix, const float* gamma, const float* beta) {
+    const int C1 = C - C0, cpg = C / groups;
+    for (int ch = c_lo + (int)threadIdx.x; ch < c_hi; ch += blockDim.x) {
+        const int g = ch / cpg;
+        double s = 0.0, ss = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float2 v = c < C0 ? reinterpret_cast<const float2*>(cs0)[(size_t)img * C0 + c] : reinterpret_cast<const float2*>(cs1)[(size_t)img * C1 + c - C0];
+            s += (double)v.x; ss += (double)v.y;
+        }
+        const double n = (double)npix * cpg, mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float a = rsqrtf((float)var + eps) * gamma[ch];
+        sc[ch] = make_float2(a, beta[ch] - (float)mean * a);
+    }
+}
+
+// the same for the BN channels [n0, n0 + BN) only, with (mean, rstd) kept: ce[cl] = (a, b, mean, rstd); every thread sums its own group
+// from global memory (<= 24 pairs, L2 hits).  No barrier inside: the caller synchronises before ce is read.
+__device__ inline void tr_gn_coeffs_tile(float4* ce, int BN, int n0, const float* cs0, const float* cs1, int C0, int C, int img, int groups,
+                                         float eps, int npix, const float* gamma, const float* beta) {
+    const int C1 = C - C0, cpg = C / groups;
+    for (int cl = threadIdx.x; cl < BN; cl += blockDim.x) {
+        const int ch = n0 + cl;
+        if (ch >= C) { ce[cl] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        const int g = ch / cpg;
+        double s = 0.0, ss = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float2 v = c < C0 ? reinterpret_cast<const float2*>(cs0)[(size_t)img * C0 + c] : reinterpret_cast<const float2*>(cs1)[(size_t)img * C1 + c - C0];
+            s += (double)v.x; ss += (double)v.y;
+        }
+        const double n = (double)npix * cpg, mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float rstd = rsqrtf((float)var + eps), a = rstd * gamma[ch];
+        ce[cl] = make_float4(a, beta[ch] - (float)mean * a, (float)mean, rstd);
+    }
+}
+
+// Epilogue of a fused conv over the finished fp32 tile in LDS (tile[pl * (BN + 1) + cl], PT pixels of ONE image x BN channels):
+// thread (channel cl = tid % BN, pixel group tid / BN) walks its pixels: + bias / row / residual (add_terms), the GroupNorm-backward
+// transform where asked, the store (coalesced along the channels), and the per-channel sums, which reach cs_out / gs_out as one atomic
+// per (workgroup, channel, component).  colacc: [2 * BN] floats of LDS.
+template <int BN, int PT, int NT>
+__device__ inline void tr_tile_epilogue(const float* tile, float* colacc, const float4* ce, const TrConv& p, const TrFuse& f, int px0,
+                                        int n0, int img, bool add_terms, bool store_y) {
+    constexpr int NPG = NT / BN, IT = PT / NPG, U = IT < 16 ? IT : 16;      // pixels per thread; loads in flight per batch
+    const int tid = threadIdx.x, cl = tid % BN, pg = tid / BN, ch = n0 + cl, N = p.N;
+    for (int e = tid; e < 2 * BN; e += NT) colacc[e] = 0.f;
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    if (ch < N) {
+        float addc = 0.f;
+        if (add_terms) {
+            if (p.bias) addc += p.bias[ch];
+            if (p.rowadd) addc += p.rowadd[(size_t)img * p.rowadd_ld + ch];
+        }
+        const bool gn = f.gs_out != nullptr, act = gn && f.gsilu != 0;
+        const float4 c4 = gn ? ce[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* __restrict__ gsrc = nullptr;
+        int gld = 0;
+        if (gn) {
+            if (ch < f.G0) { gsrc = f.g0 + ch; gld = f.G0; }
+            else { gsrc = f.g1 + (ch - f.G0); gld = N - f.G0; }
+        }
+        const float* __restrict__ rsrc = (add_terms && p.res) ? p.res + ch : nullptr;
+        float* __restrict__ ydst = p.y + ch;
+        // (all of a batch's loads are issued before its first store: one memory latency per batch, not per pixel)
+        for (int i0 = 0; i0 < IT; i0 += U) {
+            float rv[U], gv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t gp = (size_t)px0 + pg + (i0 + u) * NPG;
+                rv[u] = rsrc ? rsrc[gp * N] : 0.f;
+                gv[u] = gn ? gsrc[gp * gld] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pl = pg + (i0 + u) * NPG;
+                const size_t gp = (size_t)px0 + pl;
+                float v = tile[pl * (BN + 1) + cl] + addc + rv[u];
+                if (gn) {
+                    const float g = gv[u], xh = (g - c4.z) * c4.w;
+                    if (act) {
+                        const float z = g * c4.x + c4.y, sg = tr_sigmoid(z);
+                        v *= sg * (1.f + z * (1.f - sg));
+                    }
+                    s1 += v;
+                    s2 += v * xh;
+                    ydst[gp * N] = v;
+                } else {
+                    s1 += v;
+                    s2 += v * v;
+                    if (store_y) ydst[gp * N] = v;
+                }
+            }
+        }
+    }
+    atomicAdd(&colacc[2 * cl], s1);
+    atomicAdd(&colacc[2 * cl + 1], s2);
+    __syncthreads();
+    float* out = f.gs_out ? f.gs_out : f.cs_out;
+    for (int e = tid; e < 2 * BN; e += NT) {
+        const int c2 = n0 + (e >> 1);
+        if (c2 < N) unsafeAtomicAdd(out + ((size_t)img * N + c2) * 2 + (e & 1), colacc[e]);
+    }
+}
+
 // D[channel][pixel]: lane (pixel l & 31, half l >> 5) holds channels (r & 3) + 8 (r >> 2) + 4 half of its pixel.
 // A wave owns 32 pixels x 64 channels (one pixel fragment feeds two MFMAs); a workgroup 64 pixels x 128 channels.
 template <bool FAST>
@@ -160,8 +291,14 @@ __global__ __launch_bounds__(256) void tr_conv_kernel(const TrConv p) {
 // costs one memory latency (~1.5 us measured: activations of a level live in the Infinity Cache, not in L2) against 0.1 us
 // of MFMAs, so the global loads of the next D stages are kept in flight in registers (static ring, loop unrolled by D).
 // Row pitch CK * 2 + 16 bytes: an odd number of 16-byte slots, conflict-free ds_read_b128.
-template <int CK, int BN>
-__global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
+// (round 5) FU: the fused form (TrFuse) -- GroupNorm (+ SiLU) of a one- or two-source input while staging, and the tile epilogue
+// (tr_tile_epilogue: output statistics or the GroupNorm-backward transform + sums), in split-K launches run by each tile's last arriver.
+// (round 5) D: stages of global loads in flight.  D = 3 (the first three stages requested at entry, a slot refilled as soon as it has
+// been copied to LDS) was measured on the low-resolution launches (2 - 9 stages per workgroup) and changes nothing: a 4-stage 1x1 conv of
+// 16 workgroups takes 9.6 us against 9.4 us, the 3x3 convs of the 64x4 level 19.0 against 21.6 us, the step 798 against 796 samples/s --
+// those launches are bound by launch + first-touch + drain latency, not by the per-stage round trip.  Not instantiated.
+template <int CK, int BN, bool FU = false, int D = 1>
+__global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const TrFuse f) {
     static_assert(BN == 64 || BN == 128, "channel tile");
     constexpr int TPR = 256 / BN, NR = BN / 64;     // threads per weight row of a stage; 32-channel MFMA rows per wave
     constexpr int PITCH = CK + 8;                   // bf16 elements
@@ -172,6 +309,10 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     __shared__ __attribute__((aligned(16))) unsigned char raw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
     bf16_t* const sX = reinterpret_cast<bf16_t*>(raw);
     bf16_t* const sW = sX + 64 * PITCH;
+    __shared__ float2 sSc[FU ? 768 : 1];                            // (FU) input GroupNorm: (a, b) per input channel
+    __shared__ float4 sCe[FU ? BN : 1];                             // (FU) epilogue GroupNorm: (a, b, mean, rstd) per tile channel
+    __shared__ float sCol[FU ? 2 * BN : 1];
+    __shared__ int sLast;
     // (native vector types: arrays of HIP's uint4 / float4 structs are not split into registers and went through scratch;
     //  no lambda may capture the by-value argument `p` by reference either: that copies the struct to scratch)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -180,6 +321,9 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     const int l31 = lane & 31, kg = lane >> 5;
     const int P = p.B * Wout * Hout;
     const int px0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
+    const int img = FU ? px0 / (Wout * Hout) : 0;                   // (FU: a tile lies inside one image)
+    const bool in_gn = FU && f.cs0 != nullptr;
+    const int fC0 = FU ? f.C0 : Cin;
     // staging roles
     const int spx = tid >> 2, spart = tid & 3;      // x: pixel row of the tile, quarter of the CK channels
     const int swr = tid / TPR, shalf = tid % TPR;   // w: weight row of the tile, 1 / TPR of the CK channels
@@ -196,11 +340,14 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     int tap = 0, cc = 0;
     const float* xs = xbase;
     float live = 0.f;
+    int sp_cur = 0, scc = 0;                        // (FU) source pixel of the current tap; chunk of the data in the staging registers
+    const float* const x1p = FU ? f.x1 : nullptr;
     auto new_tap = [&]() __attribute__((always_inline)) {
         const int dw = taps == 9 ? tap / 3 - 1 : 0, dh = taps == 9 ? tap % 3 - 1 : 0;
         const int sp = gpx_ok ? src_pixel(sb, swo, sho, dw, dh, p.stride, p.mode, p.Win, p.Hin) : -1;
         live = sp < 0 ? 0.f : 1.f;
-        xs = xbase + (size_t)(sp < 0 ? 0 : sp) * Cin;
+        sp_cur = sp < 0 ? 0 : sp;
+        xs = xbase + (size_t)sp_cur * Cin;
     };
     // split K: workgroup z of gridDim.z contracts stages [it0, it1) and adds its partial tile to y atomically (y zeroed by the
     // launcher; z == 0 carries bias / row / residual).  The low-resolution levels have 32 - 128 output tiles for 36 - 72
@@ -211,18 +358,25 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     wptr += (size_t)tap * Cin_pad + cc * CK;
     new_tap();
     xs += cc * CK;
-    f32x4 xr[XV][2];
-    u32x4 wr[WV];
-    float lv = 0.f;
-    auto fetch = [&]() __attribute__((always_inline)) {
-        lv = live;
-#pragma unroll
-        for (int q = 0; q < XV; ++q) {
-            xr[q][0] = reinterpret_cast<const f32x4*>(xs)[2 * q];
-            xr[q][1] = reinterpret_cast<const f32x4*>(xs)[2 * q + 1];
+    f32x4 xr[D][XV][2];                             // (ring slots: every index below is a compile-time constant after unrolling)
+    u32x4 wr[D][WV];
+    float lvs[D];
+    int sccs[D];
+    auto fetch = [&](const int slot) __attribute__((always_inline)) {
+        lvs[slot] = live;
+        const float* src = xs;
+        if constexpr (FU) {                         // two sources: the chunk lies in one of them (C0 % CK == 0)
+            const int c = cc * CK + spart * (CK / 4);
+            src = c < fC0 ? p.x + (size_t)sp_cur * fC0 + c : x1p + (size_t)sp_cur * (Cin - fC0) + (c - fC0);
+            sccs[slot] = cc;
         }
 #pragma unroll
-        for (int q = 0; q < WV; ++q) wr[q] = reinterpret_cast<const u32x4*>(wptr)[q];
+        for (int q = 0; q < XV; ++q) {
+            xr[slot][q][0] = reinterpret_cast<const f32x4*>(src)[2 * q];
+            xr[slot][q][1] = reinterpret_cast<const f32x4*>(src)[2 * q + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < WV; ++q) wr[slot][q] = reinterpret_cast<const u32x4*>(wptr)[q];
         xs += CK;
         wptr += CK;
         if (++cc == nck) {
@@ -232,17 +386,31 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
             new_tap();
         }
     };
-    auto stash = [&]() __attribute__((always_inline)) {
+    auto stash = [&](const int slot) __attribute__((always_inline)) {
+        const float lv = lvs[slot];
 #pragma unroll
         for (int q = 0; q < XV; ++q) {
-            const f32x4 a = xr[q][0], b = xr[q][1];
+            f32x4 a = xr[slot][q][0], b = xr[slot][q][1];
+            if constexpr (FU) {
+                if (in_gn) {                        // GroupNorm (+ SiLU) of the staged values (zero padding applies to the result: lv below)
+                    const float2* co = sSc + sccs[slot] * CK + spart * (CK / 4) + 8 * q;
+                    const bool act = f.silu != 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float2 c0_ = co[e], c1_ = co[4 + e];
+                        float z0 = a[e] * c0_.x + c0_.y, z1 = b[e] * c1_.x + c1_.y;
+                        if (act) { z0 *= tr_sigmoid(z0); z1 *= tr_sigmoid(z1); }
+                        a[e] = z0; b[e] = z1;
+                    }
+                }
+            }
             u32x4 u;
             u.x = rldm::pack_bf16x2(a.x * lv, a.y * lv); u.y = rldm::pack_bf16x2(a.z * lv, a.w * lv);
             u.z = rldm::pack_bf16x2(b.x * lv, b.y * lv); u.w = rldm::pack_bf16x2(b.z * lv, b.w * lv);
             *reinterpret_cast<u32x4*>(sX + spx * PITCH + spart * (CK / 4) + 8 * q) = u;
         }
 #pragma unroll
-        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / TPR) + 8 * q) = wr[q];
+        for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(sW + swr * PITCH + shalf * (CK / TPR) + 8 * q) = wr[slot][q];
     };
     f32x16 acc0, acc1;
 #pragma unroll
@@ -250,20 +418,37 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
     const bf16_t* bx = sX + ((wave & 1) * 32 + l31) * PITCH + 8 * kg;
     const bf16_t* aw0 = sW + ((wave >> 1) * (BN / 2) + l31) * PITCH + 8 * kg;
     const bf16_t* aw1 = aw0 + (NR == 2 ? 32 : 0) * PITCH;
-    fetch();
-    for (int it = it0; it < it1; ++it) {
-        __syncthreads();                            // everyone is done reading the previous stage
-        stash();
-        __syncthreads();
-        if (it + 1 < it1) fetch();                  // in flight during the MFMAs below
 #pragma unroll
-        for (int ks = 0; ks < CK / 16; ++ks) {
-            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aw0 + 16 * ks);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
-            if (NR == 2) {
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+    for (int d = 0; d < D; ++d)
+        if (it0 + d < it1) fetch(d);
+    if constexpr (FU) {
+        // (behind the first stage's loads; a K split only needs the chunks of its own stages; visible after the loop's first barrier)
+        if (in_gn) {
+            const bool all = it1 - it0 >= nck;
+            const int c_lo = all ? 0 : (it0 % nck) * CK, c_hi = all ? Cin : c_lo + (it1 - it0) * CK;
+            tr_gn_coeffs(sSc, c_lo, min(c_hi, Cin), f.cs0, f.cs1, fC0, Cin, img, f.groups, f.eps, p.Win * p.Hin, f.gamma, f.beta);
+            if (c_hi > Cin) tr_gn_coeffs(sSc, 0, c_hi - Cin, f.cs0, f.cs1, fC0, Cin, img, f.groups, f.eps, p.Win * p.Hin, f.gamma, f.beta);
+        }
+        if (f.gs_out && gridDim.z == 1)
+            tr_gn_coeffs_tile(sCe, BN, n0, f.gcs0, f.gcs1, f.G0, N, img, f.ggroups, f.geps, Wout * Hout, f.ggamma, f.gbeta);
+    }
+    for (int it = it0; it < it1; it += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (D > 1 && it + d >= it1) break;
+            __syncthreads();                        // everyone is done reading the previous stage
+            stash(d);
+            __syncthreads();
+            if (it + d + D < it1) fetch(d);         // the slot just copied out is requested again: in flight during D stages of MFMAs
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + 16 * ks);
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aw0 + 16 * ks);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
+                if (NR == 2) {
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+                }
             }
         }
     }
@@ -294,7 +479,59 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
             }
             unsafeAtomicAdd(p.y + (size_t)gp * p.N + ch, u);
         }
+        if constexpr (FU) {
+            if (f.cs_out || f.gs_out) {
+                // the tile's last arriver runs the epilogue over the finished sums.  The partial tiles travel as device-scope atomics --
+                // performed at the coherence point, never dirty in an L2 -- so "published" = every wave has its atomics acknowledged
+                // (s_waitcnt vmcnt(0)) before one lane draws the ticket: no write-back fence (cdna_hip_programming.md prices it at 1.7 -
+                // 6.5 us per workgroup).  The last arriver added to every line of the tile itself (an atomic drops the line from its L2)
+                // and never read one (nothing in its L1): it re-reads the tile with L1-bypassing loads, no invalidate.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned* tk = f.tickets + blockIdx.y * gridDim.x + blockIdx.x;
+                    const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = t == gridDim.z - 1;
+                    if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sLast = last;
+                }
+                __syncthreads();
+                if (!sLast) return;
+                if (f.gs_out) tr_gn_coeffs_tile(sCe, BN, n0, f.gcs0, f.gcs1, f.G0, N, img, f.ggroups, f.geps, Wout * Hout, f.ggamma, f.gbeta);
+                if ((N & 3) == 0) {
+                    for (int e = tid; e < 64 * (BN / 4); e += 256) {
+                        const int pl = e / (BN / 4), cl = (e % (BN / 4)) * 4;
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (n0 + cl < N) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.y + (size_t)(px0 + pl) * N + n0 + cl));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) tile[pl * (BN + 1) + cl + q] = v[q];
+                    }
+                } else {
+                    for (int e = tid; e < 64 * BN; e += 256) {
+                        const int pl = e / BN, cl = e % BN;
+                        const int ch = n0 + cl;
+                        tile[pl * (BN + 1) + cl] = ch < N ? __hip_atomic_load(p.y + (size_t)(px0 + pl) * N + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    }
+                }
+                __syncthreads();
+                tr_tile_epilogue<BN, 64, 256>(tile, sCol, sCe, p, f, px0, n0, img, false, false);
+            }
+        }
         return;
+    }
+    if constexpr (FU) {
+        if (f.cs_out || f.gs_out) {
+            float* tile = reinterpret_cast<float*>(raw);
+            __syncthreads();
+            float* trow = tile + ((wave & 1) * 32 + l31) * (BN + 1) + (wave >> 1) * (BN / 2);
+#pragma unroll
+            for (int h = 0; h < NR; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) trow[32 * h + 8 * (r >> 2) + 4 * kg + (r & 3)] = h ? acc1[r] : acc0[r];
+            __syncthreads();
+            tr_tile_epilogue<BN, 64, 256>(tile, sCol, sCe, p, f, px0, n0, img, true, true);
+            return;
+        }
     }
     const int px = px0 + (wave & 1) * 32 + l31;
     if (px >= P) return;
@@ -338,8 +575,8 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p) {
 // (64 / H + 2) azimuth columns x (H + 2) beams, circular in azimuth, zero rows above and below -- and the nine taps read
 // their B fragments from it at a uniform row offset dw * (H + 2) + dh; only the weight tile is staged per tap.  x traffic
 // and fp32->bf16 conversions drop 5x.  Stage order: chunk-major, tap fastest.
-template <int BN, int PT>
-__global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
+template <int BN, int PT, bool FU = false>
+__global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p, const TrFuse f) {
     static_assert(BN == 64 || BN == 128, "channel tile");
     constexpr int CK = 64;
     static_assert(PT == 64 || PT == 128, "pixel tile");
@@ -348,8 +585,14 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
     constexpr int PITCH = CK + 8;
     constexpr int WV = CK / (8 * TPR);
     constexpr int MAXHP = PT == 64 ? 136 : 264;     // (PT / H + 2) * (H + 2) for H = 2 .. 32
-    __shared__ __attribute__((aligned(16))) bf16_t sXh[MAXHP * PITCH];
-    __shared__ __attribute__((aligned(16))) bf16_t sW[BN * PITCH];
+    // (FU: one buffer, the fp32 output tile [PT][BN + 1] of the fused epilogue afterwards)
+    constexpr int STAGE_BYTES = (MAXHP + BN) * PITCH * 2, TILE_BYTES = FU ? PT * (BN + 1) * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char hraw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
+    bf16_t* const sXh = reinterpret_cast<bf16_t*>(hraw);
+    bf16_t* const sW = sXh + MAXHP * PITCH;
+    __shared__ float2 sSc[FU ? 768 : 1];
+    __shared__ float4 sCe[FU ? BN : 1];
+    __shared__ float sCol[FU ? 2 * BN : 1];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int Cin = p.Cin, Cin_pad = p.Cin_pad, W = p.Wout, H = p.Hout, N = p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -357,9 +600,13 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
     const int px0 = blockIdx.x * PT, n0 = blockIdx.y * BN;
     const int WCt = PT / H, HP2 = H + 2, HP = (WCt + 2) * HP2;
     const int b = px0 / (W * H), w0 = (px0 / H) % W;                 // the tile = WCt whole columns of image b
+    const bool in_gn = FU && f.cs0 != nullptr;
+    const int fC0 = FU ? f.C0 : Cin;
+    const float* const x1p = FU ? f.x1 : nullptr;
     // halo staging roles: pass j: halo pixel hp = PT j + (tid >> 2), quarter (tid & 3) of the chunk's 64 channels
     const int sq = tid & 3;
     const float* hsrc[3];
+    size_t hpix[3];
     bool hlive[3], hin[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -370,7 +617,8 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
         w = w < 0 ? w + W : (w >= W ? w - W : w);
         const int h = hr - 1;
         hlive[j] = hin[j] && h >= 0 && h < H;
-        hsrc[j] = p.x + ((size_t)(b * W + w) * H + (hlive[j] ? h : 0)) * Cin + sq * 16;
+        hpix[j] = (size_t)(b * W + w) * H + (hlive[j] ? h : 0);
+        hsrc[j] = p.x + hpix[j] * Cin + sq * 16;
     }
     const int npass = (HP + PT - 1) / PT;                            // 2, or 3 (H = 2)
     const int swr = tid / TPR, shalf = tid % TPR;
@@ -384,11 +632,16 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < npass && hin[j]) {
+                const float* src = hsrc[j] + cc * CK;
+                if constexpr (FU) {                 // two sources: the chunk lies in one of them (C0 % 64 == 0)
+                    const int c = cc * CK + sq * 16;
+                    src = c < fC0 ? p.x + hpix[j] * fC0 + c : x1p + hpix[j] * (Cin - fC0) + (c - fC0);
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xr[j][q] = reinterpret_cast<const f32x4*>(hsrc[j] + cc * CK)[q];
+                for (int q = 0; q < 4; ++q) xr[j][q] = reinterpret_cast<const f32x4*>(src)[q];
             }
     };
-    auto stash_x = [&]() __attribute__((always_inline)) {
+    auto stash_x = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < npass && hin[j]) {
@@ -396,7 +649,20 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
                 bf16_t* dst = sXh + (PT * j + (tid >> 2)) * PITCH + sq * 16;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const f32x4 a = xr[j][2 * q], c = xr[j][2 * q + 1];
+                    f32x4 a = xr[j][2 * q], c = xr[j][2 * q + 1];
+                    if constexpr (FU) {
+                        if (in_gn) {                // GroupNorm (+ SiLU) once per staged element; the halo's zero rows stay zeros (lv)
+                            const float2* co = sSc + cc * CK + sq * 16 + 8 * q;
+                            const bool act = f.silu != 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float2 c0_ = co[e], c1_ = co[4 + e];
+                                float z0 = a[e] * c0_.x + c0_.y, z1 = c[e] * c1_.x + c1_.y;
+                                if (act) { z0 *= tr_sigmoid(z0); z1 *= tr_sigmoid(z1); }
+                                a[e] = z0; c[e] = z1;
+                            }
+                        }
+                    }
                     u32x4 u;
                     u.x = rldm::pack_bf16x2(a.x * lv, a.y * lv); u.y = rldm::pack_bf16x2(a.z * lv, a.w * lv);
                     u.z = rldm::pack_bf16x2(c.x * lv, c.y * lv); u.w = rldm::pack_bf16x2(c.z * lv, c.w * lv);
@@ -426,11 +692,15 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
     HALO_FETCH_W(0, 0, 0)
     HALO_FETCH_W(1, 1, 0)
     HALO_FETCH_W(2, 2, 0)
+    if constexpr (FU) {                             // (behind the first loads; visible after the loop's first barrier)
+        if (in_gn) tr_gn_coeffs(sSc, 0, Cin, f.cs0, f.cs1, fC0, Cin, b, f.groups, f.eps, W * H, f.gamma, f.beta);
+        if (f.gs_out) tr_gn_coeffs_tile(sCe, BN, n0, f.gcs0, f.gcs1, f.G0, N, b, f.ggroups, f.geps, W * H, f.ggamma, f.gbeta);
+    }
     for (int cc = 0; cc < nck; ++cc) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {         // (unrolled: the ring slot tap % D is a compile-time register set)
             __syncthreads();                        // everyone is done reading the previous stage (and, at tap 0, the halo tile)
-            if (tap == 0) stash_x();
+            if (tap == 0) stash_x(cc);
             HALO_STASH_W(tap % D)
             __syncthreads();
             if (tap + D < 9) HALO_FETCH_W(tap % D, tap + D, cc)
@@ -448,6 +718,20 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p) {
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
                 }
             }
+        }
+    }
+    if constexpr (FU) {
+        if (f.cs_out || f.gs_out) {
+            float* tile = reinterpret_cast<float*>(hraw);
+            __syncthreads();
+            float* trow = tile + lp * (BN + 1) + (wave / PG) * (BN / 2);
+#pragma unroll
+            for (int h = 0; h < NR; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) trow[32 * h + 8 * (r >> 2) + 4 * kg + (r & 3)] = h ? acc1[r] : acc0[r];
+            __syncthreads();
+            tr_tile_epilogue<BN, PT, NT>(tile, sCol, sCe, p, f, px0, n0, b, true, true);
+            return;
         }
     }
     const int px = px0 + lp;
@@ -602,8 +886,9 @@ struct TrWgrad2 {
     float* total;              //   rows[b][n] += sum over image b's pixels, total[n] += sum over all pixels; either may be null
 };
 
-template <int TAPS>
-__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
+// (round 5) FU: x = act(GroupNorm(cat(x, x1))) rebuilt while staging (TrFuse's input side; the 64-channel tile lies in one source)
+template <int TAPS, bool FU = false>
+__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const TrFuse f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
     constexpr int NC = TAPS == 9 ? 3 : 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -635,25 +920,69 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
     const int sh = p.mode ? 1 : 0;
     struct WgStage { f32x4 d0, d1, xm, x0, x1, x2; };
     const float* const dyb = p.dy + n0 + 4 * cq;
-    const float* const xb = p.x + c0 + 4 * cq;
+    // (FU, two sources: the tile's 64 channels lie in one of them -- C0 % 64 == 0; xld = that source's channels per pixel)
+    const bool second = FU && f.x1 != nullptr && c0 >= f.C0;
+    const float* const xb = second ? f.x1 + (c0 - f.C0) + 4 * cq : p.x + c0 + 4 * cq;
+    const int xld = FU ? (second ? Cin - f.C0 : f.C0) : Cin;
     const int Win = p.Win, Hin = p.Hin, lwc = p.lwc;
+    // (FU) GroupNorm coefficients of the tile's channels for every image: sCo[b * 64 + c] = (a, b); after sB in the dynamic LDS
+    float2* const sCo = reinterpret_cast<float2*>(sB + NC * 64 * pitchB);
+    const bool in_gn = FU && f.cs0 != nullptr;
+    if constexpr (FU) {
+        if (in_gn) {
+            const int cpg = Cin / f.groups, C1 = Cin - f.C0, npix = Win * Hin;
+            for (int e = tid; e < p.B * 64; e += 256) {
+                const int bi = e >> 6, ch = c0 + (e & 63), g = ch / cpg;
+                double s_ = 0.0, ss_ = 0.0;
+                for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                    const float2 v = c < f.C0 ? reinterpret_cast<const float2*>(f.cs0)[(size_t)bi * f.C0 + c]
+                                              : reinterpret_cast<const float2*>(f.cs1)[(size_t)bi * C1 + c - f.C0];
+                    s_ += (double)v.x; ss_ += (double)v.y;
+                }
+                const double n = (double)npix * cpg, mean = s_ / n;
+                double var = ss_ / n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const float a = (float)(1.0 / sqrt(var + (double)f.eps)) * f.gamma[ch];
+                sCo[e] = make_float2(a, f.beta[ch] - (float)mean * a);
+            }
+            // (visible after the first __syncthreads() of the chunk loop, before the first stash)
+        }
+    }
     auto fetch = [&](int pp, int b, int w0, WgStage& r) __attribute__((always_inline)) {
         const int k = 2 * pp, h = k >> lwc, wl = k & (WC - 1), hs = h >> sh;
         const float* src = dyb + ((size_t)(b * W + w0 + wl) * H + h) * N;
         r.d0 = *reinterpret_cast<const f32x4*>(src);
         r.d1 = *reinterpret_cast<const f32x4*>(src + (size_t)H * N);
-        r.x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + ((w0 + wl) >> sh)) * Hin + hs) * Cin);
-        r.x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + ((w0 + wl + 1) >> sh)) * Hin + hs) * Cin);
+        r.x0 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + ((w0 + wl) >> sh)) * Hin + hs) * xld);
+        r.x1 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + ((w0 + wl + 1) >> sh)) * Hin + hs) * xld);
         if (TAPS == 9) {
             int wm = w0 + wl - 1, w2 = w0 + wl + 2;
             wm = wm < 0 ? wm + W : wm;
             w2 = w2 >= W ? w2 - W : w2;
-            r.xm = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + (wm >> sh)) * Hin + hs) * Cin);
-            r.x2 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + (w2 >> sh)) * Hin + hs) * Cin);
+            r.xm = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + (wm >> sh)) * Hin + hs) * xld);
+            r.x2 = *reinterpret_cast<const f32x4*>(xb + ((size_t)(b * Win + (w2 >> sh)) * Hin + hs) * xld);
         }
     };
-    auto stash = [&](int pp, const WgStage& r) __attribute__((always_inline)) {
+    auto stash = [&](int pp, WgStage& r, int b) __attribute__((always_inline)) {
         const int k = 2 * pp, h = k >> lwc, wl = k & (WC - 1);
+        if constexpr (FU) {
+            if (in_gn) {
+                const float2* co = sCo + b * 64 + 4 * cq;
+                const bool act = f.silu != 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 cf = co[e];
+                    float z0 = r.x0[e] * cf.x + cf.y, z1 = r.x1[e] * cf.x + cf.y;
+                    if (act) { z0 *= tr_sigmoid(z0); z1 *= tr_sigmoid(z1); }
+                    r.x0[e] = z0; r.x1[e] = z1;
+                    if (TAPS == 9) {
+                        float zm = r.xm[e] * cf.x + cf.y, z2 = r.x2[e] * cf.x + cf.y;
+                        if (act) { zm *= tr_sigmoid(zm); z2 *= tr_sigmoid(z2); }
+                        r.xm[e] = zm; r.x2[e] = z2;
+                    }
+                }
+            }
+        }
         uint32_t* da = reinterpret_cast<uint32_t*>(sA + (4 * cq) * pitchA + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) da[e * (pitchA >> 1)] = rldm::pack_bf16x2(r.d0[e], r.d1[e]);
@@ -687,7 +1016,7 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p) {
         __syncthreads();                                             // the previous chunk's fragments have been read
 #pragma unroll
         for (int it = 0; it < 4; ++it)
-            if (2 * (ppl + 16 * it) < KP) stash(ppl + 16 * it, R[it]);
+            if (2 * (ppl + 16 * it) < KP) stash(ppl + 16 * it, R[it], b);
         __syncthreads();
         if (do_sums) {                                               // thread (row n = tid >> 2, quarter of the chunk's pixels)
             const bf16_t* r = sA + (tid >> 2) * pitchA + (tid & 3) * (KP >> 2);
@@ -1243,6 +1572,107 @@ __global__ __launch_bounds__(256) void tr_gn_bwd_apply_kernel(const float* __res
     dx[i] = accumulate ? dx[i] + v : v;
 }
 
+// ---- (round 5) per-channel statistics and the GroupNorm backward apply of the fused tape -------------------------------------
+// cs[b][c] += (sum, sum of squares) over a slab of image b's pixels: for tensors no fused conv produced (conv_in's output).
+// grid (slabs, B); thread (pixel lane t / Q, channel quad t % Q), Q = C / 4 <= 256.
+__global__ __launch_bounds__(256) void tr_chan_stats_kernel(const float* __restrict__ x, int npix, int C, int slab, float* __restrict__ cs) {
+    __shared__ float sacc[2 * 1024];
+    const int b = blockIdx.y, Q = C >> 2, step = 256 / Q;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
+    for (int e = threadIdx.x; e < 2 * C; e += 256) sacc[e] = 0.f;
+    __syncthreads();
+    if (pl < step) {
+        const int p0 = blockIdx.x * slab, p1 = min(p0 + slab, npix);
+        const float* base = x + (size_t)b * npix * C + 4 * q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int px = p0 + pl; px < p1; px += step) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)px * C);
+            s += v;
+            ss += v * v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&sacc[(4 * q + e) * 2], s[e]);
+            atomicAdd(&sacc[(4 * q + e) * 2 + 1], ss[e]);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) unsafeAtomicAdd(cs + (size_t)b * C * 2 + e, sacc[e]);
+}
+
+// dx = rstd (gamma dz - s1 / n - xhat s2 / n) [+ res] of a GroupNorm over cat(x0, x1), from dz = dy act'(z) (stored by the data-gradient
+// conv's epilogue) and gs[b][c] = (sum dz, sum dz xhat): s1 = sum over the group of gamma gs.x, s2 = ... gamma gs.y.  The result is
+// written (or added) to the two sources' gradients separately; d gamma / d beta are finished by block (0, 0).  grid (slabs, B).
+struct TrGnApply {
+    const float* dz; const float* x0; const float* x1; const float* cs0; const float* cs1; const float* gs; const float* gamma;
+    const float* res; float* dx0; float* dx1; float* dgamma; float* dbeta;
+    int B, npix, C, C0, groups, slab, acc0, acc1; float eps;
+};
+__global__ __launch_bounds__(256) void tr_gn_bwd_apply2_kernel(const TrGnApply a) {
+    __shared__ float4 sT[768];                  // per channel: (rstd gamma, rstd s1 / n, rstd s2 / n, -)
+    __shared__ float2 sM[768];                  // per channel: (mean, rstd)
+    __shared__ float4 sG[64];                   // per group: (mean, rstd, s1, s2)
+    const int tid = threadIdx.x, b = blockIdx.y, C = a.C, C0 = a.C0, C1 = C - C0, cpg = C / a.groups;
+    for (int c = tid; c < C; c += 256) {
+        const float2 v = c < C0 ? reinterpret_cast<const float2*>(a.cs0)[(size_t)b * C0 + c] : reinterpret_cast<const float2*>(a.cs1)[(size_t)b * C1 + c - C0];
+        const float2 g = reinterpret_cast<const float2*>(a.gs)[(size_t)b * C + c];
+        const float ga = a.gamma[c];
+        sM[c] = v;
+        sT[c] = make_float4(ga, g.x * ga, g.y * ga, 0.f);
+    }
+    __syncthreads();
+    const double n = (double)a.npix * cpg;
+    for (int g = tid; g < a.groups; g += 256) {
+        double s = 0.0, ss = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += (double)sM[c].x; ss += (double)sM[c].y; s1 += (double)sT[c].y; s2 += (double)sT[c].z; }
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        sG[g] = make_float4((float)mean, (float)(1.0 / sqrt(var + (double)a.eps)), (float)(s1 / n), (float)(s2 / n));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float4 g = sG[c / cpg];
+        const float ga = sT[c].x;
+        sM[c] = make_float2(g.x, g.y);
+        sT[c] = make_float4(g.y * ga, g.y * g.z, g.y * g.w, 0.f);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && b == 0 && a.dgamma)
+        for (int c = tid; c < C; c += 256) {
+            float dg = 0.f, db = 0.f;
+            for (int bi = 0; bi < a.B; ++bi) {
+                const float2 g = reinterpret_cast<const float2*>(a.gs)[(size_t)bi * C + c];
+                db += g.x; dg += g.y;
+            }
+            a.dgamma[c] += dg;
+            a.dbeta[c] += db;
+        }
+    const int p0 = blockIdx.x * a.slab, p1 = min(p0 + a.slab, a.npix);
+    const int Q = C >> 2, n4 = (p1 - p0) * Q;
+    const size_t pix0 = (size_t)b * a.npix + p0;
+    for (int i = tid; i < n4; i += 256) {
+        const int pl = i / Q, c = (i - pl * Q) * 4;
+        const size_t px = pix0 + pl;
+        const f32x4 dz = *reinterpret_cast<const f32x4*>(a.dz + px * C + c);
+        const bool first = c < C0;
+        const size_t off = first ? px * C0 + c : px * C1 + (c - C0);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>((first ? a.x0 : a.x1) + off);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float4 t = sT[c + e];
+            const float2 m = sM[c + e];
+            out[e] = t.x * dz[e] - t.y - (xv[e] - m.x) * m.y * t.z;
+        }
+        if (a.res) out += *reinterpret_cast<const f32x4*>(a.res + px * C + c);
+        float* dst = (first ? a.dx0 : a.dx1) + off;
+        if (first ? a.acc0 : a.acc1) out += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = out;
+    }
+}
+
 // ---- attention, head_dim 8 -----------------------------------------------------------------------------------------------
 // q, k, v, o: [B][L][C] fp32, head h = channels 8h .. 8h + 8.  grid (ceil(L / 128), heads, B), 128 threads = 128 queries.
 // The other side (keys / values, or queries / dO) passes through LDS in tiles of ATT_TK rows (16-18 KB: ten workgroups per
@@ -1796,8 +2226,73 @@ int rldm_train_conv_splits(const rldm_train_conv_desc* d, int rowadd_ld) {
     return ksplit;
 }
 
+// arrival counters of the fused split-K launches: zeroed once, every launch leaves them zeroed (one caller thread, stream ordered;
+// never reallocated during a stream capture: the first, eager, step of a shape sizes it)
+static int fuse_tickets(size_t count, hipStream_t st, unsigned** out) {
+    static unsigned* buf = nullptr;
+    static size_t cap = 0;
+    if (count > cap) {
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (buf) RLDM_HIP_CHECK(hipFree(buf));
+        buf = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(count, 16384);
+        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&buf), want * sizeof(unsigned)));
+        RLDM_HIP_CHECK(hipMemset(buf, 0, want * sizeof(unsigned)));
+        cap = want;
+    }
+    *out = buf;
+    return 0;
+}
+
+static TrFuse to_device_fuse(const rldm_train_fuse* fu, int Cin, int N) {
+    TrFuse f{};
+    if (!fu) { f.C0 = Cin; return f; }
+    f.x1 = fu->x1; f.C0 = fu->x1 ? fu->C0 : Cin;
+    f.cs0 = fu->cs0; f.cs1 = fu->cs1; f.gamma = fu->gamma; f.beta = fu->beta; f.silu = fu->silu; f.groups = fu->groups; f.eps = fu->eps;
+    f.cs_out = fu->cs_out;
+    f.g0 = fu->g0; f.g1 = fu->g1; f.G0 = fu->g1 ? fu->G0 : N; f.gcs0 = fu->gcs0; f.gcs1 = fu->gcs1; f.ggamma = fu->ggamma; f.gbeta = fu->gbeta;
+    f.gsilu = fu->gsilu; f.ggroups = fu->ggroups; f.geps = fu->geps; f.gs_out = fu->gs_out;
+    return f;
+}
+
+// can the fused conv kernels run this launch?  (LDS-staged kernels; tiles inside one image; chunks inside one source)
+static bool conv_fuse_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, int rowadd_ld) {
+    const int sh = d->mode ? 1 : 0;
+    const int Wout = (d->Win << sh) / d->stride, Hout = (d->Hin << sh) / d->stride;
+    const int P = d->B * Wout * Hout, CK = d->Cin % 64 == 0 ? 64 : 32;
+    if (!(P >= 64 && (rowadd_ld & 3) == 0 && d->Cin % 32 == 0 && (Wout * Hout) % 64 == 0)) return false;
+    if (fu->x1 && (fu->C0 <= 0 || fu->C0 >= d->Cin || fu->C0 % CK != 0 || (d->Cin - fu->C0) % 4 != 0 || fu->C0 % 4 != 0)) return false;
+    if (fu->cs0 && (d->Cin > 768 || fu->groups < 1 || fu->groups > 64 || d->Cin % fu->groups != 0 || !fu->gamma || !fu->beta || (fu->x1 && !fu->cs1))) return false;
+    if (fu->cs_out && fu->gs_out) return false;
+    if (fu->gs_out) {
+        if (!fu->g0 || !fu->gcs0 || !fu->ggamma || !fu->gbeta || fu->ggroups < 1 || d->N % fu->ggroups != 0) return false;
+        if (fu->g1 && (!fu->gcs1 || fu->G0 <= 0 || fu->G0 >= d->N)) return false;
+    }
+    return true;
+}
+
+int rldm_train_conv_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, int rowadd_ld) {
+    return d && fu && d->stride >= 1 && conv_fuse_ok(d, fu, rowadd_ld) ? 1 : 0;
+}
+
+static int train_conv_impl(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* x, const void* w_packed, const float* bias,
+                           const float* rowadd, int rowadd_ld, const float* res, float* y, int accumulate, void* stream);
+
 int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* rowadd,
                     int rowadd_ld, const float* res, float* y, int accumulate, void* stream) {
+    return train_conv_impl(d, nullptr, x, w_packed, bias, rowadd, rowadd_ld, res, y, accumulate, stream);
+}
+
+int rldm_train_conv_fused(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* x, const void* w_packed, const float* bias,
+                          const float* rowadd, int rowadd_ld, const float* res, float* y, int prezeroed, void* stream) {
+    RLDM_REQUIRE(d && fu, "null argument");
+    RLDM_REQUIRE(conv_fuse_ok(d, fu, rowadd_ld), "rldm_train_conv_fused: shape not supported (ask rldm_train_conv_fused_ok)");
+    return train_conv_impl(d, fu, x, w_packed, bias, rowadd, rowadd_ld, res, y, prezeroed, stream);
+}
+
+static int train_conv_impl(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* x, const void* w_packed, const float* bias,
+                           const float* rowadd, int rowadd_ld, const float* res, float* y, int accumulate, void* stream) {
     RLDM_REQUIRE(d && x && w_packed && y, "null argument");
     RLDM_REQUIRE((d->taps == 1 || d->taps == 9) && (d->stride == 1 || d->stride == 2) && d->mode >= 0 && d->mode <= 2, "bad conv desc");
     RLDM_REQUIRE(d->B > 0 && d->Win > 0 && d->Hin > 0 && d->Cin > 0 && d->N > 0, "bad shape");
@@ -1813,6 +2308,7 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
     const bool aligned = (rowadd_ld & 3) == 0;         // (vector epilogue reads the per-sample row 16 bytes at a time)
     const bool lds = P >= 64 && aligned;               // Linear layers on a handful of rows: the direct kernel
     hipStream_t st = (hipStream_t)stream;
+    TrFuse f = to_device_fuse(fu, p.Cin, p.N);
     if (lds && p.Cin % 32 == 0) {
         bool narrow;
         int ksplit;
@@ -1821,6 +2317,10 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
         if (ksplit > 1) {
             if (!accumulate) tr_zero_kernel<<<nblk((size_t)P * p.N / 4 + 1), 256, 0, st>>>(y, (size_t)P * p.N);   // (a kernel, not a memset node: see tr_zero_kernel)
             grid.z = ksplit;
+            if (fu && (f.cs_out || f.gs_out) && fuse_tickets((size_t)grid.x * grid.y, st, &f.tickets)) return 1;
+        } else if (fu && (f.cs_out || f.gs_out)) {
+            RLDM_REQUIRE(!accumulate, "rldm_train_conv_fused: the fused epilogue writes y (no accumulation)");
+            p.accumulate = 0;
         }
         static const bool nohalo_env = getenv("RLDM_TR_NO_HALO") != nullptr;           // A/B: the per-tap staging kernel
         const int H = p.Hout;
@@ -1828,21 +2328,35 @@ int rldm_train_conv(const rldm_train_conv_desc* d, const float* x, const void* w
                           H >= 2 && H <= 32 && (H & (H - 1)) == 0 && (p.Wout * H) % 64 == 0 && p.Wout % (64 / H) == 0 && p.Wout >= 64 / H + 2;
         static const int pt_env = getenv("RLDM_TR_PT") ? atoi(getenv("RLDM_TR_PT")) : 0;
         const bool wide_px = pt_env == 128 && halo && !narrow && (p.Wout * H) % 128 == 0 && p.Wout % (128 / H) == 0 && p.Wout >= 128 / H + 2;
-        if (halo && wide_px) {
+        if (fu) {                                   // the fused instances (conv_fuse_ok held)
+            if (halo) {
+                if (narrow) tr_conv_halo_kernel<64, 64, true><<<grid, 256, 0, st>>>(p, f);
+                else tr_conv_halo_kernel<128, 64, true><<<grid, 256, 0, st>>>(p, f);
+            } else if (p.Cin % 64 == 0) {
+                if (narrow) tr_conv_lds_kernel<64, 64, true><<<grid, 256, 0, st>>>(p, f);
+                else tr_conv_lds_kernel<64, 128, true><<<grid, 256, 0, st>>>(p, f);
+            } else {
+                if (narrow) tr_conv_lds_kernel<32, 64, true><<<grid, 256, 0, st>>>(p, f);
+                else tr_conv_lds_kernel<32, 128, true><<<grid, 256, 0, st>>>(p, f);
+            }
+        } else if (halo && wide_px) {
             grid.x = P / 128;
-            tr_conv_halo_kernel<128, 128><<<grid, 512, 0, st>>>(p);
+            tr_conv_halo_kernel<128, 128><<<grid, 512, 0, st>>>(p, f);
         } else if (halo) {
-            if (narrow) tr_conv_halo_kernel<64, 64><<<grid, 256, 0, st>>>(p);
-            else tr_conv_halo_kernel<128, 64><<<grid, 256, 0, st>>>(p);
+            if (narrow) tr_conv_halo_kernel<64, 64><<<grid, 256, 0, st>>>(p, f);
+            else tr_conv_halo_kernel<128, 64><<<grid, 256, 0, st>>>(p, f);
         } else if (p.Cin % 64 == 0) {
-            if (narrow) tr_conv_lds_kernel<64, 64><<<grid, 256, 0, st>>>(p);
-            else tr_conv_lds_kernel<64, 128><<<grid, 256, 0, st>>>(p);
+            if (narrow) tr_conv_lds_kernel<64, 64><<<grid, 256, 0, st>>>(p, f);
+            else tr_conv_lds_kernel<64, 128><<<grid, 256, 0, st>>>(p, f);
         } else {
-            if (narrow) tr_conv_lds_kernel<32, 64><<<grid, 256, 0, st>>>(p);
-            else tr_conv_lds_kernel<32, 128><<<grid, 256, 0, st>>>(p);
+            if (narrow) tr_conv_lds_kernel<32, 64><<<grid, 256, 0, st>>>(p, f);
+            else tr_conv_lds_kernel<32, 128><<<grid, 256, 0, st>>>(p, f);
         }
-    } else if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, st>>>(p);
-    else tr_conv_kernel<false><<<grid, 256, 0, st>>>(p);
+    } else {
+        RLDM_REQUIRE(!fu, "rldm_train_conv_fused: not an LDS-staged shape");
+        if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, st>>>(p);
+        else tr_conv_kernel<false><<<grid, 256, 0, st>>>(p);
+    }
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -1851,8 +2365,39 @@ int rldm_train_wgrad(const rldm_train_conv_desc* d, const float* dy, const float
     return rldm_train_wgrad_bias(d, dy, x, dw, nullptr, 0, 0, nullptr, stream);
 }
 
+static bool wgrad_v2_shape(const rldm_train_conv_desc* d) {
+    const int sh = d->mode ? 1 : 0;
+    const int Wout = (d->Win << sh) / d->stride, Hout = (d->Hin << sh) / d->stride;
+    if (!(d->stride == 1 && d->mode <= 1 && d->N % 64 == 0 && d->Cin % 64 == 0 && Hout >= 2 && Hout <= 16 && (Hout & (Hout - 1)) == 0)) return false;
+    for (int l = 6; l >= 3; --l)
+        if ((Hout << l) <= 128 && ((Hout + 2) << l) <= 160 && Wout % (1 << l) == 0) return true;
+    return false;
+}
+
+int rldm_train_wgrad_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* fu) {
+    if (!d || !fu || getenv("RLDM_TR_WG_V1")) return 0;
+    if (!wgrad_v2_shape(d) || d->mode != 0 || d->B > 16) return 0;
+    if (fu->x1 && (fu->C0 <= 0 || fu->C0 >= d->Cin || fu->C0 % 64 != 0)) return 0;
+    if (fu->cs0 && (fu->groups < 1 || d->Cin % fu->groups != 0 || !fu->gamma || !fu->beta || (fu->x1 && !fu->cs1))) return 0;
+    return 1;
+}
+
+static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* dy, const float* x, float* dw, float* rows,
+                            int rows_ld, int rows_accumulate, float* total, void* stream);
+
 int rldm_train_wgrad_bias(const rldm_train_conv_desc* d, const float* dy, const float* x, float* dw, float* rows, int rows_ld,
                           int rows_accumulate, float* total, void* stream) {
+    return train_wgrad_impl(d, nullptr, dy, x, dw, rows, rows_ld, rows_accumulate, total, stream);
+}
+
+int rldm_train_wgrad_fused(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* dy, const float* x, float* dw, float* rows,
+                           int rows_ld, int rows_accumulate, float* total, void* stream) {
+    RLDM_REQUIRE(d && fu && rldm_train_wgrad_fused_ok(d, fu), "rldm_train_wgrad_fused: shape not supported (ask rldm_train_wgrad_fused_ok)");
+    return train_wgrad_impl(d, fu, dy, x, dw, rows, rows_ld, rows_accumulate, total, stream);
+}
+
+static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* dy, const float* x, float* dw, float* rows,
+                            int rows_ld, int rows_accumulate, float* total, void* stream) {
     RLDM_REQUIRE(d && dy && x && dw, "null argument");
     RLDM_REQUIRE((d->taps == 1 || d->taps == 9) && (d->stride == 1 || d->stride == 2) && d->mode >= 0 && d->mode <= 2, "bad conv desc");
     TrWgrad p;
@@ -1917,21 +2462,29 @@ int rldm_train_wgrad_bias(const rldm_train_conv_desc* d, const float* dy, const 
         w2.rows = rows; w2.rows_ld = rows_ld; w2.total = total;
         if (rows && !rows_accumulate) tr_zero2d_kernel<<<nblk((size_t)p.B * p.N), 256, 0, st>>>(rows, rows_ld, p.N, p.B);
         size_t smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
+        if (fu) smem += (size_t)p.B * 64 * sizeof(float2);          // GroupNorm coefficients of the tile's channels per image
         if (w2.dw) smem = std::max(smem, (size_t)32 * (64 * p.taps + 1) * sizeof(float));
         static bool attr = false;
         if (!attr) {
             RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
         const dim3 grid((p.N / 64) * (p.Cin / 64), splits);
-        if (p.taps == 9) tr_wgrad2_kernel<9><<<grid, 256, smem, st>>>(w2);
-        else tr_wgrad2_kernel<1><<<grid, 256, smem, st>>>(w2);
+        const TrFuse f = to_device_fuse(fu, p.Cin, p.N);
+        if (fu) {
+            if (p.taps == 9) tr_wgrad2_kernel<9, true><<<grid, 256, smem, st>>>(w2, f);
+            else tr_wgrad2_kernel<1, true><<<grid, 256, smem, st>>>(w2, f);
+        } else if (p.taps == 9) tr_wgrad2_kernel<9><<<grid, 256, smem, st>>>(w2, f);
+        else tr_wgrad2_kernel<1><<<grid, 256, smem, st>>>(w2, f);
         TR_LAUNCH_CHECK();
         if (!w2.dw) tr_wgrad_reduce_vec_kernel<<<nblk((size_t)p.N * p.Cin * p.taps / 4), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
         TR_LAUNCH_CHECK();
         return 0;
     }
+    RLDM_REQUIRE(!fu, "rldm_train_wgrad_fused: not an all-taps shape");
     if (rows || total) {                              // the one-tap kernel does not carry the column sums
         const int rc = rldm_train_colsum(dy, p.B, p.Wout * p.Hout, p.N, rows, rows_ld, rows_accumulate, total, stream);
         if (rc) return rc;
@@ -2059,6 +2612,35 @@ int rldm_train_gn_backward(const float* x, const float* dy, const float* stats, 
         tr_gn_bwd_apply_kernel<<<nblk(total), 256, 0, st>>>(x, dy, reinterpret_cast<const float2*>(stats),
                                                         reinterpret_cast<const float2*>(scratch), gamma, beta, npix, C, groups, silu,
                                                         accumulate, total, dx);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_chan_stats(const float* x, int B, int npix, int C, float* cs, void* stream) {
+    RLDM_REQUIRE(x && cs && B > 0 && npix > 0, "null argument");
+    RLDM_REQUIRE(C % 4 == 0 && C <= 1024, "channels: a multiple of 4, <= 1024");
+    const int slab = npix >= 4096 ? 256 : 64;
+    tr_chan_stats_kernel<<<dim3((npix + slab - 1) / slab, B), 256, 0, (hipStream_t)stream>>>(x, npix, C, slab, cs);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int rldm_train_gn_backward_apply(const float* dz, const float* x0, const float* x1, int C0, const float* cs0, const float* cs1,
+                                 const float* gs, int B, int npix, int C, int groups, float eps, const float* gamma, const float* res,
+                                 float* dx0, int accumulate0, float* dx1, int accumulate1, float* dgamma, float* dbeta, void* stream) {
+    RLDM_REQUIRE(dz && x0 && cs0 && gs && gamma && dx0, "null argument");
+    RLDM_REQUIRE(C % 4 == 0 && C <= 768 && groups >= 1 && groups <= 64 && C % groups == 0, "channels: a multiple of 4 and of the groups, <= 768");
+    RLDM_REQUIRE(!x1 || (cs1 && dx1 && C0 > 0 && C0 < C && C0 % 4 == 0), "two sources: C0 a multiple of 4 inside (0, C)");
+    RLDM_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "d gamma and d beta come together");
+    TrGnApply a;
+    a.dz = dz; a.x0 = x0; a.x1 = x1; a.cs0 = cs0; a.cs1 = cs1; a.gs = gs; a.gamma = gamma; a.res = res; a.dx0 = dx0; a.dx1 = dx1;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.B = B; a.npix = npix; a.C = C; a.C0 = x1 ? C0 : C; a.groups = groups;
+    a.acc0 = accumulate0; a.acc1 = accumulate1; a.eps = eps;
+    // slabs of >= 16 pixels, ~1024 blocks at most
+    int slab = 16;
+    while ((long long)B * ((npix + slab - 1) / slab) > 1024) slab *= 2;
+    a.slab = slab;
+    tr_gn_bwd_apply2_kernel<<<dim3((npix + slab - 1) / slab, B), 256, 0, (hipStream_t)stream>>>(a);
     TR_LAUNCH_CHECK();
     return 0;
 }

@@ -299,3 +299,132 @@ def adamw_dyn(params, grads, exp_avg, exp_avg_sq, dyn, betas=(0.9, 0.999), eps=1
     _chk(_lib.lib().rldm_train_adamw_dyn(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(ema), _p(sqnorm_dev),
                                          params.numel(), C.byref(c), _p(dyn), 1 if zero_grads else 0, _s(params)),
          "rldm_train_adamw_dyn")
+
+
+# ---- fused tape (round 5; include/rangeldm_hip.h "fused tape") ------------------------------------------------------------
+class Src:
+    """A forward tensor together with the per-(image, channel) (sum, sumsq) pairs its producer accumulated (None: not known)."""
+    __slots__ = ("t", "cs")
+
+    def __init__(self, t, cs=None):
+        self.t, self.cs = t, cs
+
+
+class GN:
+    """A GroupNorm (+ SiLU) to be rebuilt by the consumers of its input: affine parameters + hyper-parameters."""
+    __slots__ = ("gamma", "beta", "silu", "groups", "eps")
+
+    def __init__(self, gamma, beta, silu, groups, eps):
+        self.gamma, self.beta, self.silu, self.groups, self.eps = gamma, beta, bool(silu), int(groups), float(eps)
+
+
+def zeros_stats(B, Cc, like):
+    """A zeroed [B][C][2] accumulator: a slice of the step's zero arena when one is installed (one fill per step)."""
+    t = _arena.take((B, Cc, 2)) if _arena is not None else None
+    return t if t is not None else torch.zeros((B, Cc, 2), dtype=torch.float32, device=like.device)
+
+
+def _fuse(srcs=None, gn=None, cs_out=None, gsrcs=None, ggn=None, gs_out=None):
+    """-> (TrainFuseC, keep-alive list)"""
+    f = _lib.TrainFuseC()
+    keep = []
+    if srcs is not None and len(srcs) == 2:
+        f.x1, f.C0 = srcs[1].t.data_ptr(), srcs[0].t.shape[-1]
+        keep.append(srcs[1].t)
+    if gn is not None:
+        f.cs0 = srcs[0].cs.data_ptr()
+        f.cs1 = srcs[1].cs.data_ptr() if len(srcs) == 2 else None
+        f.gamma, f.beta, f.silu, f.groups, f.eps = gn.gamma.data_ptr(), gn.beta.data_ptr(), 1 if gn.silu else 0, gn.groups, gn.eps
+        keep += [s.cs for s in srcs] + [gn.gamma, gn.beta]
+    if cs_out is not None:
+        f.cs_out = cs_out.data_ptr()
+        keep.append(cs_out)
+    if gs_out is not None:
+        f.g0, f.gcs0 = gsrcs[0].t.data_ptr(), gsrcs[0].cs.data_ptr()
+        if len(gsrcs) == 2:
+            f.g1, f.gcs1, f.G0 = gsrcs[1].t.data_ptr(), gsrcs[1].cs.data_ptr(), gsrcs[0].t.shape[-1]
+        f.ggamma, f.gbeta, f.gsilu, f.ggroups, f.geps = (ggn.gamma.data_ptr(), ggn.beta.data_ptr(), 1 if ggn.silu else 0, ggn.groups,
+                                                         ggn.eps)
+        f.gs_out = gs_out.data_ptr()
+        keep += [s.t for s in gsrcs] + [s.cs for s in gsrcs] + [ggn.gamma, ggn.beta, gs_out]
+    return f, keep
+
+
+def _cin(srcs):
+    return sum(s.t.shape[-1] for s in srcs)
+
+
+def _desc_srcs(srcs, N, taps, stride, mode):
+    d = _lib.TrainConvDescC()
+    d.B, d.Win, d.Hin = srcs[0].t.shape[:3]
+    d.Cin = _cin(srcs)
+    d.N, d.taps, d.stride, d.mode = N, taps, stride, mode
+    return d
+
+
+def conv_fused_ok(srcs, N, taps, stride=1, mode=0, gn=None, want_stats=False, gsrcs=None, ggn=None, rowadd=None):
+    d = _desc_srcs(srcs, N, taps, stride, mode)
+    dummy = srcs[0].t
+    f, _ = _fuse(srcs, gn, dummy if want_stats else None, gsrcs, ggn, dummy if gsrcs is not None else None)
+    return bool(_lib.lib().rldm_train_conv_fused_ok(C.byref(d), C.byref(f), 0 if rowadd is None else rowadd.stride(0)))
+
+
+def conv_fused(srcs, w_packed, N, taps, stride=1, mode=0, gn=None, bias=None, rowadd=None, res=None, want_stats=False,
+               gsrcs=None, ggn=None):
+    """y = conv(act(GN(cat(srcs)))) + bias + rowadd[b] + res with everything folded into one launch.
+    want_stats: -> (y, cs_y).  gsrcs / ggn (data gradient): y is stored as dz = y act'(z) -> (dz, gs)."""
+    x = srcs[0].t
+    B = x.shape[0]
+    d = _desc_srcs(srcs, N, taps, stride, mode)
+    Wo, Ho = out_size(x.shape[1], x.shape[2], stride, mode)
+    out2 = zeros_stats(B, N, x) if (want_stats or gsrcs is not None) else None
+    f, keep = _fuse(srcs, gn, out2 if want_stats else None, gsrcs, ggn, out2 if gsrcs is not None else None)
+    y, pre = None, 0
+    if _arena is not None and _lib.lib().rldm_train_conv_splits(C.byref(d), 0 if rowadd is None else rowadd.stride(0)) > 1:
+        y = _arena.take((B, Wo, Ho, N))
+        pre = 1 if y is not None else 0
+    if y is None:
+        y = empty((B, Wo, Ho, N), x)
+    _chk(_lib.lib().rldm_train_conv_fused(C.byref(d), C.byref(f), _p(x), _p(w_packed), _p(bias), _p(rowadd),
+                                          0 if rowadd is None else rowadd.stride(0), _p(res), _p(y), pre, _s(x)),
+         "rldm_train_conv_fused")
+    return (y, out2) if out2 is not None else y
+
+
+def wgrad_fused_ok(srcs, N, taps, gn=None):
+    d = _desc_srcs(srcs, N, taps, 1, 0)
+    f, _ = _fuse(srcs, gn)
+    return bool(_lib.lib().rldm_train_wgrad_fused_ok(C.byref(d), C.byref(f)))
+
+
+def wgrad_fused(dy, srcs, dw, taps, gn=None, rows=None, total=None, rows_accumulate=False):
+    """dw += dy (x) act(GN(cat(srcs))) (+ the column sums of dy as wgrad_bias)."""
+    d = _desc_srcs(srcs, dy.shape[3], taps, 1, 0)
+    f, keep = _fuse(srcs, gn)
+    _chk(_lib.lib().rldm_train_wgrad_fused(C.byref(d), C.byref(f), _p(dy), _p(srcs[0].t), _p(dw), _p(rows),
+                                           0 if rows is None else rows.stride(0), 1 if rows_accumulate else 0, _p(total), _s(dy)),
+         "rldm_train_wgrad_fused")
+
+
+def chan_stats(x):
+    B, W, H, Cc = x.shape
+    cs = zeros_stats(B, Cc, x)
+    _chk(_lib.lib().rldm_train_chan_stats(_p(x), B, W * H, Cc, _p(cs), _s(x)), "rldm_train_chan_stats")
+    return cs
+
+
+def gn_backward_apply(dz, srcs, gs, gn, dgamma, dbeta, res=None, dsts=None, accumulate=(False, False)):
+    """-> the input gradients of GroupNorm(cat(srcs)) (one tensor per source), from dz / gs of a fused data-gradient conv;
+    dsts[i] given: written (accumulate[i]: added) in place."""
+    B, W, H, Cc = dz.shape
+    dsts = list(dsts) if dsts is not None else [None] * len(srcs)
+    for i, s in enumerate(srcs):
+        if dsts[i] is None:
+            dsts[i] = torch.empty_like(s.t)
+    two = len(srcs) == 2
+    _chk(_lib.lib().rldm_train_gn_backward_apply(_p(dz), _p(srcs[0].t), _p(srcs[1].t) if two else None, srcs[0].t.shape[-1],
+                                                 _p(srcs[0].cs), _p(srcs[1].cs) if two else None, _p(gs), B, W * H, Cc, gn.groups,
+                                                 gn.eps, _p(gn.gamma), _p(res), _p(dsts[0]), 1 if accumulate[0] else 0,
+                                                 _p(dsts[1]) if two else None, 1 if (two and accumulate[1]) else 0, _p(dgamma),
+                                                 _p(dbeta), _s(dz)), "rldm_train_gn_backward_apply")
+    return dsts

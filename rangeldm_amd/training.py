@@ -12,6 +12,7 @@ Parity: tests/test_training.py compares every parameter gradient of a small UNet
 steps, with torch autograd / torch.optim.AdamW on the oracle (oracle/unet.py).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -164,6 +165,14 @@ class UNetTrainer:
         self._step_dev = torch.zeros((), dtype=torch.int64, device=self.device)
         self._step_dev_mirror = 0
         self._dyn = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # fused tape (round 5): GroupNorm folded into its producers / consumers, concatenations read in place
+        # (RLDM_TRAIN_FUSED=0: the op-per-layer tape, kept as the cross-check)
+        self.fused_tape = os.environ.get("RLDM_TRAIN_FUSED", "1") != "0"
+        self.fused_min_pixels = int(os.environ.get("RLDM_TRAIN_FUSED_MINPX", "1024"))
+        self._cs = {}
+        # weight gradients on a second stream (they are off the dy -> dx chain): forked per launch, joined ONCE in front of the
+        # time-embedding MLP's backward / at gradient-bucket cuts (RLDM_TR_WG_STREAM=1; experiment)
+        self._wg_stream = torch.cuda.Stream(self.device) if os.environ.get("RLDM_TR_WG_STREAM", "0") == "1" else None
 
     # ---- parameters -------------------------------------------------------------------------------------------
     def _view(self, flat, n):
@@ -276,6 +285,7 @@ class UNetTrainer:
                 if lo <= i < hi:
                     self._ready[b] -= 1
                     if self._ready[b] == 0:
+                        self._wg_join()                          # the bucket's weight gradients have been enqueued on the side stream
                         if self._on_bucket is not None:          # stream capture: cut the graph here, reduce at replay
                             self._on_bucket(b)
                         else:
@@ -306,11 +316,30 @@ class UNetTrainer:
         return _Work()
 
     # ---- ops --------------------------------------------------------------------------------------------------
-    def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True, done=None):
+    def _wg(self, fn, *tensors):
+        """Run a weight-gradient launch: on the side stream when there is one (it waits for what the main stream has enqueued so
+        far; the operands stay allocated until it has run)."""
+        if self._wg_stream is None:
+            return fn()
+        self._wg_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._wg_stream):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self._wg_stream)
+
+    def _wg_join(self):
+        if self._wg_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._wg_stream)
+
+    def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True, done=None, stats=False):
         w = name + ".weight"
         N, _, taps = self.layers[w][:3]
         done = done or (w, name + ".bias")
-        y = T.conv(x, self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], rowadd=rowadd, res=res)
+        if stats and rowadd is None and res is None and T.conv_fused_ok([T.Src(x)], N, taps, stride, mode, want_stats=True):
+            y, self._cs[id(y)] = T.conv_fused([T.Src(x)], self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], want_stats=True)
+        else:
+            y = T.conv(x, self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], rowadd=rowadd, res=res)
 
         def bwd():
             dy = self._pop(y)
@@ -325,8 +354,9 @@ class UNetTrainer:
                     if id(rows) not in self._grad:       # zeroed once for all 22 slices (they accumulate into it)
                         self._grad[id(rows)] = (torch.zeros(rows.shape, dtype=torch.float32, device=rows.device), True)
                     drow = self._grad[id(rows)][0][:, off:off + rowadd.shape[1]]
-            T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"],
-                         rows_accumulate=rowadd is not None and self._row_parent.get(id(rowadd)) is not None)
+            racc_ = rowadd is not None and self._row_parent.get(id(rowadd)) is not None
+            self._wg(lambda: T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"],
+                                          rows_accumulate=racc_), dy, x)
             self._done(*done)
             if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)
@@ -463,15 +493,155 @@ class UNetTrainer:
         self._tape.append(bwd)
         return self._conv(o, p + ".to_out.0", res=x)
 
+    # ---- fused tape (round 5) ---------------------------------------------------------------------------------
+    class Cat:
+        """`torch.cat([a, b], dim=1)` of the up blocks, never materialised: the consumers read the two sources in place."""
+        __slots__ = ("a", "b")
+
+        def __init__(self, a, b):
+            self.a, self.b = a, b
+
+    def fused_shape_ok(self, B, W, H):
+        """Do the fused kernels cover every layer of this network at this input size?  (tiles inside one image, 64-channel
+        chunks inside one source, the all-taps weight-gradient kernel at every level, the fused parameter groups)"""
+        cfg = self.cfg
+        if not self.fused_tape or B > 16 or "time_emb_proj_all" not in self.fused:
+            return False
+        if cfg.norm_num_groups > 64 or any(c % 64 or c % cfg.norm_num_groups or c > 384 for c in cfg.block_out_channels):
+            return False
+        for lvl in range(len(cfg.block_out_channels)):
+            w, h = W >> lvl, H >> lvl
+            if (w << lvl) != W or (h << lvl) != H or (w * h) % 64 or h < 2 or h > 16 or (h & (h - 1)) or w % 8:
+                return False
+        attn = [f"down_blocks.{i}.attentions.{j}" for i, bt in enumerate(cfg.down_block_types) if bt == "AttnDownBlock2D"
+                for j in range(cfg.layers_per_block)]
+        attn += [f"up_blocks.{i}.attentions.{j}" for i, bt in enumerate(cfg.up_block_types) if bt == "AttnUpBlock2D"
+                 for j in range(cfg.layers_per_block + 1)]
+        if cfg.add_attention:
+            attn.append("mid_block.attentions.0")
+        return all((a + ".to_qkv") in self.fused for a in attn)
+
+    def _srcs(self, x):
+        """The one or two source tensors of a (possibly concatenated) activation, each with its (sum, sumsq) pairs."""
+        ts = (x.a, x.b) if isinstance(x, UNetTrainer.Cat) else (x,)
+        out = []
+        for t in ts:
+            cs = self._cs.get(id(t))
+            if cs is None:                              # no fused conv produced it (conv_in): one statistics launch
+                cs = self._cs[id(t)] = T.chan_stats(t)
+            out.append(T.Src(t, cs))
+        return out
+
+    def _drow(self, rowadd):
+        """Where the time-embedding row gradient of a conv goes: (buffer, accumulate?)"""
+        parent = self._row_parent.get(id(rowadd))
+        if parent is None:
+            return T.empty(rowadd.shape, rowadd), False
+        rows, off = parent
+        if id(rows) not in self._grad:                   # zeroed once for all 22 slices (they accumulate into it)
+            self._grad[id(rows)] = (torch.zeros(rows.shape, dtype=torch.float32, device=rows.device), True)
+        return self._grad[id(rows)][0][:, off:off + rowadd.shape[1]], True
+
+    def _resnet_f(self, x, p):
+        """ResnetBlock2D in three launches: conv1 and conv2 normalise + activate their inputs while staging and accumulate their
+        outputs' statistics; the 1x1 shortcut reads the (concatenated) input in place.  Backward: per conv one weight-gradient
+        launch (operand rebuilt from the raw input) and one data-gradient launch (GroupNorm-backward transform + sums in the
+        epilogue), per GroupNorm one apply launch (+ the residual-path gradient, split over the concatenation's sources)."""
+        cfg = self.cfg
+        srcs = self._srcs(x)
+        Cin = sum(s.t.shape[3] for s in srcs)
+        n1, n2, c1, c2, sc_n = p + ".norm1", p + ".norm2", p + ".conv1", p + ".conv2", p + ".conv_shortcut"
+        N = self.layers[c1 + ".weight"][0]
+        gn1 = T.GN(self.p[n1 + ".weight"], self.p[n1 + ".bias"], True, cfg.norm_num_groups, cfg.norm_eps)
+        gn2 = T.GN(self.p[n2 + ".weight"], self.p[n2 + ".bias"], True, cfg.norm_num_groups, cfg.norm_eps)
+        row = self._rows[p + ".time_emb_proj"]
+        h1, cs1 = T.conv_fused(srcs, self.wf[c1 + ".weight"], N, 9, gn=gn1, bias=self.p[c1 + ".bias"], rowadd=row, want_stats=True)
+        s1 = [T.Src(h1, cs1)]
+        has_sc = (sc_n + ".weight") in self.shapes
+        sc = T.conv_fused(srcs, self.wf[sc_n + ".weight"], N, 1, bias=self.p[sc_n + ".bias"]) if has_sc else srcs[0].t
+        y, csy = T.conv_fused(s1, self.wf[c2 + ".weight"], N, 9, gn=gn2, bias=self.p[c2 + ".bias"], res=sc, want_stats=True)
+        self._cs[id(y)] = csy
+
+        def bwd():
+            dy = self._pop(y)
+            self._wg(lambda: T.wgrad_fused(dy, s1, self.g[c2 + ".weight"], 9, gn=gn2, total=self.g[c2 + ".bias"]), dy, h1, cs1)
+            self._done(c2 + ".weight", c2 + ".bias")
+            dz2, gs2 = T.conv_fused([T.Src(dy)], self.wt[c2 + ".weight"], N, 9, gsrcs=s1, ggn=gn2)
+            dh1, = T.gn_backward_apply(dz2, s1, gs2, gn2, self.g[n2 + ".weight"], self.g[n2 + ".bias"])
+            self._done(n2 + ".weight", n2 + ".bias")
+            drow, racc = self._drow(row)
+            self._wg(lambda: T.wgrad_fused(dh1, srcs, self.g[c1 + ".weight"], 9, gn=gn1, rows=drow, total=self.g[c1 + ".bias"],
+                                           rows_accumulate=racc), dh1, *[s.t for s in srcs], *[s.cs for s in srcs])
+            self._done(c1 + ".weight", c1 + ".bias")
+            if not racc:
+                self._acc(row, drow, True)
+            dz1, gs1 = T.conv_fused([T.Src(dh1)], self.wt[c1 + ".weight"], Cin, 9, gsrcs=srcs, ggn=gn1)
+            if has_sc:
+                self._wg(lambda: T.wgrad_fused(dy, srcs, self.g[sc_n + ".weight"], 1, total=self.g[sc_n + ".bias"]), dy, *[s.t for s in srcs])
+                self._done(sc_n + ".weight", sc_n + ".bias")
+                res = T.conv(dy, self.wt[sc_n + ".weight"], Cin, 1)
+            else:
+                res = dy
+            curs = [self._slot(s.t) for s in srcs]
+            outs = T.gn_backward_apply(dz1, srcs, gs1, gn1, self.g[n1 + ".weight"], self.g[n1 + ".bias"], res=res, dsts=curs,
+                                       accumulate=[c is not None for c in curs] + [False])
+            self._done(n1 + ".weight", n1 + ".bias")
+            for s, o, c in zip(srcs, outs, curs):
+                if c is None:
+                    self._acc(s.t, o, True)
+        self._tape.append(bwd)
+        return y
+
+    def _attention_f(self, x, p):
+        """Attention block: group_norm folded into the fused q/k/v projection's staging, to_out carries the residual and the
+        output statistics; backward as _resnet_f (the projection's data gradient ends in the GroupNorm-backward epilogue)."""
+        cfg = self.cfg
+        B, W, H, Cc = x.shape
+        srcs = self._srcs(x)
+        gnn, wq, wo = p + ".group_norm", p + ".to_qkv", p + ".to_out.0"
+        grp = self.fused[wq]
+        gna = T.GN(self.p[gnn + ".weight"], self.p[gnn + ".bias"], False, cfg.norm_num_groups, cfg.norm_eps)
+        qkv = T.conv_fused(srcs, self.wf[wq + ".weight"], 3 * Cc, 1, gn=gna, bias=self.p[wq + ".bias"])
+        qkv3 = qkv.view(B, W * H, 3 * Cc)
+        o3, lse = T.attention_qkv_forward(qkv3)
+        o = o3.view(B, W, H, Cc)
+        y, csy = T.conv_fused([T.Src(o)], self.wf[wo + ".weight"], Cc, 1, bias=self.p[wo + ".bias"], res=x, want_stats=True)
+        self._cs[id(y)] = csy
+
+        def bwd():
+            dy = self._pop(y)
+            self._wg(lambda: T.wgrad_bias(dy, o, self.g[wo + ".weight"], 1, total=self.g[wo + ".bias"]), dy, o)
+            self._done(wo + ".weight", wo + ".bias")
+            do = T.conv(dy, self.wt[wo + ".weight"], Cc, 1)
+            dqkv = T.attention_qkv_backward(qkv3, o3, do.view(B, W * H, Cc), lse).view(qkv.shape)
+            self._wg(lambda: T.wgrad_fused(dqkv, srcs, self.g[wq + ".weight"], 1, gn=gna, total=self.g[wq + ".bias"]), dqkv, x, srcs[0].cs)
+            self._done(*(grp["weights"] + grp["biases"]))
+            dz, gs = T.conv_fused([T.Src(dqkv)], self.wt[wq + ".weight"], Cc, 1, gsrcs=srcs, ggn=gna)
+            cur = self._slot(x)
+            out, = T.gn_backward_apply(dz, srcs, gs, gna, self.g[gnn + ".weight"], self.g[gnn + ".bias"], res=dy, dsts=[cur],
+                                       accumulate=[cur is not None, False])
+            self._done(gnn + ".weight", gnn + ".bias")
+            if cur is None:
+                self._acc(x, out, True)
+        self._tape.append(bwd)
+        return y
+
+    def _conv_stats(self, x, name, stride=1, mode=0):
+        """A conv whose input is used as it is (down / up samplers) and whose output a GroupNorm will read: `_conv` with the
+        output's statistics accumulated by the forward launch."""
+        return self._conv(x, name, stride=stride, mode=mode, stats=True)
+
     # ---- network ----------------------------------------------------------------------------------------------
     def forward(self, sample_nchw, timesteps, pos_encoding=False):
         """sample (B, C, W, H) fp32 on the device; pos_encoding=True appends the azimuth-0 marker channel here (the
         `torch.cat([noisy_images, pos_encoding], dim=1)` of ldm/train_unconditional.py:500-501), so C + 1 == in_channels.
         timesteps (B,) int64 -> model_output (B, W, H, out_channels) NHWC.  Records the tape for `backward`."""
         cfg = self.cfg
-        self._tape, self._grad = [], {}
+        self._tape, self._grad, self._cs = [], {}, {}
         T.set_zero_arena(self._arena)                   # split-K conv outputs of this step: pre-zeroed slices, one fill
         self._arena.begin()
+        fz = self.fused_shape_ok(sample_nchw.shape[0], sample_nchw.shape[2], sample_nchw.shape[3])
+        self.last_forward_fused = fz
         x = T.pack_input(sample_nchw.float().contiguous(), pos_encoding)
         if x.shape[3] != cfg.in_channels:
             raise ValueError(f"sample has {x.shape[3]} channels (incl. pos-encoding), the UNet expects {cfg.in_channels}")
@@ -487,6 +657,7 @@ class UNetTrainer:
         if "time_emb_proj_all" in self.fused:           # every resnet's time_emb_proj in one launch; the resnets add column slices
             grp = self.fused["time_emb_proj_all"]
             rows = self._linear(temb_act, "time_emb_proj_all", done=grp["weights"] + grp["biases"])
+            self._tape.append(self._wg_join)            # (runs BEFORE that linear's backward: the row gradients are complete)
             off = 0
             for wn in grp["weights"]:
                 view = rows[:, off:off + self.shapes[wn][0]]
@@ -496,27 +667,46 @@ class UNetTrainer:
         h = self._conv(x, "conv_in", need_dx=False)
         skips = [h]
         nl = len(cfg.block_out_channels)
+        # per level: the fused blocks where they pay (measured per shape, profiles/round5_train_by_grid_*: at >= `fused_min_pixels`
+        # pixels per image the GroupNorm passes they remove cost more than what they add to the conv launches; below, a launch of
+        # either kind sits at its ~8 us floor and the op-per-layer blocks are as fast)
+        W0, H0 = sample_nchw.shape[2], sample_nchw.shape[3]
+        fzl = [fz and (W0 >> l) * (H0 >> l) >= self.fused_min_pixels for l in range(nl)]
+        self.last_forward_fused_levels = fzl
+
+        def resnet(t, p, l):
+            if fzl[l]:
+                return self._resnet_f(t, p)
+            if isinstance(t, UNetTrainer.Cat):
+                t = self._concat(t.a, t.b)
+            return self._resnet(t, p, temb_act)
+
+        def attention(t, p, l):
+            return self._attention_f(t, p) if fzl[l] else self._attention(t, p)
+
         for i, bt in enumerate(cfg.down_block_types):
             for j in range(cfg.layers_per_block):
-                h = self._resnet(h, f"down_blocks.{i}.resnets.{j}", temb_act)
+                h = resnet(h, f"down_blocks.{i}.resnets.{j}", i)
                 if bt == "AttnDownBlock2D":
-                    h = self._attention(h, f"down_blocks.{i}.attentions.{j}")
+                    h = attention(h, f"down_blocks.{i}.attentions.{j}", i)
                 skips.append(h)
             if i != nl - 1:
-                h = self._conv(h, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+                # (the output's statistics ride in the conv's epilogue when the next level's blocks will ask for them)
+                h = self._conv(h, f"down_blocks.{i}.downsamplers.0.conv", stride=2, stats=fzl[i + 1])
                 skips.append(h)
-        h = self._resnet(h, "mid_block.resnets.0", temb_act)
+        h = resnet(h, "mid_block.resnets.0", nl - 1)
         if cfg.add_attention:
-            h = self._attention(h, "mid_block.attentions.0")
-        h = self._resnet(h, "mid_block.resnets.1", temb_act)
+            h = attention(h, "mid_block.attentions.0", nl - 1)
+        h = resnet(h, "mid_block.resnets.1", nl - 1)
         for i, bt in enumerate(cfg.up_block_types):
+            l = nl - 1 - i
             for j in range(cfg.layers_per_block + 1):
-                h = self._concat(h, skips.pop())
-                h = self._resnet(h, f"up_blocks.{i}.resnets.{j}", temb_act)
+                h = UNetTrainer.Cat(h, skips.pop())
+                h = resnet(h, f"up_blocks.{i}.resnets.{j}", l)
                 if bt == "AttnUpBlock2D":
-                    h = self._attention(h, f"up_blocks.{i}.attentions.{j}")
+                    h = attention(h, f"up_blocks.{i}.attentions.{j}", l)
             if i != nl - 1:
-                h = self._conv(h, f"up_blocks.{i}.upsamplers.0.conv", mode=1)
+                h = self._conv(h, f"up_blocks.{i}.upsamplers.0.conv", mode=1, stats=fzl[l - 1])
         assert not skips
         h = self._gn(h, "conv_norm_out", True)
         self._out = self._conv(h, "conv_out")
@@ -540,7 +730,8 @@ class UNetTrainer:
         self._acc(self._out, dpred, False)
         for fn in reversed(self._tape):
             fn()
-        self._tape, self._grad = [], {}
+        self._wg_join()
+        self._tape, self._grad, self._cs = [], {}, {}
         T.set_zero_arena(None)
         if launch_collectives:
             for w in self._pending:

@@ -39,6 +39,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.ConvDescC) == 4 * 13
     assert ctypes.sizeof(_lib.TrainConvDescC) == 4 * 8 and ctypes.sizeof(_lib.AdamWConfigC) == 4 * 8
     assert ctypes.sizeof(_lib.PackDescC) == 48 and _lib.PackDescC.N.offset == 32
+    assert ctypes.sizeof(_lib.TrainFuseC) == 152 and _lib.TrainFuseC.cs_out.offset == 64 and _lib.TrainFuseC.gs_out.offset == 144
     assert ctypes.sizeof(_lib.LidarConfigC) == 4 * (7 + 3 + 6 + 1)
     assert _lib.SamplerConfigC.coef.offset == 24 and _lib.SamplerConfigC.timesteps.offset == 32
     assert _lib.SamplerConfigC.plan_flags.offset == 40 and ctypes.sizeof(_lib.SamplerConfigC) == 48

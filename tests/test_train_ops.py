@@ -225,3 +225,69 @@ def test_adamw_clip_ema_match_torch():
         assert abs(float(sq) - float((g.double() ** 2).sum())) < 1e-6 * float((g.double() ** 2).sum())
         T.adamw(pd, gd, m, v, step, 1e-3, (0.95, 0.999), 1e-8, 1e-6, ema=ema, ema_decay=decay, sqnorm_dev=sq, max_grad_norm=1.0)
         assert rel(pd, p.detach()) < 1e-6 and rel(ema, ema_ref) < 1e-6
+
+
+# ---- fused tape (round 5): GroupNorm folded into its consumers / producers ------------------------------------------------
+@pytest.mark.parametrize("B,C0,C1,N,W,H,taps,silu", [
+    (8, 256, 0, 256, 32, 2, 9, True),        # 32x2 level: split-K launch, the tile's last arriver runs the epilogue
+    (8, 256, 128, 256, 64, 4, 9, True),      # two sources, 12 channels per group (groups straddle the seam), split-K
+    (4, 128, 0, 128, 256, 16, 9, True),      # halo-tile kernel, 64-channel tiles
+    (8, 128, 0, 128, 256, 16, 9, True),      # halo-tile kernel, 128-channel tiles
+    (2, 128, 128, 384, 128, 8, 1, False),    # 1x1 (to_q/k/v form: no SiLU), two sources, no split
+    (2, 96, 0, 64, 32, 4, 9, True),          # 32-channel chunks, 3 channels per group
+    (2, 512, 256, 256, 32, 2, 1, True),      # 768 input channels (24 per group)
+    (3, 64, 64, 64, 64, 2, 9, True),         # three halo passes, two sources
+])
+def test_fused_norm_conv_forward_backward(B, C0, C1, N, W, H, taps, silu):
+    """act(GN(cat(x0, x1))) -> conv + bias + row + res in ONE launch with the output's statistics; backward: the data gradient with
+    the GroupNorm-backward transform in its epilogue + rldm_train_gn_backward_apply; the weight gradient rebuilding its operand."""
+    from rangeldm_amd import train_ops as T
+    k = 3 if taps == 9 else 1
+    Cin = C0 + C1
+    x = (rnd(B, Cin, W, H, seed=1) * 1.5 + 0.3).requires_grad_()
+    g = (1 + 0.3 * rnd(Cin, seed=2)).requires_grad_()
+    b = (0.2 * rnd(Cin, seed=3)).requires_grad_()
+    w = (rnd(N, Cin, k, k, seed=4) / (Cin * taps) ** 0.5).requires_grad_()
+    bias, row, res = rnd(N, seed=5), rnd(B, N, seed=6), rnd(B, N, W, H, seed=7)
+    h = o_ops.group_norm_silu(x, g, b, 32, 1e-5, silu)
+    ref = o_ops.circ_conv2d(h, w, bias, 1, 1 if taps == 9 else 0) + row[:, :, None, None] + res
+    dy = rnd(*ref.shape, seed=8)
+    ref.backward(dy)
+    xd = nhwc(x.detach())
+    srcs = [T.Src(xd[..., :C0].contiguous())] + ([T.Src(xd[..., C0:].contiguous())] if C1 else [])
+    for s in srcs:
+        s.cs = T.chan_stats(s.t)
+        xs = nchw(s.t)
+        assert rel(s.cs[..., 0].cpu(), xs.sum((2, 3))) < TOL_F32 and rel(s.cs[..., 1].cpu(), (xs * xs).sum((2, 3))) < TOL_F32
+    gn = T.GN(g.detach().cuda(), b.detach().cuda(), silu, 32, 1e-5)
+    wf, wt = T.pack_weights(w.detach().cuda(), taps)
+    assert T.conv_fused_ok(srcs, N, taps, gn=gn, want_stats=True)
+    y, cs = T.conv_fused(srcs, wf, N, taps, gn=gn, bias=bias.cuda(), rowadd=row.cuda(), res=nhwc(res), want_stats=True)
+    assert rel(nchw(y), ref.detach()) < TOL_MM
+    yr = nchw(y)
+    assert rel(cs[..., 0].cpu(), yr.sum((2, 3))) < 1e-4 and rel(cs[..., 1].cpu(), (yr * yr).sum((2, 3))) < 1e-4
+    # the same without the statistics epilogue (register epilogue of the fused instance)
+    y1 = T.conv_fused(srcs, wf, N, taps, gn=gn, bias=bias.cuda(), rowadd=row.cuda(), res=nhwc(res))
+    assert rel(nchw(y1), ref.detach()) < TOL_MM
+    # backward: d act(GN(x)) = conv^T(dy), transformed to dz in the epilogue
+    dyd = nhwc(dy)
+    dsrc = [T.Src(dyd)]
+    assert T.conv_fused_ok(dsrc, Cin, taps, gsrcs=srcs, ggn=gn)
+    dz, gs = T.conv_fused(dsrc, wt, Cin, taps, gsrcs=srcs, ggn=gn)
+    dg, db = torch.zeros(Cin).cuda(), torch.zeros(Cin).cuda()
+    extra = nhwc(rnd(B, Cin, W, H, seed=9))                       # a residual-path gradient added by the same launch
+    pre1 = torch.full_like(srcs[-1].t, 0.5)
+    dsts = T.gn_backward_apply(dz, srcs, gs, gn, dg, db, res=extra, dsts=[None, pre1][:len(srcs)], accumulate=(False, True))
+    want = x.grad + nchw(extra)
+    assert rel(nchw(dsts[0]), want[:, :C0]) < TOL_MM
+    if C1:
+        assert rel(nchw(dsts[1]), want[:, C0:] + 0.5) < TOL_MM
+    assert rel(dg.cpu(), g.grad) < TOL_MM and rel(db.cpu(), b.grad) < TOL_MM
+    # weight gradient with the operand rebuilt from the raw sources
+    if T.wgrad_fused_ok(srcs, N, taps, gn=gn):
+        dw, rows, tot = torch.zeros_like(w.detach()).cuda(), torch.zeros(B, N).cuda(), torch.zeros(N).cuda()
+        T.wgrad_fused(dyd, srcs, dw, taps, gn=gn, rows=rows, total=tot)
+        assert rel(dw.cpu(), w.grad) < TOL_MM
+        assert rel(rows.cpu(), dy.sum((2, 3))) < 3e-3 and rel(tot.cpu(), dy.sum((0, 2, 3))) < 3e-3
+    else:
+        assert Cin % 64 != 0

@@ -104,6 +104,10 @@ def test_parameter_order_makes_fused_groups_contiguous():
     (dict(**SMALL), 2, None),
     (dict(sample_size=(16, 4), block_out_channels=(32, 64), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
           up_block_types=("AttnUpBlock2D", "UpBlock2D")), 3, [0.3, 1.0, 0.6]),
+    # the fused tape (round 5: GroupNorm inside its producers / consumers, concatenations read in place) needs 64-multiples of
+    # channels and >= 64-pixel images at every level
+    (dict(sample_size=(64, 8), block_out_channels=(64, 128), down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+          up_block_types=("AttnUpBlock2D", "UpBlock2D")), 2, [0.4, 1.0]),
 ])
 def test_unet_gradients_match_autograd(kw, B, weights):
     cfg = UNetConfig(**kw)
@@ -115,8 +119,10 @@ def test_unet_gradients_match_autograd(kw, B, weights):
     w = None if weights is None else torch.tensor(weights)
     pred_ref, loss_ref, gref = oracle_grads(cfg, sd, x, t, target, w)
     tr = TR.UNetTrainer(cfg, sd, use_ema=False)
+    tr.fused_min_pixels = 0                     # (every level on the fused blocks where the shapes allow them)
     from rangeldm_amd import train_ops as T
     pred = tr.forward(x.cuda(), t.cuda())
+    assert tr.last_forward_fused == (cfg.block_out_channels[0] == 64)
     assert rel(T.unpack_output(pred), pred_ref) < 2e-2
     loss, dpred = T.mse(pred, target.cuda(), None if w is None else w.cuda())
     assert abs(float(loss) - loss_ref) < 2e-2 * loss_ref
@@ -458,6 +464,41 @@ def test_training_step_loop_body_unconditional_and_conditional():
     l1 = [float(TR.training_step(trc, vae, sched, imgs.cuda(), generator=torch.Generator().manual_seed(1), pos_encoding=False,
                                  condition=cond)) for _ in range(6)]
     assert all(math.isfinite(v) for v in l1) and l1[-1] < l1[0]
+
+
+@pytest.mark.gpu
+def test_fused_tape_equals_layer_tape_full_config():
+    """BASELINE config-5 shapes, batch 2: the fused tape (3 launches per resnet forward; GroupNorm only inside conv kernels) against
+    the op-per-layer tape (RLDM_TRAIN_FUSED=0's path) on the same weights: same prediction and same gradients up to the bf16
+    rounding of operands (z = x a + b against ((x - mean) rstd) gamma + beta: last-bit differences in fp32 flip bf16 roundings, which
+    a 60-conv network amplifies to 4e-3 on the prediction) and the order of the fp32 atomics."""
+    from rangeldm_amd import train_ops as T
+    cfg = UNetConfig()
+    sd = synth_state_dict(unet_param_shapes(cfg))
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, 256, 16, generator=g).cuda()
+    target = torch.randn(2, 4, 256, 16, generator=g).cuda()
+    t = torch.tensor([101, 902]).cuda()
+    out = []
+    for fused, min_px in ((True, 0), (False, 0), (True, 1024)):
+        tr = TR.UNetTrainer(cfg, sd, use_ema=False)
+        tr.fused_tape, tr.fused_min_pixels = fused, min_px
+        pred = tr.forward(x, t, pos_encoding=True)
+        assert tr.last_forward_fused == fused
+        assert tr.last_forward_fused_levels == ([fused] * 4 if min_px == 0 else [True, True, False, False])
+        loss, dpred = T.mse(pred, target)
+        tr.backward(dpred)
+        out.append((pred.clone(), float(loss), tr.grads.clone(), {n: tr.g[n].clone() for n in tr.names}))
+    (pa, la, ga, da), (pb, lb, gb, db), (pc, lc, gc, dc) = out
+    # (the default: fused blocks at the two high-resolution levels, op-per-layer blocks below)
+    assert rel(pc, pb) < 8e-3 and abs(lc - lb) < 2e-3 * lb and rel(gc, gb) < 2e-2, (rel(pc, pb), lc, lb, rel(gc, gb))
+    assert rel(pa, pb) < 8e-3 and abs(la - lb) < 2e-3 * lb, (rel(pa, pb), la, lb)
+    assert rel(ga, gb) < 2e-2, rel(ga, gb)
+    rms = float(gb.double().norm() / gb.numel() ** 0.5)
+    worst = sorted(((float((da[n].double() - db[n].double()).norm()) /
+                     (float(db[n].double().norm()) + 2e-2 * rms * db[n].numel() ** 0.5), n) for n in da), reverse=True)
+    assert worst[0][0] < 5e-2, worst[:6]
+    print('fused vs layer tape:', rel(pa, pb), rel(ga, gb), worst[:3])
 
 
 @pytest.mark.gpu

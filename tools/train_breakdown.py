@@ -47,6 +47,14 @@ wrap("linear_rows_wgrad", lambda dy, x, *r: f"{shp(x)}->{dy.shape[1]}")
 wrap("sum2x2", lambda x: shp(x))
 wrap("adamw", lambda p, *r, **kw: shp(p))
 wrap("sqnorm", lambda g: shp(g))
+# fused tape (round 5)
+srcshp = lambda srcs: "+".join(shp(s_.t) for s_ in srcs)   # noqa: E731
+wrap("wgrad_bias", lambda dy, x, dw, taps, stride=1, mode=0, **kw: f"{shp(x)}->{dy.shape[3]} t{taps} s{stride} m{mode}")
+wrap("conv_fused", lambda srcs, w, N, taps, stride=1, mode=0, gn=None, want_stats=False, gsrcs=None, **kw:
+     f"{srcshp(srcs)}->{N} t{taps} s{stride} m{mode}" + (" gn" if gn is not None else "") + (" st" if want_stats else "") + (" gnb" if gsrcs is not None else ""))
+wrap("wgrad_fused", lambda dy, srcs, dw, taps, gn=None, **kw: f"{srcshp(srcs)}->{dy.shape[3]} t{taps}" + (" gn" if gn is not None else ""))
+wrap("gn_backward_apply", lambda dz, srcs, *r, **kw: srcshp(srcs))
+wrap("chan_stats", lambda x: shp(x))
 
 cfg = UNetConfig()
 tr = TR.UNetTrainer(cfg, synth_state_dict(unet_param_shapes(cfg)), use_ema=True)
