@@ -313,6 +313,12 @@ int rldm_train_conv_fused(const rldm_train_conv_desc* d, const rldm_train_fuse* 
 int rldm_train_wgrad_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* f);
 int rldm_train_wgrad_fused(const rldm_train_conv_desc* d, const rldm_train_fuse* f, const float* dy, const float* x, float* dw,
                            float* rows, int rows_ld, int rows_accumulate, float* total, void* stream);
+/* The all-taps weight-gradient kernel leaves partial tiles that a reduction adds into dw.  With deferral on, that reduction is not
+ * launched on its own: it rides (as extra workgroups) on the next rldm_train_conv / _conv_fused launch on the same stream -- the
+ * data gradient of the same layer, which does not depend on it -- or is launched by whatever comes first of: the next weight-gradient
+ * call, rldm_train_flush_reduce, rldm_train_defer_reduce(0).  Call rldm_train_flush_reduce before anything else reads dw. */
+int rldm_train_defer_reduce(int on);
+int rldm_train_flush_reduce(void);
 /* cs [B][C][2] += (sum, sumsq) per (image, channel) of x [B][npix][C]: for tensors no fused conv produced. */
 int rldm_train_chan_stats(const float* x, int B, int npix, int C, float* cs, void* stream);
 /* dx = rstd (gamma dz - mean_g(gamma dz) - xhat mean_g(gamma dz xhat)) + res, the GroupNorm over cat(x0, x1) [C0 | C - C0

@@ -128,6 +128,8 @@ PROTOTYPES = {
     "rldm_train_conv_fused": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "rldm_train_wgrad_fused_ok": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC)]),
     "rldm_train_wgrad_fused": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "rldm_train_defer_reduce": (C.c_int, [C.c_int]),
+    "rldm_train_flush_reduce": (C.c_int, []),
     "rldm_train_chan_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_train_gn_backward_apply": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P,
                                                _P, C.c_int, _P, C.c_int, _P, _P, _P]),

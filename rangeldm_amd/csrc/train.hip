@@ -47,6 +47,30 @@ inline bool attention_scalar() {
     return v;
 }
 
+// dw[n][c][t] += sum over slices of part[t][slice][n][c], four channels per thread (Cin % 4 == 0), `nb` workgroups of `nt` threads
+// striding over the (tap, channel quad) items: the body of tr_wgrad_reduce_vec_kernel, also run as a rider of the next conv launch.
+__device__ inline void tr_wgrad_reduce_items(const float* __restrict__ part, int slices, int N, int Cin, int taps, float* __restrict__ dw,
+                                             int block, int nb, int nt) {
+    const size_t nc = (size_t)N * Cin, nc4 = nc >> 2, items = nc4 * taps;
+    for (size_t i = (size_t)block * nt + threadIdx.x; i < items; i += (size_t)nb * nt) {
+        const int t = (int)(i / nc4);
+        const size_t e = (i - (size_t)t * nc4) * 4;
+        const float* src = part + (size_t)t * slices * nc + e;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int sidx = 0;
+        for (; sidx + 8 <= slices; sidx += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(sidx + j) * nc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; sidx < slices; ++sidx) acc += *reinterpret_cast<const f32x4*>(src + (size_t)sidx * nc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dw[(e + q) * taps + t] += acc[q];
+    }
+}
+
 // source pixel of output pixel (b, wo, ho) under tap (dw, dh): index into the input's pixel array, or -1 for a zero.
 // mode 0: plain; 1: nearest x2 (virtual input is twice as large); 2: zero insertion (virtual odd coordinates are zeros)
 __device__ inline int src_pixel(int b, int wo, int ho, int dw, int dh, int stride, int mode, int Win, int Hin) {
@@ -95,6 +119,9 @@ struct TrFuse {
     const float* ggamma; const float* gbeta; int gsilu, ggroups; float geps;
     float* gs_out;
     unsigned* tickets;                             // split-K launches: a zeroed arrival counter per output tile (left zeroed)
+    // a rider: the reduction of the PREVIOUS weight-gradient launch's partial tiles (it does not depend on this conv, and as a launch of
+    // its own it cost ~10 us 47 times per step): run by extra z-planes of this launch's grid (rz0 = the first of them; rblocks = 0: none)
+    const float* rpart; float* rdw; int rslices, rN, rCin, rtaps, rz0, rblocks;
 };
 
 // (v_exp_f32 + v_rcp_f32: the IEEE division of 1.f / x costs ten more instructions per element of every staged tile)
@@ -316,6 +343,12 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
     // (native vector types: arrays of HIP's uint4 / float4 structs are not split into registers and went through scratch;
     //  no lambda may capture the by-value argument `p` by reference either: that copies the struct to scratch)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int ksplit = f.rblocks ? f.rz0 : (int)gridDim.z;          // (z-planes from rz0 on carry the rider)
+    if ((int)blockIdx.z >= ksplit) {
+        const int rb = ((int)blockIdx.z - ksplit) * (int)(gridDim.x * gridDim.y) + (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        if (rb < f.rblocks) tr_wgrad_reduce_items(f.rpart, f.rslices, f.rN, f.rCin, f.rtaps, f.rdw, rb, f.rblocks, 256);
+        return;
+    }
     const int Cin = p.Cin, Cin_pad = p.Cin_pad, taps = p.taps, Wout = p.Wout, Hout = p.Hout, N = p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
@@ -352,7 +385,7 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
     // split K: workgroup z of gridDim.z contracts stages [it0, it1) and adds its partial tile to y atomically (y zeroed by the
     // launcher; z == 0 carries bias / row / residual).  The low-resolution levels have 32 - 128 output tiles for 36 - 72
     // serial stages of ~0.7 us each: latency, not work, was their whole cost.
-    const int it0 = (int)((long long)niter * blockIdx.z / gridDim.z), it1 = (int)((long long)niter * (blockIdx.z + 1) / gridDim.z);
+    const int it0 = (int)((long long)niter * blockIdx.z / ksplit), it1 = (int)((long long)niter * (blockIdx.z + 1) / ksplit);
     tap = it0 / nck;
     cc = it0 - tap * nck;
     wptr += (size_t)tap * Cin_pad + cc * CK;
@@ -429,7 +462,7 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
             tr_gn_coeffs(sSc, c_lo, min(c_hi, Cin), f.cs0, f.cs1, fC0, Cin, img, f.groups, f.eps, p.Win * p.Hin, f.gamma, f.beta);
             if (c_hi > Cin) tr_gn_coeffs(sSc, 0, c_hi - Cin, f.cs0, f.cs1, fC0, Cin, img, f.groups, f.eps, p.Win * p.Hin, f.gamma, f.beta);
         }
-        if (f.gs_out && gridDim.z == 1)
+        if (f.gs_out && ksplit == 1)
             tr_gn_coeffs_tile(sCe, BN, n0, f.gcs0, f.gcs1, f.G0, N, img, f.ggroups, f.geps, Wout * Hout, f.ggamma, f.gbeta);
     }
     for (int it = it0; it < it1; it += D) {
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
             }
         }
     }
-    if (gridDim.z > 1) {
+    if (ksplit > 1) {
         // through LDS so that the atomics run along the channels (one cache line per 32 lanes; lane = pixel would touch 64 lines
         // per instruction: measured 4x slower than not splitting at all)
         float* tile = reinterpret_cast<float*>(raw);
@@ -491,7 +524,7 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
                 if (tid == 0) {
                     unsigned* tk = f.tickets + blockIdx.y * gridDim.x + blockIdx.x;
                     const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int last = t == gridDim.z - 1;
+                    const int last = (int)t == ksplit - 1;
                     if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sLast = last;
                 }
@@ -594,6 +627,11 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p, co
     __shared__ float4 sCe[FU ? BN : 1];
     __shared__ float sCol[FU ? 2 * BN : 1];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (f.rblocks && (int)blockIdx.z >= f.rz0) {                    // the rider's z-planes
+        const int rb = ((int)blockIdx.z - f.rz0) * (int)(gridDim.x * gridDim.y) + (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        if (rb < f.rblocks) tr_wgrad_reduce_items(f.rpart, f.rslices, f.rN, f.rCin, f.rtaps, f.rdw, rb, f.rblocks, NT);
+        return;
+    }
     const int Cin = p.Cin, Cin_pad = p.Cin_pad, W = p.Wout, H = p.Hout, N = p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
@@ -1110,24 +1148,7 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const 
 // four channels per thread, eight slices in flight (Cin % 4 == 0): the scalar kernel below ran at 2 TB/s over 38 MB of partials
 __global__ __launch_bounds__(256) void tr_wgrad_reduce_vec_kernel(const float* __restrict__ part, int slices, int N, int Cin, int taps,
                                                                   float* __restrict__ dw) {
-    const size_t nc = (size_t)N * Cin, nc4 = nc >> 2;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nc4 * taps) return;
-    const int t = (int)(i / nc4);
-    const size_t e = (i - (size_t)t * nc4) * 4;
-    const float* src = part + (size_t)t * slices * nc + e;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int sidx = 0;
-    for (; sidx + 8 <= slices; sidx += 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(sidx + j) * nc);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += v[j];
-    }
-    for (; sidx < slices; ++sidx) acc += *reinterpret_cast<const f32x4*>(src + (size_t)sidx * nc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dw[(e + q) * taps + t] += acc[q];
+    tr_wgrad_reduce_items(part, slices, N, Cin, taps, dw, blockIdx.x, gridDim.x, 256);
 }
 
 // dw[n][c][t] += sum over slices of part[t][slice][n][c]   (one thread per (t, n, c); reads coalesced along c)
@@ -2245,6 +2266,42 @@ static int fuse_tickets(size_t count, hipStream_t st, unsigned** out) {
     return 0;
 }
 
+// The reduction of the last all-taps weight-gradient launch's partial tiles, waiting for a conv launch to ride on
+// (rldm_train_defer_reduce; one caller thread, stream ordered).
+struct PendingReduce { const float* part = nullptr; float* dw = nullptr; int slices = 0, N = 0, Cin = 0, taps = 0; hipStream_t st = nullptr; };
+static PendingReduce g_red;
+static int g_defer_reduce = 0;
+
+static int flush_reduce() {
+    if (!g_red.part) return 0;
+    tr_wgrad_reduce_vec_kernel<<<nblk((size_t)g_red.N * g_red.Cin * g_red.taps / 4), 256, 0, g_red.st>>>(g_red.part, g_red.slices, g_red.N,
+                                                                                                      g_red.Cin, g_red.taps, g_red.dw);
+    g_red.part = nullptr;
+    RLDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// attach the pending reduction to a conv launch of gx x gy workgroups per z-plane: -> extra z-planes
+static int attach_reduce(TrFuse& f, hipStream_t st, unsigned gx, unsigned gy, unsigned gz) {
+    if (!g_red.part) return 0;
+    if (g_red.st != st) { if (flush_reduce()) return -1; return 0; }
+    const size_t items = (size_t)g_red.N * g_red.Cin * g_red.taps / 4;
+    const int want = (int)std::min<size_t>((items + 255) / 256, 512);
+    const int planes = (int)((want + (size_t)gx * gy - 1) / ((size_t)gx * gy));
+    if (gz + planes > 65535) { if (flush_reduce()) return -1; return 0; }
+    f.rpart = g_red.part; f.rdw = g_red.dw; f.rslices = g_red.slices; f.rN = g_red.N; f.rCin = g_red.Cin; f.rtaps = g_red.taps;
+    f.rz0 = (int)gz; f.rblocks = want;
+    g_red.part = nullptr;
+    return planes;
+}
+
+int rldm_train_defer_reduce(int on) {
+    g_defer_reduce = on;
+    return on ? 0 : flush_reduce();
+}
+
+int rldm_train_flush_reduce(void) { return flush_reduce(); }
+
 static TrFuse to_device_fuse(const rldm_train_fuse* fu, int Cin, int N) {
     TrFuse f{};
     if (!fu) { f.C0 = Cin; return f; }
@@ -2322,12 +2379,17 @@ static int train_conv_impl(const rldm_train_conv_desc* d, const rldm_train_fuse*
             RLDM_REQUIRE(!accumulate, "rldm_train_conv_fused: the fused epilogue writes y (no accumulation)");
             p.accumulate = 0;
         }
+        {                                           // the previous weight gradient's reduction rides on this launch
+            const int planes = attach_reduce(f, st, grid.x, grid.y, grid.z);
+            if (planes < 0) return 1;
+            grid.z += planes;
+        }
         static const bool nohalo_env = getenv("RLDM_TR_NO_HALO") != nullptr;           // A/B: the per-tap staging kernel
         const int H = p.Hout;
         const bool halo = !nohalo_env && ksplit == 1 && p.taps == 9 && p.stride == 1 && p.mode == 0 && p.Cin % 64 == 0 && p.N % 4 == 0 &&
                           H >= 2 && H <= 32 && (H & (H - 1)) == 0 && (p.Wout * H) % 64 == 0 && p.Wout % (64 / H) == 0 && p.Wout >= 64 / H + 2;
         static const int pt_env = getenv("RLDM_TR_PT") ? atoi(getenv("RLDM_TR_PT")) : 0;
-        const bool wide_px = pt_env == 128 && halo && !narrow && (p.Wout * H) % 128 == 0 && p.Wout % (128 / H) == 0 && p.Wout >= 128 / H + 2;
+        const bool wide_px = pt_env == 128 && !f.rblocks && halo && !narrow && (p.Wout * H) % 128 == 0 && p.Wout % (128 / H) == 0 && p.Wout >= 128 / H + 2;
         if (fu) {                                   // the fused instances (conv_fuse_ok held)
             if (halo) {
                 if (narrow) tr_conv_halo_kernel<64, 64, true><<<grid, 256, 0, st>>>(p, f);
@@ -2354,6 +2416,7 @@ static int train_conv_impl(const rldm_train_conv_desc* d, const rldm_train_fuse*
         }
     } else {
         RLDM_REQUIRE(!fu, "rldm_train_conv_fused: not an LDS-staged shape");
+        if (flush_reduce()) return 1;
         if (p.Cin % 16 == 0) tr_conv_kernel<true><<<grid, 256, 0, st>>>(p);
         else tr_conv_kernel<false><<<grid, 256, 0, st>>>(p);
     }
@@ -2399,6 +2462,7 @@ int rldm_train_wgrad_fused(const rldm_train_conv_desc* d, const rldm_train_fuse*
 static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* dy, const float* x, float* dw, float* rows,
                             int rows_ld, int rows_accumulate, float* total, void* stream) {
     RLDM_REQUIRE(d && dy && x && dw, "null argument");
+    if (flush_reduce()) return 1;                     // (the partial-tile scratch is about to be rewritten)
     RLDM_REQUIRE((d->taps == 1 || d->taps == 9) && (d->stride == 1 || d->stride == 2) && d->mode >= 0 && d->mode <= 2, "bad conv desc");
     TrWgrad p;
     p.dy = dy; p.x = x; p.dw = dw;
@@ -2480,7 +2544,12 @@ static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse
         } else if (p.taps == 9) tr_wgrad2_kernel<9><<<grid, 256, smem, st>>>(w2, f);
         else tr_wgrad2_kernel<1><<<grid, 256, smem, st>>>(w2, f);
         TR_LAUNCH_CHECK();
-        if (!w2.dw) tr_wgrad_reduce_vec_kernel<<<nblk((size_t)p.N * p.Cin * p.taps / 4), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
+        if (!w2.dw) {
+            if (g_defer_reduce) {                     // rides on the next conv launch (or is flushed by whatever comes first)
+                g_red.part = scratch; g_red.dw = dw; g_red.slices = splits; g_red.N = p.N; g_red.Cin = p.Cin; g_red.taps = p.taps; g_red.st = st;
+            } else
+                tr_wgrad_reduce_vec_kernel<<<nblk((size_t)p.N * p.Cin * p.taps / 4), 256, 0, st>>>(scratch, splits, p.N, p.Cin, p.taps, dw);
+        }
         TR_LAUNCH_CHECK();
         return 0;
     }

@@ -428,3 +428,12 @@ def gn_backward_apply(dz, srcs, gs, gn, dgamma, dbeta, res=None, dsts=None, accu
                                                  _p(dsts[1]) if two else None, 1 if (two and accumulate[1]) else 0, _p(dgamma),
                                                  _p(dbeta), _s(dz)), "rldm_train_gn_backward_apply")
     return dsts
+
+
+def defer_reduce(on):
+    """Weight-gradient partial-tile reductions ride on the next conv launch (rldm_train_defer_reduce); off: flush + launch eagerly."""
+    _chk(_lib.lib().rldm_train_defer_reduce(1 if on else 0), "rldm_train_defer_reduce")
+
+
+def flush_reduce():
+    _chk(_lib.lib().rldm_train_flush_reduce(), "rldm_train_flush_reduce")

@@ -169,6 +169,8 @@ class UNetTrainer:
         # (RLDM_TRAIN_FUSED=0: the op-per-layer tape, kept as the cross-check)
         self.fused_tape = os.environ.get("RLDM_TRAIN_FUSED", "1") != "0"
         self.fused_min_pixels = int(os.environ.get("RLDM_TRAIN_FUSED_MINPX", "1024"))
+        # the reduction of a weight gradient's partial tiles rides on the layer's data-gradient launch (RLDM_TR_DEFER_REDUCE=0: own launch)
+        self.defer_reduce = os.environ.get("RLDM_TR_DEFER_REDUCE", "1") != "0"
         self._cs = {}
         # weight gradients on a second stream (they are off the dy -> dx chain): forked per launch, joined ONCE in front of the
         # time-embedding MLP's backward / at gradient-bucket cuts (RLDM_TR_WG_STREAM=1; experiment)
@@ -285,6 +287,7 @@ class UNetTrainer:
                 if lo <= i < hi:
                     self._ready[b] -= 1
                     if self._ready[b] == 0:
+                        T.flush_reduce()                         # (the last weight gradient's reduction may still be waiting for a conv to ride on)
                         self._wg_join()                          # the bucket's weight gradients have been enqueued on the side stream
                         if self._on_bucket is not None:          # stream capture: cut the graph here, reduce at replay
                             self._on_bucket(b)
@@ -728,8 +731,12 @@ class UNetTrainer:
             avg = torch.distributed.get_backend() == "nccl" or D.cabi_communicator() is not None
             self._reduce_op = torch.distributed.ReduceOp.AVG if avg else torch.distributed.ReduceOp.SUM
         self._acc(self._out, dpred, False)
-        for fn in reversed(self._tape):
-            fn()
+        T.defer_reduce(self.defer_reduce and self._wg_stream is None)
+        try:
+            for fn in reversed(self._tape):
+                fn()
+        finally:
+            T.defer_reduce(False)                       # (flushes: every gradient is final from here on)
         self._wg_join()
         self._tape, self._grad, self._cs = [], {}, {}
         T.set_zero_arena(None)
