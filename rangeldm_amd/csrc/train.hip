@@ -2166,9 +2166,46 @@ __global__ __launch_bounds__(256) void tr_linear_rows_wgrad_kernel(const float* 
 // 120 MB of weights (337 us).  Here the tile's rows are read as contiguous segments (64 * taps floats per n), parked in LDS
 // as bf16 (row pitch = odd number of dwords) and written out along c (forward copy) and along n (transposed copy, taps
 // flipped).  descs[i].first = cumulative TILE count.  Pads (Cin -> 16-multiple, N -> 16-multiple) are written as zeros.
+// (round 5) whole tiles (N, Cin multiples of 64 -- all but a handful of layers): 16-byte global loads and stores, TAPS a compile-time
+// constant (the scalar form below divided by run-time constants per element and stored 2 bytes per lane: 246 us for 120 MB in, 120 MB out)
+template <int TAPS>
+__device__ __forceinline__ void tr_pack_tile_fast(const float* __restrict__ w, bf16_t* tile, bf16_t* __restrict__ wf, bf16_t* __restrict__ wt,
+                                                  int N, int Cin, int n0, int c0) {
+    constexpr int ROW = 64 * TAPS, PITCH = ROW + 2, R4 = ROW / 4;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * R4; e += 256) {
+        const int nl = e / R4, rem = (e - nl * R4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + ((size_t)(n0 + nl) * Cin + c0) * TAPS + rem);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(tile + nl * PITCH + rem);
+        dst[0] = rldm::pack_bf16x2(v[0], v[1]);
+        dst[1] = rldm::pack_bf16x2(v[2], v[3]);
+    }
+    __syncthreads();
+    typedef unsigned short u16;
+    const u16* t16 = reinterpret_cast<const u16*>(tile);
+    for (int e = tid; e < 64 * TAPS * 8; e += 256) {                 // (nl, t, 8 channels), channel octet fastest
+        const int c8 = e & 7, q = e >> 3, t = q % TAPS, nl = q / TAPS;
+        const u16* src = t16 + nl * PITCH + (8 * c8) * TAPS + t;
+        uint4 u;
+        u.x = src[0] | ((uint32_t)src[TAPS] << 16); u.y = src[2 * TAPS] | ((uint32_t)src[3 * TAPS] << 16);
+        u.z = src[4 * TAPS] | ((uint32_t)src[5 * TAPS] << 16); u.w = src[6 * TAPS] | ((uint32_t)src[7 * TAPS] << 16);
+        *reinterpret_cast<uint4*>(wf + ((size_t)(n0 + nl) * TAPS + t) * Cin + c0 + 8 * c8) = u;
+    }
+    if (wt) {
+        for (int e = tid; e < 64 * TAPS * 8; e += 256) {             // (cl, t, 8 output channels), octet fastest
+            const int n8 = e & 7, q = e >> 3, t = q % TAPS, cl = q / TAPS;
+            const u16* src = t16 + (8 * n8) * PITCH + cl * TAPS + t;
+            uint4 u;
+            u.x = src[0] | ((uint32_t)src[PITCH] << 16); u.y = src[2 * PITCH] | ((uint32_t)src[3 * PITCH] << 16);
+            u.z = src[4 * PITCH] | ((uint32_t)src[5 * PITCH] << 16); u.w = src[6 * PITCH] | ((uint32_t)src[7 * PITCH] << 16);
+            *reinterpret_cast<uint4*>(wt + ((size_t)(c0 + cl) * TAPS + (TAPS - 1 - t)) * N + n0 + 8 * n8) = u;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tr_pack_tiles_kernel(const float* __restrict__ params, const rldm_pack_desc* __restrict__ d,
                                                             int nlayers) {
-    __shared__ bf16_t tile[64 * (64 * 9 + 2)];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * (64 * 9 + 2)];
     int lo = 0, hi = nlayers - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -2180,8 +2217,15 @@ __global__ __launch_bounds__(256) void tr_pack_tiles_kernel(const float* __restr
     const int ctiles = (Cin + 63) / 64;
     const int tl = (int)(blockIdx.x - L.first);
     const int n0 = (tl / ctiles) * 64, c0 = (tl % ctiles) * 64;
-    const int row = 64 * taps, pitch = row + 2;
     const float* w = params + L.param_offset;
+    if ((N & 63) == 0 && (Cin & 63) == 0 && (taps == 9 || taps == 1) && (L.param_offset & 3) == 0) {
+        bf16_t* wf_ = static_cast<bf16_t*>(L.w_forward);
+        bf16_t* wt_ = static_cast<bf16_t*>(L.w_transposed);
+        if (taps == 9) tr_pack_tile_fast<9>(w, tile, wf_, wt_, N, Cin, n0, c0);
+        else tr_pack_tile_fast<1>(w, tile, wf_, wt_, N, Cin, n0, c0);
+        return;
+    }
+    const int row = 64 * taps, pitch = row + 2;
     const int ncol = min(64, Cin - c0) * taps;                       // valid floats of a row segment
     for (int e = threadIdx.x; e < 64 * row; e += 256) {
         const int nl = e / row, rem = e - nl * row;
@@ -2707,7 +2751,7 @@ int rldm_train_gn_backward_apply(const float* dz, const float* x0, const float* 
     a.acc0 = accumulate0; a.acc1 = accumulate1; a.eps = eps;
     // slabs of >= 16 pixels, ~1024 blocks at most
     int slab = 16;
-    while ((long long)B * ((npix + slab - 1) / slab) > 1024) slab *= 2;
+    while ((long long)B * ((npix + slab - 1) / slab) > 512) slab *= 2;
     a.slab = slab;
     tr_gn_bwd_apply2_kernel<<<dim3((npix + slab - 1) / slab, B), 256, 0, (hipStream_t)stream>>>(a);
     TR_LAUNCH_CHECK();
