@@ -125,7 +125,14 @@ struct TrFuse {
 };
 
 // (v_exp_f32 + v_rcp_f32: the IEEE division of 1.f / x costs ten more instructions per element of every staged tile)
+#ifndef RLDM_TR_ABL
+#define RLDM_TR_ABL 0          /* timing experiments (wrong results): 1 no statistics atomics, 2 no sigmoid in the staging transforms */
+#endif
+#if RLDM_TR_ABL & 2
+__device__ inline float tr_sigmoid(float z) { return z; }
+#else
 __device__ inline float tr_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+#endif
 
 // y = x * a + b = GroupNorm(x) for the channels [c_lo, c_hi) of image `img` of a (possibly two-source) tensor with npix pixels per
 // image: sc[c] = (a, b).  Every thread sums its own channel's group from global memory (<= 24 pairs, L2 hits): no barrier inside, the
@@ -177,65 +184,77 @@ __device__ inline void tr_gn_coeffs_tile(float4* ce, int BN, int n0, const float
 template <int BN, int PT, int NT>
 __device__ inline void tr_tile_epilogue(const float* tile, float* colacc, const float4* ce, const TrConv& p, const TrFuse& f, int px0,
                                         int n0, int img, bool add_terms, bool store_y) {
-    constexpr int NPG = NT / BN, IT = PT / NPG, U = IT < 16 ? IT : 16;      // pixels per thread; loads in flight per batch
-    const int tid = threadIdx.x, cl = tid % BN, pg = tid / BN, ch = n0 + cl, N = p.N;
+    // thread (channel quad cq = tid % (BN / 4), pixel group tid / (BN / 4)): 16-byte global accesses, all of a thread's loads in flight
+    // at once (the 4-byte form of this pass -- a channel per thread, 32 pixels in two batches -- was ~5 us of every fused launch)
+    constexpr int NQ = BN / 4, NPG = NT / NQ, IT = PT / NPG;        // BN = 128, 256 threads: 32 quads x 8 groups, 8 pixels per thread
+    static_assert(PT % NPG == 0 && IT <= 16, "tile epilogue shape");
+    const int tid = threadIdx.x, cq = tid % NQ, pg = tid / NQ, cl = 4 * cq, ch = n0 + cl, N = p.N;
     for (int e = tid; e < 2 * BN; e += NT) colacc[e] = 0.f;
     __syncthreads();
-    float s1 = 0.f, s2 = 0.f;
-    if (ch < N) {
-        float addc = 0.f;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (ch < N) {                                                   // (N % 4 == 0: a quad is inside or outside)
+        f32x4 addc = {0.f, 0.f, 0.f, 0.f};
         if (add_terms) {
-            if (p.bias) addc += p.bias[ch];
-            if (p.rowadd) addc += p.rowadd[(size_t)img * p.rowadd_ld + ch];
+            if (p.bias) addc += *reinterpret_cast<const f32x4*>(p.bias + ch);
+            if (p.rowadd) addc += *reinterpret_cast<const f32x4*>(p.rowadd + (size_t)img * p.rowadd_ld + ch);
         }
         const bool gn = f.gs_out != nullptr, act = gn && f.gsilu != 0;
-        const float4 c4 = gn ? ce[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 c4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c4[q] = gn ? ce[cl + q] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float* __restrict__ gsrc = nullptr;
         int gld = 0;
-        if (gn) {
+        if (gn) {                                                   // (G0 % 4 == 0: the quad lies in one source)
             if (ch < f.G0) { gsrc = f.g0 + ch; gld = f.G0; }
             else { gsrc = f.g1 + (ch - f.G0); gld = N - f.G0; }
         }
         const float* __restrict__ rsrc = (add_terms && p.res) ? p.res + ch : nullptr;
         float* __restrict__ ydst = p.y + ch;
-        // (all of a batch's loads are issued before its first store: one memory latency per batch, not per pixel)
-        for (int i0 = 0; i0 < IT; i0 += U) {
-            float rv[U], gv[U];
+        f32x4 rv[IT], gv[IT];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const size_t gp = (size_t)px0 + pg + (i0 + u) * NPG;
-                rv[u] = rsrc ? rsrc[gp * N] : 0.f;
-                gv[u] = gn ? gsrc[gp * gld] : 0.f;
-            }
+        for (int u = 0; u < IT; ++u) {
+            const size_t gp = (size_t)px0 + pg + u * NPG;
+            rv[u] = rsrc ? *reinterpret_cast<const f32x4*>(rsrc + gp * N) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gv[u] = gn ? *reinterpret_cast<const f32x4*>(gsrc + gp * gld) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pl = pg + (i0 + u) * NPG;
-                const size_t gp = (size_t)px0 + pl;
-                float v = tile[pl * (BN + 1) + cl] + addc + rv[u];
-                if (gn) {
-                    const float g = gv[u], xh = (g - c4.z) * c4.w;
+        for (int u = 0; u < IT; ++u) {
+            const int pl = pg + u * NPG;
+            const size_t gp = (size_t)px0 + pl;
+            const float* tr_ = tile + pl * (BN + 1) + cl;
+            f32x4 v = {tr_[0], tr_[1], tr_[2], tr_[3]};
+            v += addc + rv[u];
+            if (gn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float g = gv[u][q], xh = (g - c4[q].z) * c4[q].w;
                     if (act) {
-                        const float z = g * c4.x + c4.y, sg = tr_sigmoid(z);
-                        v *= sg * (1.f + z * (1.f - sg));
+                        const float z = g * c4[q].x + c4[q].y, sg = tr_sigmoid(z);
+                        v[q] *= sg * (1.f + z * (1.f - sg));
                     }
-                    s1 += v;
-                    s2 += v * xh;
-                    ydst[gp * N] = v;
-                } else {
-                    s1 += v;
-                    s2 += v * v;
-                    if (store_y) ydst[gp * N] = v;
+                    s1[q] += v[q];
+                    s2[q] += v[q] * xh;
                 }
+                *reinterpret_cast<f32x4*>(ydst + gp * N) = v;
+            } else {
+                s1 += v;
+                s2 += v * v;
+                if (store_y) *reinterpret_cast<f32x4*>(ydst + gp * N) = v;
             }
         }
     }
-    atomicAdd(&colacc[2 * cl], s1);
-    atomicAdd(&colacc[2 * cl + 1], s2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        atomicAdd(&colacc[2 * (cl + q)], s1[q]);
+        atomicAdd(&colacc[2 * (cl + q) + 1], s2[q]);
+    }
     __syncthreads();
     float* out = f.gs_out ? f.gs_out : f.cs_out;
     for (int e = tid; e < 2 * BN; e += NT) {
         const int c2 = n0 + (e >> 1);
+#if !(RLDM_TR_ABL & 1)
         if (c2 < N) unsafeAtomicAdd(out + ((size_t)img * N + c2) * 2 + (e & 1), colacc[e]);
+#endif
     }
 }
 
@@ -679,7 +698,25 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p, co
                 for (int q = 0; q < 4; ++q) xr[j][q] = reinterpret_cast<const f32x4*>(src)[q];
             }
     };
-    auto stash_x = [&](int cc) __attribute__((always_inline)) {
+    // (FU) GroupNorm (+ SiLU) of halo pass j's staged values, in their registers.  For every chunk but the first it runs during the previous
+    // chunk's last three taps, between their MFMAs (the values have been in flight since tap 2) -- as part of stash_x the whole workgroup
+    // did VALU work between two barriers while the matrix pipe idled: + 9 us per 256x16 conv.
+    auto xform = [&](int cc, int j) __attribute__((always_inline)) {
+        if (j < npass && hin[j]) {
+            const float2* co = sSc + cc * CK + sq * 16;
+            const bool act = f.silu != 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 c_ = co[4 * q + e];
+                    float z = xr[j][q][e] * c_.x + c_.y;
+                    if (act) z *= tr_sigmoid(z);
+                    xr[j][q][e] = z;
+                }
+        }
+    };
+    auto stash_x = [&](int cc, bool xformed) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < npass && hin[j]) {
@@ -689,7 +726,7 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p, co
                 for (int q = 0; q < 2; ++q) {
                     f32x4 a = xr[j][2 * q], c = xr[j][2 * q + 1];
                     if constexpr (FU) {
-                        if (in_gn) {                // GroupNorm (+ SiLU) once per staged element; the halo's zero rows stay zeros (lv)
+                        if (in_gn && !xformed) {    // GroupNorm (+ SiLU) once per staged element; the halo's zero rows stay zeros (lv)
                             const float2* co = sSc + cc * CK + sq * 16 + 8 * q;
                             const bool act = f.silu != 0;
 #pragma unroll
@@ -738,7 +775,7 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p, co
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {         // (unrolled: the ring slot tap % D is a compile-time register set)
             __syncthreads();                        // everyone is done reading the previous stage (and, at tap 0, the halo tile)
-            if (tap == 0) stash_x(cc);
+            if (tap == 0) stash_x(cc, cc > 0);
             HALO_STASH_W(tap % D)
             __syncthreads();
             if (tap + D < 9) HALO_FETCH_W(tap % D, tap + D, cc)
@@ -755,6 +792,9 @@ __global__ __launch_bounds__(PT * 4) void tr_conv_halo_kernel(const TrConv p, co
                     const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aw1 + 16 * ks);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
                 }
+            }
+            if constexpr (FU) {
+                if (in_gn && tap >= 6 && cc + 1 < nck) xform(cc + 1, tap - 6);
             }
         }
     }
@@ -2366,9 +2406,10 @@ static bool conv_fuse_ok(const rldm_train_conv_desc* d, const rldm_train_fuse* f
     if (fu->x1 && (fu->C0 <= 0 || fu->C0 >= d->Cin || fu->C0 % CK != 0 || (d->Cin - fu->C0) % 4 != 0 || fu->C0 % 4 != 0)) return false;
     if (fu->cs0 && (d->Cin > 768 || fu->groups < 1 || fu->groups > 64 || d->Cin % fu->groups != 0 || !fu->gamma || !fu->beta || (fu->x1 && !fu->cs1))) return false;
     if (fu->cs_out && fu->gs_out) return false;
+    if ((fu->cs_out || fu->gs_out) && d->N % 4 != 0) return false;          // (the tile epilogue works on channel quads)
     if (fu->gs_out) {
         if (!fu->g0 || !fu->gcs0 || !fu->ggamma || !fu->gbeta || fu->ggroups < 1 || d->N % fu->ggroups != 0) return false;
-        if (fu->g1 && (!fu->gcs1 || fu->G0 <= 0 || fu->G0 >= d->N)) return false;
+        if (fu->g1 && (!fu->gcs1 || fu->G0 <= 0 || fu->G0 >= d->N || fu->G0 % 4 != 0)) return false;
     }
     return true;
 }
