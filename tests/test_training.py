@@ -422,16 +422,16 @@ def test_graphed_steps_cut_at_gradient_buckets_on_one_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["--eager", "--graphed"])
+@pytest.mark.parametrize("mode", ["--eager", "--graphed", "--full"])
 def test_two_data_parallel_ranks_on_one_gpu(mode):
     """tools/dp_probe.py: two real ranks (gloo on device tensors; RCCL refuses two ranks per device) through the eager and the
     captured, bucket-cut step: identical parameters on both ranks, equal to one process trained on the concatenated batch."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29541 + (mode == "--graphed")
+    port = 29541 + ["--eager", "--graphed", "--full"].index(mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tools", "dp_probe.py")] + ([mode] if mode == "--eager" else [])
+           "--master-port", str(port), os.path.join(root, "tools", "dp_probe.py")] + ([mode] if mode != "--graphed" else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "max |rank0 - rank1| = 0.000e+00" in r.stdout, r.stdout[-1000:]
