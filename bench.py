@@ -160,6 +160,40 @@ def cpu_baseline_c1(seed, budget_s=40.0):
                   f"median of {len(runs)} full runs ({med:.2f} s per image), nothing extrapolated"})
 
 
+def in_graph_launch_us(preset, seed, batch, kernel, dev):
+    """The dominant kernel's duration INSIDE the sampler's captured step graph (the production regime): a second sampler built
+    with rldm_debug_set_flags(8192) has a one-thread kernel write the 100 MHz real-time counter between consecutive launches
+    (tools/graph_trace.py).  The HIP-event figure of `roofline` times launches enqueued one by one, which spaces them out and
+    lengthens each; this one is what the launch costs back to back.  -> (average us of `kernel`, us of the whole UNet forward)"""
+    import ctypes as C
+    from rangeldm_amd import _lib
+    from rangeldm_amd.pipelines import LDMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    from rangeldm_amd.synth import latent_noise
+    base_flags = int(os.environ.get("RLDM_DBG_FLAGS", "0"))
+    _lib.lib().rldm_debug_set_flags(8192 | base_flags)
+    try:
+        p, unet, vae, _, _ = build_models(preset, seed)
+        pipe = LDMPipelineRange(vae=vae, unet=unet, scheduler=DDIMSchedulerHIP(), pos_encoding=p["pos_encoding"])
+        shape = (p["unet"].out_channels, *p["unet"].sample_size)
+        x = torch.from_numpy(np.stack([latent_noise(1, j, shape) for j in range(batch)])).to(dev)
+        for _ in range(2):
+            pipe(batch_size=batch, num_inference_steps=10, latents=x, output_type="torch")
+        torch.cuda.synchronize()
+        stamps = (C.c_ulonglong * 4096)()
+        names = C.create_string_buffer(1 << 16)
+        n = _lib.lib().rldm_debug_graph_trace(stamps, 4096, names, len(names))
+        if n <= 0:
+            return None
+        nm = names.value.decode().split("\n")[:n]
+        t = np.array([stamps[i] for i in range(n + 1)], dtype=np.int64)
+        d = (t[1:] - t[:-1]) * 0.01                     # us (100 MHz)
+        mine = [v for k, v in zip(nm, d) if k == kernel]
+        return (float(np.mean(mine)) if mine else None), float(d.sum()), n
+    finally:
+        _lib.lib().rldm_debug_set_flags(base_flags)
+
+
 def roofline(pipe, sampler_handle, x_T, steps):
     from rangeldm_amd import _lib
     buf = C.create_string_buffer(1 << 16)
@@ -537,6 +571,17 @@ def main():
                 t_oc = time.perf_counter()
                 res["other_configs"] = other_configs(args.seed, dev)
                 res["other_configs_seconds"] = round(time.perf_counter() - t_oc, 1)
+                try:                                    # (after everything timed; its stamp launches must not touch `value`)
+                    ig = in_graph_launch_us(args.preset, args.seed, B, rl["kernel"], dev)
+                    if ig and ig[0]:
+                        ach = rl["alg_flops_per_launch"] / (ig[0] * 1e-6) / 1e12
+                        rl["in_graph"] = {"avg_launch_us": round(ig[0], 2), "achieved": round(ach, 1), "frac": round(ach / rl["peak"], 4),
+                                          "unet_forward_us": round(ig[1], 1), "launches": ig[2],
+                                          "note": "the same kernel timed inside the sampler's captured step graph (device real-time "
+                                                  "counter between launches, tools/graph_trace.py); `achieved` / `frac` above are the "
+                                                  "HIP-event figures of launches enqueued one by one"}
+                except Exception as e:                  # noqa: BLE001  (a secondary figure: never fail the line)
+                    rl["in_graph"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
     D.barrier()
     D.close()
