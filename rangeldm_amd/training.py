@@ -172,9 +172,6 @@ class UNetTrainer:
         # the reduction of a weight gradient's partial tiles rides on the layer's data-gradient launch (RLDM_TR_DEFER_REDUCE=0: own launch)
         self.defer_reduce = os.environ.get("RLDM_TR_DEFER_REDUCE", "1") != "0"
         self._cs = {}
-        # weight gradients on a second stream (they are off the dy -> dx chain): forked per launch, joined ONCE in front of the
-        # time-embedding MLP's backward / at gradient-bucket cuts (RLDM_TR_WG_STREAM=1; experiment)
-        self._wg_stream = torch.cuda.Stream(self.device) if os.environ.get("RLDM_TR_WG_STREAM", "0") == "1" else None
 
     # ---- parameters -------------------------------------------------------------------------------------------
     def _view(self, flat, n):
@@ -288,7 +285,6 @@ class UNetTrainer:
                     self._ready[b] -= 1
                     if self._ready[b] == 0:
                         T.flush_reduce()                         # (the last weight gradient's reduction may still be waiting for a conv to ride on)
-                        self._wg_join()                          # the bucket's weight gradients have been enqueued on the side stream
                         if self._on_bucket is not None:          # stream capture: cut the graph here, reduce at replay
                             self._on_bucket(b)
                         else:
@@ -319,28 +315,13 @@ class UNetTrainer:
         return _Work()
 
     # ---- ops --------------------------------------------------------------------------------------------------
-    def _wg(self, fn, *tensors):
-        """Run a weight-gradient launch: on the side stream when there is one (it waits for what the main stream has enqueued so
-        far; the operands stay allocated until it has run)."""
-        if self._wg_stream is None:
-            return fn()
-        self._wg_stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self._wg_stream):
-            fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self._wg_stream)
-
-    def _wg_join(self):
-        if self._wg_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._wg_stream)
-
     def _conv(self, x, name, stride=1, mode=0, rowadd=None, res=None, need_dx=True, done=None, stats=False):
         w = name + ".weight"
         N, _, taps = self.layers[w][:3]
         done = done or (w, name + ".bias")
         if stats and rowadd is None and res is None and T.conv_fused_ok([T.Src(x)], N, taps, stride, mode, want_stats=True):
-            y, self._cs[id(y)] = T.conv_fused([T.Src(x)], self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], want_stats=True)
+            y, cs_y = T.conv_fused([T.Src(x)], self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], want_stats=True)
+            self._cs[id(y)] = cs_y
         else:
             y = T.conv(x, self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], rowadd=rowadd, res=res)
 
@@ -357,9 +338,8 @@ class UNetTrainer:
                     if id(rows) not in self._grad:       # zeroed once for all 22 slices (they accumulate into it)
                         self._grad[id(rows)] = (torch.zeros(rows.shape, dtype=torch.float32, device=rows.device), True)
                     drow = self._grad[id(rows)][0][:, off:off + rowadd.shape[1]]
-            racc_ = rowadd is not None and self._row_parent.get(id(rowadd)) is not None
-            self._wg(lambda: T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"],
-                                          rows_accumulate=racc_), dy, x)
+            T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"],
+                         rows_accumulate=rowadd is not None and self._row_parent.get(id(rowadd)) is not None)
             self._done(*done)
             if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)
@@ -567,20 +547,19 @@ class UNetTrainer:
 
         def bwd():
             dy = self._pop(y)
-            self._wg(lambda: T.wgrad_fused(dy, s1, self.g[c2 + ".weight"], 9, gn=gn2, total=self.g[c2 + ".bias"]), dy, h1, cs1)
+            T.wgrad_fused(dy, s1, self.g[c2 + ".weight"], 9, gn=gn2, total=self.g[c2 + ".bias"])
             self._done(c2 + ".weight", c2 + ".bias")
             dz2, gs2 = T.conv_fused([T.Src(dy)], self.wt[c2 + ".weight"], N, 9, gsrcs=s1, ggn=gn2)
             dh1, = T.gn_backward_apply(dz2, s1, gs2, gn2, self.g[n2 + ".weight"], self.g[n2 + ".bias"])
             self._done(n2 + ".weight", n2 + ".bias")
             drow, racc = self._drow(row)
-            self._wg(lambda: T.wgrad_fused(dh1, srcs, self.g[c1 + ".weight"], 9, gn=gn1, rows=drow, total=self.g[c1 + ".bias"],
-                                           rows_accumulate=racc), dh1, *[s.t for s in srcs], *[s.cs for s in srcs])
+            T.wgrad_fused(dh1, srcs, self.g[c1 + ".weight"], 9, gn=gn1, rows=drow, total=self.g[c1 + ".bias"], rows_accumulate=racc)
             self._done(c1 + ".weight", c1 + ".bias")
             if not racc:
                 self._acc(row, drow, True)
             dz1, gs1 = T.conv_fused([T.Src(dh1)], self.wt[c1 + ".weight"], Cin, 9, gsrcs=srcs, ggn=gn1)
             if has_sc:
-                self._wg(lambda: T.wgrad_fused(dy, srcs, self.g[sc_n + ".weight"], 1, total=self.g[sc_n + ".bias"]), dy, *[s.t for s in srcs])
+                T.wgrad_fused(dy, srcs, self.g[sc_n + ".weight"], 1, total=self.g[sc_n + ".bias"])
                 self._done(sc_n + ".weight", sc_n + ".bias")
                 res = T.conv(dy, self.wt[sc_n + ".weight"], Cin, 1)
             else:
@@ -613,11 +592,11 @@ class UNetTrainer:
 
         def bwd():
             dy = self._pop(y)
-            self._wg(lambda: T.wgrad_bias(dy, o, self.g[wo + ".weight"], 1, total=self.g[wo + ".bias"]), dy, o)
+            T.wgrad_bias(dy, o, self.g[wo + ".weight"], 1, total=self.g[wo + ".bias"])
             self._done(wo + ".weight", wo + ".bias")
             do = T.conv(dy, self.wt[wo + ".weight"], Cc, 1)
             dqkv = T.attention_qkv_backward(qkv3, o3, do.view(B, W * H, Cc), lse).view(qkv.shape)
-            self._wg(lambda: T.wgrad_fused(dqkv, srcs, self.g[wq + ".weight"], 1, gn=gna, total=self.g[wq + ".bias"]), dqkv, x, srcs[0].cs)
+            T.wgrad_fused(dqkv, srcs, self.g[wq + ".weight"], 1, gn=gna, total=self.g[wq + ".bias"])
             self._done(*(grp["weights"] + grp["biases"]))
             dz, gs = T.conv_fused([T.Src(dqkv)], self.wt[wq + ".weight"], Cc, 1, gsrcs=srcs, ggn=gna)
             cur = self._slot(x)
@@ -660,7 +639,6 @@ class UNetTrainer:
         if "time_emb_proj_all" in self.fused:           # every resnet's time_emb_proj in one launch; the resnets add column slices
             grp = self.fused["time_emb_proj_all"]
             rows = self._linear(temb_act, "time_emb_proj_all", done=grp["weights"] + grp["biases"])
-            self._tape.append(self._wg_join)            # (runs BEFORE that linear's backward: the row gradients are complete)
             off = 0
             for wn in grp["weights"]:
                 view = rows[:, off:off + self.shapes[wn][0]]
@@ -731,13 +709,12 @@ class UNetTrainer:
             avg = torch.distributed.get_backend() == "nccl" or D.cabi_communicator() is not None
             self._reduce_op = torch.distributed.ReduceOp.AVG if avg else torch.distributed.ReduceOp.SUM
         self._acc(self._out, dpred, False)
-        T.defer_reduce(self.defer_reduce and self._wg_stream is None)
+        T.defer_reduce(self.defer_reduce)
         try:
             for fn in reversed(self._tape):
                 fn()
         finally:
             T.defer_reduce(False)                       # (flushes: every gradient is final from here on)
-        self._wg_join()
         self._tape, self._grad, self._cs = [], {}, {}
         T.set_zero_arena(None)
         if launch_collectives:
