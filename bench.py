@@ -415,11 +415,11 @@ def main():
 
     rank, world, local = D.init_from_env("nccl")
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    if world > 1 and "RLDM_COLLECTIVE" not in os.environ:
-        # a scaling record must not be a silently re-routed one: with N > 1 ranks on RCCL the exchange goes through the C-ABI
-        # communicator or the run FAILS (every rank together: distributed.Communicator's agreement rounds); RLDM_COLLECTIVE=torch asks
-        # for torch.distributed's collective explicitly, and the line's `comm.collective` says which one carried the images
-        os.environ["RLDM_REQUIRE_CABI"] = "1"
+    # With N > 1 ranks the finished images travel through the C-ABI RCCL communicator (rldm_comm_*).  If it cannot be bound or
+    # bootstrapped on ANY rank, all ranks learn it in the bootstrap's agreement rounds and all of them use torch.distributed's
+    # all-gather instead (backend "nccl" = the same RCCL) -- never silently: the reason is printed and the line's `comm` block says
+    # `"collective": "torch"` + `"cabi_unavailable": "<reason>"`.  The first multi-GPU run of a round happens on the driver's node,
+    # unobserved: a measured, labelled record beats an aborted one.  RLDM_REQUIRE_CABI=1 turns the fall-back into an error.
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
