@@ -93,6 +93,34 @@ def snr_weights(alphas_cumprod, timesteps, snr_gamma):
     return (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).float()
 
 
+def fused_tape_supported(cfg, fused_groups, B, W, H):
+    """Can the fused blocks (rldm_train_conv_fused / _wgrad_fused) run EVERY layer of this UNet at this input size?  Pure shape
+    logic: pixel tiles of 64 inside one image at every level, 64-channel chunks inside one source of a concatenation (and <= 768
+    input channels), the all-taps weight-gradient kernel's geometry (2 - 16 beams, a power of two; azimuth a multiple of 8),
+    batch <= 16 (its per-image coefficient table), and the fused parameter groups (all time_emb_proj layers; to_q / to_k / to_v of
+    every attention block).  `fused_groups`: the keys of plan_parameter_order's second result."""
+    if B > 16 or "time_emb_proj_all" not in fused_groups:
+        return False
+    if cfg.norm_num_groups > 64 or any(c % 64 or c % cfg.norm_num_groups or c > 384 for c in cfg.block_out_channels):
+        return False
+    for lvl in range(len(cfg.block_out_channels)):
+        w, h = W >> lvl, H >> lvl
+        if (w << lvl) != W or (h << lvl) != H or (w * h) % 64 or h < 2 or h > 16 or (h & (h - 1)) or w % 8:
+            return False
+    attn = [f"down_blocks.{i}.attentions.{j}" for i, bt in enumerate(cfg.down_block_types) if bt == "AttnDownBlock2D"
+            for j in range(cfg.layers_per_block)]
+    attn += [f"up_blocks.{i}.attentions.{j}" for i, bt in enumerate(cfg.up_block_types) if bt == "AttnUpBlock2D"
+             for j in range(cfg.layers_per_block + 1)]
+    if cfg.add_attention:
+        attn.append("mid_block.attentions.0")
+    return all((a + ".to_qkv") in fused_groups for a in attn)
+
+
+def fused_levels(W, H, num_levels, min_pixels):
+    """Per level: do its blocks run fused?  (from `min_pixels` pixels per image on: measured per shape)"""
+    return [(W >> l) * (H >> l) >= min_pixels for l in range(num_levels)]
+
+
 class UNetTrainer:
     def __init__(self, config, state_dict, device="cuda", lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8,
                  max_grad_norm=1.0, use_ema=True, ema_max_decay=0.9999, ema_inv_gamma=1.0, ema_power=0.75,
@@ -485,24 +513,8 @@ class UNetTrainer:
             self.a, self.b = a, b
 
     def fused_shape_ok(self, B, W, H):
-        """Do the fused kernels cover every layer of this network at this input size?  (tiles inside one image, 64-channel
-        chunks inside one source, the all-taps weight-gradient kernel at every level, the fused parameter groups)"""
-        cfg = self.cfg
-        if not self.fused_tape or B > 16 or "time_emb_proj_all" not in self.fused:
-            return False
-        if cfg.norm_num_groups > 64 or any(c % 64 or c % cfg.norm_num_groups or c > 384 for c in cfg.block_out_channels):
-            return False
-        for lvl in range(len(cfg.block_out_channels)):
-            w, h = W >> lvl, H >> lvl
-            if (w << lvl) != W or (h << lvl) != H or (w * h) % 64 or h < 2 or h > 16 or (h & (h - 1)) or w % 8:
-                return False
-        attn = [f"down_blocks.{i}.attentions.{j}" for i, bt in enumerate(cfg.down_block_types) if bt == "AttnDownBlock2D"
-                for j in range(cfg.layers_per_block)]
-        attn += [f"up_blocks.{i}.attentions.{j}" for i, bt in enumerate(cfg.up_block_types) if bt == "AttnUpBlock2D"
-                 for j in range(cfg.layers_per_block + 1)]
-        if cfg.add_attention:
-            attn.append("mid_block.attentions.0")
-        return all((a + ".to_qkv") in self.fused for a in attn)
+        """Do the fused kernels cover every layer of this network at this input size?"""
+        return self.fused_tape and fused_tape_supported(self.cfg, self.fused, B, W, H)
 
     def _srcs(self, x):
         """The one or two source tensors of a (possibly concatenated) activation, each with its (sum, sumsq) pairs."""
@@ -652,7 +664,7 @@ class UNetTrainer:
         # pixels per image the GroupNorm passes they remove cost more than what they add to the conv launches; below, a launch of
         # either kind sits at its ~8 us floor and the op-per-layer blocks are as fast)
         W0, H0 = sample_nchw.shape[2], sample_nchw.shape[3]
-        fzl = [fz and (W0 >> l) * (H0 >> l) >= self.fused_min_pixels for l in range(nl)]
+        fzl = [fz and on for on in fused_levels(W0, H0, nl, self.fused_min_pixels)]
         self.last_forward_fused_levels = fzl
 
         def resnet(t, p, l):

@@ -76,6 +76,22 @@ def test_bucketed_gradient_average_world2_gloo():
     assert out[0] and out[1]
 
 
+def test_fused_tape_shape_logic():
+    """Which networks / input sizes the fused training blocks cover, and at which levels they run (host logic, no GPU)."""
+    full = UNetConfig()
+    _, groups = TR.plan_parameter_order(list(unet_param_shapes(full)), unet_param_shapes(full))
+    assert TR.fused_tape_supported(full, groups, 8, 256, 16) and TR.fused_tape_supported(full, groups, 16, 256, 16)
+    assert not TR.fused_tape_supported(full, groups, 17, 256, 16)           # the weight gradient's per-image coefficient table
+    assert not TR.fused_tape_supported(full, groups, 8, 128, 8)             # the lowest level would be 16 pixels: tiles straddle images
+    assert not TR.fused_tape_supported(full, groups, 8, 256, 32)            # 32 beams: outside the all-taps weight-gradient geometry
+    assert not TR.fused_tape_supported(full, {k: v for k, v in groups.items() if k != "time_emb_proj_all"}, 8, 256, 16)
+    small = UNetConfig(**SMALL)                                             # 32-channel levels: no 64-channel chunks
+    _, g2 = TR.plan_parameter_order(list(unet_param_shapes(small)), unet_param_shapes(small))
+    assert not TR.fused_tape_supported(small, g2, 2, 32, 8)
+    assert TR.fused_levels(256, 16, 4, 1024) == [True, True, False, False] and TR.fused_levels(256, 16, 4, 0) == [True] * 4
+    assert TR.fused_levels(64, 8, 2, 1024) == [False, False]
+
+
 def test_parameter_order_makes_fused_groups_contiguous():
     """plan_parameter_order: a permutation of the state-dict names in which the weights (and the biases) of every fused group
     -- all time_emb_proj layers, to_q / to_k / to_v of each attention block -- are consecutive, so one [sum N][K] matrix in
