@@ -114,7 +114,21 @@ int rldm_sched_ddim_step(const float coef[5], const float* eps, const float* x, 
  * coef = {sqrt_alpha_t, sqrt_beta_t, c_x0, c_xt, sigma}. */
 int rldm_sched_ddpm_step(const float coef[5], const float* eps, const float* x, const float* noise, float* x_prev,
                          int64_t n, void* stream);
-/* replaces DDPMScheduler.add_noise (ldm/train_unconditional.py:498): out = sa[b]*x0 + sb[b]*noise (sa, sb HOST [B]). */
+/* The same two steps for any `prediction_type` of the scheduler config (ldm/train_unconditional.py:345-352 passes it through;
+ * :505-510 trains epsilon or v_prediction): what the network output means --
+ *   RLDM_PRED_EPSILON  x0 = (x - sqrt_beta_t*out)/sqrt_alpha_t,      eps = out                 (the two entry points above)
+ *   RLDM_PRED_V        x0 = sqrt_alpha_t*x - sqrt_beta_t*out,        eps = sqrt_alpha_t*out + sqrt_beta_t*x
+ *   RLDM_PRED_SAMPLE   x0 = out,                                     eps = (x - sqrt_alpha_t*out)/sqrt_beta_t
+ * then DDIM: prev = coef[2]*x0 + coef[3]*eps + coef[4]*noise; DDPM: prev = coef[2]*x0 + coef[3]*x + coef[4]*noise (coef as above).
+ * sampler_mode: RLDM_SAMPLER_DDIM | RLDM_SAMPLER_DDPM. */
+#define RLDM_PRED_EPSILON 0
+#define RLDM_PRED_V 1
+#define RLDM_PRED_SAMPLE 2
+int rldm_sched_step(int sampler_mode, int prediction_type, const float coef[5], const float* model_output, const float* x,
+                    const float* noise, float* x_prev, int64_t n, void* stream);
+/* replaces DDPMScheduler.add_noise (ldm/train_unconditional.py:498): out = sa[b]*x0 + sb[b]*noise (sa, sb HOST [B]).
+ * DDPMScheduler.get_velocity (ldm/train_unconditional.py:508) is the same map: v = sa[b]*noise - sb[b]*x0, i.e. this entry point
+ * with (x0, noise) swapped and sb negated (rangeldm_amd/schedulers.py get_velocity). */
 int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_alpha, const float* sqrt_beta, int B,
                          int64_t per_sample, float* out, void* stream);
 
@@ -135,6 +149,8 @@ typedef struct rldm_sampler_config {
     /* routing options of THIS sampler's plans: the bits of rldm_debug_set_flags, scoped to the sampler (0: defaults).
      * 1 << 24 = every layer a launch of its own -- what a host sets for a sampler it knows will share the GPU.         */
     int32_t plan_flags;
+    /* RLDM_PRED_*: what the UNet's output means to the scheduler step (scheduler.config.prediction_type)               */
+    int32_t prediction_type;
 } rldm_sampler_config;
 
 /* replaces Pipeline.__init__ + the per-call setup of ldm/pipelines.py:329-349; vae may be NULL (pixel-space RangeDM) */

@@ -18,7 +18,8 @@ class _Base:
     def __init__(self, config: SchedulerConfig = None):
         self.config = config or SchedulerConfig()
         c = self.config
-        assert c.beta_schedule == "linear" and c.prediction_type == "epsilon" and c.timestep_spacing == "leading"
+        assert c.beta_schedule == "linear" and c.timestep_spacing == "leading"
+        assert c.prediction_type in ("epsilon", "v_prediction", "sample")
         self.betas = torch.linspace(c.beta_start, c.beta_end, c.num_train_timesteps, dtype=torch.float32)
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
@@ -39,6 +40,25 @@ class _Base:
         n = self.num_inference_steps or self.config.num_train_timesteps
         return t - self.config.num_train_timesteps // n
 
+    def _x0_eps(self, model_output, sample, a_t):
+        """diffusers' `prediction_type` branches (DDIMScheduler.step / DDPMScheduler.step [3P], published forms):
+        (pred_original_sample, pred_epsilon) from the network output."""
+        b_t = 1 - a_t
+        pt = self.config.prediction_type
+        if pt == "epsilon":
+            return (sample - b_t ** 0.5 * model_output) / a_t ** 0.5, model_output
+        if pt == "sample":
+            return model_output, (sample - a_t ** 0.5 * model_output) / b_t ** 0.5
+        return a_t ** 0.5 * sample - b_t ** 0.5 * model_output, a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+
+    def get_velocity(self, sample, noise, timesteps):
+        """DDPMScheduler.get_velocity [3P]: v = sqrt(alpha_prod) * noise - sqrt(1 - alpha_prod) * sample
+        (call site: ldm/train_unconditional.py:508)."""
+        a = self.alphas_cumprod[timesteps]
+        sa = (a ** 0.5).view(-1, *([1] * (sample.dim() - 1)))
+        sb = ((1 - a) ** 0.5).view(-1, *([1] * (sample.dim() - 1)))
+        return sa * noise - sb * sample
+
     def add_noise(self, x0, noise, timesteps):
         a = self.alphas_cumprod[timesteps]
         sa = (a ** 0.5).view(-1, *([1] * (x0.dim() - 1)))
@@ -56,7 +76,7 @@ class OracleDDPMScheduler(_Base):
         b_t, b_prev = 1 - a_t, 1 - a_prev
         cur_a = a_t / a_prev
         cur_b = 1 - cur_a
-        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        x0, _ = self._x0_eps(model_output, sample, a_t)
         mean = (a_prev ** 0.5 * cur_b) / b_t * x0 + cur_a ** 0.5 * b_prev / b_t * sample
         if t > 0:
             if noise is None:
@@ -86,10 +106,10 @@ class OracleDDIMScheduler(_Base):
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
         b_t, b_prev = 1 - a_t, 1 - a_prev
-        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        x0, pred_eps = self._x0_eps(model_output, sample, a_t)
         var = (b_prev / b_t) * (1 - a_t / a_prev)
         std = eta * var ** 0.5
-        direction = (1 - a_prev - std ** 2) ** 0.5 * model_output
+        direction = (1 - a_prev - std ** 2) ** 0.5 * pred_eps
         prev = a_prev ** 0.5 * x0 + direction
         if eta > 0:
             if noise is None:

@@ -28,7 +28,7 @@ class VAEConfigC(C.Structure):
 class SamplerConfigC(C.Structure):
     _fields_ = [("batch", C.c_int32), ("num_steps", C.c_int32), ("mode", C.c_int32), ("pos_encoding", C.c_int32),
                 ("cond_channels", C.c_int32), ("coef", C.POINTER(C.c_float)), ("timesteps", C.POINTER(C.c_int64)),
-                ("plan_flags", C.c_int32)]
+                ("plan_flags", C.c_int32), ("prediction_type", C.c_int32)]
 
 
 class ConvDescC(C.Structure):
@@ -91,6 +91,7 @@ PROTOTYPES = {
     "rldm_diag_gaussian_sample": (C.c_int, [_P, _P, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_sched_ddim_step": (C.c_int, [C.POINTER(C.c_float), _P, _P, _P, _P, C.c_int64, _P]),
     "rldm_sched_ddpm_step": (C.c_int, [C.POINTER(C.c_float), _P, _P, _P, _P, C.c_int64, _P]),
+    "rldm_sched_step": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P, _P, _P, C.c_int64, _P]),
     "rldm_sched_add_noise": (C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int64, _P, _P]),
     "rldm_sampler_create": (C.c_int, [_P, _P, C.POINTER(SamplerConfigC), C.POINTER(_P)]),
     "rldm_sampler_destroy": (None, [_P]),

@@ -739,8 +739,7 @@ __global__ void __launch_bounds__(256, 2) conv_o4_kernel(const ConvParams p) {
                 p.y_nchw[i] = e[ch];
                 if (sched) {
                     const float x = p.sch.x[i];
-                    const float x0 = (x - c1 * e[ch]) / c0;
-                    float prev = (p.sch.mode == 0) ? c2 * x0 + c3 * e[ch] : c2 * x0 + c3 * x;
+                    float prev = sched_prev(p.sch.mode, c0, c1, c2, c3, x, e[ch]);
                     if (nz) prev += c4 * nz[i];
                     p.sch.x_prev[i] = prev;
                     if (p.sch.pack) p.sch.pack[(((size_t)b * p.Wout + ow) * p.Hout + oh) * p.sch.pack_ld + ch] = f32_to_bf16(prev);

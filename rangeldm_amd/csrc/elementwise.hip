@@ -168,8 +168,7 @@ __global__ void __launch_bounds__(256) sched_step_kernel(const SchedParams p) {
     const bool use_noise = nz != nullptr && c4 != 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (long long)gridDim.x * 256) {
         const float x = p.x[i], e = p.eps[i];
-        const float x0 = (x - c1 * e) / c0;
-        float prev = (p.mode == 0) ? c2 * x0 + c3 * e : c2 * x0 + c3 * x;
+        float prev = sched_prev(p.mode, c0, c1, c2, c3, x, e);
         if (use_noise) prev += c4 * nz[i];
         p.x_prev[i] = prev;
     }

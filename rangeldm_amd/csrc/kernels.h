@@ -29,6 +29,28 @@ struct NormView {
 // The scheduler step fused into conv_out's fp32 NCHW epilogue (conv_igemm.hip): the thread that produces eps[i] also holds the
 // index of x[i], so x_prev[i] = step(x[i], eps[i], noise[i]) costs one more load and store instead of a launch of its own
 // (DDIMScheduler.step / DDPMScheduler.step; same arithmetic as sched_step_kernel).
+// One scheduler step without its noise term.  mode = (ddpm ? 1 : 0) | prediction << 1, prediction 0 epsilon | 1 v_prediction | 2 sample
+// (diffusers DDIMScheduler.step / DDPMScheduler.step [3P]; the `prediction_type` branches ahead of the update).
+// c0 = sqrt(alpha_prod_t), c1 = sqrt(beta_prod_t); DDIM: c2 = sqrt(alpha_prod_prev), c3 = direction coefficient (multiplies the
+// predicted epsilon); DDPM: c2 / c3 = the posterior mean's coefficients of x0 / x_t.  The epsilon branch is the expression the
+// kernels have always used (bit-identical).
+__device__ __forceinline__ float sched_prev(const int mode, const float c0, const float c1, const float c2, const float c3, const float x,
+                                            const float e) {
+    const int pred = mode >> 1;
+    float x0, pe;
+    if (pred == 0) {
+        x0 = (x - c1 * e) / c0;
+        pe = e;
+    } else if (pred == 1) {
+        x0 = c0 * x - c1 * e;
+        pe = c0 * e + c1 * x;
+    } else {
+        x0 = e;
+        pe = (x - c0 * e) / c1;
+    }
+    return (mode & 1) == 0 ? c2 * x0 + c3 * pe : c2 * x0 + c3 * x;
+}
+
 struct SchedFuse {
     const float* coef_table;  // device [steps][5]; null: not fused
     const int* step_ptr;
@@ -36,7 +58,7 @@ struct SchedFuse {
     const float* noise;       // [steps][noise_step_stride] or null
     long long noise_step_stride;
     float* x_prev;
-    int mode;                 // 0 ddim, 1 ddpm
+    int mode;                 // 0 ddim, 1 ddpm; | prediction type << 1 (sched_prev)
     // the NEXT step's conv_in input (pack_input's bf16 [B][W][H][pack_ld] tensor): the thread that holds x_prev[i] stores its bf16 image
     // too, so a step's first launch is conv_in instead of a pack launch (the pos-encoding / condition channels never change); or null
     bf16_t* pack;
@@ -386,7 +408,7 @@ int launch_temb(const TembParams& p, hipStream_t stream);
 
 // scheduler steps; coef on host (baked) or read from device table row *step_ptr
 struct SchedParams {
-    int mode;                 // 0 ddim, 1 ddpm
+    int mode;                 // 0 ddim, 1 ddpm; | prediction type << 1 (sched_prev)
     float coef[5];
     const float* coef_table;  // device [steps][5] or null
     const int* step_ptr;

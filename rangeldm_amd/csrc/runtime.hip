@@ -3114,7 +3114,7 @@ static int sampler_enqueue_step(rldm_sampler* s, SamplerLane* ln, const float* n
     if (fused) return 0;
     SchedParams sp;
     memset(&sp, 0, sizeof(sp));
-    sp.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
+    sp.mode = (s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1) | (s->cfg.prediction_type << 1);
     sp.coef_table = s->coef.as<float>();
     sp.step_ptr = ln->step.as<int>();
     sp.eps = ln->eps.as<float>();
@@ -3177,7 +3177,7 @@ static int sampler_build_plans(rldm_sampler* s) {
             f.noise = nullptr;                          // per call: sampler_enqueue_step
             f.noise_step_stride = s->n_latent;
             f.x_prev = ln->x.as<float>();
-            f.mode = s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1;
+            f.mode = (s->cfg.mode == RLDM_SAMPLER_DDIM ? 0 : 1) | (s->cfg.prediction_type << 1);
             io.step_inc = ln->step.as<int>();
             // ... and the next step's conv_in input: no pack_input launch inside the steps (rldm_debug_set_flags(64) keeps it)
             if (!((g_dbg_flags | s->plan_flags) & 64) && io.xin && io.sample_scale == 1.f) {
@@ -3475,6 +3475,12 @@ int rldm_sched_ddpm_step(const float coef[5], const float* eps, const float* x, 
                          int64_t n, void* stream) {
     return sched_step(1, coef, eps, x, noise, x_prev, n, stream);
 }
+int rldm_sched_step(int sampler_mode, int prediction_type, const float coef[5], const float* model_output, const float* x,
+                    const float* noise, float* x_prev, int64_t n, void* stream) {
+    RLDM_REQUIRE(sampler_mode == RLDM_SAMPLER_DDIM || sampler_mode == RLDM_SAMPLER_DDPM, "unknown sampler mode");
+    RLDM_REQUIRE(prediction_type >= RLDM_PRED_EPSILON && prediction_type <= RLDM_PRED_SAMPLE, "unknown prediction type");
+    return sched_step((sampler_mode == RLDM_SAMPLER_DDIM ? 0 : 1) | (prediction_type << 1), coef, model_output, x, noise, x_prev, n, stream);
+}
 int rldm_sched_add_noise(const float* x0, const float* noise, const float* sqrt_alpha, const float* sqrt_beta, int B,
                          int64_t per_sample, float* out, void* stream) {
     RLDM_REQUIRE(x0 && noise && sqrt_alpha && sqrt_beta && out, "null argument");
@@ -3506,6 +3512,7 @@ int rldm_sampler_create(rldm_unet* unet, rldm_vae* vae, const rldm_sampler_confi
     RLDM_REQUIRE(unet->params.finalized, "unet not finalized");
     RLDM_REQUIRE(!vae || vae->params.finalized, "vae not finalized");
     RLDM_REQUIRE(cfg->batch >= 1 && cfg->num_steps >= 1 && cfg->coef && cfg->timesteps, "bad sampler config");
+    RLDM_REQUIRE(cfg->prediction_type >= RLDM_PRED_EPSILON && cfg->prediction_type <= RLDM_PRED_SAMPLE, "bad sampler config: prediction_type");
     const auto& uc = unet->cfg;
     RLDM_REQUIRE(uc.out_channels + (cfg->pos_encoding ? 1 : 0) + cfg->cond_channels == uc.in_channels,
                  "unet.in_channels != out_channels + pos_encoding + cond_channels (ldm/pipelines.py:351,480)");

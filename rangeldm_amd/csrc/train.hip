@@ -965,8 +965,12 @@ struct TrWgrad2 {
 };
 
 // (round 5) FU: x = act(GroupNorm(cat(x, x1))) rebuilt while staging (TrFuse's input side; the 64-channel tile lies in one source)
-template <int TAPS, bool FU = false>
-__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const TrFuse f) {
+// (round 6) the kernel's body as a function of its place in the launch -- tile bx of the layer, K slice z of Z -- so that ONE launch can
+// run the weight gradients of many layers (tr_wgrad2_group_kernel below).  GROUP: the slices of a tile meet through an arrival ticket
+// and the LAST arriver sums the partial tiles in slice order into dw (deterministic; no reduction launch); Z == 1: the tile goes
+// straight into dw.
+template <int TAPS, bool FU, bool GROUP>
+__device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& f, const int bx, const int z, const int Z, unsigned* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
     constexpr int NC = TAPS == 9 ? 3 : 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -978,8 +982,7 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const 
     bf16_t* sA = reinterpret_cast<bf16_t*>(wg_smem);                 // [64][pitchA]
     bf16_t* sB = sA + 64 * pitchA;                                   // [NC][64][pitchB]
     const int ct = Cin >> 6;
-    const int n0 = (blockIdx.x / ct) * 64, c0 = (blockIdx.x % ct) * 64;
-    const int z = blockIdx.y;
+    const int n0 = (bx / ct) * 64, c0 = (bx % ct) * 64;
     const int wi = wave >> 1, wj = wave & 1;                         // this wave's 32 x 32 quarter of the tile
     if (TAPS == 9) {                                                 // zero beam rows -1 and H of the three copies
         for (int e = tid; e < NC * 64 * 2 * WC; e += 256) {
@@ -1156,9 +1159,9 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const 
         if (p.total) unsafeAtomicAdd(p.total + n0 + (tid >> 2), sum_all);
     }
     // lane (column c = c0 + 32 wj + l31, half kg), register r <-> row n0 + 32 wi + (r & 3) + 8 (r >> 2) + 4 kg
-    if (p.dw) {
+    if (GROUP ? Z == 1 : p.dw != nullptr) {
         // the tile in the gradient's own layout ([n][c][tap]: 64 * TAPS contiguous floats per row) through LDS, 32 rows at a
-        // time, then atomics along a row: one cache line per 32 lanes
+        // time, then along a row: one cache line per 32 lanes (atomics; GROUP with one slice: this workgroup is the tile's only writer)
         constexpr int TP = 64 * TAPS + 1;
         float* tile = reinterpret_cast<float*>(wg_smem);
         for (int half = 0; half < 2; ++half) {
@@ -1172,17 +1175,102 @@ __global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const 
             __syncthreads();
             for (int e = tid; e < 32 * 64 * TAPS; e += 256) {
                 const int row = e / (64 * TAPS), col = e - row * (64 * TAPS);
-                unsafeAtomicAdd(p.dw + ((size_t)(n0 + 32 * half + row) * Cin + c0) * TAPS + col, tile[row * TP + col]);
+                float* dst = p.dw + ((size_t)(n0 + 32 * half + row) * Cin + c0) * TAPS + col;
+                if (GROUP) *dst += tile[row * TP + col];
+                else unsafeAtomicAdd(dst, tile[row * TP + col]);
             }
         }
         return;
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-        float* part = p.part + (((size_t)t * gridDim.y + z) * N + n0 + 32 * wi + 4 * kg) * Cin + c0 + 32 * wj + l31;
+        float* part = p.part + (((size_t)t * Z + z) * N + n0 + 32 * wi + 4 * kg) * Cin + c0 + 32 * wj + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[t][r];
     }
+    if constexpr (GROUP) {
+        // the tile's Z slices meet here: every workgroup publishes its partial tile (release at agent scope: the stores are written back
+        // past this XCD's L2) and takes a ticket; the last one invalidates its caches (acquire) and sums the Z partial tiles in slice
+        // order -- the same order whatever the arrival order, so the gradient is bit-reproducible -- into dw, and re-arms the ticket.
+        __shared__ unsigned s_last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(tickets + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)(Z - 1) ? 1u : 0u;
+            if (s_last) __hip_atomic_store(tickets + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // 16 columns x 16 rows per pass (a thread = one (row, column quad): 16-byte loads along c), slices in flight eight at a time
+        const size_t nc = (size_t)N * Cin;
+        const int cq4 = (tid & 15) * 4, rr = tid >> 4;
+        for (int t = 0; t < TAPS; ++t)
+            for (int r0 = 0; r0 < 64; r0 += 16) {
+                const size_t e = (size_t)(n0 + r0 + rr) * Cin + c0 + cq4;
+                const float* src = p.part + (size_t)t * Z * nc + e;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                int sidx = 0;
+                for (; sidx + 8 <= Z; sidx += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(sidx + j) * nc);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += v[j];
+                }
+                for (; sidx < Z; ++sidx) a += *reinterpret_cast<const f32x4*>(src + (size_t)sidx * nc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p.dw[(e + q) * TAPS + t] += a[q];
+            }
+    }
+}
+
+template <int TAPS, bool FU = false>
+__global__ __launch_bounds__(256) void tr_wgrad2_kernel(const TrWgrad2 p, const TrFuse f) {
+    tr_wgrad2_body<TAPS, FU, false>(p, f, blockIdx.x, blockIdx.y, gridDim.y, nullptr);
+}
+
+// ---- (round 6) the weight gradients of MANY layers in one launch --------------------------------------------------------------------
+// A weight gradient depends on nothing that comes after it in backward, and nothing in backward depends on it: launched where the tape
+// reaches them, the ~85 all-taps launches of a step each ran alone on the chip at its launch + first-touch + drain floor (1.8 ms of a
+// 9.3 ms step for 0.27 TFLOP).  The host queues them instead (rldm_train_wgrad_group) and hands the queue to this kernel in groups of
+// up to kWgGroupMax layers of one instantiation (the kernel-argument block holds the records: capture-safe, no descriptor upload):
+// block id -> (layer, tile, K slice).
+constexpr int kWgGroupMax = 22;
+struct WgItem {
+    const float* dy; const float* x; const float* x1; float* dw; float* rows; float* total; float* part;
+    const float* cs0; const float* cs1; const float* gamma; const float* beta;
+    int B, W, H, Win, Hin, Cin, N, mode, lwc, cpw, nchunks, Z, rows_ld, C0, silu, groups;
+    float eps;
+    unsigned ticket_off;
+};
+struct WgGroup {
+    int n;
+    unsigned* tickets;
+    int first[kWgGroupMax + 1];         // first block of layer i (first[n] = the grid)
+    WgItem item[kWgGroupMax];
+};
+static_assert(sizeof(WgGroup) <= 4096, "the group record is the kernel's argument block");
+
+template <int TAPS, bool FU>
+__global__ __launch_bounds__(256) void tr_wgrad2_group_kernel(const WgGroup g) {
+    const int bid = blockIdx.x;
+    int l = 0;
+    for (int i = 1; i < g.n; ++i) l = bid >= g.first[i] ? i : l;
+    const WgItem& it = g.item[l];
+    TrWgrad2 p;
+    p.dy = it.dy; p.x = it.x; p.part = it.part; p.dw = it.dw; p.rows = it.rows; p.rows_ld = it.rows_ld; p.total = it.total;
+    p.B = it.B; p.W = it.W; p.H = it.H; p.Win = it.Win; p.Hin = it.Hin; p.Cin = it.Cin; p.N = it.N; p.mode = it.mode; p.lwc = it.lwc;
+    p.cpw = it.cpw; p.nchunks = it.nchunks;
+    p.pitchA = (it.H << it.lwc) + 8;
+    p.pitchB = ((TAPS == 9 ? it.H + 2 : it.H) << it.lwc) + 8;
+    TrFuse f;
+    f.x1 = it.x1; f.C0 = it.C0; f.cs0 = it.cs0; f.cs1 = it.cs1; f.gamma = it.gamma; f.beta = it.beta; f.silu = it.silu;
+    f.groups = it.groups; f.eps = it.eps;
+    const int local = bid - g.first[l];
+    const int tiles = (it.N >> 6) * (it.Cin >> 6);
+    tr_wgrad2_body<TAPS, FU, true>(p, f, local % tiles, local / tiles, it.Z, g.tickets + it.ticket_off);
 }
 
 // four channels per thread, eight slices in flight (Cin % 4 == 0): the scalar kernel below ran at 2 TB/s over 38 MB of partials
@@ -2530,6 +2618,96 @@ int rldm_train_wgrad_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fu
     return 1;
 }
 
+// ---- (round 6) grouped weight gradients: the queue ------------------------------------------------------------------------------------
+// rldm_train_wgrad_group(1): all-taps weight gradients are queued instead of launched; rldm_train_wgrad_group_flush (or group(0)) runs
+// the queue as a few launches of tr_wgrad2_group_kernel.  One caller thread, one stream per queue (a call on another stream flushes
+// first); the caller keeps every queued operand alive and unmodified until the flush (rangeldm_amd/training.py does).
+struct WgQueued { WgItem it; int taps; bool fu; int tiles; size_t part_floats; size_t smem; };
+static std::vector<WgQueued> g_wgq;
+static hipStream_t g_wgq_stream = nullptr;
+static int g_wg_group = 0;
+
+static int wg_group_flush() {
+    if (g_wgq.empty()) return 0;
+    hipStream_t st = g_wgq_stream;
+    // scratch of the partial tiles (layers with more than one K slice) and the arrival tickets: grown outside captures only (the first,
+    // eager, step of a shape sizes them -- as every scratch buffer of this file)
+    size_t need = 0, ntick = 0;
+    for (auto& q : g_wgq) { need += q.part_floats; ntick += (size_t)q.tiles; }
+    static float* scratch = nullptr;
+    static size_t scratch_cap = 0;
+    static unsigned* tickets = nullptr;
+    static size_t tick_cap = 0;
+    if (need > scratch_cap) {
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (scratch) RLDM_HIP_CHECK(hipFree(scratch));
+        scratch = nullptr; scratch_cap = 0;
+        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), need * sizeof(float)));
+        scratch_cap = need;
+    }
+    if (ntick > tick_cap) {
+        RLDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (tickets) RLDM_HIP_CHECK(hipFree(tickets));
+        tickets = nullptr; tick_cap = 0;
+        const size_t want = std::max<size_t>(ntick, 4096);
+        RLDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tickets), want * sizeof(unsigned)));
+        RLDM_HIP_CHECK(hipMemset(tickets, 0, want * sizeof(unsigned)));        // zeroed once; every launch leaves them zeroed
+        tick_cap = want;
+    }
+    static bool attr = false;
+    if (!attr) {
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    size_t poff = 0, toff = 0;
+    for (auto& q : g_wgq) {
+        q.it.part = scratch + poff; poff += q.part_floats;
+        q.it.ticket_off = (unsigned)toff; toff += (size_t)q.tiles;
+    }
+    // one launch per (instantiation, <= kWgGroupMax layers), long workgroups first (the layers with the most pixels per slice)
+    for (int cls = 0; cls < 4; ++cls) {
+        const int taps = (cls & 1) ? 1 : 9;
+        const bool fu = (cls & 2) != 0;
+        std::vector<const WgQueued*> sel;
+        for (auto& q : g_wgq) if (q.taps == taps && q.fu == fu) sel.push_back(&q);
+        std::stable_sort(sel.begin(), sel.end(), [](const WgQueued* a, const WgQueued* b) {
+            return (long long)a->it.cpw * (a->it.H << a->it.lwc) > (long long)b->it.cpw * (b->it.H << b->it.lwc); });
+        for (size_t i0 = 0; i0 < sel.size(); i0 += kWgGroupMax) {
+            WgGroup g;
+            memset(&g, 0, sizeof(g));
+            g.n = (int)std::min<size_t>(kWgGroupMax, sel.size() - i0);
+            g.tickets = tickets;
+            size_t smem = 0;
+            int blocks = 0;
+            for (int i = 0; i < g.n; ++i) {
+                const WgQueued* q = sel[i0 + i];
+                g.item[i] = q->it;
+                g.first[i] = blocks;
+                blocks += q->tiles * q->it.Z;
+                smem = std::max(smem, q->smem);
+            }
+            g.first[g.n] = blocks;
+            if (taps == 9) { if (fu) tr_wgrad2_group_kernel<9, true><<<blocks, 256, smem, st>>>(g); else tr_wgrad2_group_kernel<9, false><<<blocks, 256, smem, st>>>(g); }
+            else { if (fu) tr_wgrad2_group_kernel<1, true><<<blocks, 256, smem, st>>>(g); else tr_wgrad2_group_kernel<1, false><<<blocks, 256, smem, st>>>(g); }
+            TR_LAUNCH_CHECK();
+        }
+    }
+    g_wgq.clear();
+    return 0;
+}
+
+int rldm_train_wgrad_group(int on) {
+    g_wg_group = on;
+    return on ? 0 : wg_group_flush();
+}
+
+int rldm_train_wgrad_group_flush(void) { return wg_group_flush(); }
+
+int rldm_train_wgrad_group_pending(void) { return (int)g_wgq.size(); }
+
 static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse* fu, const float* dy, const float* x, float* dw, float* rows,
                             int rows_ld, int rows_accumulate, float* total, void* stream);
 
@@ -2591,9 +2769,42 @@ static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse
             need = (size_t)p.taps * Z * p.N * p.Cin * sizeof(float);
         }
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (v2 && g_wg_group) {
+        // queued for a grouped launch (tr_wgrad2_group_kernel).  K slices: with every layer of the step in one launch the chip is full
+        // whatever a single layer brings, so a workgroup takes ~16 chunks of 128 pixels x 9 taps (a 1x1 tap set costs about a third)
+        // and the slices per tile -- partial tiles to write, to re-read, a last arriver to sum them -- shrink from 64 to <= 16
+        if (!g_wgq.empty() && g_wgq_stream != st && wg_group_flush()) return 1;
+        g_wgq_stream = st;
+        static const int budget_env = getenv("RLDM_TR_WG_GROUP_CPW") ? atoi(getenv("RLDM_TR_WG_GROUP_CPW")) : 16;
+        const int KP = w2.H << w2.lwc;
+        const double unit = (KP / 128.0) * (p.taps == 9 ? 1.0 : 0.35);
+        int cpw = std::max(1, (int)(budget_env / unit + 0.5));
+        cpw = std::min(cpw, w2.nchunks);
+        int Z = (w2.nchunks + cpw - 1) / cpw;
+        cpw = (w2.nchunks + Z - 1) / Z;
+        Z = (w2.nchunks + cpw - 1) / cpw;
+        WgQueued q{};
+        WgItem& it = q.it;
+        it.dy = dy; it.x = x; it.dw = dw; it.rows = rows; it.total = total; it.rows_ld = rows_ld;
+        it.B = w2.B; it.W = w2.W; it.H = w2.H; it.Win = w2.Win; it.Hin = w2.Hin; it.Cin = w2.Cin; it.N = w2.N; it.mode = w2.mode;
+        it.lwc = w2.lwc; it.cpw = cpw; it.nchunks = w2.nchunks; it.Z = Z;
+        const TrFuse f = to_device_fuse(fu, p.Cin, p.N);
+        it.x1 = f.x1; it.C0 = f.C0; it.cs0 = f.cs0; it.cs1 = f.cs1; it.gamma = f.gamma; it.beta = f.beta; it.silu = f.silu;
+        it.groups = f.groups; it.eps = f.eps;
+        q.taps = p.taps; q.fu = fu != nullptr;
+        q.tiles = (p.N / 64) * (p.Cin / 64);
+        q.part_floats = Z > 1 ? (size_t)p.taps * Z * p.N * p.Cin : 0;
+        q.smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
+        if (fu) q.smem += (size_t)p.B * 64 * sizeof(float2);
+        q.smem = std::max(q.smem, (size_t)32 * (64 * p.taps + 1) * sizeof(float));      // (Z == 1: the tile goes through LDS into dw)
+        if (rows && !rows_accumulate) tr_zero2d_kernel<<<nblk((size_t)p.B * p.N), 256, 0, st>>>(rows, rows_ld, p.N, p.B);
+        TR_LAUNCH_CHECK();
+        g_wgq.push_back(q);
+        return 0;
+    }
     static float* scratch = nullptr;                   // (one caller thread; launches are stream ordered)
     static size_t scratch_cap = 0;
-    hipStream_t st = (hipStream_t)stream;
     if (need > scratch_cap) {
         RLDM_HIP_CHECK(hipStreamSynchronize(st));
         if (scratch) RLDM_HIP_CHECK(hipFree(scratch));

@@ -32,7 +32,8 @@ class _FusedSampler:
         # keyed by the model objects themselves (kept alive by the cache entry, so an id is never reused for another
         # model); weights reloaded through load_state_dict are picked up by the library: rldm_sample re-plans and
         # re-captures when the model's generation counter moved (include/rangeldm_hip.h, rldm_unet_finalize)
-        key = (id(unet), id(vae), batch, steps, mode, bool(pos_encoding), cond_channels, float(eta))
+        pred = int(getattr(scheduler, "prediction_code", 0))
+        key = (id(unet), id(vae), batch, steps, mode, bool(pos_encoding), cond_channels, float(eta), pred)
         ent = self._cache.get(key)
         if ent is not None:
             return ent[0]
@@ -48,6 +49,7 @@ class _FusedSampler:
         cfg.batch, cfg.num_steps, cfg.mode = batch, steps, mode
         cfg.pos_encoding = 1 if pos_encoding else 0
         cfg.cond_channels = cond_channels
+        cfg.prediction_type = pred
         cfg.coef = coef.ctypes.data_as(C.POINTER(C.c_float))
         cfg.timesteps = ts.ctypes.data_as(C.POINTER(C.c_int64))
         h = C.c_void_p()

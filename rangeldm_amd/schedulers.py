@@ -34,6 +34,10 @@ def randn_tensor(shape, generator=None, device=None, dtype=None):
     return x.to(device)
 
 
+# scheduler.config.prediction_type -> RLDM_PRED_* (include/rangeldm_hip.h, rldm_sched_step)
+PREDICTION_TYPES = {"epsilon": 0, "v_prediction": 1, "sample": 2}
+
+
 class _SchedulerBase:
     init_noise_sigma = 1.0
     order = 1
@@ -47,9 +51,12 @@ class _SchedulerBase:
             config = SchedulerConfig(**{k: getattr(config, k) for k in SchedulerConfig.__dataclass_fields__
                                         if hasattr(config, k)})
         c = self._cfg = config
-        if c.beta_schedule != "linear" or c.prediction_type != "epsilon" or c.timestep_spacing != "leading":
-            raise NotImplementedError("only the reference's scheduler config is supported "
-                                      "(linear betas, epsilon prediction, leading spacing)")
+        if c.beta_schedule != "linear" or c.timestep_spacing != "leading":
+            raise NotImplementedError("only the reference's scheduler config is supported (linear betas, leading spacing)")
+        if c.prediction_type not in PREDICTION_TYPES:
+            # (the message of diffusers' schedulers; ldm/train_unconditional.py:505-510 accepts epsilon and v_prediction)
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample` or `v_prediction`")
+        self.prediction_code = PREDICTION_TYPES[c.prediction_type]
         if c.clip_sample:
             raise NotImplementedError("clip_sample=True (the reference sets clip_sample=False)")
         self.config = SimpleNamespace(**c.to_dict())
@@ -128,15 +135,33 @@ class _SchedulerBase:
             _lib.stream_ptr(x0.device)), "rldm_sched_add_noise")
         return out
 
-    def _launch(self, fn, coef, model_output, sample, noise):
+    def get_velocity(self, sample, noise, timesteps):
+        """`DDPMScheduler.get_velocity` (the v_prediction target, ldm/train_unconditional.py:507-508):
+        v = sqrt(alpha_prod_t) * noise - sqrt(1 - alpha_prod_t) * sample.  The same elementwise map as add_noise with the two
+        tensors swapped and the second coefficient negated (rldm_sched_add_noise)."""
+        x0 = sample.to(dtype=torch.float32).contiguous()
+        nz = noise.to(device=x0.device, dtype=torch.float32).contiguous()
+        t = timesteps.detach().to("cpu", torch.int64).reshape(-1)
+        a = self.alphas_cumprod[t]
+        sa = (a ** 0.5).numpy().astype(np.float32)
+        sb = (-((1 - a) ** 0.5)).numpy().astype(np.float32)
+        B = x0.shape[0]
+        out = torch.empty_like(x0)
+        _lib.check(_lib.lib().rldm_sched_add_noise(
+            C.c_void_p(nz.data_ptr()), C.c_void_p(x0.data_ptr()), sa.ctypes.data_as(C.POINTER(C.c_float)),
+            sb.ctypes.data_as(C.POINTER(C.c_float)), B, x0.numel() // B, C.c_void_p(out.data_ptr()),
+            _lib.stream_ptr(x0.device)), "rldm_sched_add_noise (get_velocity)")
+        return out
+
+    def _launch(self, sampler_mode, coef, model_output, sample, noise):
         e = model_output.to(dtype=torch.float32).contiguous()
         x = sample.to(device=e.device, dtype=torch.float32).contiguous()
         nz = None if noise is None else noise.to(device=e.device, dtype=torch.float32).contiguous()
         out = torch.empty_like(x)
         cf = (C.c_float * 5)(*[float(v) for v in coef])
-        _lib.check(fn(cf, C.c_void_p(e.data_ptr()), C.c_void_p(x.data_ptr()),
-                      C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_void_p(out.data_ptr()), x.numel(),
-                      _lib.stream_ptr(e.device)), "scheduler step")
+        _lib.check(_lib.lib().rldm_sched_step(sampler_mode, self.prediction_code, cf, C.c_void_p(e.data_ptr()), C.c_void_p(x.data_ptr()),
+                                              C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_void_p(out.data_ptr()),
+                                              x.numel(), _lib.stream_ptr(e.device)), "scheduler step")
         return out
 
 
@@ -161,7 +186,7 @@ class DDPMSchedulerHIP(_SchedulerBase):
         if coef[4] != 0.0 and noise is None:
             noise = randn_tensor(model_output.shape, generator=generator, device=model_output.device,
                                  dtype=torch.float32)
-        prev = self._launch(_lib.lib().rldm_sched_ddpm_step, coef, model_output, sample, noise if coef[4] != 0.0 else None)
+        prev = self._launch(1, coef, model_output, sample, noise if coef[4] != 0.0 else None)
         return SchedulerOutput(prev) if return_dict else (prev,)
 
 
@@ -185,5 +210,5 @@ class DDIMSchedulerHIP(_SchedulerBase):
         if coef[4] != 0.0 and noise is None:
             noise = randn_tensor(model_output.shape, generator=generator, device=model_output.device,
                                  dtype=torch.float32)
-        prev = self._launch(_lib.lib().rldm_sched_ddim_step, coef, model_output, sample, noise if coef[4] != 0.0 else None)
+        prev = self._launch(0, coef, model_output, sample, noise if coef[4] != 0.0 else None)
         return SchedulerOutput(prev) if return_dict else (prev,)

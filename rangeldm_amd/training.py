@@ -86,10 +86,13 @@ def ema_decay(optimization_step, max_decay=0.9999, inv_gamma=1.0, power=0.75, mi
     return max(min(1.0 - (1.0 + step / inv_gamma) ** -power, max_decay), min_decay)
 
 
-def snr_weights(alphas_cumprod, timesteps, snr_gamma):
-    """min(SNR, gamma) / SNR (ldm/train_unconditional.py:529-538, epsilon prediction)."""
+def snr_weights(alphas_cumprod, timesteps, snr_gamma, v_prediction=False):
+    """min(SNR, gamma) / SNR (ldm/train_unconditional.py:529-538); v_prediction: "add one to SNR values before we divide by them"
+    (:532-534 -- the +1 goes into BOTH the min and the divisor, as the reference writes it)."""
     ac = alphas_cumprod[timesteps.cpu()].double()
     snr = ac / (1.0 - ac)
+    if v_prediction:
+        snr = snr + 1.0
     return (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).float()
 
 
@@ -893,7 +896,7 @@ def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, p
                   noise=None, timesteps=None, condition=None, graphed=False, latents=None):
     """One iteration of the reference's loop body (ldm/train_unconditional.py:479-556) with `with_vae: True`:
     latents = vae.encode(x).latent_dist.sample() * scaling_factor; eps ~ N(0, 1); t ~ U{0..T-1}; add_noise; pos-encoding
-    channel; epsilon-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA.
+    channel; epsilon- or v-prediction MSE (optionally min-SNR weighted); backward; clip; AdamW; lr schedule; EMA.
     condition (B, Cc, W, H): the conditional twin (ldm/train_conditional.py:418-447) -- the encoded low-resolution image
     (`condition_encoder(batch["down"])`) or `cat([masked latents, mask])`, concatenated to the noisy latents.
     graphed: replay the UNet forward / backward / optimizer from captured HIP graphs (UNetTrainer.train_step_graphed).
@@ -912,10 +915,18 @@ def training_step(trainer, vae, noise_scheduler, clean_images, generator=None, p
     if timesteps is None:
         timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (B,), generator=generator).long()
     noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+    # the regression target (ldm/train_unconditional.py:505-510): the noise, or the velocity for a v_prediction scheduler
+    ptype = getattr(noise_scheduler.config, "prediction_type", "epsilon")
+    if ptype == "epsilon":
+        target = noise
+    elif ptype == "v_prediction":
+        target = noise_scheduler.get_velocity(latents, noise, timesteps)
+    else:
+        raise ValueError(f"Unknown prediction type {ptype}")
     if condition is not None:
         noisy = torch.cat([noisy, condition.to(dev).float()], dim=1)        # (a copy: ldm/train_conditional.py:447)
     w = None
     if snr_gamma is not None:
-        w = snr_weights(noise_scheduler.alphas_cumprod, timesteps, snr_gamma).to(dev)
+        w = snr_weights(noise_scheduler.alphas_cumprod, timesteps, snr_gamma, v_prediction=ptype == "v_prediction").to(dev)
     step = trainer.train_step_graphed if graphed else trainer.train_step
-    return step(noisy, timesteps.to(dev), noise, w, pos_encoding)
+    return step(noisy, timesteps.to(dev), target, w, pos_encoding)

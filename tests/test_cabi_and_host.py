@@ -43,6 +43,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.LidarConfigC) == 4 * (7 + 3 + 6 + 1)
     assert _lib.SamplerConfigC.coef.offset == 24 and _lib.SamplerConfigC.timesteps.offset == 32
     assert _lib.SamplerConfigC.plan_flags.offset == 40 and ctypes.sizeof(_lib.SamplerConfigC) == 48
+    assert _lib.SamplerConfigC.prediction_type.offset == 44
 
 
 def test_product_has_no_cpu_fallback():
@@ -84,6 +85,52 @@ def test_scheduler_host_side_matches_oracle():
     assert s.init_noise_sigma == 1.0 and s.scale_model_input("x", 3) == "x"
     import inspect
     assert "eta" in inspect.signature(s.step).parameters and "eta" not in inspect.signature(p.step).parameters
+
+
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction", "sample"])
+def test_oracle_scheduler_prediction_types_known_answers(ptype):
+    """The oracle's `prediction_type` branches (restated from diffusers' published forms; the reference trains epsilon or
+    v_prediction, ldm/train_unconditional.py:505-510) against the closed forms evaluated in float64, the velocity target, the
+    min-SNR `+ 1` of :532-534, and the host shim's acceptance of the three types."""
+    import numpy as np
+    from rangeldm_amd.config import SchedulerConfig
+    from rangeldm_amd.training import snr_weights
+    from oracle.schedulers import OracleDDIMScheduler, OracleDDPMScheduler
+    cfg = SchedulerConfig(prediction_type=ptype)
+    g = torch.Generator().manual_seed(11)
+    x, o = torch.randn(2, 3, 4, 4, generator=g), torch.randn(2, 3, 4, 4, generator=g)
+    ac = np.cumprod(1.0 - np.linspace(1e-4, 0.02, 1000, dtype=np.float32).astype(np.float64))
+    for t, tp in ((980, 960), (20, 0)):
+        a_t, a_p = ac[t], ac[tp]
+        xd, od = x.double().numpy(), o.double().numpy()
+        if ptype == "epsilon":
+            x0, pe = (xd - np.sqrt(1 - a_t) * od) / np.sqrt(a_t), od
+        elif ptype == "v_prediction":
+            x0, pe = np.sqrt(a_t) * xd - np.sqrt(1 - a_t) * od, np.sqrt(a_t) * od + np.sqrt(1 - a_t) * xd
+        else:
+            x0, pe = od, (xd - np.sqrt(a_t) * od) / np.sqrt(1 - a_t)
+        d = OracleDDIMScheduler(cfg)
+        d.set_timesteps(50)
+        got = d.step(o, t, x).prev_sample.double().numpy()
+        want = np.sqrt(a_p) * x0 + np.sqrt(1 - a_p) * pe
+        assert np.abs(got - want).max() < 3e-5 * (1 + np.abs(want).max())
+        p = OracleDDPMScheduler(cfg)
+        p.set_timesteps(50)
+        gotp = p.step(o, t, x, noise=torch.zeros_like(x)).prev_sample.double().numpy()
+        cur_a = a_t / a_p
+        wantp = np.sqrt(a_p) * (1 - cur_a) / (1 - a_t) * x0 + np.sqrt(cur_a) * (1 - a_p) / (1 - a_t) * xd
+        assert np.abs(gotp - wantp).max() < 3e-5 * (1 + np.abs(wantp).max())
+    ts = torch.tensor([3, 977])
+    v = OracleDDPMScheduler(cfg).get_velocity(x, o, ts).double().numpy()
+    sa, sb = np.sqrt(ac[[3, 977]]).reshape(2, 1, 1, 1), np.sqrt(1 - ac[[3, 977]]).reshape(2, 1, 1, 1)
+    assert np.abs(v - (sa * o.double().numpy() - sb * x.double().numpy())).max() < 3e-6
+    acf = torch.from_numpy(ac).float()
+    w = snr_weights(acf, ts, 5.0, v_prediction=True).double().numpy()
+    snr = ac[[3, 977]] / (1 - ac[[3, 977]]) + 1.0
+    assert np.abs(w - np.minimum(snr, 5.0) / snr).max() < 1e-6
+    with pytest.raises(ValueError, match="must be one of"):
+        from rangeldm_amd.schedulers import DDPMSchedulerHIP
+        DDPMSchedulerHIP(SchedulerConfig(prediction_type="velocity"))
 
 
 def test_condition_encoder_matches_oracle():

@@ -270,14 +270,19 @@ def test_diag_gaussian_sample(golden):
     assert (s - T(g["dg_sample_ref"])).abs().max() < 1e-5
 
 
-def test_scheduler_steps_match_oracle():
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction", "sample"])
+def test_scheduler_steps_match_oracle(ptype):
+    """DDIM / DDPM steps for every `prediction_type` diffusers' schedulers accept (the reference trains epsilon or v_prediction,
+    ldm/train_unconditional.py:505-510), add_noise and get_velocity, against the oracle twin + float64 known answers."""
+    from rangeldm_amd.config import SchedulerConfig
     from rangeldm_amd.schedulers import DDIMSchedulerHIP, DDPMSchedulerHIP
     x = T(normal(5, "sx", (2, 4, 32, 8)))
     e = T(normal(5, "se", (2, 4, 32, 8)))
     z = T(normal(5, "sz", (2, 4, 32, 8)))
+    cfgp = SchedulerConfig(prediction_type=ptype)
     for n in (50, 10):
-        s, so = DDIMSchedulerHIP(), o_sched.OracleDDIMScheduler()
-        p, po = DDPMSchedulerHIP(), o_sched.OracleDDPMScheduler()
+        s, so = DDIMSchedulerHIP(cfgp), o_sched.OracleDDIMScheduler(cfgp)
+        p, po = DDPMSchedulerHIP(cfgp), o_sched.OracleDDPMScheduler(cfgp)
         for sch in (s, so, p, po):
             sch.set_timesteps(n)
         assert s.timesteps.tolist() == so.timesteps.tolist()
@@ -290,17 +295,63 @@ def test_scheduler_steps_match_oracle():
             a_eta = s.step(e.cuda(), t, x.cuda(), eta=0.5, variance_noise=z.cuda()).prev_sample.cpu()
             r_eta = so.step(e, t, x, eta=0.5, noise=z).prev_sample
             assert (a_eta - r_eta).abs().max() < 2e-5 * (1 + r_eta.abs().max())
-    # known answers, SURVEY.md B.4
-    s = DDIMSchedulerHIP()
+    # known answers: SURVEY.md B.4 (epsilon); the other prediction types from the published closed forms in float64
+    s = DDIMSchedulerHIP(cfgp)
     s.set_timesteps(50)
     xk = torch.tensor([1.5409961, -0.2934289, -2.1787894, 0.5684313]).view(1, 1, 2, 2)
     ek = torch.tensor([-1.0845224, -1.3985955, 0.4033468, 0.8380263]).view(1, 1, 2, 2)
     out = s.step(ek.cuda(), 980, xk.cuda()).prev_sample.cpu().flatten()
-    assert torch.allclose(out, torch.tensor([2.1102533, -0.0538026, -2.7386351, 0.5099728]), atol=3e-6)
-    # add_noise (ldm/train_unconditional.py:498)
+    if ptype == "epsilon":
+        assert torch.allclose(out, torch.tensor([2.1102533, -0.0538026, -2.7386351, 0.5099728]), atol=3e-6)
+    ac = np.cumprod(1.0 - np.linspace(1e-4, 0.02, 1000, dtype=np.float32).astype(np.float64))
+    a_t, a_p = ac[980], ac[960]
+    xd, od = xk.double().numpy().ravel(), ek.double().numpy().ravel()
+    if ptype == "epsilon":
+        x0, pe = (xd - np.sqrt(1 - a_t) * od) / np.sqrt(a_t), od
+    elif ptype == "v_prediction":
+        x0, pe = np.sqrt(a_t) * xd - np.sqrt(1 - a_t) * od, np.sqrt(a_t) * od + np.sqrt(1 - a_t) * xd
+    else:
+        x0, pe = od, (xd - np.sqrt(a_t) * od) / np.sqrt(1 - a_t)
+    want = np.sqrt(a_p) * x0 + np.sqrt(1 - a_p) * pe
+    assert np.abs(out.double().numpy() - want).max() < 2e-5 * (1 + np.abs(want).max())
+    pk = DDPMSchedulerHIP(cfgp)
+    pk.set_timesteps(50)
+    outp = pk.step(ek.cuda(), 980, xk.cuda(), noise=torch.zeros_like(xk).cuda()).prev_sample.cpu().double().numpy().ravel()
+    cur_a = a_t / a_p
+    wantp = np.sqrt(a_p) * (1 - cur_a) / (1 - a_t) * x0 + np.sqrt(cur_a) * (1 - a_p) / (1 - a_t) * xd
+    assert np.abs(outp - wantp).max() < 2e-5 * (1 + np.abs(wantp).max())
+    # add_noise (ldm/train_unconditional.py:498) and get_velocity (:508)
     t = torch.tensor([3, 977])
     got = s.add_noise(x.cuda(), e.cuda(), t).cpu()
     assert (got - o_sched.OracleDDPMScheduler().add_noise(x, e, t)).abs().max() < 1e-6
+    vel = pk.get_velocity(x.cuda(), e.cuda(), t).cpu()
+    assert (vel - po.get_velocity(x, e, t)).abs().max() < 1e-6
+    sa, sb = np.sqrt(ac[[3, 977]]), np.sqrt(1 - ac[[3, 977]])
+    wantv = sa[:, None] * e.double().numpy().reshape(2, -1) - sb[:, None] * x.double().numpy().reshape(2, -1)
+    assert np.abs(vel.double().numpy().reshape(2, -1) - wantv).max() < 1e-5
+
+
+@pytest.mark.parametrize("ptype", ["v_prediction", "sample"])
+def test_captured_sampler_honours_prediction_type(ptype):
+    """The scheduler tail fused into conv_out's epilogue (captured sampler) against the same pipeline stepping through
+    scheduler.step (`fused=False`) and against the oracle's loop, for a non-epsilon scheduler."""
+    from rangeldm_amd.config import SchedulerConfig
+    from rangeldm_amd.pipelines import DDIMPipelineRange
+    from rangeldm_amd.schedulers import DDIMSchedulerHIP
+    cfg = UNetConfig(**SMALL)
+    m, sd = hip_unet(cfg, "vp.")
+    cfgp = SchedulerConfig(prediction_type=ptype)
+    x_T = T(normal(17, "xT", (2, 4, 64, 8)))
+    outs = []
+    for fused in (True, False):
+        pipe = DDIMPipelineRange(unet=m, scheduler=DDIMSchedulerHIP(cfgp), pos_encoding=True)
+        outs.append(pipe(batch_size=2, num_inference_steps=6, latents=x_T, output_type="torch", fused=fused).cpu())
+    assert torch.isfinite(outs[0]).all() and rel_l2(outs[0], outs[1]) < 1e-5
+    ref = o_pipe.ddim_pipeline(o_unet.OracleUNet(cfg, sd), o_sched.OracleDDIMScheduler(cfgp), x_T, 6, pos_encoding=True)
+    eps_run = DDIMPipelineRange(unet=m, scheduler=DDIMSchedulerHIP(), pos_encoding=True)(
+        batch_size=2, num_inference_steps=6, latents=x_T, output_type="torch").cpu()
+    assert rel_l2(outs[0], ref) < 3 * TOL_FWD
+    assert rel_l2(outs[0], eps_run) > 0.1                               # (the prediction type does reach the kernel)
 
 
 def _small_unet(in_ch, out_ch, prefix):
