@@ -335,6 +335,15 @@ int rldm_train_wgrad_fused(const rldm_train_conv_desc* d, const rldm_train_fuse*
  * call, rldm_train_flush_reduce, rldm_train_defer_reduce(0).  Call rldm_train_flush_reduce before anything else reads dw. */
 int rldm_train_defer_reduce(int on);
 int rldm_train_flush_reduce(void);
+/* (round 6) Grouped weight gradients.  The weight gradients of a step (`loss.backward()`, ldm/train_unconditional.py:545) depend on
+ * nothing behind them in the backward pass and nothing in it depends on them.  With grouping on, rldm_train_wgrad_bias / _wgrad_fused
+ * calls that the all-taps kernel covers are QUEUED (their dy / x / statistics operands must stay alive and unmodified), and
+ * rldm_train_wgrad_group_flush -- or group(0), or a queued call on another stream -- runs the queue as a handful of launches that each
+ * compute up to 22 layers (block id -> layer, tile, K slice; the K slices of a tile are summed in slice order by the tile's last
+ * arriver: no reduction launches, bit-reproducible gradients).  dw / rows / total are final only after the flush.  One caller thread. */
+int rldm_train_wgrad_group(int on);
+int rldm_train_wgrad_group_flush(void);
+int rldm_train_wgrad_group_pending(void);   /* queued layers (tests) */
 /* cs [B][C][2] += (sum, sumsq) per (image, channel) of x [B][npix][C]: for tensors no fused conv produced. */
 int rldm_train_chan_stats(const float* x, int B, int npix, int C, float* cs, void* stream);
 /* dx = rstd (gamma dz - mean_g(gamma dz) - xhat mean_g(gamma dz xhat)) + res, the GroupNorm over cat(x0, x1) [C0 | C - C0

@@ -131,6 +131,9 @@ PROTOTYPES = {
     "rldm_train_wgrad_fused": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "rldm_train_defer_reduce": (C.c_int, [C.c_int]),
     "rldm_train_flush_reduce": (C.c_int, []),
+    "rldm_train_wgrad_group": (C.c_int, [C.c_int]),
+    "rldm_train_wgrad_group_flush": (C.c_int, []),
+    "rldm_train_wgrad_group_pending": (C.c_int, []),
     "rldm_train_chan_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rldm_train_gn_backward_apply": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P,
                                                _P, C.c_int, _P, C.c_int, _P, _P, _P]),

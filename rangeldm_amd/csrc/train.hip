@@ -25,6 +25,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 namespace rldm {
 // train_attn.hip: the same three passes on the matrix cores (bf16 operands, fp32 statistics / accumulation)
@@ -1268,6 +1270,10 @@ __global__ __launch_bounds__(256) void tr_wgrad2_group_kernel(const WgGroup g) {
     TrFuse f;
     f.x1 = it.x1; f.C0 = it.C0; f.cs0 = it.cs0; f.cs1 = it.cs1; f.gamma = it.gamma; f.beta = it.beta; f.silu = it.silu;
     f.groups = it.groups; f.eps = it.eps;
+    // block -> (K slice, tile): tile fastest.  (Measured and dropped: a layout [Z / 8][tile][8] that puts the tiles of a slice -- which
+    // read the same pixels of dy and x -- on one XCD behind one L2: 873 against 780 us for the 3x3 launch of the two high-resolution
+    // levels, and the one-slice layers of the low levels, each on a single XCD, 529 against 307 us.  The kernel is bound by its staging
+    // pipeline per CU -- one chunk of loads in flight, a transposing LDS write, two barriers per chunk -- not by L2 misses.)
     const int local = bid - g.first[l];
     const int tiles = (it.N >> 6) * (it.Cin >> 6);
     tr_wgrad2_body<TAPS, FU, true>(p, f, local % tiles, local / tiles, it.Z, g.tickets + it.ticket_off);
@@ -2622,7 +2628,7 @@ int rldm_train_wgrad_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fu
 // rldm_train_wgrad_group(1): all-taps weight gradients are queued instead of launched; rldm_train_wgrad_group_flush (or group(0)) runs
 // the queue as a few launches of tr_wgrad2_group_kernel.  One caller thread, one stream per queue (a call on another stream flushes
 // first); the caller keeps every queued operand alive and unmodified until the flush (rangeldm_amd/training.py does).
-struct WgQueued { WgItem it; int taps; bool fu; int tiles; size_t part_floats; size_t smem; };
+struct WgQueued { WgItem it; int taps; bool fu; int tiles; size_t part_floats; size_t smem; double unit; };
 static std::vector<WgQueued> g_wgq;
 static hipStream_t g_wgq_stream = nullptr;
 static int g_wg_group = 0;
@@ -2630,6 +2636,29 @@ static int g_wg_group = 0;
 static int wg_group_flush() {
     if (g_wgq.empty()) return 0;
     hipStream_t st = g_wgq_stream;
+    // K slices.  With every layer of a class in one launch the chip is full whatever a single layer brings, so the slices per tile --
+    // partial tiles to write and re-read, a last arriver to sum them -- shrink from the launch-per-layer form's 64 to <= 16: a workgroup
+    // takes `budget` units of work (a unit = a chunk of 128 pixels x 9 taps; a 1x1 tap set costs about a third), the budget being what
+    // spreads the class over ~3 rounds of the 256 CUs, between 2 and 16 units.
+    static const int budget_env = getenv("RLDM_TR_WG_GROUP_CPW") ? atoi(getenv("RLDM_TR_WG_GROUP_CPW")) : 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int taps = (cls & 1) ? 1 : 9;
+        const bool fu = (cls & 2) != 0;
+        double total = 0;
+        for (auto& q : g_wgq) if (q.taps == taps && q.fu == fu) total += q.unit * q.it.nchunks * q.tiles;
+        const double budget = budget_env ? (double)budget_env : std::min(16.0, std::max(2.0, total / 768.0));
+        for (auto& q : g_wgq) {
+            if (q.taps != taps || q.fu != fu) continue;
+            WgItem& it = q.it;
+            int cpw = std::max(1, (int)(budget / q.unit + 0.5));
+            cpw = std::min(cpw, it.nchunks);
+            int Z = (it.nchunks + cpw - 1) / cpw;
+            cpw = (it.nchunks + Z - 1) / Z;
+            Z = (it.nchunks + cpw - 1) / cpw;
+            it.cpw = cpw; it.Z = Z;
+            q.part_floats = Z > 1 ? (size_t)q.taps * Z * it.N * it.Cin : 0;
+        }
+    }
     // scratch of the partial tiles (layers with more than one K slice) and the arrival tickets: grown outside captures only (the first,
     // eager, step of a shape sizes them -- as every scratch buffer of this file)
     size_t need = 0, ntick = 0;
@@ -2654,12 +2683,12 @@ static int wg_group_flush() {
         RLDM_HIP_CHECK(hipMemset(tickets, 0, want * sizeof(unsigned)));        // zeroed once; every launch leaves them zeroed
         tick_cap = want;
     }
-    static bool attr = false;
+    static bool attr = false;                       // (128 KiB: the kernel also has a static LDS word, the tiles need <= 80 KiB)
     if (!attr) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
     size_t poff = 0, toff = 0;
@@ -2677,7 +2706,7 @@ static int wg_group_flush() {
             return (long long)a->it.cpw * (a->it.H << a->it.lwc) > (long long)b->it.cpw * (b->it.H << b->it.lwc); });
         for (size_t i0 = 0; i0 < sel.size(); i0 += kWgGroupMax) {
             WgGroup g;
-            memset(&g, 0, sizeof(g));
+            memset(static_cast<void*>(&g), 0, sizeof(g));
             g.n = (int)std::min<size_t>(kWgGroupMax, sel.size() - i0);
             g.tickets = tickets;
             size_t smem = 0;
@@ -2771,30 +2800,22 @@ static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse
     }
     hipStream_t st = (hipStream_t)stream;
     if (v2 && g_wg_group) {
-        // queued for a grouped launch (tr_wgrad2_group_kernel).  K slices: with every layer of the step in one launch the chip is full
-        // whatever a single layer brings, so a workgroup takes ~16 chunks of 128 pixels x 9 taps (a 1x1 tap set costs about a third)
-        // and the slices per tile -- partial tiles to write, to re-read, a last arriver to sum them -- shrink from 64 to <= 16
+        // queued for a grouped launch (tr_wgrad2_group_kernel; K slices: wg_group_flush)
         if (!g_wgq.empty() && g_wgq_stream != st && wg_group_flush()) return 1;
         g_wgq_stream = st;
-        static const int budget_env = getenv("RLDM_TR_WG_GROUP_CPW") ? atoi(getenv("RLDM_TR_WG_GROUP_CPW")) : 16;
         const int KP = w2.H << w2.lwc;
-        const double unit = (KP / 128.0) * (p.taps == 9 ? 1.0 : 0.35);
-        int cpw = std::max(1, (int)(budget_env / unit + 0.5));
-        cpw = std::min(cpw, w2.nchunks);
-        int Z = (w2.nchunks + cpw - 1) / cpw;
-        cpw = (w2.nchunks + Z - 1) / Z;
-        Z = (w2.nchunks + cpw - 1) / cpw;
         WgQueued q{};
+        q.unit = (KP / 128.0) * (p.taps == 9 ? 1.0 : 0.35);
         WgItem& it = q.it;
         it.dy = dy; it.x = x; it.dw = dw; it.rows = rows; it.total = total; it.rows_ld = rows_ld;
         it.B = w2.B; it.W = w2.W; it.H = w2.H; it.Win = w2.Win; it.Hin = w2.Hin; it.Cin = w2.Cin; it.N = w2.N; it.mode = w2.mode;
-        it.lwc = w2.lwc; it.cpw = cpw; it.nchunks = w2.nchunks; it.Z = Z;
+        it.lwc = w2.lwc; it.cpw = 1; it.nchunks = w2.nchunks; it.Z = 1;         // (cpw / Z: decided per class at the flush)
         const TrFuse f = to_device_fuse(fu, p.Cin, p.N);
         it.x1 = f.x1; it.C0 = f.C0; it.cs0 = f.cs0; it.cs1 = f.cs1; it.gamma = f.gamma; it.beta = f.beta; it.silu = f.silu;
         it.groups = f.groups; it.eps = f.eps;
         q.taps = p.taps; q.fu = fu != nullptr;
         q.tiles = (p.N / 64) * (p.Cin / 64);
-        q.part_floats = Z > 1 ? (size_t)p.taps * Z * p.N * p.Cin : 0;
+        q.part_floats = 0;
         q.smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
         if (fu) q.smem += (size_t)p.B * 64 * sizeof(float2);
         q.smem = std::max(q.smem, (size_t)32 * (64 * p.taps + 1) * sizeof(float));      // (Z == 1: the tile goes through LDS into dw)

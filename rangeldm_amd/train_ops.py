@@ -437,3 +437,17 @@ def defer_reduce(on):
 
 def flush_reduce():
     _chk(_lib.lib().rldm_train_flush_reduce(), "rldm_train_flush_reduce")
+
+
+def wgrad_group(on):
+    """Queue the all-taps weight gradients instead of launching them (rldm_train_wgrad_group); off: flush."""
+    _chk(_lib.lib().rldm_train_wgrad_group(1 if on else 0), "rldm_train_wgrad_group")
+
+
+def wgrad_group_flush():
+    """Run the queued weight gradients as grouped launches on the stream they were queued on."""
+    _chk(_lib.lib().rldm_train_wgrad_group_flush(), "rldm_train_wgrad_group_flush")
+
+
+def wgrad_group_pending():
+    return int(_lib.lib().rldm_train_wgrad_group_pending())

@@ -202,6 +202,11 @@ class UNetTrainer:
         self.fused_min_pixels = int(os.environ.get("RLDM_TRAIN_FUSED_MINPX", "1024"))
         # the reduction of a weight gradient's partial tiles rides on the layer's data-gradient launch (RLDM_TR_DEFER_REDUCE=0: own launch)
         self.defer_reduce = os.environ.get("RLDM_TR_DEFER_REDUCE", "1") != "0"
+        # (round 6) the weight gradients of the step are queued and run as a few grouped launches (rldm_train_wgrad_group: nothing in
+        # backward waits for a weight gradient, and ~85 launches of them each sat at its launch floor); RLDM_TR_WGRAD_GROUP=0: launched
+        # where the tape reaches them.  _wg_keep: the queued launches' operands (dy, inputs, statistics), alive until the flush
+        self.wgrad_group = os.environ.get("RLDM_TR_WGRAD_GROUP", "1") != "0"
+        self._wg_on, self._wg_keep = False, []
         self._cs = {}
 
     # ---- parameters -------------------------------------------------------------------------------------------
@@ -305,6 +310,17 @@ class UNetTrainer:
         g = self._grad.get(id(t))
         return g[0] if g is not None and g[1] else None
 
+    def _pin(self, *tensors):
+        """Operands of a (possibly queued) weight-gradient launch: kept alive until the queue is flushed."""
+        if self._wg_on:
+            self._wg_keep.extend(t for t in tensors if t is not None)
+
+    def _wg_flush(self):
+        """Run the queued weight gradients (their dw / bias / time-embedding-row outputs are final behind this)."""
+        if self._wg_on:
+            T.wgrad_group_flush()
+            self._wg_keep.clear()
+
     def _done(self, *names):
         """The gradients of these parameters are final: launch the all-reduce of every bucket that just completed."""
         if self._ready is None:
@@ -315,6 +331,7 @@ class UNetTrainer:
                 if lo <= i < hi:
                     self._ready[b] -= 1
                     if self._ready[b] == 0:
+                        self._wg_flush()                         # (the bucket's weight gradients may still be queued)
                         T.flush_reduce()                         # (the last weight gradient's reduction may still be waiting for a conv to ride on)
                         if self._on_bucket is not None:          # stream capture: cut the graph here, reduce at replay
                             self._on_bucket(b)
@@ -371,11 +388,14 @@ class UNetTrainer:
                     drow = self._grad[id(rows)][0][:, off:off + rowadd.shape[1]]
             T.wgrad_bias(dy, x, self.g[w], taps, stride, mode, rows=drow, total=self.g[name + ".bias"],
                          rows_accumulate=rowadd is not None and self._row_parent.get(id(rowadd)) is not None)
+            self._pin(dy, x, drow)
             self._done(*done)
             if rowadd is not None and self._row_parent.get(id(rowadd)) is None:
                 self._acc(rowadd, drow, True)
             if res is not None:
-                self._acc(res, dy, dy_owned)            # (everything below that reads dy is enqueued before anyone adds to it)
+                # (everything below that reads dy is enqueued before anyone adds to it -- unless the weight gradient above is
+                #  queued: then dy must stay as it is until the flush, and later gradients of `res` go to a buffer of their own)
+                self._acc(res, dy, dy_owned and not self._wg_on)
             if need_dx:
                 wt = self.wt[w]
                 Cin = x.shape[3]
@@ -403,6 +423,7 @@ class UNetTrainer:
         y = T.linear_rows(x2d, self.wf[w], N, bias=self.p[name + ".bias"])
 
         def bwd():
+            self._wg_flush()                             # (dy may be the time-embedding-row sums of queued weight gradients)
             dy = self._pop(y)
             T.linear_rows_wgrad(dy, x2d, self.g[w], self.g[name + ".bias"])
             self._done(*done)
@@ -418,6 +439,7 @@ class UNetTrainer:
         y2 = y4.view(x2d.shape[0], N)
 
         def bwd():
+            self._wg_flush()
             dy = self._pop(y2)
             dy4 = dy.view(dy.shape[0], 1, 1, N)
             T.wgrad(dy4, x4, self.g[w], 1)
@@ -563,18 +585,21 @@ class UNetTrainer:
         def bwd():
             dy = self._pop(y)
             T.wgrad_fused(dy, s1, self.g[c2 + ".weight"], 9, gn=gn2, total=self.g[c2 + ".bias"])
+            self._pin(dy, h1, cs1)
             self._done(c2 + ".weight", c2 + ".bias")
             dz2, gs2 = T.conv_fused([T.Src(dy)], self.wt[c2 + ".weight"], N, 9, gsrcs=s1, ggn=gn2)
             dh1, = T.gn_backward_apply(dz2, s1, gs2, gn2, self.g[n2 + ".weight"], self.g[n2 + ".bias"])
             self._done(n2 + ".weight", n2 + ".bias")
             drow, racc = self._drow(row)
             T.wgrad_fused(dh1, srcs, self.g[c1 + ".weight"], 9, gn=gn1, rows=drow, total=self.g[c1 + ".bias"], rows_accumulate=racc)
+            self._pin(dh1, drow, *[s.t for s in srcs], *[s.cs for s in srcs])
             self._done(c1 + ".weight", c1 + ".bias")
             if not racc:
                 self._acc(row, drow, True)
             dz1, gs1 = T.conv_fused([T.Src(dh1)], self.wt[c1 + ".weight"], Cin, 9, gsrcs=srcs, ggn=gn1)
             if has_sc:
                 T.wgrad_fused(dy, srcs, self.g[sc_n + ".weight"], 1, total=self.g[sc_n + ".bias"])
+                self._pin(dy, *[s.t for s in srcs])
                 self._done(sc_n + ".weight", sc_n + ".bias")
                 res = T.conv(dy, self.wt[sc_n + ".weight"], Cin, 1)
             else:
@@ -608,10 +633,12 @@ class UNetTrainer:
         def bwd():
             dy = self._pop(y)
             T.wgrad_bias(dy, o, self.g[wo + ".weight"], 1, total=self.g[wo + ".bias"])
+            self._pin(dy, o)
             self._done(wo + ".weight", wo + ".bias")
             do = T.conv(dy, self.wt[wo + ".weight"], Cc, 1)
             dqkv = T.attention_qkv_backward(qkv3, o3, do.view(B, W * H, Cc), lse).view(qkv.shape)
             T.wgrad_fused(dqkv, srcs, self.g[wq + ".weight"], 1, gn=gna, total=self.g[wq + ".bias"])
+            self._pin(dqkv, *[s.t for s in srcs], *[s.cs for s in srcs])
             self._done(*(grp["weights"] + grp["biases"]))
             dz, gs = T.conv_fused([T.Src(dqkv)], self.wt[wq + ".weight"], Cc, 1, gsrcs=srcs, ggn=gna)
             cur = self._slot(x)
@@ -725,10 +752,15 @@ class UNetTrainer:
             self._reduce_op = torch.distributed.ReduceOp.AVG if avg else torch.distributed.ReduceOp.SUM
         self._acc(self._out, dpred, False)
         T.defer_reduce(self.defer_reduce)
+        self._wg_on = bool(self.wgrad_group)
+        T.wgrad_group(self._wg_on)
         try:
             for fn in reversed(self._tape):
                 fn()
         finally:
+            T.wgrad_group(False)                        # (runs what is still queued)
+            self._wg_on = False
+            self._wg_keep.clear()
             T.defer_reduce(False)                       # (flushes: every gradient is final from here on)
         self._tape, self._grad, self._cs = [], {}, {}
         T.set_zero_arena(None)

@@ -556,6 +556,40 @@ def test_fused_tape_equals_layer_tape_full_config():
 
 
 @pytest.mark.gpu
+def test_grouped_weight_gradients_equal_per_layer_launches():
+    """(round 6) BASELINE config-5 shapes, batch 2: the weight gradients of the step queued and run as grouped launches
+    (rldm_train_wgrad_group: block id -> layer, tile, K slice; the slices of a tile summed by its last arriver) against one launch
+    per layer where the tape reaches it.  Same kernels' body on the same operands: the differences are the K-slice boundaries and the
+    summation order of fp32 partial sums (and the atomics of the data path: the two runs are two runs).  Also: nothing stays queued
+    behind backward, a second backward accumulates (the ticket counters re-arm), and the step captured in graphs replays it."""
+    from rangeldm_amd import train_ops as T
+    cfg = UNetConfig()
+    sd = synth_state_dict(unet_param_shapes(cfg))
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(2, 4, 256, 16, generator=g).cuda()
+    target = torch.randn(2, 4, 256, 16, generator=g).cuda()
+    t = torch.tensor([77, 640]).cuda()
+    grads = []
+    for grouped in (True, False):
+        tr = TR.UNetTrainer(cfg, sd, use_ema=False)
+        tr.wgrad_group = grouped
+        loss, dpred = T.mse(tr.forward(x, t, pos_encoding=True), target)
+        tr.backward(dpred)
+        assert T.wgrad_group_pending() == 0
+        g1 = tr.grads.clone()
+        tr.backward(T.mse(tr.forward(x, t, pos_encoding=True), target)[1])
+        assert rel(tr.grads, 2 * g1) < 5e-3                     # (the gate of the run-to-run comparisons of this file)
+        grads.append((g1, {n: tr.g[n].clone() * 0.5 for n in tr.names}))
+    (ga, da), (gb, db) = grads
+    assert rel(ga, gb) < 5e-3, rel(ga, gb)
+    rms = float(gb.double().norm() / gb.numel() ** 0.5)
+    worst = sorted(((float((da[n].double() - db[n].double()).norm()) /
+                     (float(db[n].double().norm()) + 2e-2 * rms * db[n].numel() ** 0.5), n) for n in da), reverse=True)
+    print("grouped vs per-layer weight gradients:", rel(ga, gb), worst[:3])
+    assert worst[0][0] < 1e-2, worst[:6]
+
+
+@pytest.mark.gpu
 def test_full_config_gradient_is_the_directional_derivative():
     """BASELINE config-5 shapes (RangeLDM UNet, 256 x 16 latents, batch reduced to 2): a size-independent property instead of
     the CPU oracle -- along the gradient direction the loss must change at the rate |g|:
