@@ -504,6 +504,18 @@ int rldm_test_attention_qkv(const float* x, int B, int L, int C, int groups, flo
 /* HIP-event time of that launch alone on synthetic data (tools/bench_attn.py) */
 int rldm_bench_attention_qkv(int B, int L, int C, int warmup, int iters, float* avg_us, void* stream);
 
+/* ---- calibration of the box (bench.py `calibration`; the metric's definition) -----------------------------------
+ * What this GPU does right now, measured in the benchmark's own process so that a throughput line can be read against it:
+ * mfma_tflops / mfma_clock_mhz = a pure v_mfma_f32_32x32x16_bf16 loop on every SIMD (HIP events) and the shader clock while it runs
+ * (s_memtime ticks per s_memrealtime tick x 100 MHz); copy_gbs = a 1 GiB device-to-device copy, bytes read + written per second.
+ * Synchronises the stream; allocates and frees 2 GiB. */
+int rldm_calibrate(double* mfma_tflops, double* mfma_clock_mhz, double* copy_gbs, void* stream);
+/* Clock stamps around any work on `stream`: RLDM_CALIB_STAMP_BLOCKS workgroups (block ids go round the XCDs) each write
+ * slots[4 * block + {0, 1, 2, 3}] = {XCC id, s_memtime, s_memrealtime, 1}.  Two stamps of the same XCC id: (d s_memtime / d s_memrealtime)
+ * x 100 MHz = the mean shader clock over what ran between them.  slots: device, 4 * RLDM_CALIB_STAMP_BLOCKS uint64. */
+#define RLDM_CALIB_STAMP_BLOCKS 16
+int rldm_calib_clock_stamp(unsigned long long* slots, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,8 @@ PROTOTYPES = {
     "rldm_train_wgrad_fused": (C.c_int, [C.POINTER(TrainConvDescC), C.POINTER(TrainFuseC), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "rldm_train_defer_reduce": (C.c_int, [C.c_int]),
     "rldm_train_flush_reduce": (C.c_int, []),
+    "rldm_calibrate": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "rldm_calib_clock_stamp": (C.c_int, [_P, _P]),
     "rldm_train_wgrad_group": (C.c_int, [C.c_int]),
     "rldm_train_wgrad_group_flush": (C.c_int, []),
     "rldm_train_wgrad_group_pending": (C.c_int, []),

@@ -204,7 +204,7 @@ __device__ __forceinline__ void attention_proj_tail(const AttnQkvParams& p, cons
 
 // =====================================================================================================================
 // Second generation of the fused launch (round 2).  Same contract as attention_qkv_d8_kernel; what changed and why
-// (per-wave s_memtime stamps of both generations: tools/attn_timeline2.py, profiles/round2_attn_timeline.txt):
+// (per-wave s_memtime stamps of both generations: tools/attn_timeline2.py, docs/history/profiles/round2_attn_timeline.txt):
 //   * The prologue of the first generation was FIVE dependent global round trips of ~2 us each (statistics partials ->
 //     gamma / beta -> the head's weight fragments -> its bias -> the x rows of the wave's second query tile): 12 of the 44 us of
 //     an L = 1024 launch, 6 of the 7 us of an L = 64 one.  None of them depends on another: every one is now requested in the

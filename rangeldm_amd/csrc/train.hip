@@ -127,6 +127,9 @@ struct TrFuse {
 };
 
 // (v_exp_f32 + v_rcp_f32: the IEEE division of 1.f / x costs ten more instructions per element of every staged tile)
+#ifndef RLDM_TR_LAST_ACQUIRE
+#define RLDM_TR_LAST_ACQUIRE 1  /* the last arriver of a fused split-K tile acquires (agent scope) before it re-reads the tile */
+#endif
 #ifndef RLDM_TR_ABL
 #define RLDM_TR_ABL 0          /* timing experiments (wrong results): 1 no statistics atomics, 2 no sigmoid in the staging transforms */
 #endif
@@ -544,13 +547,19 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
                 __syncthreads();
                 if (tid == 0) {
                     unsigned* tk = f.tickets + blockIdx.y * gridDim.x + blockIdx.x;
-                    const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     const int last = (int)t == ksplit - 1;
                     if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sLast = last;
                 }
                 __syncthreads();
                 if (!sLast) return;
+#if RLDM_TR_LAST_ACQUIRE
+                // (round 6) the argument above rests on what an atomic does to a line of the issuing XCD's L2, which nothing documents:
+                // the ONE workgroup per tile that re-reads the sums pairs the release on the ticket with an agent-scope acquire (an
+                // invalidate of what its caches may hold of the tile) before it does.  -DRLDM_TR_LAST_ACQUIRE=0: the round-5 form.
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                 if (f.gs_out) tr_gn_coeffs_tile(sCe, BN, n0, f.gcs0, f.gcs1, f.G0, N, img, f.ggroups, f.geps, Wout * Hout, f.ggamma, f.gbeta);
                 if ((N & 3) == 0) {
                     for (int e = tid; e < 64 * (BN / 4); e += 256) {
@@ -2638,15 +2647,14 @@ static int wg_group_flush() {
     hipStream_t st = g_wgq_stream;
     // K slices.  With every layer of a class in one launch the chip is full whatever a single layer brings, so the slices per tile --
     // partial tiles to write and re-read, a last arriver to sum them -- shrink from the launch-per-layer form's 64 to <= 16: a workgroup
-    // takes `budget` units of work (a unit = a chunk of 128 pixels x 9 taps; a 1x1 tap set costs about a third), the budget being what
-    // spreads the class over ~3 rounds of the 256 CUs, between 2 and 16 units.
+    // takes `budget` units of work (a unit = a chunk of 128 pixels x 9 taps; a 1x1 tap set costs about a third).  Measured per class at
+    // the RangeLDM size, batch 8 (profiles/round6_wgrad_group_budget.txt): 3x3 launches are fastest at 32 units (712 / 276 us; 16: 769 /
+    // 307, 8: 996 / 434, 4: 1543 / 514 -- the last arriver's serial sum over the slices is the tail), the 1x1 launches at 8 - 16.
     static const int budget_env = getenv("RLDM_TR_WG_GROUP_CPW") ? atoi(getenv("RLDM_TR_WG_GROUP_CPW")) : 0;
     for (int cls = 0; cls < 4; ++cls) {
         const int taps = (cls & 1) ? 1 : 9;
         const bool fu = (cls & 2) != 0;
-        double total = 0;
-        for (auto& q : g_wgq) if (q.taps == taps && q.fu == fu) total += q.unit * q.it.nchunks * q.tiles;
-        const double budget = budget_env ? (double)budget_env : std::min(16.0, std::max(2.0, total / 768.0));
+        const double budget = budget_env ? (double)budget_env : (taps == 9 ? 32.0 : 12.0);
         for (auto& q : g_wgq) {
             if (q.taps != taps || q.fu != fu) continue;
             WgItem& it = q.it;

@@ -22,11 +22,14 @@ def _free_port():
     return p
 
 
-def _run_bench(nproc, extra, timeout=900):
+def _run_bench(nproc, extra, timeout=900, steps=2, dump=None):
     env = dict(os.environ, RLDM_DIST_BACKEND="gloo", RLDM_DBG_FLAGS=str(1 << 24), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-pipelined", "--no-other-configs"] + extra
+    if dump:
+        env["RLDM_BENCH_DUMP"] = dump
+    launcher = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                 "--master-port", str(_free_port())] if nproc > 1 else [sys.executable])
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", "1",
+                      "--no-cpu-baseline", "--no-pipelined", "--no-other-configs"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -56,3 +59,26 @@ def test_bench_two_ranks_strong_scaling_config3_line():
     assert res["config"]["global_batch"] == 32 and res["config"]["batch_per_gpu"] == 16
     assert abs(res["value"] - 32 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["value"]
     assert res["comm"]["allgather_bytes_per_rank"] == 16 * 2 * 1024 * 32 * 4
+
+
+def test_bench_eight_ranks_strong_scaling_config3_line(tmp_path):
+    """The driver's N = 8 command for BASELINE config 3, rehearsed as EIGHT ranks on one GPU (4 of the 32 images each): the JSON
+    contract, all eight ranks met in the gather, and the gathered images are those of ONE rank sampling all 32 -- x_T is a function of
+    the global sample index (ldm/inference.py:56,159-183 indexes files by it), so the shard boundaries must not show.  The batch-4 and
+    the batch-32 plans route layers to different kernels: equal up to the bf16 tolerance of two routings, not bit for bit."""
+    import torch
+    from tests.hip_util import rel_l2
+    extra = ["--scaling", "strong", "--preset", "nuscenes", "--batch", "32"]
+    d8, d1 = str(tmp_path / "r8.pt"), str(tmp_path / "r1.pt")
+    res = _run_bench(8, extra, timeout=1500, steps=1, dump=d8)
+    assert res["n_gpus"] == 8 and res["scaling"] == "strong" and res["steps"] == 1
+    assert res["comm"]["world"] == 8 and res["comm"]["ranks_seen"] == list(range(8))
+    assert res["config"]["global_batch"] == 32 and res["config"]["batch_per_gpu"] == 4
+    assert abs(res["value"] - 32 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["value"]
+    assert res["comm"]["allgather_bytes_per_rank"] == 4 * 2 * 1024 * 32 * 4
+    one = _run_bench(1, extra, steps=1, dump=d1)
+    assert one["n_gpus"] == 1 and one["config"]["batch_per_gpu"] == 32
+    a, b = torch.load(d8), torch.load(d1)
+    assert a.shape == b.shape == (32, 2, 1024, 32)
+    worst = max(rel_l2(a[i], b[i]) for i in range(32))
+    assert worst < 2e-2, worst
