@@ -131,7 +131,7 @@ struct TrFuse {
 #define RLDM_TR_LAST_ACQUIRE 1  /* the last arriver of a fused split-K tile acquires (agent scope) before it re-reads the tile */
 #endif
 #ifndef RLDM_TR_ABL
-#define RLDM_TR_ABL 0          /* timing experiments (wrong results): 1 no statistics atomics, 2 no sigmoid in the staging transforms */
+#define RLDM_TR_ABL 0          /* timing experiments (wrong results): 1 no statistics atomics, 2 no sigmoid in the staging transforms, 4 no split-K output atomics, 8 plain stores instead of them */
 #endif
 #if RLDM_TR_ABL & 2
 __device__ inline float tr_sigmoid(float z) { return z; }
@@ -534,7 +534,13 @@ __global__ __launch_bounds__(256) void tr_conv_lds_kernel(const TrConv p, const 
                 if (p.rowadd) u += p.rowadd[(size_t)(gp / HW) * p.rowadd_ld + ch];
                 if (p.res) u += p.res[(size_t)gp * p.N + ch];
             }
+#if RLDM_TR_ABL & 4
+            if (u == 12345.678f) p.y[(size_t)gp * p.N + ch] = u;      // (timing experiment: no split-K atomics)
+#elif RLDM_TR_ABL & 8
+            p.y[(size_t)gp * p.N + ch] = u;                          // (timing experiment: plain stores instead of atomics)
+#else
             unsafeAtomicAdd(p.y + (size_t)gp * p.N + ch, u);
+#endif
         }
         if constexpr (FU) {
             if (f.cs_out || f.gs_out) {
