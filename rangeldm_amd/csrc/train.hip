@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace rldm {
@@ -2440,11 +2441,25 @@ int rldm_train_conv_splits(const rldm_train_conv_desc* d, int rowadd_ld) {
     return ksplit;
 }
 
+// The scratch buffers of this file (arrival tickets, partial tiles, fp64 accumulators) are process-wide and live on the device that was
+// current when the first of them was allocated: ONE training device per process (one process per GPU is how this library scales).
+// A call on another device is refused instead of handing it a pointer into the first device's memory.
+static int tr_scratch_device_ok() {
+    static int dev0 = -1;
+    int dev = -1;
+    RLDM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev0 < 0) dev0 = dev;
+    RLDM_REQUIRE(dev == dev0, "the training scratch buffers of this process live on device " + std::to_string(dev0) +
+                                  ": one training device per process (current device " + std::to_string(dev) + ")");
+    return 0;
+}
+
 // arrival counters of the fused split-K launches: zeroed once, every launch leaves them zeroed (one caller thread, stream ordered;
 // never reallocated during a stream capture: the first, eager, step of a shape sizes it)
 static int fuse_tickets(size_t count, hipStream_t st, unsigned** out) {
     static unsigned* buf = nullptr;
     static size_t cap = 0;
+    if (tr_scratch_device_ok()) return 1;
     if (count > cap) {
         RLDM_HIP_CHECK(hipStreamSynchronize(st));
         if (buf) RLDM_HIP_CHECK(hipFree(buf));
@@ -2650,6 +2665,7 @@ static int g_wg_group = 0;
 
 static int wg_group_flush() {
     if (g_wgq.empty()) return 0;
+    if (tr_scratch_device_ok()) return 1;
     hipStream_t st = g_wgq_stream;
     // K slices.  With every layer of a class in one launch the chip is full whatever a single layer brings, so the slices per tile --
     // partial tiles to write and re-read, a last arriver to sum them -- shrink from the launch-per-layer form's 64 to <= 16: a workgroup
@@ -2840,6 +2856,7 @@ static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse
     }
     static float* scratch = nullptr;                   // (one caller thread; launches are stream ordered)
     static size_t scratch_cap = 0;
+    if (tr_scratch_device_ok()) return 1;
     if (need > scratch_cap) {
         RLDM_HIP_CHECK(hipStreamSynchronize(st));
         if (scratch) RLDM_HIP_CHECK(hipFree(scratch));
@@ -2932,6 +2949,7 @@ int rldm_train_colsum(const float* dy, int B, int npix, int N, float* rows, int 
 static int gn_accumulators(size_t count, hipStream_t st, double** out) {
     static double* buf = nullptr;
     static size_t cap = 0;
+    if (tr_scratch_device_ok()) return 1;
     if (count > cap) {
         RLDM_HIP_CHECK(hipStreamSynchronize(st));
         if (buf) RLDM_HIP_CHECK(hipFree(buf));

@@ -59,7 +59,10 @@ class _GroupExchange:
         pass                                             # (the collectives above are their own rendezvous)
 
 
-_LIVE_STORES = []        # TCPStore servers this process hosts stay referenced: a slower peer may still be reading its last key
+# The TCPStore of the default path (MASTER_ADDR : MASTER_PORT + 1), one per process and endpoint: rank 0 HOSTS it and must keep it while
+# a slower peer may still be reading its last key, and a second Communicator built later in the same process reuses it (the keys carry a
+# generation, so the bootstraps never read each other's answers) instead of trying to bind the port a second time.
+_LIVE_STORES = {}
 
 
 class _StoreExchange:
@@ -73,12 +76,14 @@ class _StoreExchange:
 
     def __init__(self, rank, world, store=None, timeout=120.0):
         import datetime
-        self.rank, self.world = rank, world
-        self.store = store or dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                                            int(os.environ.get("MASTER_PORT", "29500")) + 1, world, rank == 0,
-                                            timeout=datetime.timedelta(seconds=timeout))
-        if rank == 0:
-            _LIVE_STORES.append(self.store)
+        self.rank, self.world, self.timeout = rank, world, float(timeout)
+        if store is None:
+            addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1
+            store = _LIVE_STORES.get((addr, port, rank, world))
+            if store is None:
+                store = dist.TCPStore(addr, port, world, rank == 0, timeout=datetime.timedelta(seconds=timeout))
+                _LIVE_STORES[(addr, port, rank, world)] = store
+        self.store = store
         self.gen = int(self.store.add(f"rldm_comm_gen_r{rank}", 1))
 
     def _key(self, what, rank=None):
@@ -96,8 +101,18 @@ class _StoreExchange:
     def finish(self):
         self.store.set(self._key("done", self.rank), b"1")
         if self.rank == 0:
-            for r in range(self.world):
-                self.store.get(self._key("done", r))
+            # ONE deadline for all ranks (a failed bootstrap must not cost world x timeout before its error surfaces)
+            import datetime
+            import time
+            keys = [self._key("done", r) for r in range(self.world)]
+            left = max(1.0, self.timeout)
+            t0 = time.monotonic()
+            try:
+                self.store.wait(keys, datetime.timedelta(seconds=left))
+            except Exception:
+                pass                                     # (a rank never arrived: the caller already holds the error to raise)
+            finally:
+                _ = time.monotonic() - t0
 
 
 class CommunicatorUnavailable(RuntimeError):

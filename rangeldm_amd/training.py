@@ -369,7 +369,7 @@ class UNetTrainer:
         done = done or (w, name + ".bias")
         if stats and rowadd is None and res is None and T.conv_fused_ok([T.Src(x)], N, taps, stride, mode, want_stats=True):
             y, cs_y = T.conv_fused([T.Src(x)], self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], want_stats=True)
-            self._cs[id(y)] = cs_y
+            self._cs_set(y, cs_y)
         else:
             y = T.conv(x, self.wf[w], N, taps, stride, mode, bias=self.p[name + ".bias"], rowadd=rowadd, res=res)
 
@@ -538,7 +538,10 @@ class UNetTrainer:
             self.a, self.b = a, b
 
     def fused_shape_ok(self, B, W, H):
-        """Do the fused kernels cover every layer of this network at this input size?"""
+        """Do the fused kernels cover every layer of this network at this input size?  (RLDM_TR_WG_V1, the A/B switch that makes the
+        library refuse the all-taps weight-gradient kernel, also switches the fused blocks off: they have no other weight gradient)"""
+        if os.environ.get("RLDM_TR_WG_V1"):
+            return False
         return self.fused_tape and fused_tape_supported(self.cfg, self.fused, B, W, H)
 
     def _srcs(self, x):
@@ -546,11 +549,20 @@ class UNetTrainer:
         ts = (x.a, x.b) if isinstance(x, UNetTrainer.Cat) else (x,)
         out = []
         for t in ts:
-            cs = self._cs.get(id(t))
+            cs = self._cs_get(t)
             if cs is None:                              # no fused conv produced it (conv_in): one statistics launch
-                cs = self._cs[id(t)] = T.chan_stats(t)
+                cs = T.chan_stats(t)
+                self._cs_set(t, cs)
             out.append(T.Src(t, cs))
         return out
+
+    def _cs_set(self, t, cs):
+        """The (sum, sumsq) pairs of tensor t, keyed by id(t) WITH a reference to t: the id cannot be recycled while the entry lives."""
+        self._cs[id(t)] = (t, cs)
+
+    def _cs_get(self, t):
+        e = self._cs.get(id(t))
+        return e[1] if e is not None and e[0] is t else None
 
     def _drow(self, rowadd):
         """Where the time-embedding row gradient of a conv goes: (buffer, accumulate?)"""
@@ -580,7 +592,7 @@ class UNetTrainer:
         has_sc = (sc_n + ".weight") in self.shapes
         sc = T.conv_fused(srcs, self.wf[sc_n + ".weight"], N, 1, bias=self.p[sc_n + ".bias"]) if has_sc else srcs[0].t
         y, csy = T.conv_fused(s1, self.wf[c2 + ".weight"], N, 9, gn=gn2, bias=self.p[c2 + ".bias"], res=sc, want_stats=True)
-        self._cs[id(y)] = csy
+        self._cs_set(y, csy)
 
         def bwd():
             dy = self._pop(y)
@@ -628,7 +640,7 @@ class UNetTrainer:
         o3, lse = T.attention_qkv_forward(qkv3)
         o = o3.view(B, W, H, Cc)
         y, csy = T.conv_fused([T.Src(o)], self.wf[wo + ".weight"], Cc, 1, bias=self.p[wo + ".bias"], res=x, want_stats=True)
-        self._cs[id(y)] = csy
+        self._cs_set(y, csy)
 
         def bwd():
             dy = self._pop(y)

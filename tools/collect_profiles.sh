@@ -17,7 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$TAG/$c -o pmc -- $BENCH > /tmp/prof_$TAG/$c.log 2>&1
   python tools/pmc_summary.py /tmp/prof_$TAG/$c > $OUT/${TAG}_pmc_$(echo $c | tr A-Z a-z).txt
 done
-python tools/traffic_json.py /tmp/prof_$TAG/FETCH_SIZE /tmp/prof_$TAG/WRITE_SIZE > $OUT/${TAG}_traffic.json; cp $OUT/${TAG}_traffic.json profiles/round5_traffic.json 2>/dev/null
+python tools/traffic_json.py /tmp/prof_$TAG/FETCH_SIZE /tmp/prof_$TAG/WRITE_SIZE > $OUT/${TAG}_traffic.json; cp $OUT/${TAG}_traffic.json profiles/round6_traffic.json 2>/dev/null
 # (bench.py after the traffic passes: its roofline.traffic reads the newest profiles/round*_traffic.json)
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --train --steps 20 --warmup 3 > $OUT/${TAG}_bench_train.json 2>> $OUT/${TAG}_bench.err
@@ -30,6 +30,8 @@ python tools/pmc_summary.py /tmp/prof_$TAG/valu > $OUT/${TAG}_pmc_valu.txt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/tr -o tr -- python tools/bench_train.py --steps 5 --warmup 2 --eager > /tmp/prof_$TAG/tr.log 2>&1
 DB=$(find /tmp/prof_$TAG/tr -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py $DB > $OUT/${TAG}_train_rocprof_kernel_stats.txt
+[ -n "$DB" ] && python tools/rocprof_summary.py $DB --by-grid > $OUT/${TAG}_train_by_grid.txt
+# (the trace holds 7 steps: 2 warm-ups + 5; TOTAL calls / 7 = launches per step, VAE encode included)
 python tools/graph_trace.py --top 120 > $OUT/${TAG}_graph_trace.txt 2>&1
 tail -3 $OUT/${TAG}_gpu_tests.txt; head -c 400 $OUT/${TAG}_bench.json; echo; head -c 300 $OUT/${TAG}_bench_train.json; echo
 ls -la $OUT | grep ${TAG}_
