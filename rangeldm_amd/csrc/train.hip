@@ -132,7 +132,7 @@ struct TrFuse {
 #define RLDM_TR_LAST_ACQUIRE 1  /* the last arriver of a fused split-K tile acquires (agent scope) before it re-reads the tile */
 #endif
 #ifndef RLDM_TR_ABL
-#define RLDM_TR_ABL 0          /* timing experiments (wrong results): 1 no statistics atomics, 2 no sigmoid in the staging transforms, 4 no split-K output atomics, 8 plain stores instead of them */
+#define RLDM_TR_ABL 0          /* timing experiments (wrong results): 1 no statistics atomics, 2 no sigmoid in the staging transforms, 4 no split-K output atomics, 8 plain stores instead of them; weight gradient: 16 no LDS stash, 32 no MFMA loop, 64 no global fetch of the next chunk */
 #endif
 #if RLDM_TR_ABL & 2
 __device__ inline float tr_sigmoid(float z) { return z; }
@@ -987,7 +987,17 @@ struct TrWgrad2 {
 // run the weight gradients of many layers (tr_wgrad2_group_kernel below).  GROUP: the slices of a tile meet through an arrival ticket
 // and the LAST arriver sums the partial tiles in slice order into dw (deterministic; no reduction launch); Z == 1: the tile goes
 // straight into dw.
-template <int TAPS, bool FU, bool GROUP>
+// (round 6) V3: the staging rebuilt for images of 8 / 16 beams (the two high-resolution levels).  A LANE owns a channel of the tile and a
+// wave every fourth 8-beam SEGMENT of the chunk: a wave-load is one 256-byte line, the contraction index runs beam-fastest
+// (k = column * H + beam), so a segment is 16 contiguous bytes of its channel's LDS row (one ds_write_b128 instead of eight transposing
+// ds_write_b32), GroupNorm + SiLU are applied once per element (the round-5 staging transformed every input element for each of its four
+// azimuth-shifted roles) with the channel's coefficients in two registers, and the three copies a 3x3 needs are BEAM-shifted -- built
+// from the segment's own ten registers -- while the azimuth taps are a shift by H elements (16-byte aligned for H >= 8) into a row
+// staged with one halo column each side.  84 KB instead of 98 KB of fp32 per chunk and a fifth of the staging instructions -- and the
+// grouped 3x3 launch of the two high-resolution levels takes 684 instead of 701 us (1x1: 174 / 180): what bounds these launches is not
+// the staging but the L2-MISS TRAFFIC of fp32 activations (every (layer, slice) is read by (N / 64)(C / 64) tiles spread over the eight
+// XCDs: 1.5 GB per launch at ~2.3 TB/s; profiles/round6_wgrad_ablation.txt).  bf16 activations would halve it; the tape stores fp32.
+template <int TAPS, bool FU, bool GROUP, bool V3 = false>
 __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& f, const int bx, const int z, const int Z, unsigned* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
     constexpr int NC = TAPS == 9 ? 3 : 1;
@@ -996,13 +1006,13 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
     const int l31 = lane & 31, kg = lane >> 5;
     const int WC = 1 << p.lwc, H = p.H, W = p.W, N = p.N, Cin = p.Cin;
     const int KP = WC * H;
-    const int pitchA = p.pitchA, pitchB = p.pitchB;
+    const int pitchA = p.pitchA, pitchB = V3 ? (WC + (TAPS == 9 ? 2 : 0)) * H + 8 : p.pitchB;
     bf16_t* sA = reinterpret_cast<bf16_t*>(wg_smem);                 // [64][pitchA]
     bf16_t* sB = sA + 64 * pitchA;                                   // [NC][64][pitchB]
     const int ct = Cin >> 6;
     const int n0 = (bx / ct) * 64, c0 = (bx % ct) * 64;
     const int wi = wave >> 1, wj = wave & 1;                         // this wave's 32 x 32 quarter of the tile
-    if (TAPS == 9) {                                                 // zero beam rows -1 and H of the three copies
+    if (TAPS == 9 && !V3) {                                          // zero beam rows -1 and H of the three copies
         for (int e = tid; e < NC * 64 * 2 * WC; e += 256) {
             const int wl = e & (WC - 1), r = (e >> p.lwc) & 1, rc = e >> (p.lwc + 1);
             sB[rc * pitchB + (r ? (H + 1) * WC : 0) + wl] = (bf16_t)0;
@@ -1103,6 +1113,7 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
     const bool do_sums = (p.rows || p.total) && c0 == 0;
     int sum_b = -1;
     float sum_img = 0.f, sum_all = 0.f;
+    if constexpr (!V3) {
     WgStage R[4];                                                    // one chunk of staging data (1 - 4 iterations of 6 loads)
     if (z * p.cpw < chunk_end) {
         const int c0_ = z * p.cpw, b0_ = c0_ / nwc, w00 = (c0_ - b0_ * nwc) << p.lwc;
@@ -1113,9 +1124,11 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
     for (int chunk = z * p.cpw; chunk < chunk_end; ++chunk) {
         const int b = chunk / nwc, w0 = (chunk - b * nwc) << p.lwc;
         __syncthreads();                                             // the previous chunk's fragments have been read
+#if !(RLDM_TR_ABL & 16)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
             if (2 * (ppl + 16 * it) < KP) stash(ppl + 16 * it, R[it], b);
+#endif
         __syncthreads();
         if (do_sums) {                                               // thread (row n = tid >> 2, quarter of the chunk's pixels)
             const bf16_t* r = sA + (tid >> 2) * pitchA + (tid & 3) * (KP >> 2);
@@ -1134,12 +1147,17 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
             sum_img += sacc;
             sum_all += sacc;
         }
+#if !(RLDM_TR_ABL & 64)
         if (chunk + 1 < chunk_end) {                                 // the next chunk's loads fly during this chunk's MFMAs
             const int nb_ = (chunk + 1) / nwc, nw0 = ((chunk + 1) - nb_ * nwc) << p.lwc;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 if (2 * (ppl + 16 * it) < KP) fetch(ppl + 16 * it, nb_, nw0, R[it]);
         }
+#endif
+#if RLDM_TR_ABL & 32
+        if (chunk >= 0) continue;
+#endif
         const bf16_t* fa = sA + (32 * wi + l31) * pitchA + 8 * kg;
         const bf16_t* fb = sB + (32 * wj + l31) * pitchB + 8 * kg;
         // fragments of k-step k + 1 are requested before the MFMAs of k-step k (one wave per SIMD: nothing else hides the LDS latency)
@@ -1169,6 +1187,156 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
                 const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + k));
                 const bf16x8 Bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + k));
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[0], 0, 0, 0);
+            }
+        }
+    }
+    } else {
+        // ---- V3 staging (see the comment above the function) ----
+        constexpr int HALO = TAPS == 9 ? 1 : 0, NE = TAPS == 9 ? 10 : 8;
+        const int hsh = H == 16 ? 1 : 0, hmask = (1 << hsh) - 1;       // 8-beam segments per column: 1 << hsh
+        const int nsx = (WC + 2 * HALO) << hsh;                          // segments of the (halo'd) input chunk; dy has KP / 8 = 16
+        const float* const dyc = p.dy + n0 + lane;
+        const float* const xc = (second ? f.x1 + (c0 - f.C0) : p.x + c0) + lane;
+        const size_t sN = (size_t)N, sX = (size_t)xld;
+        float dv[4][8], xv[5][NE];
+        auto fetch3 = [&](const int b, const int w0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sg = wave + 4 * i, wl = sg >> hsh, h0 = (sg & hmask) * 8;
+                const float* src = dyc + ((size_t)(b * W + w0 + wl) * H + h0) * sN;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[i][e] = src[(size_t)e * sN];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int sg = wave + 4 * i;
+                if (sg < nsx) {
+                    const int j = sg >> hsh, h0 = (sg & hmask) * 8;
+                    int w = w0 + j - HALO;
+                    w = w < 0 ? w + W : (w >= W ? w - W : w);
+                    const float* src = xc + ((size_t)(b * W + w) * H + h0) * sX;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int h = h0 + e - HALO;
+                        xv[i][e] = (h >= 0 && h < H) ? src[((ptrdiff_t)e - HALO) * (ptrdiff_t)sX] : 0.f;
+                    }
+                }
+            }
+        };
+        auto stash3 = [&](const int b) __attribute__((always_inline)) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sg = wave + 4 * i;
+                u32x4 u;
+                u.x = rldm::pack_bf16x2(dv[i][0], dv[i][1]); u.y = rldm::pack_bf16x2(dv[i][2], dv[i][3]);
+                u.z = rldm::pack_bf16x2(dv[i][4], dv[i][5]); u.w = rldm::pack_bf16x2(dv[i][6], dv[i][7]);
+                *reinterpret_cast<u32x4*>(sA + lane * pitchA + 8 * sg) = u;
+            }
+            float2 cf = make_float2(1.f, 0.f);
+            if constexpr (FU) {
+                if (in_gn) cf = sCo[b * 64 + lane];
+            }
+            const bool act = FU && in_gn && f.silu != 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int sg = wave + 4 * i;
+                if (sg < nsx) {
+                    const int h0 = (sg & hmask) * 8;
+                    float v[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        float zz = xv[i][e];
+                        if constexpr (FU) {
+                            if (in_gn) {
+                                zz = zz * cf.x + cf.y;
+                                if (act) zz *= tr_sigmoid(zz);
+                            }
+                        }
+                        v[e] = zz;
+                    }
+                    bf16_t* dst = sB + lane * pitchB + 8 * sg;
+                    if constexpr (TAPS == 9) {
+                        // (zero padding applies to the ACTIVATED tensor: the beams above / below the image)
+                        if (h0 == 0) v[0] = 0.f;
+                        if (h0 + 8 == H) v[9] = 0.f;
+                        const unsigned p01 = rldm::pack_bf16x2(v[0], v[1]), p23 = rldm::pack_bf16x2(v[2], v[3]), p45 = rldm::pack_bf16x2(v[4], v[5]),
+                                       p67 = rldm::pack_bf16x2(v[6], v[7]), p89 = rldm::pack_bf16x2(v[8], v[9]);
+                        u32x4 m, lo, hi;                             // copies dh = 0 | -1 | +1: position h holds a[h + dh]
+                        m.x = rldm::pack_bf16x2(v[1], v[2]); m.y = rldm::pack_bf16x2(v[3], v[4]); m.z = rldm::pack_bf16x2(v[5], v[6]); m.w = rldm::pack_bf16x2(v[7], v[8]);
+                        lo.x = p01; lo.y = p23; lo.z = p45; lo.w = p67;
+                        hi.x = p23; hi.y = p45; hi.z = p67; hi.w = p89;
+                        *reinterpret_cast<u32x4*>(dst) = lo;
+                        *reinterpret_cast<u32x4*>(dst + 64 * pitchB) = m;
+                        *reinterpret_cast<u32x4*>(dst + 128 * pitchB) = hi;
+                    } else {
+                        u32x4 m;
+                        m.x = rldm::pack_bf16x2(v[0], v[1]); m.y = rldm::pack_bf16x2(v[2], v[3]); m.z = rldm::pack_bf16x2(v[4], v[5]); m.w = rldm::pack_bf16x2(v[6], v[7]);
+                        *reinterpret_cast<u32x4*>(dst) = m;
+                    }
+                }
+            }
+        };
+        if (z * p.cpw < chunk_end) {
+            const int c0_ = z * p.cpw, b0_ = c0_ / nwc, w00 = (c0_ - b0_ * nwc) << p.lwc;
+            fetch3(b0_, w00);
+        }
+        for (int chunk = z * p.cpw; chunk < chunk_end; ++chunk) {
+            const int b = chunk / nwc;
+            __syncthreads();                                         // the previous chunk's fragments have been read
+            stash3(b);
+            __syncthreads();
+            if (do_sums) {                                           // thread (row n = tid >> 2, quarter of the chunk's pixels)
+                const bf16_t* r = sA + (tid >> 2) * pitchA + (tid & 3) * (KP >> 2);
+                float sacc = 0.f;
+                for (int k = 0; k < (KP >> 2); k += 2) {
+                    const uint32_t u = *reinterpret_cast<const uint32_t*>(r + k);
+                    sacc += rldm::bf16lo(u) + rldm::bf16hi(u);
+                }
+                sacc += __shfl_xor(sacc, 1);
+                sacc += __shfl_xor(sacc, 2);
+                if (b != sum_b) {
+                    if (sum_b >= 0 && p.rows && (tid & 3) == 0) unsafeAtomicAdd(p.rows + (size_t)sum_b * p.rows_ld + n0 + (tid >> 2), sum_img);
+                    sum_b = b;
+                    sum_img = 0.f;
+                }
+                sum_img += sacc;
+                sum_all += sacc;
+            }
+            if (chunk + 1 < chunk_end) {                             // the next chunk's loads fly during this chunk's MFMAs
+                const int nb_ = (chunk + 1) / nwc, nw0 = ((chunk + 1) - nb_ * nwc) << p.lwc;
+                fetch3(nb_, nw0);
+            }
+            const bf16_t* fa = sA + (32 * wi + l31) * pitchA + 8 * kg;
+            const bf16_t* fb = sB + (32 * wj + l31) * pitchB + 8 * kg;
+            if (TAPS == 9) {
+                // tap t = (dw + 1) * 3 + (dh + 1): copy t % 3 (beam shift), t / 3 columns of H elements into the halo'd row
+                uint4 Ac = *reinterpret_cast<const uint4*>(fa), Bc[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) Bc[t] = *reinterpret_cast<const uint4*>(fb + (t % 3) * 64 * pitchB + (t / 3) * H);
+                for (int k = 0; k < KP; k += 16) {
+                    uint4 An = Ac, Bn[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) Bn[t] = Bc[t];
+                    if (k + 16 < KP) {
+                        An = *reinterpret_cast<const uint4*>(fa + k + 16);
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) Bn[t] = *reinterpret_cast<const uint4*>(fb + (t % 3) * 64 * pitchB + k + 16 + (t / 3) * H);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ac), __builtin_bit_cast(bf16x8, Bc[t]), acc[t], 0, 0, 0);
+                    Ac = An;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) Bc[t] = Bn[t];
+                }
+            } else {
+#pragma unroll 2
+                for (int k = 0; k < KP; k += 16) {
+                    const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + k));
+                    const bf16x8 Bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + k));
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[0], 0, 0, 0);
+                }
             }
         }
     }
@@ -1271,7 +1439,7 @@ struct WgGroup {
 };
 static_assert(sizeof(WgGroup) <= 4096, "the group record is the kernel's argument block");
 
-template <int TAPS, bool FU>
+template <int TAPS, bool FU, bool V3>
 __global__ __launch_bounds__(256) void tr_wgrad2_group_kernel(const WgGroup g) {
     const int bid = blockIdx.x;
     int l = 0;
@@ -1292,7 +1460,7 @@ __global__ __launch_bounds__(256) void tr_wgrad2_group_kernel(const WgGroup g) {
     // pipeline per CU -- one chunk of loads in flight, a transposing LDS write, two barriers per chunk -- not by L2 misses.)
     const int local = bid - g.first[l];
     const int tiles = (it.N >> 6) * (it.Cin >> 6);
-    tr_wgrad2_body<TAPS, FU, true>(p, f, local % tiles, local / tiles, it.Z, g.tickets + it.ticket_off);
+    tr_wgrad2_body<TAPS, FU, true, V3>(p, f, local % tiles, local / tiles, it.Z, g.tickets + it.ticket_off);
 }
 
 // four channels per thread, eight slices in flight (Cin % 4 == 0): the scalar kernel below ran at 2 TB/s over 38 MB of partials
@@ -2658,7 +2826,7 @@ int rldm_train_wgrad_fused_ok(const rldm_train_conv_desc* d, const rldm_train_fu
 // rldm_train_wgrad_group(1): all-taps weight gradients are queued instead of launched; rldm_train_wgrad_group_flush (or group(0)) runs
 // the queue as a few launches of tr_wgrad2_group_kernel.  One caller thread, one stream per queue (a call on another stream flushes
 // first); the caller keeps every queued operand alive and unmodified until the flush (rangeldm_amd/training.py does).
-struct WgQueued { WgItem it; int taps; bool fu; int tiles; size_t part_floats; size_t smem; double unit; };
+struct WgQueued { WgItem it; int taps; bool fu, v3; int tiles; size_t part_floats; size_t smem; double unit; };
 static std::vector<WgQueued> g_wgq;
 static hipStream_t g_wgq_stream = nullptr;
 static int g_wg_group = 0;
@@ -2673,12 +2841,12 @@ static int wg_group_flush() {
     // the RangeLDM size, batch 8 (profiles/round6_wgrad_group_budget.txt): 3x3 launches are fastest at 32 units (712 / 276 us; 16: 769 /
     // 307, 8: 996 / 434, 4: 1543 / 514 -- the last arriver's serial sum over the slices is the tail), the 1x1 launches at 8 - 16.
     static const int budget_env = getenv("RLDM_TR_WG_GROUP_CPW") ? atoi(getenv("RLDM_TR_WG_GROUP_CPW")) : 0;
-    for (int cls = 0; cls < 4; ++cls) {
+    for (int cls = 0; cls < 8; ++cls) {
         const int taps = (cls & 1) ? 1 : 9;
-        const bool fu = (cls & 2) != 0;
+        const bool fu = (cls & 2) != 0, v3 = (cls & 4) != 0;
         const double budget = budget_env ? (double)budget_env : (taps == 9 ? 32.0 : 12.0);
         for (auto& q : g_wgq) {
-            if (q.taps != taps || q.fu != fu) continue;
+            if (q.taps != taps || q.fu != fu || q.v3 != v3) continue;
             WgItem& it = q.it;
             int cpw = std::max(1, (int)(budget / q.unit + 0.5));
             cpw = std::min(cpw, it.nchunks);
@@ -2713,12 +2881,15 @@ static int wg_group_flush() {
         RLDM_HIP_CHECK(hipMemset(tickets, 0, want * sizeof(unsigned)));        // zeroed once; every launch leaves them zeroed
         tick_cap = want;
     }
-    static bool attr = false;                       // (128 KiB: the kernel also has a static LDS word, the tiles need <= 80 KiB)
+    typedef void (*GroupKernel)(const WgGroup);
+    static const GroupKernel kernels[8] = {tr_wgrad2_group_kernel<9, false, false>, tr_wgrad2_group_kernel<1, false, false>,
+                                           tr_wgrad2_group_kernel<9, true, false>,  tr_wgrad2_group_kernel<1, true, false>,
+                                           tr_wgrad2_group_kernel<9, false, true>,  tr_wgrad2_group_kernel<1, false, true>,
+                                           tr_wgrad2_group_kernel<9, true, true>,   tr_wgrad2_group_kernel<1, true, true>};
+    static bool attr = false;                       // (128 KiB: the kernel also has a static LDS word, the tiles need <= 88 KiB)
     if (!attr) {
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_wgrad2_group_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        for (int k = 0; k < 8; ++k)
+            RLDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
     size_t poff = 0, toff = 0;
@@ -2727,11 +2898,11 @@ static int wg_group_flush() {
         q.it.ticket_off = (unsigned)toff; toff += (size_t)q.tiles;
     }
     // one launch per (instantiation, <= kWgGroupMax layers), long workgroups first (the layers with the most pixels per slice)
-    for (int cls = 0; cls < 4; ++cls) {
+    for (int cls = 0; cls < 8; ++cls) {
         const int taps = (cls & 1) ? 1 : 9;
-        const bool fu = (cls & 2) != 0;
+        const bool fu = (cls & 2) != 0, v3 = (cls & 4) != 0;
         std::vector<const WgQueued*> sel;
-        for (auto& q : g_wgq) if (q.taps == taps && q.fu == fu) sel.push_back(&q);
+        for (auto& q : g_wgq) if (q.taps == taps && q.fu == fu && q.v3 == v3) sel.push_back(&q);
         std::stable_sort(sel.begin(), sel.end(), [](const WgQueued* a, const WgQueued* b) {
             return (long long)a->it.cpw * (a->it.H << a->it.lwc) > (long long)b->it.cpw * (b->it.H << b->it.lwc); });
         for (size_t i0 = 0; i0 < sel.size(); i0 += kWgGroupMax) {
@@ -2749,8 +2920,7 @@ static int wg_group_flush() {
                 smem = std::max(smem, q->smem);
             }
             g.first[g.n] = blocks;
-            if (taps == 9) { if (fu) tr_wgrad2_group_kernel<9, true><<<blocks, 256, smem, st>>>(g); else tr_wgrad2_group_kernel<9, false><<<blocks, 256, smem, st>>>(g); }
-            else { if (fu) tr_wgrad2_group_kernel<1, true><<<blocks, 256, smem, st>>>(g); else tr_wgrad2_group_kernel<1, false><<<blocks, 256, smem, st>>>(g); }
+            kernels[cls]<<<blocks, 256, smem, st>>>(g);
             TR_LAUNCH_CHECK();
         }
     }
@@ -2844,9 +3014,12 @@ static int train_wgrad_impl(const rldm_train_conv_desc* d, const rldm_train_fuse
         it.x1 = f.x1; it.C0 = f.C0; it.cs0 = f.cs0; it.cs1 = f.cs1; it.gamma = f.gamma; it.beta = f.beta; it.silu = f.silu;
         it.groups = f.groups; it.eps = f.eps;
         q.taps = p.taps; q.fu = fu != nullptr;
+        static const bool v3_off = getenv("RLDM_TR_WG_V3") && atoi(getenv("RLDM_TR_WG_V3")) == 0;       // (A/B: the round-5 staging)
+        q.v3 = !v3_off && w2.H >= 8 && w2.mode == 0;
         q.tiles = (p.N / 64) * (p.Cin / 64);
         q.part_floats = 0;
-        q.smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * w2.pitchB * 2;
+        const int pitchB = q.v3 ? ((1 << w2.lwc) + (p.taps == 9 ? 2 : 0)) * w2.H + 8 : w2.pitchB;
+        q.smem = (size_t)64 * w2.pitchA * 2 + (size_t)(p.taps == 9 ? 3 : 1) * 64 * pitchB * 2;
         if (fu) q.smem += (size_t)p.B * 64 * sizeof(float2);
         q.smem = std::max(q.smem, (size_t)32 * (64 * p.taps + 1) * sizeof(float));      // (Z == 1: the tile goes through LDS into dw)
         if (rows && !rows_accumulate) tr_zero2d_kernel<<<nblk((size_t)p.B * p.N), 256, 0, st>>>(rows, rows_ld, p.N, p.B);
