@@ -2592,7 +2592,9 @@ static void conv_lds_plan(int P, int N, int Cin, int taps, bool* narrow_out, int
     static const int ks_env = getenv("RLDM_TR_KSPLIT") ? atoi(getenv("RLDM_TR_KSPLIT")) : -1;
     const int niter = taps * (Cin / (Cin % 64 == 0 ? 64 : 32));
     const long long wgs = gx * gy;
-    int ksplit = wgs > 192 ? 1 : (int)std::min<long long>((512 + wgs - 1) / wgs, niter / 3);
+    static const int tgt_env = getenv("RLDM_TR_KSPLIT_TARGET") ? atoi(getenv("RLDM_TR_KSPLIT_TARGET")) : 512;
+    static const int minst_env = getenv("RLDM_TR_KSPLIT_MINSTAGES") ? atoi(getenv("RLDM_TR_KSPLIT_MINSTAGES")) : 3;
+    int ksplit = wgs > 192 ? 1 : (int)std::min<long long>((tgt_env + wgs - 1) / wgs, niter / minst_env);
     if (ks_env >= 0) ksplit = ks_env;
     *narrow_out = narrow;
     *ksplit_out = std::max(1, std::min(ksplit, niter));

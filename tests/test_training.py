@@ -518,6 +518,26 @@ def test_training_step_loop_body_unconditional_and_conditional():
     l1 = [float(TR.training_step(trc, vae, sched, imgs.cuda(), generator=torch.Generator().manual_seed(1), pos_encoding=False,
                                  condition=cond)) for _ in range(6)]
     assert all(math.isfinite(v) for v in l1) and l1[-1] < l1[0]
+    # v_prediction (ldm/train_unconditional.py:505-510, :532-534): the target is the velocity, the min-SNR weights use SNR + 1; the
+    # first loss of a step on given latents / noise / timesteps equals the oracle's, computed from the same model output
+    from rangeldm_amd.config import SchedulerConfig
+    from oracle.schedulers import OracleDDPMScheduler
+    from rangeldm_amd import train_ops as T
+    sv = DDPMSchedulerHIP(SchedulerConfig(prediction_type="v_prediction"))
+    trv = TR.UNetTrainer(cfg, synth_state_dict(unet_param_shapes(cfg), prefix="tr."), lr_warmup_steps=0, lr=1e-3)
+    lat = torch.randn(2, 4, 32, 8, generator=g)
+    noise = torch.randn(2, 4, 32, 8, generator=g)
+    ts = torch.tensor([120, 870])
+    pe = torch.zeros(2, 1, 32, 8)
+    pe[:, :, 0, :] = 1
+    pred = T.unpack_output(trv.forward(torch.cat([sv.add_noise(lat.cuda(), noise.cuda(), ts).cpu(), pe], 1).cuda(), ts.cuda())).cpu()
+    target = OracleDDPMScheduler(SchedulerConfig(prediction_type="v_prediction")).get_velocity(lat, noise, ts)
+    w = TR.snr_weights(sv.alphas_cumprod, ts, 5.0, v_prediction=True)
+    want = float(((pred - target) ** 2).mean((1, 2, 3)).mul(w).mean())
+    got = float(TR.training_step(trv, None, sv, lat.cuda(), pos_encoding=True, snr_gamma=5.0, noise=noise.cuda(), timesteps=ts))
+    assert abs(got - want) < 2e-3 * want, (got, want)
+    with pytest.raises(ValueError, match="Unknown prediction type"):
+        TR.training_step(trv, None, DDPMSchedulerHIP(SchedulerConfig(prediction_type="sample")), lat.cuda(), noise=noise.cuda(), timesteps=ts)
 
 
 @pytest.mark.gpu
