@@ -620,6 +620,8 @@ def main():
                     rl["workload_clock_mhz"] = wclk
                 # `value` per calibration TFLOP/s: the figure that should agree between boxes running the same build
                 res["value_per_calibration_tflops"] = round(res["value"] / world / cal["mfma_tflops"], 5) if cal["mfma_tflops"] else None
+                # ... and per GHz of the clock the chip held under THIS workload (agrees within ~1 % between boxes)
+                res["value_per_workload_ghz"] = round(res["value"] / world / (wclk / 1000.0), 2) if wclk else None
             except Exception as e:                      # noqa: BLE001  (secondary figures: never fail the line)
                 res["calibration"] = {"error": str(e)[:200]}
             if world == 1 and not args.no_cpu_baseline:
