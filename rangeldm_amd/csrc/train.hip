@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
         // ---- V3 staging (see the comment above the function) ----
         constexpr int HALO = TAPS == 9 ? 1 : 0, NE = TAPS == 9 ? 10 : 8;
         const int hsh = H == 16 ? 1 : 0, hmask = (1 << hsh) - 1;       // 8-beam segments per column: 1 << hsh
-        const int nsx = (WC + 2 * HALO) << hsh;                          // segments of the (halo'd) input chunk; dy has KP / 8 = 16
+        const int nsx = (WC + 2 * HALO) << hsh, nsd = WC << hsh;         // segments of the (halo'd) input chunk / of dy (KP / 8 <= 16)
         const float* const dyc = p.dy + n0 + lane;
         const float* const xc = (second ? f.x1 + (c0 - f.C0) : p.x + c0) + lane;
         const size_t sN = (size_t)N, sX = (size_t)xld;
@@ -1203,9 +1203,11 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int sg = wave + 4 * i, wl = sg >> hsh, h0 = (sg & hmask) * 8;
-                const float* src = dyc + ((size_t)(b * W + w0 + wl) * H + h0) * sN;
+                if (sg < nsd) {
+                    const float* src = dyc + ((size_t)(b * W + w0 + wl) * H + h0) * sN;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dv[i][e] = src[(size_t)e * sN];
+                    for (int e = 0; e < 8; ++e) dv[i][e] = src[(size_t)e * sN];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -1228,10 +1230,12 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int sg = wave + 4 * i;
-                u32x4 u;
-                u.x = rldm::pack_bf16x2(dv[i][0], dv[i][1]); u.y = rldm::pack_bf16x2(dv[i][2], dv[i][3]);
-                u.z = rldm::pack_bf16x2(dv[i][4], dv[i][5]); u.w = rldm::pack_bf16x2(dv[i][6], dv[i][7]);
-                *reinterpret_cast<u32x4*>(sA + lane * pitchA + 8 * sg) = u;
+                if (sg < nsd) {
+                    u32x4 u;
+                    u.x = rldm::pack_bf16x2(dv[i][0], dv[i][1]); u.y = rldm::pack_bf16x2(dv[i][2], dv[i][3]);
+                    u.z = rldm::pack_bf16x2(dv[i][4], dv[i][5]); u.w = rldm::pack_bf16x2(dv[i][6], dv[i][7]);
+                    *reinterpret_cast<u32x4*>(sA + lane * pitchA + 8 * sg) = u;
+                }
             }
             float2 cf = make_float2(1.f, 0.f);
             if constexpr (FU) {

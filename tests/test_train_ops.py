@@ -90,6 +90,23 @@ def test_conv_forward_dgrad_wgrad(B, Cin, N, W, H, taps, stride, mode):
     tot = torch.zeros(N).cuda()
     T.colsum(dyd, rows=rows, total=tot)
     assert rel(rows.cpu(), dy.sum((2, 3))) < TOL_F32 and rel(tot.cpu(), dy.sum((0, 2, 3))) < TOL_F32
+    # (round 6) the same weight gradients QUEUED and run by the grouped launch (rldm_train_wgrad_group: shapes the all-taps kernel
+    # covers are queued, the others launch at once): two layers' worth in one flush, into a zeroed and into a pre-filled buffer
+    dw4, dw5 = torch.zeros_like(dw), dw3.clone()
+    rows4, tot4 = torch.zeros(B, N).cuda(), torch.zeros(N).cuda()
+    T.wgrad_group(True)
+    try:
+        T.wgrad_bias(dyd, xd, dw4, taps, stride, mode, rows=rows4, total=tot4)
+        T.wgrad(dyd, xd, dw5, taps, stride, mode)
+        queued = T.wgrad_group_pending()
+        assert queued in (0, 2)
+    finally:
+        T.wgrad_group(False)
+    assert T.wgrad_group_pending() == 0
+    assert rel(dw4.cpu(), w.grad) < TOL_MM and rel(dw5.cpu(), 2 * w.grad) < TOL_MM
+    assert rel(rows4.cpu(), dy.sum((2, 3))) < 3e-3 and rel(tot4.cpu(), dy.sum((0, 2, 3))) < 3e-3
+    if queued:                                      # same kernel body, same operands: the K-slice boundaries differ, nothing else
+        assert rel(dw4, dw3) < 1e-4
 
 
 @pytest.mark.parametrize("B,C,W,H,silu", [(2, 64, 16, 8, True), (3, 32, 8, 4, False), (1, 128, 4, 2, True), (2, 512, 4, 2, True),
@@ -289,5 +306,15 @@ def test_fused_norm_conv_forward_backward(B, C0, C1, N, W, H, taps, silu):
         T.wgrad_fused(dyd, srcs, dw, taps, gn=gn, rows=rows, total=tot)
         assert rel(dw.cpu(), w.grad) < TOL_MM
         assert rel(rows.cpu(), dy.sum((2, 3))) < 3e-3 and rel(tot.cpu(), dy.sum((0, 2, 3))) < 3e-3
+        # (round 6) queued + grouped launch (the V3 staging where the image has 8 / 16 beams, the round-5 staging below)
+        dw2, rows2, tot2 = torch.zeros_like(dw), torch.zeros(B, N).cuda(), torch.zeros(N).cuda()
+        T.wgrad_group(True)
+        try:
+            T.wgrad_fused(dyd, srcs, dw2, taps, gn=gn, rows=rows2, total=tot2)
+            assert T.wgrad_group_pending() == 1
+        finally:
+            T.wgrad_group(False)
+        assert rel(dw2.cpu(), w.grad) < TOL_MM and rel(dw2, dw) < 2e-3
+        assert rel(rows2.cpu(), dy.sum((2, 3))) < 3e-3 and rel(tot2.cpu(), dy.sum((0, 2, 3))) < 3e-3
     else:
         assert Cin % 64 != 0
