@@ -1202,12 +1202,12 @@ __device__ __forceinline__ void tr_wgrad2_body(const TrWgrad2& p, const TrFuse& 
         auto fetch3 = [&](const int b, const int w0) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int sg = wave + 4 * i, wl = sg >> hsh, h0 = (sg & hmask) * 8;
-                if (sg < nsd) {
-                    const float* src = dyc + ((size_t)(b * W + w0 + wl) * H + h0) * sN;
+                // (a chunk of fewer than 16 segments -- 64 pixels -- : the surplus slots re-load the last segment and are not stored; a
+                //  branch around the loads instead cost the common 16-segment case 20 %: 840 against 684 us for the grouped 3x3 launch)
+                const int sg = min(wave + 4 * i, nsd - 1), wl = sg >> hsh, h0 = (sg & hmask) * 8;
+                const float* src = dyc + ((size_t)(b * W + w0 + wl) * H + h0) * sN;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dv[i][e] = src[(size_t)e * sN];
-                }
+                for (int e = 0; e < 8; ++e) dv[i][e] = src[(size_t)e * sN];
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
