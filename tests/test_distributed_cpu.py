@@ -223,3 +223,35 @@ def test_cabi_bootstrap_missing_library_is_an_outcome_not_an_exception(monkeypat
         assert not t.is_alive()
     assert [o[0] for o in out] == ["unavailable", "unavailable"], out
     assert out[0][2].created == [] and "not found" in out[1][1]
+
+
+def test_cabi_bootstrap_default_store_is_reused_by_a_second_communicator(monkeypatch):
+    """The DEFAULT path (no store passed: a TCPStore at MASTER_ADDR : MASTER_PORT + 1, hosted by rank 0 and kept while peers may still
+    read it): a second Communicator built later in the same process must not try to bind the port again (EADDRINUSE on rank 0, its peers
+    then waiting a full timeout for generation-2 keys nobody writes) -- it reuses the process's store, with fresh generation-tagged keys."""
+    import threading
+    port = _free_port()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port - 1))
+    world = 2
+    for rnd in (1, 2):
+        out = [None] * world
+
+        def run(rank):
+            lib = _FakeRccl(rank)
+            try:
+                c = D.Communicator(rank=rank, world=world, lib=lib)
+                out[rank] = ("ok", lib, c)
+            except Exception as e:                                   # pragma: no cover
+                out[rank] = ("error", lib, repr(e))
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+            assert not t.is_alive(), "a rank hung in the bootstrap"
+        for rank, r in enumerate(out):
+            assert r[0] == "ok", r
+            assert r[2]._exchange.gen == rnd and r[1].created == [(bytes([0x40]) * 128, rank, world)]
+            r[2]._h = None
+    assert len([k for k in D._LIVE_STORES if k[1] == port]) == world      # one store per (endpoint, rank): created once, used twice
