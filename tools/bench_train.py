@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--overlap-vae", action="store_true", help="encode batch i + 1 on a second stream while batch i trains (measured: 4 % slower than in-step)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured step graphs")
+    ap.add_argument("--prio", action="store_true", help="with --overlap-vae: the training step on a HIGH-priority stream, the encode on a default-priority one")
     ap.add_argument("--seed", type=int, default=20240310)
     a = ap.parse_args()
     from rangeldm_amd import distributed as D
@@ -75,13 +76,19 @@ def main():
             ahead[i + 1] = encode_ahead(vae, imgs[i + 1], side, generator=gen)
         losses.append(training_step(tr, None, sched, imgs[i], generator=gen, pos_encoding=True, graphed=not a.eager, latents=lat))
 
-    for i in range(a.warmup):
-        one(i)
-    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, n_iter):
-        one(i)
-    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    import contextlib
+    main_ctx = contextlib.nullcontext()
+    if a.prio:
+        lo, hi = torch.cuda.Stream.priority_range()
+        main_ctx = torch.cuda.stream(torch.cuda.Stream(dev, priority=hi))
+    with main_ctx:
+        for i in range(a.warmup):
+            one(i)
+        torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, n_iter):
+            one(i)
+        torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         sps = world * B * a.steps / dt
